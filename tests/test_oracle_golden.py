@@ -1,0 +1,116 @@
+"""Pin the CPU oracle (oracle/beso_oracle.py) against vectors produced by the reference itself
+(tests/golden/make_fixtures.py).  The reference has no tests of its own for this path."""
+import numpy as np
+import pytest
+
+from oracle import beso_oracle as O
+from conftest import load_golden, weights_from_fixture, rel_err
+
+TOL = 2e-5   # fp32 oracle (numpy/OpenBLAS) vs fp32 reference (torch CPU): summation-order noise only
+
+
+def _weights(fx, cfg):
+    w = weights_from_fixture(fx)
+    if not w:
+        w = O.make_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+        ws = sum(float(np.abs(v.astype(np.float64)).sum()) for v in w.values())
+        assert abs(ws - float(fx["wsum"])) <= 1e-9 * ws, "seeded weight recipe drifted"
+    return w
+
+
+@pytest.mark.parametrize("fixture,cfg_name", [
+    ("tiny_forward.npz", "tiny"), ("tiny_mlp_head_forward.npz", "tiny_mlp_head"),
+    ("tiny_nogoal_forward.npz", "tiny_nogoal"), ("kitchen_forward_std002.npz", "kitchen"),
+    ("kitchen_forward_std008.npz", "kitchen"), ("block_push_forward.npz", "block_push"),
+    ("long_horizon_forward.npz", "long_horizon")])
+def test_forward_matches_reference(fixture, cfg_name):
+    fx = load_golden(fixture)
+    cfg = O.CONFIGS[cfg_name]
+    w = _weights(fx, cfg)
+    for t in fx["ts"]:
+        p = f"t{int(t)}::"
+        s, g, a, sig = fx[p + "state"], fx[p + "goal"], fx[p + "action"], fx[p + "sigma"]
+        assert rel_err(O.score_gpt_forward(w, cfg, s, a, g, sig), fx[p + "inner"]) < TOL
+        assert rel_err(O.denoise(w, cfg, s, a, g, sig), fx[p + "denoised"]) < TOL
+        assert rel_err(O.denoise(w, cfg, s, a, g, sig, uncond=True), fx[p + "denoised_uncond"]) < TOL
+        # fp64 arbiter agrees with the fp32 reference to fp32 round-off as well
+        assert rel_err(O.denoise(w, cfg, s, a, g, sig, dtype=np.float64), fx[p + "denoised"]) < TOL
+
+
+def test_param_count_matches_survey():
+    assert O.n_params(O.KITCHEN) == 9_381_249
+    assert O.n_params(O.BLOCK_PUSH) == 2_783_762
+    assert O.n_params(O.LONG_HORIZON) == 18_959_881
+    assert O.KITCHEN.flops_per_sample() == 206_514_000
+    assert O.BLOCK_PUSH.flops_per_sample() == 66_947_040
+    assert O.LONG_HORIZON.flops_per_sample() == 2_585_961_472
+
+
+@pytest.mark.parametrize("fixture,cfg_name", [
+    ("kitchen_samplers.npz", "kitchen"), ("block_push_heun_cfg.npz", "block_push"),
+    ("long_horizon_euler.npz", "long_horizon")])
+def test_samplers_match_reference(fixture, cfg_name):
+    fx = load_golden(fixture)
+    cfg = O.CONFIGS[cfg_name]
+    w = _weights(fx, cfg)
+    lam = float(fx["cond_lambda"])
+    model = O.make_model(w, cfg, cond_lambda=None if lam < 0 else lam)
+    keys = sorted(k[:-len("::out")] for k in fx if k.endswith("::out"))
+    assert keys
+    for key in keys:
+        sampler, n, schedule = key.split("_")[0], int(key.split("_")[-2]), key.split("_")[-1]
+        sampler = key[: key.index(f"_{n}_")]
+        sig = fx[key + "::sigmas"]
+        # schedules are restated too
+        if schedule == "karras":
+            mine = O.get_sigmas_karras(n, float(fx["sigma_min"]), float(fx["sigma_max"]), 5.0)
+        else:
+            mine = O.SCHEDULES[schedule](n, float(fx["sigma_min"]), float(fx["sigma_max"]))
+        np.testing.assert_allclose(mine, sig, rtol=2e-6, atol=0)
+        out = O.SAMPLERS[sampler](model, fx["state"], fx["x_t"], fx["goal"], sig)
+        # many-step samplers accumulate fp32 round-off; 50-step Heun x CFG stays below 2e-4
+        tol = 5e-5 if n <= 10 else 3e-4
+        assert rel_err(out, fx[key + "::out"]) < tol, key
+
+
+def test_euler_ancestral_with_injected_noise():
+    fx = load_golden("tiny_euler_ancestral.npz")
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=int(fx["seed"]), std=0.02)
+    out = O.sample_euler_ancestral(O.make_model(w, cfg), fx["state"], fx["x_t"], fx["goal"], fx["sigmas"],
+                                   noise_list=fx["noise"])
+    assert rel_err(out, fx["out"]) < TOL
+
+
+def test_classifier_free_guidance():
+    fx = load_golden("block_push_cfg.npz")
+    cfg = O.BLOCK_PUSH
+    w = _weights(fx, cfg)
+    for lam in fx["lambdas"]:
+        out = O.denoise_cfg(w, cfg, fx["state"], fx["action"], fx["goal"], fx["sigma"], float(lam))
+        assert rel_err(out, fx[f"lam{float(lam)}"]) < TOL
+
+
+def test_loss_and_sigma_density():
+    fx = load_golden("tiny_loss.npz")
+    cfg = O.TINY
+    w = _weights(fx, cfg)
+    loss = O.score_matching_loss(w, cfg, fx["state"], fx["action"], fx["goal"], fx["noise"], fx["sigma"])
+    assert abs(float(loss) - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
+    s = O.log_logistic_from_uniform(fx["loglogistic::u"], np.log(0.5), 0.5, 0.005, 1.0)
+    np.testing.assert_allclose(s, fx["loglogistic::sigma"], rtol=1e-6)
+
+
+def test_schedules():
+    fx = load_golden("schedules.npz")
+    fns = {"exponential": lambda n: O.get_sigmas_exponential(n, 0.005, 1.0),
+           "linear": lambda n: O.get_sigmas_linear(n, 0.005, 1.0),
+           "karras": lambda n: O.get_sigmas_karras(n, 0.005, 1.0, 5.0),
+           "polyexponential": lambda n: O.get_sigmas_polyexponential(n, 0.005, 1.0),
+           "vp": lambda n: O.get_sigmas_vp(n), "ve": lambda n: O.get_sigmas_ve(n, 0.005, 1.0),
+           "cosine_beta": lambda n: O.cosine_beta_schedule(n)}
+    for key, ref in fx.items():
+        name, n = key.rsplit("_", 1)
+        mine = fns[name](int(n))
+        assert mine.shape == ref.shape and mine[-1] == 0
+        np.testing.assert_allclose(mine, ref, rtol=3e-6, atol=1e-9, err_msg=key)
