@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising-steps/sec of the score-GPT forward at the Franka-kitchen shape.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE denoising step = one GCDenoiser.forward (score-GPT forward + Karras preconditioning)
+over one batch of synthetic kitchen inputs: BASELINE.json configs[1] (kitchen, B=4096 per GPU, bf16
+MFMA, inputs resident in HBM).  Samples are independent, so N GPUs run N shards of the job with no
+collective in the loop (weak scaling: 4096 samples per GPU per step); value = all steps of all
+ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line with the driver's fields plus
+  "roofline":     the dominant kernel's achieved TFLOP/s (algorithmic FLOPs / HIP-event time on the
+                  launch stream) against the dense bf16 MFMA peak;
+  "cpu_baseline": the CPU oracle (numpy port of the reference) timed on this box's host cores on a
+                  bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}       # dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def build_model(cfg, w, precision, dev):
+    from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
+    from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser
+    inner = DiffusionGPT(state_dim=cfg.obs_dim, device=dev, goal_conditioned=cfg.goal_conditioned,
+                         action_dim=cfg.act_dim, embed_dim=cfg.embed_dim, embed_pdrob=0, attn_pdrop=0,
+                         resid_pdrop=0, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=cfg.goal_seq_len,
+                         obs_seq_len=cfg.obs_seq_len, sigma_vocab_size=3, time_embedding_fn=None,
+                         linear_output=cfg.linear_output, precision=precision)
+    m = GCDenoiser(inner, sigma_data=cfg.sigma_data)
+    sd = m.state_dict()
+    sd.update({k: torch.from_numpy(v.copy()) for k, v in w.items()})
+    m.load_state_dict(sd)
+    return m.to(dev).eval()
+
+
+def cpu_baseline(cfg, w, batch, budget_s=15.0):
+    """The oracle (numpy fp32 port of the reference path) on the host cores, bounded to ~budget_s."""
+    from oracle import beso_oracle as O
+    sample_b = 256
+    s, g, a = O.make_inputs(cfg, sample_b, seed=0)
+    sig = np.full(sample_b, 0.3, np.float32)
+    O.denoise(w, cfg, s[:8], a[:8], g[:8], sig[:8])           # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        O.denoise(w, cfg, s, a, g, sig)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    samples_per_s = n * sample_b / el
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": samples_per_s / batch, "unit": f"denoise-steps/s (B={batch} per step)", "cores": int(cores),
+            "kind": "port",
+            "sample": f"{n} forwards of B={sample_b} kitchen samples, sigma=0.3 ({el:.1f} s of numpy fp32 on "
+                      f"{os.cpu_count()} host cores), scaled to B={batch}",
+            "samples_per_s": samples_per_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4096, help="samples per GPU per denoising step")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--config", default="kitchen", choices=["kitchen", "block_push", "long_horizon"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--site", default=None, help="launch site timed for the roofline object")
+    args = ap.parse_args()
+
+    from beso_amd import distributed as bdist
+    from oracle import beso_oracle as O           # cpu_baseline leg + shared synthetic-input recipe
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        bdist.init_from_env("nccl")
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(dev)
+
+    cfg = O.CONFIGS[args.config]
+    w = O.make_weights(cfg, seed=0, std=0.02)
+    model = build_model(cfg, w, args.precision, dev)
+    inner = model.inner_model
+    B = args.batch
+    # every rank owns its own shard of the job: different samples per rank, seeded
+    s_np, g_np, a_np = O.make_inputs(cfg, B, seed=1000 + rank)
+    state, goal, action = (torch.from_numpy(v).to(dev) for v in (s_np, g_np, a_np))
+    sigma = torch.full((B,), 0.3, device=dev)
+    rt = inner.runtime(cfg.sigma_data)
+    packed = inner.packed_weights()
+
+    def step():
+        return rt.denoise(packed, state, action, goal, sigma, precondition=True)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        # which launch site dominates?  time each once, then instrument the dominant one
+        sites = ["fused_layer", "gemm_fc1", "gemm_fc2", "gemm_qkv", "gemm_proj", "attention", "layernorm"]
+        site_ms = {}
+        for site in sites:
+            rt.profile_enable(site)
+            step()
+            torch.cuda.synchronize()
+            ms, n = rt.profile_read()
+            if n:
+                site_ms[site] = (ms, n)
+        rt.profile_enable("off")
+        dominant = args.site or max(site_ms, key=lambda k: site_ms[k][0])
+        rt.profile_enable(dominant)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        elapsed = time.perf_counter() - t0
+        kern_ms, kern_n = rt.profile_read()
+        rt.profile_enable("off")
+    assert torch.isfinite(out).all()
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        F = cfg.flops_per_sample()
+        D, T = cfg.embed_dim, cfg.block_size
+        M = B * T
+        # algorithmic FLOPs of ONE launch of each launch site
+        site_flops = {"gemm_qkv": 2.0 * M * 3 * D * D, "gemm_proj": 2.0 * M * D * D, "gemm_fc1": 2.0 * M * 4 * D * D,
+                      "gemm_fc2": 2.0 * M * 4 * D * D, "attention": 4.0 * B * T * T * D,
+                      "fused_layer": (24.0 * T * D * D + 4.0 * T * T * D) * B, "forward": float(F) * B}
+        steps_per_s = world * args.steps / elapsed
+        fwd_tflops = B * F * args.steps / elapsed / 1e12          # per GPU
+        avg_ms = kern_ms / max(kern_n, 1)
+        ach = site_flops.get(dominant, 0.0) / (avg_ms * 1e-3) / 1e12 if kern_n else 0.0
+        peak = PEAK_TFLOPS[args.precision]
+        result = {
+            "metric": "denoising-steps/sec (score-GPT fwd) at kitchen obs-dim",
+            "value": steps_per_s, "unit": f"denoise-steps/s (one step = GCDenoiser.forward over B={B} samples per GPU)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: Franka {args.config} score-GPT fwd "
+                                   f"(GCDenoiser.forward), batch={B} synthetic obs/goal per GPU, 1 NFE per step",
+                       "obs_dim": cfg.obs_dim, "act_dim": cfg.act_dim, "window": cfg.obs_seq_len,
+                       "goal_seq_len": cfg.goal_seq_len, "embed_dim": D, "n_layers": cfg.n_layers,
+                       "n_heads": cfg.n_heads, "tokens_per_sample": T, "batch_per_gpu": B,
+                       "parallelism": f"batch-sharded x{world}, no collective in the loop",
+                       "weights": "seeded N(0,0.02) recipe (no trained checkpoints shipped)", "sigma": 0.3},
+            "sample_nfe_per_s": steps_per_s * B,
+            "flops_per_sample_forward": F,
+            "forward_tflops_per_gpu": fwd_tflops,
+            "forward_frac_of_mfma_peak": fwd_tflops / peak,
+            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak, "traffic": None, "launches": kern_n, "avg_launch_ms": avg_ms,
+                         "flops_per_launch": site_flops.get(dominant, 0.0),
+                         "site_ms_one_forward": {k: v[0] for k, v in site_ms.items()}},
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, w, B)
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

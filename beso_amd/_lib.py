@@ -1,0 +1,95 @@
+"""ctypes binding of libbeso_hip.so (include/beso_hip.h).  The product path has no CPU fallback:
+if the library is missing or fails to load, importing callers get a RuntimeError."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbeso_hip.so")
+
+PREC_BF16, PREC_FP32, PREC_BF16X3 = 0, 1, 2
+PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
+FLAG_UNCOND = 1
+SAMPLER_IDS = {"ddim": 0, "euler": 1, "heun": 2}
+STEP_DDIM, STEP_EULER, STEP_HEUN_PREDICT, STEP_HEUN_CORRECT = 0, 1, 2, 3
+SITES = {"off": 0, "gemm_qkv": 1, "gemm_proj": 2, "gemm_fc1": 3, "gemm_fc2": 4, "attention": 5,
+         "layernorm": 6, "embed": 7, "head": 8, "forward": 9, "fused_layer": 10}
+
+# every symbol include/beso_hip.h declares (tests check that the library exports all of them)
+EXPORTS = ["beso_version", "beso_status_string", "beso_num_params", "beso_packed_bytes", "beso_pack_weights",
+           "beso_workspace_bytes", "beso_score_fwd", "beso_denoise_fwd", "beso_sampler_step", "beso_sample",
+           "beso_profile_enable", "beso_profile_read"]
+
+
+class BesoConfig(C.Structure):
+    """struct beso_config (include/beso_hip.h)."""
+    _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("embed_dim", C.c_int32),
+                ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("goal_seq_len", C.c_int32),
+                ("obs_seq_len", C.c_int32), ("linear_output", C.c_int32), ("sigma_data", C.c_float)]
+
+
+class BesoHipError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Fails loudly -- there is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise BesoHipError(
+                f"{LIB_PATH} not found: build it with `python -m beso_amd.build` (hipcc, gfx950). "
+                "beso_amd has no CPU or eager fallback for the score-denoising path.")
+        lib = C.CDLL(LIB_PATH)
+        vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+        cfgp = C.POINTER(BesoConfig)
+        lib.beso_version.restype = C.c_char_p
+        lib.beso_version.argtypes = []
+        lib.beso_status_string.restype = C.c_char_p
+        lib.beso_status_string.argtypes = [i32]
+        lib.beso_num_params.restype = i32
+        lib.beso_num_params.argtypes = [cfgp]
+        lib.beso_packed_bytes.restype = sz
+        lib.beso_packed_bytes.argtypes = [cfgp, i32]
+        lib.beso_pack_weights.restype = i32
+        lib.beso_pack_weights.argtypes = [cfgp, C.POINTER(vp), i32, vp, sz, i32, vp]
+        lib.beso_workspace_bytes.restype = sz
+        lib.beso_workspace_bytes.argtypes = [cfgp, i32, i32, i32, i32]
+        lib.beso_score_fwd.restype = i32
+        lib.beso_score_fwd.argtypes = [cfgp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]
+        lib.beso_denoise_fwd.restype = i32
+        lib.beso_denoise_fwd.argtypes = [cfgp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]
+        lib.beso_sampler_step.restype = i32
+        lib.beso_sampler_step.argtypes = [i32, vp, vp, vp, vp, vp, f32, f32, sz, vp]
+        lib.beso_sample.restype = i32
+        lib.beso_sample.argtypes = [cfgp, vp, i32, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_float), i32, f32,
+                                    vp, sz, vp]
+        lib.beso_profile_enable.restype = None
+        lib.beso_profile_enable.argtypes = [i32]
+        lib.beso_profile_read.restype = i32
+        lib.beso_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    """Non-zero status -> exception.  Shape/config/argument errors are ValueError, matching the
+    reference's conventions (ValueError for unknown sampler / schedule: beso_agent.py:455,598;
+    `assert t <= block_size`: score_gpts.py:282); runtime failures are BesoHipError."""
+    if status == 0:
+        return
+    msg = load().beso_status_string(status).decode()
+    text = f"beso_hip: {what + ': ' if what else ''}{msg} (status {status})"
+    if status in (-1, -2, -3, -5):
+        raise ValueError(text)
+    raise BesoHipError(text)

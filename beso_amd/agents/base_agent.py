@@ -1,0 +1,84 @@
+"""Agent base class (reference: beso/agents/base_agent.py:15-166): builds model / optimizer /
+input encoder from their configs and turns a batch dict into scaled (state, action, goal) tensors."""
+import abc
+import logging
+import os
+
+import torch
+
+from .._instantiate import instantiate
+
+log = logging.getLogger(__name__)
+
+
+class BaseAgent(abc.ABC):
+    def __init__(self, model, input_encoder, optimization, obs_modalities: list, goal_modalities: list,
+                 target_modality: str, device: str, max_train_steps: int, eval_every_n_steps: int,
+                 max_epochs: int):
+        self.scaler = None
+        self.model = instantiate(model).to(device)
+        self.optimizer = instantiate(optimization, params=self.model.get_params())
+        self.obs_modalities = obs_modalities
+        self.goal_modalities = goal_modalities
+        self.target_modality = target_modality
+        self.input_encoder = instantiate(input_encoder)
+        self.device = device
+        self.steps = 0
+        self.epochs = max_epochs
+        self.max_train_steps = int(max_train_steps)
+        self.eval_every_n_steps = eval_every_n_steps
+        self.working_dir = os.getcwd()
+        self.epochs_no_improvement = 0
+        log.info("The model has a total amount of %d parameters", sum(p.numel() for p in self.model.get_params()))
+
+    @abc.abstractmethod
+    def train_agent(self, train_loader, test_loader):
+        ...
+
+    @abc.abstractmethod
+    def train_step(self, batch):
+        ...
+
+    @abc.abstractmethod
+    def evaluate(self, batch):
+        ...
+
+    @abc.abstractmethod
+    def predict(self, batch) -> torch.Tensor:
+        ...
+
+    def get_scaler(self, scaler):
+        self.scaler = scaler
+
+    def load_pretrained_model(self, weights_path: str, sv_name=None) -> None:
+        name = "model_state_dict.pth" if sv_name is None else sv_name
+        self.model.load_state_dict(torch.load(os.path.join(weights_path, name)))
+        log.info('Loaded pre-trained model parameters')
+
+    def store_model_weights(self, store_path: str, sv_name=None) -> None:
+        name = "model_state_dict.pth" if sv_name is None else sv_name
+        torch.save(self.model.state_dict(), os.path.join(store_path, name))
+
+    @torch.no_grad()
+    def process_batch(self, batch: dict, predict: bool = True):
+        """Scaled (state, action, goal) -- or (state, goal, task_name / None) when the batch holds no
+        target (base_agent.py:111-142).  Ten-feature goals keep only the block positions (:119-120)."""
+        state, goal = self.input_encoder(batch)
+        state = self.scaler.scale_input(state)
+        goal = self.scaler.scale_input(goal)
+        if goal.shape[-1] == 10:
+            goal[..., [2, 5, 6, 7, 8, 9]] = 0
+        if self.target_modality in batch:
+            return state, self.scaler.scale_output(batch[self.target_modality]), goal
+        if not predict:
+            return state, goal
+        return state, goal, batch.get('goal_task_name')
+
+    def early_stopping(self, best_test_mse, mean_mse, patience, epochs):
+        if mean_mse < best_test_mse:
+            best_test_mse = mean_mse
+            self.store_model_weights(self.working_dir)
+            self.epochs_no_improvement = 0
+        else:
+            self.epochs_no_improvement += 1
+        return self.epochs_no_improvement > patience, best_test_mse

@@ -1,0 +1,381 @@
+"""Drop-in for ``beso.agents.diffusion_agents.beso_agent.BesoAgent`` (reference: beso_agent.py:28-598).
+
+Same constructor kwargs (Hydra ``_target_`` swap), same public methods and externally mutated
+attributes (``model``, ``sigma_min/max``, ``use_kde`` ...).  What changes underneath:
+
+  * ``predict`` / ``evaluate`` evaluate the EMA weights through a packed kernel image of the EMA
+    shadow that is refreshed only after ``ema_helper.update`` -- the reference clones all parameters,
+    copies the shadow in and copies the originals back on EVERY call (beso_agent.py:343-345,380-381);
+  * ``sample_loop`` hands ddim / euler / heun to the HIP library as one enqueue of all steps;
+  * ``train_step`` all-reduces the score-matching gradients over the data-parallel ranks (RCCL over
+    xGMI) before the optimizer step when a process group is initialised.
+"""
+import contextlib
+import logging
+import math
+import os
+from collections import deque
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import distributed as bdist
+from ..._instantiate import instantiate
+from ...networks.ema_helper.ema import ExponentialMovingAverage
+from ..base_agent import BaseAgent
+from .k_diffusion import gc_sampling as ks
+from .k_diffusion import utils
+from .k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
+from .k_diffusion.score_gpts import DiffusionGPT
+from .k_diffusion.score_wrappers import GCDenoiser
+
+log = logging.getLogger(__name__)
+
+try:                      # logging only; absent on the GPU box
+    import wandb
+except ImportError:       # pragma: no cover
+    wandb = None
+
+
+def _wandb_log(payload):
+    if wandb is not None and getattr(wandb, "run", None) is not None:
+        wandb.log(payload)
+
+
+class BesoAgent(BaseAgent):
+    def __init__(self, model, input_encoder, optimization, device: str, obs_modalities: list,
+                 goal_modalities: list, target_modality: str, max_train_steps: int, max_epochs: int,
+                 train_method: str, eval_every_n_steps: int, use_ema: bool, goal_conditioned: bool,
+                 pred_last_action_only: bool, rho: float, num_sampling_steps: int, lr_scheduler,
+                 sampler_type: str, sigma_data: float, sigma_min: float, sigma_max: float,
+                 sigma_sample_density_type: str, sigma_sample_density_mean: float,
+                 sigma_sample_density_std: float, decay: float, update_ema_every_n_steps: int,
+                 window_size: int, goal_window_size: int, use_kde: bool = False, patience: int = 10):
+        super().__init__(model, input_encoder, optimization, obs_modalities, goal_modalities, target_modality,
+                         device, max_train_steps, eval_every_n_steps, max_epochs)
+        self.ema_helper = ExponentialMovingAverage(self.model.get_params(), decay, self.device)
+        self.use_ema = use_ema
+        self.lr_scheduler = instantiate(lr_scheduler, optimizer=self.optimizer)
+        self.gc = goal_conditioned
+        self.train_method = train_method
+        self.epochs = max_epochs
+        self.sampler_type = sampler_type
+        self.num_sampling_steps = num_sampling_steps
+        self.sigma_data = sigma_data
+        self.sigma_min = sigma_min
+        self.sigma_max = sigma_max
+        self.rho = rho
+        self.sigma_sample_density_type = sigma_sample_density_type
+        self.sigma_sample_density_mean = sigma_sample_density_mean
+        self.sigma_sample_density_std = sigma_sample_density_std
+        self.decay = decay
+        self.update_ema_every_n_steps = update_ema_every_n_steps
+        self.patience = patience
+        self.window_size = window_size
+        self.goal_window_size = goal_window_size
+        self.pred_last_action_only = pred_last_action_only
+        # rolling contexts of the rollout (beso_agent.py:96-100)
+        self.obs_context = deque(maxlen=self.window_size)
+        self.goal_context = deque(maxlen=self.goal_window_size)
+        self.action_context = deque(maxlen=self.window_size - 1)
+        self.que_actions = True
+        self.use_kde = use_kde
+        self.noise_scheduler = 'exponential'
+        # MI355X runtime state
+        self._ema_packed = None
+        self._ema_packed_key = None
+        self._grad_bucket = None
+
+    # ------------------------------------------------------------------ scaler / bounds
+    def get_scaler(self, scaler):
+        self.scaler = scaler
+
+    def set_bounds(self, scaler):
+        self.model.min_action = torch.from_numpy(scaler.y_bounds[0, :]).to(self.device)
+        self.model.max_action = torch.from_numpy(scaler.y_bounds[1, :]).to(self.device)
+
+    # ------------------------------------------------------------------ EMA evaluation scope
+    def _hip_denoiser(self):
+        """The beso_amd GCDenoiser behind ``self.model`` (which scripts may wrap in
+        ClassifierFreeSampleModel: scripts/training.py:54-55), or None."""
+        m = self.model
+        if isinstance(m, ClassifierFreeSampleModel):
+            m = m.model
+        if isinstance(m, GCDenoiser) and isinstance(m.inner_model, DiffusionGPT):
+            return m
+        return None
+
+    @contextlib.contextmanager
+    def _ema_scope(self):
+        """Evaluate with the EMA weights.  HIP model on the GPU: swap in the packed image of the
+        shadow.  Anything else: the reference's store / copy_to / restore (beso_agent.py:343-381)."""
+        if not self.use_ema:
+            yield
+            return
+        den = self._hip_denoiser()
+        params = list(self.model.get_params()) if hasattr(self.model, "get_params") else []
+        if den is not None and params and params[0].is_cuda:
+            inner = den.inner_model
+            key = (self.ema_helper.version, inner.precision, id(self.ema_helper))
+            if self._ema_packed is None or self._ema_packed_key != key:
+                self._ema_packed = inner.pack_external(self.ema_helper.shadow_params, into=self._ema_packed)
+                self._ema_packed_key = key
+            with inner.use_weights(self._ema_packed):
+                yield
+            return
+        self.ema_helper.store(self.model.parameters())
+        self.ema_helper.copy_to(self.model.parameters())
+        if den is not None:
+            den.inner_model.mark_weights_dirty()
+        try:
+            yield
+        finally:
+            self.ema_helper.restore(self.model.parameters())
+            if den is not None:
+                den.inner_model.mark_weights_dirty()
+
+    # ------------------------------------------------------------------ training
+    def train_agent(self, train_loader, test_loader):
+        if self.train_method == 'epochs':
+            self.train_agent_on_epochs(train_loader, test_loader, self.epochs)
+        elif self.train_method == 'steps':
+            self.train_agent_on_steps(train_loader, test_loader)
+        else:
+            raise ValueError('Either epochs or n_steps must be specified!')
+
+    def train_agent_on_epochs(self, train_loader, test_loader, epochs):
+        best_test_mse, mean_mse, avg_test_mse = 1e10, 1e10, 1e10
+        for epoch in range(epochs):
+            test_mse = [self.evaluate(batch) for batch in test_loader]
+            if test_mse:
+                mean_mse = test_mse[-1]
+                avg_test_mse = sum(test_mse) / len(test_mse)
+            stop, best_test_mse = self.early_stopping(best_test_mse, mean_mse, self.patience, epochs)
+            if stop:
+                log.info('Early stopping!')
+                break
+            losses = []
+            for batch in train_loader:
+                losses.append(self.train_step(batch))
+                _wandb_log({"training/loss": losses[-1], "training/test_loss": avg_test_mse})
+            _wandb_log({'training/epoch_loss': float(np.mean(losses)) if losses else 0.0,
+                        'training/epoch_test_loss': avg_test_mse, 'training/epoch': epoch})
+            log.info("Epoch %d: mean test mse %s, mean train loss %s", epoch, avg_test_mse,
+                     float(np.mean(losses)) if losses else None)
+        self.store_model_weights(self.working_dir)
+        log.info("Training done!")
+
+    def train_agent_on_steps(self, train_loader, test_loader):
+        """max_train_steps optimizer steps; every eval_every_n_steps: test MSE of the sampler and a
+        checkpoint on improvement (beso_agent.py:177-213)."""
+        best_test_mse, avg_test_mse = 1e10, 1e10
+        stream = iter(train_loader)
+        for step in range(self.max_train_steps):
+            if not self.steps % self.eval_every_n_steps:
+                scores = [self.evaluate(batch) for batch in test_loader]
+                if scores:
+                    avg_test_mse = sum(scores) / len(scores)
+                log.info("Step %d: Mean test mse is %s", step, avg_test_mse)
+                if avg_test_mse < best_test_mse:
+                    best_test_mse = avg_test_mse
+                    self.store_model_weights(self.working_dir)
+                    log.info('New best test loss. Stored weights have been updated!')
+            try:
+                batch = next(stream)
+            except StopIteration:
+                stream = iter(train_loader)
+                batch = next(stream)
+            loss = self.train_step(batch)
+            if not self.steps % 1000:
+                log.info("Step %d: Mean batch loss mse is %s", step, loss)
+            _wandb_log({"loss": loss, "test_loss": avg_test_mse})
+        self.store_model_weights(self.working_dir)
+        log.info("Training done!")
+
+    def train_step(self, batch: dict):
+        """One score-matching step (beso_agent.py:215-248): noise ~ N(0, I), sigma ~ the configured
+        density, loss = GCDenoiser.loss, optimizer + LR scheduler + EMA.  Under data parallelism the
+        gradients are averaged over the ranks first."""
+        state, action, goal = self.process_batch(batch, predict=False)
+        self.model.train()
+        self.model.training = True
+        noise = torch.randn_like(action)
+        sigma = self.make_sample_density()(shape=(len(action),), device=self.device)
+        loss = self.model.loss(state, action, goal, noise, sigma)
+        self.optimizer.zero_grad()
+        loss.backward()
+        if bdist.is_distributed():
+            if self._grad_bucket is None:
+                self._grad_bucket = bdist.GradientBucket(self.model.get_params())
+            self._grad_bucket.sync()
+        self.optimizer.step()
+        self.lr_scheduler.step()
+        self.steps += 1
+        if self.steps % self.update_ema_every_n_steps == 0:
+            self.ema_helper.update(self.model.parameters())
+        return loss.item()
+
+    @torch.no_grad()
+    def evaluate(self, batch: dict):
+        """MSE between sampled and ground-truth action windows; always the exponential schedule
+        (beso_agent.py:250-289)."""
+        state, action, goal = self.process_batch(batch, predict=True)
+        with self._ema_scope():
+            self.model.eval()
+            self.model.training = False
+            sigmas = ks.get_sigmas_exponential(self.num_sampling_steps, self.sigma_min, self.sigma_max, 'cpu')
+            x = torch.randn_like(action) * self.sigma_max
+            x_0 = self.sample_loop(sigmas, x, state, goal, self.sampler_type)
+            if self.pred_last_action_only:
+                x_0 = x_0.reshape(x_0.shape[0], 1, -1)
+            mse = nn.functional.mse_loss(x_0, action, reduction="none").mean().item()
+        return mse
+
+    # ------------------------------------------------------------------ rollout inference
+    def reset(self):
+        self.obs_context.clear()
+        self.action_context.clear()
+
+    @torch.no_grad()
+    def predict(self, batch: dict, new_sampler_type=None, get_mean=None, new_sampling_steps=None,
+                extra_args=None, noise_scheduler=None) -> torch.Tensor:
+        """One environment step (beso_agent.py:296-388): append the observation to the window,
+        draw x_T for the newest action, denoise the WHOLE action window (previous actions + fresh
+        noise), keep the last action, clip, un-scale, remember it."""
+        noise_scheduler = self.noise_scheduler if noise_scheduler is None else noise_scheduler
+        state, goal, _ = self.process_batch(batch, predict=True)
+        if state.dim() == 2 and self.window_size > 1:
+            self.obs_context.append(state)
+            input_state = torch.stack(tuple(self.obs_context), dim=1)
+        else:
+            input_state = state
+        if goal.dim() == 2 and self.window_size > 1:
+            goal = goal.unsqueeze(0)                                       # 'b d -> 1 b d'
+        sampler_type = self.sampler_type if new_sampler_type is None else new_sampler_type
+        n_steps = self.num_sampling_steps if new_sampling_steps is None else new_sampling_steps
+        act_dim = self.scaler.y_bounds.shape[1]
+        with self._ema_scope():
+            self.model.eval()
+            sigmas = self.get_noise_schedule(n_steps, noise_scheduler)
+            n = len(input_state) * (get_mean if get_mean is not None else 1)
+            if self.window_size > 1 or get_mean is None:
+                x = torch.randn((n, 1, act_dim), device=self.device) * self.sigma_max
+                if self.window_size > 1 and get_mean is None and len(self.action_context) > 0:
+                    x = torch.cat([torch.cat(tuple(self.action_context), dim=1), x], dim=1)
+            else:
+                x = torch.randn((n, act_dim), device=self.device) * self.sigma_max
+            x_0 = self.sample_loop(sigmas, x, input_state, goal, sampler_type, extra_args)
+            if x_0.dim() == 3 and x_0.size(1) > 1:
+                x_0 = x_0[:, -1, :]
+            x_0 = self.scaler.clip_action(x_0)
+        model_pred = self.scaler.inverse_scale_output(x_0)
+        if model_pred.dim() == 2:
+            x_0 = x_0.unsqueeze(1)
+        self.action_context.append(x_0)
+        return model_pred
+
+    def sample_loop(self, sigmas, x_t: torch.Tensor, state: torch.Tensor, goal: torch.Tensor, sampler_type: str,
+                    extra_args={}):
+        """Dispatch on ``sampler_type`` (beso_agent.py:390-456).  Only 'heun' receives s_churn / s_min;
+        a non-empty ``extra_args`` must carry both 's_churn' and 'keep_last_actions' (KeyError
+        otherwise, as in the reference :408-410)."""
+        extra_args = {} if extra_args is None else extra_args
+        s_churn = extra_args.get('s_churn', 0)
+        s_min = extra_args.get('s_min', 0)
+        reduced = {k: extra_args[k] for k in ('s_churn', 'keep_last_actions')} if extra_args else {}
+        scaler = self.scaler if extra_args.get('use_scaler', False) else None
+        m = self.model
+        if sampler_type == 'lms':
+            return ks.sample_lms(m, state, x_t, goal, sigmas, scaler=scaler, disable=True, extra_args=reduced)
+        if sampler_type == 'heun':
+            return ks.sample_heun(m, state, x_t, goal, sigmas, scaler=scaler, s_churn=s_churn, s_tmin=s_min,
+                                  disable=True)
+        if sampler_type == 'euler':
+            return ks.sample_euler(m, state, x_t, goal, sigmas, scaler=scaler, disable=True)
+        if sampler_type == 'ancestral':
+            return ks.sample_dpm_2_ancestral(m, state, x_t, goal, sigmas, scaler=scaler, disable=True)
+        if sampler_type == 'euler_ancestral':
+            return ks.sample_euler_ancestral(m, state, x_t, goal, sigmas, scaler=scaler, disable=True)
+        if sampler_type == 'dpm':
+            return ks.sample_dpm_2(m, state, x_t, goal, sigmas, disable=True)
+        if sampler_type == 'ddim':
+            return ks.sample_ddim(m, state, x_t, goal, sigmas, scaler=scaler, disable=True)
+        if sampler_type == 'dpm_adaptive':
+            return ks.sample_dpm_adaptive(m, state, x_t, goal, sigmas[-2].item(), sigmas[0].item(), disable=True)
+        if sampler_type == 'dpm_fast':
+            return ks.sample_dpm_fast(m, state, x_t, goal, sigmas[-2].item(), sigmas[0].item(), len(sigmas),
+                                      disable=True)
+        if sampler_type == 'dpmpp_2s_ancestral':
+            return ks.sample_dpmpp_2s_ancestral(m, state, x_t, goal, sigmas, scaler=scaler, disable=True)
+        if sampler_type == 'dpmpp_2s':
+            return ks.sample_dpmpp_2s(m, state, x_t, goal, sigmas, scaler=scaler, disable=True)
+        if sampler_type == 'dpmpp_2m':
+            return ks.sample_dpmpp_2m(m, state, x_t, goal, sigmas, scaler=scaler, disable=True)
+        if sampler_type == 'dpmpp_2m_sde':
+            return ks.sample_dpmpp_sde(m, state, x_t, goal, sigmas, scaler=scaler, disable=True)
+        raise ValueError('desired sampler type not found!')
+
+    # ------------------------------------------------------------------ checkpoints
+    def load_pretrained_model(self, weights_path: str, **kwargs) -> None:
+        """``model_state_dict.pth`` holds the EMA weights (beso_agent.py:458-464); the EMA shadow is
+        re-seeded from the loaded parameters."""
+        state = torch.load(os.path.join(weights_path, "model_state_dict.pth"), map_location=self.device)
+        self.model.load_state_dict(state)
+        self.ema_helper = ExponentialMovingAverage(self.model.get_params(), self.decay, self.device)
+        self._ema_packed_key = None
+        log.info('Loaded pre-trained model parameters')
+
+    def store_model_weights(self, store_path: str) -> None:
+        """EMA weights -> model_state_dict.pth, raw weights -> non_ema_model_state_dict.pth
+        (beso_agent.py:466-476)."""
+        if bdist.rank() != 0:
+            return
+        raw = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        ema = dict(raw)
+        if self.use_ema:
+            names = [n for n, p in self.model.named_parameters() if p.requires_grad]
+            for n, s in zip(names, self.ema_helper.shadow_params):
+                ema[n] = s.detach().clone()
+        torch.save(ema, os.path.join(store_path, "model_state_dict.pth"))
+        torch.save(raw, os.path.join(store_path, "non_ema_model_state_dict.pth"))
+
+    # ------------------------------------------------------------------ sigma density / schedules
+    def make_sample_density(self):
+        """Training distribution of sigma (beso_agent.py:541-580)."""
+        kind = self.sigma_sample_density_type
+        if kind == 'lognormal':
+            return partial(utils.rand_log_normal, loc=self.sigma_sample_density_mean,
+                           scale=self.sigma_sample_density_std)
+        if kind == 'loglogistic':
+            return partial(utils.rand_log_logistic, loc=math.log(self.sigma_data), scale=0.5,
+                           min_value=self.sigma_min, max_value=self.sigma_max)
+        if kind == 'loguniform':
+            return partial(utils.rand_log_uniform, min_value=self.sigma_min, max_value=self.sigma_max)
+        if kind == 'uniform':
+            return partial(utils.rand_uniform, min_value=self.sigma_min, max_value=self.sigma_max)
+        if kind == 'v-diffusion':
+            return partial(utils.rand_v_diffusion, sigma_data=self.sigma_data, min_value=self.sigma_min,
+                           max_value=self.sigma_max)
+        if kind == 'discrete':
+            return partial(utils.rand_discrete, values=self.get_noise_schedule(self.num_sampling_steps, 'exponential'))
+        raise ValueError('Unknown sample density type')
+
+    def get_noise_schedule(self, n_sampling_steps, noise_schedule_type):
+        """(beso_agent.py:582-598).  Schedules are built on the host: the samplers read them there."""
+        if noise_schedule_type == 'karras':
+            return ks.get_sigmas_karras(n_sampling_steps, self.sigma_min, self.sigma_max, self.rho, 'cpu')
+        if noise_schedule_type == 'exponential':
+            return ks.get_sigmas_exponential(n_sampling_steps, self.sigma_min, self.sigma_max, 'cpu')
+        if noise_schedule_type == 'vp':
+            return ks.get_sigmas_vp(n_sampling_steps, device='cpu')
+        if noise_schedule_type == 'linear':
+            return ks.get_sigmas_linear(n_sampling_steps, self.sigma_min, self.sigma_max, device='cpu')
+        if noise_schedule_type == 'cosine_beta':
+            return ks.cosine_beta_schedule(n_sampling_steps, device='cpu')
+        if noise_schedule_type == 've':
+            return ks.get_sigmas_ve(n_sampling_steps, self.sigma_min, self.sigma_max, device='cpu')
+        if noise_schedule_type == 'iddpm':
+            return ks.get_iddpm_sigmas(n_sampling_steps, self.sigma_min, self.sigma_max, device='cpu')
+        raise ValueError('Unknown noise schedule type')

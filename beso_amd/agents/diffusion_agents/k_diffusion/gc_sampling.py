@@ -1,0 +1,445 @@
+"""Drop-in for ``beso...k_diffusion.gc_sampling``: noise schedules and the iterative samplers of the
+goal-conditioned score model (reference: gc_sampling.py).
+
+Signature of every sampler, as in the reference:
+    sample_X(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None,
+             disable=None, ...) -> action
+where ``model(state, action, goal, sigma[B], **extra_args) -> [B, t, act]``.
+
+MI355X-first differences that do not change results:
+  * the sigma schedule is read back to the HOST once and all step coefficients are computed there
+    as fp32 scalars, so the loop never branches on a device tensor (the reference syncs on every
+    ``sigmas[i + 1] == 0`` / ``s_tmin <= sigmas[i]`` test: gc_sampling.py:198,289,301,360);
+  * when ``model`` is a ``beso_amd`` GCDenoiser (optionally inside ClassifierFreeSampleModel) and the
+    call is the plain deterministic one (no churn, no callback, no scaler, no extra args),
+    ddim / euler / heun run as ONE enqueue of the whole loop through ``beso_sample``
+    (include/beso_hip.h) -- otherwise the generic loops below call ``model`` once per evaluation.
+"""
+import math
+
+import numpy as np
+import torch
+from scipy import integrate
+
+from . import utils
+from .classifier_free_sampler import ClassifierFreeSampleModel
+from .score_wrappers import GCDenoiser
+
+f32 = np.float32
+
+
+# ------------------------------------------------------------------------------------------------
+# noise schedules (gc_sampling.py:22-95): n values + a trailing zero, fp32
+# ------------------------------------------------------------------------------------------------
+def append_zero(action):
+    return torch.cat([action, action.new_zeros([1])])
+
+
+def get_sigmas_karras(n, sigma_min, sigma_max, rho=7., device='cpu'):
+    """Karras et al. (2022) schedule (:26-32)."""
+    lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    return append_zero((hi + torch.linspace(0, 1, n) * (lo - hi)) ** rho).to(device)
+
+
+def get_sigmas_exponential(n, sigma_min, sigma_max, device='cpu'):
+    """Log-linear schedule (:35-38)."""
+    return append_zero(torch.linspace(math.log(sigma_max), math.log(sigma_min), n, device=device).exp())
+
+
+def get_sigmas_linear(n, sigma_min, sigma_max, device='cpu'):
+    """Linear schedule (:41-44)."""
+    return append_zero(torch.linspace(sigma_max, sigma_min, n, device=device))
+
+
+def cosine_beta_schedule(n, s=0.008, device='cpu'):
+    """Cosine beta schedule (:47-58)."""
+    steps = n + 1
+    grid = np.linspace(0, steps, steps)
+    abar = np.cos(((grid / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    abar = abar / abar[0]
+    betas = np.clip(1 - abar[1:] / abar[:-1], a_min=0, a_max=0.999)
+    return append_zero(torch.tensor(np.flip(betas).copy(), device=device, dtype=torch.float32))
+
+
+def get_sigmas_ve(n, sigma_min=0.02, sigma_max=100, device='cpu'):
+    """(:61-68)"""
+    t = torch.linspace(0, n + 1, n, device=device)
+    return append_zero(torch.sqrt((sigma_max ** 2) * ((sigma_min ** 2 / sigma_max ** 2) ** (t / (n - 1)))))
+
+
+def get_iddpm_sigmas(n, sigma_min=0.02, sigma_max=100, M=1000, j_0=0, C_1=0.001, C_2=0.008, device='cpu'):
+    """(:71-81)"""
+    idx = torch.arange(n, dtype=torch.float64, device=device)
+    u = torch.zeros(M + 1, dtype=torch.float64, device=device)
+    abar = lambda j: (0.5 * np.pi * j / M / (C_2 + 1)).sin() ** 2        # noqa: E731
+    for j in torch.arange(M, j_0, -1, device=device):
+        u[j - 1] = ((u[j] ** 2 + 1) / (abar(j - 1) / abar(j)).clip(min=C_1) - 1).sqrt()
+    u = u[torch.logical_and(u >= sigma_min, u <= sigma_max)]
+    return append_zero(u[((len(u) - 1) / (n - 1) * idx).round().to(torch.int64)]).to(torch.float32)
+
+
+def get_sigmas_vp(n, beta_d=19.9, beta_min=0.1, eps_s=1e-3, device='cpu'):
+    """(:84-88)"""
+    t = torch.linspace(1, eps_s, n, device=device)
+    return append_zero(torch.sqrt(torch.exp(beta_d * t ** 2 / 2 + beta_min * t) - 1))
+
+
+def get_sigmas_polyexponential(n, sigma_min, sigma_max, rho=1., device='cpu'):
+    """(:91-95)"""
+    ramp = torch.linspace(1, 0, n, device=device) ** rho
+    return append_zero(torch.exp(ramp * (math.log(sigma_max) - math.log(sigma_min)) + math.log(sigma_min)))
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def to_d(action, sigma, denoised):
+    """Karras ODE derivative (x - D(x)) / sigma (:98-100)."""
+    if not torch.is_tensor(sigma):
+        return (action - denoised) / float(sigma)
+    return (action - denoised) / utils.append_dims(sigma, action.ndim)
+
+
+def default_noise_sampler(x):
+    return lambda sigma, sigma_next: torch.randn_like(x)
+
+
+def get_ancestral_step(sigma_from, sigma_to, eta=1.):
+    """sigma_down / sigma_up of an ancestral step (:107-114), fp32 scalars."""
+    if not eta:
+        return sigma_to, 0.
+    sf, st = f32(sigma_from), f32(sigma_to)
+    up = min(st, f32(eta) * (st ** 2 * (sf ** 2 - st ** 2) / sf ** 2) ** f32(0.5))
+    down = (st ** 2 - up ** 2) ** f32(0.5)
+    return f32(down), f32(up)
+
+
+def _host_sigmas(sigmas):
+    """The schedule as host fp32 scalars: the single device->host read of a sampling loop."""
+    if torch.is_tensor(sigmas):
+        return sigmas.detach().to('cpu', torch.float32).numpy()
+    return np.asarray(sigmas, dtype=np.float32)
+
+
+def _sig_vec(action, value):
+    return action.new_full([action.shape[0]], float(value))
+
+
+def _neg_log(s):
+    with np.errstate(divide='ignore'):
+        return -np.log(f32(s))
+
+
+def _fused_target(model):
+    """(GCDenoiser, cond_lambda) when ``model`` is one the HIP sampler loop understands."""
+    if isinstance(model, GCDenoiser):
+        return model, 1.0
+    if isinstance(model, ClassifierFreeSampleModel) and isinstance(model.model, GCDenoiser):
+        return model.model, float(model.cond_lambda)
+    return None, None
+
+
+def _try_fused(name, model, state, action, goal, sigmas, scaler, extra_args, callback):
+    if scaler is not None or callback is not None or extra_args:
+        return None
+    den, lam = _fused_target(model)
+    if den is None or not action.is_cuda:
+        return None
+    return den.fused_sampler(name, state, action, goal, _host_sigmas(sigmas), cond_lambda=lam)
+
+
+def _churn(i, n, sig, s_churn, s_tmin, s_tmax):
+    gamma = min(s_churn / n, 2 ** 0.5 - 1) if s_tmin <= sig[i] <= s_tmax else 0.
+    return gamma, f32(sig[i] * f32(gamma + 1))
+
+
+# ------------------------------------------------------------------------------------------------
+# samplers
+# ------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def sample_euler(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None,
+                 s_churn=0., s_tmin=0., s_tmax=float('inf'), s_noise=1.):
+    """Algorithm 2 of Karras et al. (2022) without the second-order correction (:167-213).
+    The generic loop draws ``eps`` every step like the reference (:199), used or not; the fused
+    loop draws nothing (with s_churn = 0 the draws never enter the result)."""
+    extra_args = {} if extra_args is None else extra_args
+    if not s_churn:
+        fused = _try_fused('euler', model, state, action, goal, sigmas, scaler, extra_args, callback)
+        if fused is not None:
+            return fused
+    sig = _host_sigmas(sigmas)
+    n = len(sig) - 1
+    for i in range(n):
+        gamma, sigma_hat = _churn(i, n, sig, s_churn, s_tmin, s_tmax)
+        eps = torch.randn_like(action) * s_noise
+        if gamma > 0:
+            action = action + eps * float((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
+        denoised = model(state, action, goal, _sig_vec(action, sigma_hat), **extra_args)
+        d = to_d(action, sigma_hat, denoised)
+        if callback is not None:
+            callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
+        action = action + d * float(sig[i + 1] - sigma_hat)
+        if scaler is not None:
+            action = scaler.clip_output(action)
+    return action
+
+
+@torch.no_grad()
+def sample_euler_ancestral(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None,
+                           disable=None, eta=1.):
+    """Euler steps to sigma_down, then fresh noise of scale sigma_up (:216-256)."""
+    extra_args = {} if extra_args is None else extra_args
+    sig = _host_sigmas(sigmas)
+    for i in range(len(sig) - 1):
+        denoised = model(state, action, goal, _sig_vec(action, sig[i]), **extra_args)
+        sigma_down, sigma_up = get_ancestral_step(sig[i], sig[i + 1], eta=eta)
+        if callback is not None:
+            callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+        d = to_d(action, sig[i], denoised)
+        action = action + d * float(sigma_down - sig[i])
+        if sigma_down > 0:
+            action = action + torch.randn_like(action) * float(sigma_up)
+        if scaler is not None:
+            action = scaler.clip_output(action)
+    return action
+
+
+@torch.no_grad()
+def sample_heun(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None,
+                s_churn=0., s_tmin=0., s_tmax=float('inf'), s_noise=1.):
+    """Algorithm 2 of Karras et al. (2022): Euler predictor + trapezoid corrector; the last step
+    (sigma_next == 0) is plain Euler (:259-314)."""
+    extra_args = {} if extra_args is None else extra_args
+    if not s_churn:
+        fused = _try_fused('heun', model, state, action, goal, sigmas, scaler, extra_args, callback)
+        if fused is not None:
+            return fused
+    sig = _host_sigmas(sigmas)
+    n = len(sig) - 1
+    for i in range(n):
+        gamma, sigma_hat = _churn(i, n, sig, s_churn, s_tmin, s_tmax)
+        eps = torch.randn_like(action) * s_noise
+        if gamma > 0:
+            action = action + eps * float((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
+        denoised = model(state, action, goal, _sig_vec(action, sigma_hat), **extra_args)
+        d = to_d(action, sigma_hat, denoised)
+        if callback is not None:
+            callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
+        dt = float(sig[i + 1] - sigma_hat)
+        if sig[i + 1] == 0:
+            action = action + d * dt
+        else:
+            action_2 = action + d * dt
+            denoised_2 = model(state, action_2, goal, _sig_vec(action, sig[i + 1]), **extra_args)
+            d_2 = to_d(action_2, sig[i + 1], denoised_2)
+            action = action + (d + d_2) / 2 * dt
+        if scaler is not None:
+            action = scaler.clip_output(action)
+    return action
+
+
+def _log_midpoint(a, b):
+    la, lb = np.log(f32(a)), np.log(f32(b))
+    return f32(np.exp(f32(la + f32(0.5) * (lb - la))))        # torch.lerp(a, b, 0.5) = a + 0.5 (b - a)
+
+
+@torch.no_grad()
+def sample_dpm_2(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None,
+                 s_churn=0., s_tmin=0., s_tmax=float('inf'), s_noise=1.):
+    """DPM-Solver-2-like midpoint steps in log sigma (:317-375)."""
+    extra_args = {} if extra_args is None else extra_args
+    sig = _host_sigmas(sigmas)
+    n = len(sig) - 1
+    for i in range(n):
+        gamma, sigma_hat = _churn(i, n, sig, s_churn, s_tmin, s_tmax)
+        eps = torch.randn_like(action) * s_noise
+        if gamma > 0:
+            action = action + eps * float((sigma_hat ** 2 - sig[i] ** 2) ** 0.5)
+        denoised = model(state, action, goal, _sig_vec(action, sigma_hat), **extra_args)
+        d = to_d(action, sigma_hat, denoised)
+        if callback is not None:
+            callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
+        if sig[i + 1] == 0:
+            action = action + d * float(sig[i + 1] - sigma_hat)
+        else:
+            sigma_mid = _log_midpoint(sigma_hat, sig[i + 1])
+            action_2 = action + d * float(sigma_mid - sigma_hat)
+            denoised_2 = model(state, action_2, goal, _sig_vec(action, sigma_mid), **extra_args)
+            d_2 = to_d(action_2, sigma_mid, denoised_2)
+            action = action + d_2 * float(sig[i + 1] - sigma_hat)
+        if scaler is not None:
+            action = scaler.clip_output(action)
+    return action
+
+
+@torch.no_grad()
+def sample_dpm_2_ancestral(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None,
+                           disable=None, eta=1.):
+    """Ancestral variant of the DPM-Solver-2-like sampler (:378-413)."""
+    extra_args = {} if extra_args is None else extra_args
+    sig = _host_sigmas(sigmas)
+    for i in range(len(sig) - 1):
+        denoised = model(state, action, goal, _sig_vec(action, sig[i]), **extra_args)
+        sigma_down, sigma_up = get_ancestral_step(sig[i], sig[i + 1], eta=eta)
+        if callback is not None:
+            callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+        d = to_d(action, sig[i], denoised)
+        if sigma_down == 0:
+            action = action + d * float(sigma_down - sig[i])
+        else:
+            sigma_mid = _log_midpoint(sig[i], sigma_down)
+            action_2 = action + d * float(sigma_mid - sig[i])
+            denoised_2 = model(state, action_2, goal, _sig_vec(action, sigma_mid), **extra_args)
+            d_2 = to_d(action_2, sigma_mid, denoised_2)
+            action = action + d_2 * float(sigma_down - sig[i])
+            action = action + torch.randn_like(action) * float(sigma_up)
+        if scaler is not None:
+            action = scaler.clip_output(action)
+    return action
+
+
+def linear_multistep_coeff(order, t, i, j):
+    """Adams-Bashforth-style coefficient of the j-th stored derivative at step i (:416-429)."""
+    if order - 1 > i:
+        raise ValueError(f'Order {order} too high for step {i}')
+
+    def basis(tau):
+        prod = 1.
+        for k in range(order):
+            if k != j:
+                prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return prod
+    return integrate.quad(basis, t[i], t[i + 1], epsrel=1e-4)[0]
+
+
+@torch.no_grad()
+def sample_lms(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None,
+               order=4):
+    """Linear multistep sampler (:432-468)."""
+    extra_args = {} if extra_args is None else extra_args
+    sig = _host_sigmas(sigmas)
+    history = []
+    for i in range(len(sig) - 1):
+        denoised = model(state, action, goal, _sig_vec(action, sig[i]), **extra_args)
+        history.append(to_d(action, sig[i], denoised))
+        if len(history) > order:
+            history.pop(0)
+        if callback is not None:
+            callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+        cur = min(i + 1, order)
+        coeffs = [linear_multistep_coeff(cur, sig, i, j) for j in range(cur)]
+        action = action + sum(c * d for c, d in zip(coeffs, reversed(history)))
+        if scaler is not None:
+            action = scaler.clip_output(action)
+    return action
+
+
+def _exp_step_coeffs(s_from, s_to):
+    """(sigma_fn(t_to)/sigma_fn(t_from), expm1(-h)) of the exponential-integrator update
+    x <- ratio * x - expm1(-h) * denoised, in fp32 like the reference's 0-d tensors (:921-923)."""
+    t, t_next = _neg_log(s_from), _neg_log(s_to)
+    h = t_next - t
+    with np.errstate(over='ignore', invalid='ignore'):
+        return float(f32(np.exp(-t_next)) / f32(np.exp(-t))), float(f32(np.expm1(-h))), t, t_next, h
+
+
+@torch.no_grad()
+def sample_dpmpp_2m(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None):
+    """DPM-Solver++(2M) (:702-736)."""
+    extra_args = {} if extra_args is None else extra_args
+    sig = _host_sigmas(sigmas)
+    old_denoised = None
+    for i in range(len(sig) - 1):
+        denoised = model(state, action, goal, _sig_vec(action, sig[i]), **extra_args)
+        if callback is not None:
+            callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+        ratio, em1, t, t_next, h = _exp_step_coeffs(sig[i], sig[i + 1])
+        if old_denoised is None or sig[i + 1] == 0:
+            action = ratio * action - em1 * denoised
+        else:
+            r = (t - _neg_log(sig[i - 1])) / h
+            blended = float(1 + 1 / (2 * r)) * denoised - float(1 / (2 * r)) * old_denoised
+            action = ratio * action - em1 * blended
+        old_denoised = denoised
+    return action
+
+
+@torch.no_grad()
+def sample_ddim(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None,
+                eta=1.):
+    """DPM-Solver-1 / DDIM (:895-924).  The final step (sigma_next = 0) returns the denoised action."""
+    extra_args = {} if extra_args is None else extra_args
+    fused = _try_fused('ddim', model, state, action, goal, sigmas, None, extra_args, callback)
+    if fused is not None:
+        return fused
+    sig = _host_sigmas(sigmas)
+    for i in range(len(sig) - 1):
+        denoised = model(state, action, goal, _sig_vec(action, sig[i]), **extra_args)
+        if callback is not None:
+            callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+        ratio, em1, *_ = _exp_step_coeffs(sig[i], sig[i + 1])
+        action = ratio * action - em1 * denoised
+    return action
+
+
+@torch.no_grad()
+def sample_dpmpp_2s(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None, disable=None,
+                    eta=1.):
+    """DPM-Solver++(2S) (:928-966)."""
+    extra_args = {} if extra_args is None else extra_args
+    sig = _host_sigmas(sigmas)
+    for i in range(len(sig) - 1):
+        denoised = model(state, action, goal, _sig_vec(action, sig[i]), **extra_args)
+        if callback is not None:
+            callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+        if sig[i + 1] == 0:
+            action = action + to_d(action, sig[i], denoised) * float(sig[i + 1] - sig[i])
+        else:
+            action = _dpmpp_2s_update(model, state, action, goal, denoised, sig[i], sig[i + 1], extra_args)
+        if scaler is not None:
+            action = scaler.clip_output(action)
+    return action
+
+
+def _dpmpp_2s_update(model, state, action, goal, denoised, s_from, s_to, extra_args):
+    t, t_next = _neg_log(s_from), _neg_log(s_to)
+    r = f32(0.5)
+    h = t_next - t
+    s = t + r * h
+    x_2 = float(f32(np.exp(-s)) / f32(np.exp(-t))) * action - float(f32(np.expm1(-h * r))) * denoised
+    denoised_2 = model(state, x_2, goal, _sig_vec(action, f32(np.exp(-s))), **extra_args)
+    return float(f32(np.exp(-t_next)) / f32(np.exp(-t))) * action - float(f32(np.expm1(-h))) * denoised_2
+
+
+@torch.no_grad()
+def sample_dpmpp_2s_ancestral(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None,
+                              disable=None, eta=1., s_noise=1., noise_sampler=None):
+    """Ancestral DPM-Solver++(2S) (:969-1016)."""
+    extra_args = {} if extra_args is None else extra_args
+    noise_sampler = default_noise_sampler(action) if noise_sampler is None else noise_sampler
+    sig = _host_sigmas(sigmas)
+    for i in range(len(sig) - 1):
+        denoised = model(state, action, goal, _sig_vec(action, sig[i]), **extra_args)
+        sigma_down, sigma_up = get_ancestral_step(sig[i], sig[i + 1], eta=eta)
+        if callback is not None:
+            callback({'action': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+        if sigma_down == 0:
+            action = action + to_d(action, sig[i], denoised) * float(sigma_down - sig[i])
+        else:
+            action = _dpmpp_2s_update(model, state, action, goal, denoised, sig[i], sigma_down, extra_args)
+        action = action + noise_sampler(sig[i], sig[i + 1]) * s_noise * float(sigma_up)
+        if scaler is not None:
+            action = scaler.clip_output(action)
+    return action
+
+
+def _out_of_scope(name, why):
+    def fn(*a, **k):
+        raise NotImplementedError(f"{name} is outside the MI355X hot-path scope ({why}); see DESIGN.md")
+    fn.__name__ = name
+    return fn
+
+
+sample_dpmpp_sde = _out_of_scope('sample_dpmpp_sde', 'needs torchsde Brownian trees')
+sample_dpm_fast = _out_of_scope('sample_dpm_fast', 'DPM-Solver-fast is not on the scope table')
+sample_dpm_adaptive = _out_of_scope('sample_dpm_adaptive', 'adaptive step-size control is host-driven')

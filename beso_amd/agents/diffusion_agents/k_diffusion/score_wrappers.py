@@ -1,0 +1,75 @@
+"""Drop-in for ``beso...k_diffusion.score_wrappers.GCDenoiser``: the Karras et al. (2022)
+preconditioner around the score transformer (reference: score_wrappers.py:18-99).
+
+With a ``beso_amd`` DiffusionGPT inside, ``forward`` is ONE call into the HIP library
+(``beso_denoise_fwd``): c_in is folded into the token-embedding kernel, c_out / c_skip into the
+action-head kernel.  Any other inner model is evaluated by the textbook formula on top of it.
+"""
+import torch
+from torch import nn
+
+from ...._instantiate import instantiate
+from .score_gpts import DiffusionGPT
+from .utils import append_dims
+
+
+class GCDenoiser(nn.Module):
+    """D_theta(a; s, g, sigma) = c_skip * a + c_out * F(s, c_in * a, g, sigma)."""
+
+    def __init__(self, inner_model, sigma_data=1.):
+        super().__init__()
+        self.inner_model = inner_model if isinstance(inner_model, nn.Module) else instantiate(inner_model)
+        self.sigma_data = sigma_data
+
+    # -- reference surface ---------------------------------------------------------------------
+    def get_scalings(self, sigma):
+        """(c_skip, c_out, c_in) of score_wrappers.py:40-42."""
+        sd2 = self.sigma_data ** 2
+        total = sigma ** 2 + sd2
+        return sd2 / total, sigma * self.sigma_data / total ** 0.5, 1 / total ** 0.5
+
+    def get_params(self):
+        return self.inner_model.parameters()
+
+    def forward(self, state, action, goal, sigma, **kwargs):
+        inner = self.inner_model
+        if self._fused(inner, kwargs, state, action, goal, sigma):
+            out = inner.runtime(self.sigma_data).denoise(
+                inner.packed_weights(), state, action, goal, sigma,
+                uncond=bool(kwargs.get("uncond", False)), precondition=True)
+            return out
+        c_skip, c_out, c_in = (append_dims(c, action.ndim) for c in self.get_scalings(sigma))
+        return inner(state, action * c_in, goal, sigma, **kwargs) * c_out + action * c_skip
+
+    def loss(self, state, action, goal, noise, sigma, **kwargs):
+        """Score-matching objective (score_wrappers.py:45-79).  Mutates ``noise`` in place when
+        ``pred_last_action_only`` is set, like the reference (:63)."""
+        last_only = bool(kwargs.pop("pred_last_action_only", False))
+        if last_only:
+            noise[:, :-1, :] = 0
+        noised = action + noise * append_dims(sigma, action.ndim)
+        c_skip, c_out, c_in = (append_dims(c, action.ndim) for c in self.get_scalings(sigma))
+        out = self.inner_model(state, noised * c_in, goal, sigma, **kwargs)
+        target = (action - c_skip * noised) / c_out
+        if last_only:
+            return (out[:, -1, :] - target[:, -1, :]).pow(2).mean()
+        return (out - target).pow(2).flatten(1).mean()
+
+    # -- fused path ----------------------------------------------------------------------------
+    @staticmethod
+    def _fused(inner, kwargs, *tensors) -> bool:
+        if not isinstance(inner, DiffusionGPT):
+            return False
+        if set(kwargs) - {"uncond", "keep_last_actions"} or kwargs.get("keep_last_actions", False):
+            return False
+        if inner.training:
+            return False            # training-mode goal masking / dropout live in DiffusionGPT.forward
+        return inner._hip_eligible(*tensors)
+
+    def fused_sampler(self, sampler: str, state, x_t, goal, sigmas, cond_lambda: float = 1.0):
+        """Whole ddim / euler / heun loop as one enqueue (``beso_sample``); None if not applicable."""
+        inner = self.inner_model
+        if not self._fused(inner, {}, state, x_t, goal) or x_t.dim() != 3 or state.dim() != 3:
+            return None
+        return inner.runtime(self.sigma_data).sample(inner.packed_weights(), sampler, state, x_t, goal, sigmas,
+                                                     cond_lambda=cond_lambda)

@@ -1,0 +1,58 @@
+"""Helpers of the k-diffusion layer that sit on the hot path (reference: k_diffusion/utils.py:165-220):
+``append_dims`` and the sigma training densities.  The five alternative time-embedding classes of
+the reference are out of scope -- DiffusionGPT ignores ``time_embedding_fn`` (score_gpts.py:136,178)."""
+import math
+
+import numpy as np
+import torch
+
+
+def append_dims(x, target_dims):
+    """Trailing singleton dims until ``x.ndim == target_dims`` (utils.py:165-170)."""
+    missing = target_dims - x.ndim
+    if missing < 0:
+        raise ValueError(f'input has {x.ndim} dims but target_dims is {target_dims}, which is less')
+    return x[(...,) + (None,) * missing]
+
+
+def rand_log_normal(shape, loc=0., scale=1., device='cpu', dtype=torch.float32):
+    """exp(N(loc, scale))  (utils.py:173-175)."""
+    return torch.randn(shape, device=device, dtype=dtype).mul_(scale).add_(loc).exp_()
+
+
+def rand_log_logistic(shape, loc=0., scale=1., min_value=0., max_value=float('inf'), device='cpu',
+                      dtype=torch.float32):
+    """Truncated log-logistic, drawn in float64 like the reference (utils.py:178-185)."""
+    f64 = dict(device=device, dtype=torch.float64)
+    lo = torch.as_tensor(min_value, **f64).log().sub(loc).div(scale).sigmoid()
+    hi = torch.as_tensor(max_value, **f64).log().sub(loc).div(scale).sigmoid()
+    u = torch.rand(shape, **f64) * (hi - lo) + lo
+    return u.logit().mul(scale).add(loc).exp().to(dtype)
+
+
+def rand_log_uniform(shape, min_value, max_value, device='cpu', dtype=torch.float32):
+    lo, hi = math.log(min_value), math.log(max_value)
+    return (torch.rand(shape, device=device, dtype=dtype) * (hi - lo) + lo).exp()
+
+
+def rand_uniform(shape, min_value, max_value, device='cpu', dtype=torch.float32):
+    return torch.rand(shape, device=device, dtype=dtype) * (max_value - min_value) + min_value
+
+
+def rand_discrete(shape, values, device='cpu', dtype=torch.float32):
+    values = values.detach().cpu().numpy() if torch.is_tensor(values) else np.asarray(values)
+    return torch.tensor(np.random.choice(values, size=shape), device=device, dtype=dtype)
+
+
+def rand_v_diffusion(shape, sigma_data=1., min_value=0., max_value=float('inf'), device='cpu', dtype=torch.float32):
+    lo = math.atan(min_value / sigma_data) * 2 / math.pi
+    hi = math.atan(max_value / sigma_data) * 2 / math.pi
+    u = torch.rand(shape, device=device, dtype=dtype) * (hi - lo) + lo
+    return torch.tan(u * math.pi / 2) * sigma_data
+
+
+def rand_split_log_normal(shape, loc, scale_1, scale_2, device='cpu', dtype=torch.float32):
+    n = torch.randn(shape, device=device, dtype=dtype).abs()
+    u = torch.rand(shape, device=device, dtype=dtype)
+    left, right = n * -scale_1 + loc, n * scale_2 + loc
+    return torch.where(u < scale_1 / (scale_1 + scale_2), left, right).exp()

@@ -1,0 +1,419 @@
+// extern "C" entry points of libbeso_hip.so (include/beso_hip.h) and the host-side orchestration of
+// one score-network forward / one sampling loop.  No allocation, no synchronisation: everything is
+// enqueued on the caller's stream.
+#include <math.h>
+#include <string.h>
+#include <vector>
+#include <mutex>
+#include "common.h"
+#include "fused.h"
+
+namespace beso {
+
+// ---------------------------------------------------------------------------------------------
+int validate_config(const beso_config* c) {
+    if (!c) return BESO_ERR_BAD_ARG;
+    if (c->obs_dim < 1 || c->act_dim < 1 || c->act_dim > 64 || c->embed_dim < 8 || c->n_layers < 1 ||
+        c->n_layers > kMaxLayers || c->n_heads < 1 || c->goal_seq_len < 0 || c->obs_seq_len < 1)
+        return BESO_ERR_BAD_CONFIG;
+    if (c->embed_dim % c->n_heads != 0) return BESO_ERR_BAD_CONFIG;
+    if (c->embed_dim > 1024) return BESO_ERR_UNSUPPORTED;              // LayerNorm keeps a row in registers
+    if (c->embed_dim / c->n_heads > 128) return BESO_ERR_UNSUPPORTED;  // attention keeps q/o rows in registers
+    if (!(c->sigma_data > 0.f)) return BESO_ERR_BAD_CONFIG;
+    return BESO_OK;
+}
+
+static size_t carve(size_t& cur, size_t bytes) {
+    size_t off = cur;
+    cur = round_up_sz(cur + bytes, 256);
+    return off;
+}
+
+bool make_layout(const beso_config* c, int precision, Layout* o) {
+    if (validate_config(c) != BESO_OK) return false;
+    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32) return false;
+    memset(o, 0, sizeof(*o));
+    o->D = c->embed_dim; o->H = c->n_heads; o->hd = o->D / o->H; o->L = c->n_layers;
+    o->G = c->goal_seq_len; o->W = c->obs_seq_len; o->obs = c->obs_dim; o->act = c->act_dim;
+    o->seq_size = o->G + o->W + 1;
+    o->linear_output = c->linear_output ? 1 : 0;
+    o->Kd = round_up(o->D, 64); o->Kh = round_up(4 * o->D, 64);
+    o->Nqkv = round_up(3 * o->D, kTileMN); o->Nd = round_up(o->D, kTileMN); o->Nh = round_up(4 * o->D, kTileMN);
+    o->elem_bytes = precision == BESO_PREC_FP32 ? 4 : 2;
+    size_t cur = 0;
+    const size_t f = sizeof(float), e = (size_t)o->elem_bytes;
+    o->pos_emb = carve(cur, f * o->seq_size * o->D);
+    o->tok_w = carve(cur, f * o->D * o->obs); o->tok_b = carve(cur, f * o->D);
+    o->sig_w = carve(cur, f * o->D); o->sig_b = carve(cur, f * o->D);
+    o->act_w = carve(cur, f * o->D * o->act); o->act_b = carve(cur, f * o->D);
+    o->lnf_w = carve(cur, f * o->D); o->lnf_b = carve(cur, f * o->D);
+    if (o->linear_output) {
+        o->head_w0 = carve(cur, f * o->act * o->D); o->head_b0 = carve(cur, f * o->act);
+        o->head_w1 = o->head_w0; o->head_b1 = o->head_b0;
+    } else {
+        o->head_w0 = carve(cur, f * kHeadHidden * o->D); o->head_b0 = carve(cur, f * kHeadHidden);
+        o->head_w1 = carve(cur, f * o->act * kHeadHidden); o->head_b1 = carve(cur, f * o->act);
+    }
+    for (int l = 0; l < o->L; ++l) {
+        LayerOff& y = o->layer[l];
+        y.ln1_w = carve(cur, f * o->D); y.ln1_b = carve(cur, f * o->D);
+        y.ln2_w = carve(cur, f * o->D); y.ln2_b = carve(cur, f * o->D);
+        y.b_qkv = carve(cur, f * o->Nqkv); y.b_proj = carve(cur, f * o->Nd);
+        y.b_fc1 = carve(cur, f * o->Nh); y.b_fc2 = carve(cur, f * o->Nd);
+        y.w_qkv = carve(cur, e * o->Nqkv * o->Kd); y.w_proj = carve(cur, e * o->Nd * o->Kd);
+        y.w_fc1 = carve(cur, e * o->Nh * o->Kd); y.w_fc2 = carve(cur, e * o->Nd * o->Kh);
+    }
+    o->fused = carve(cur, fused_packed_bytes(*o, precision));
+    o->total = cur;
+    return true;
+}
+
+bool make_workspace(const beso_config* c, const Layout& lay, int batch, int t, int precision, int cfg_guidance,
+                    Workspace* w) {
+    if (batch < 1 || t < 1 || t > c->obs_seq_len) return false;
+    memset(w, 0, sizeof(*w));
+    const size_t vb = (size_t)batch * (cfg_guidance ? 2 : 1);
+    const size_t T = 1 + lay.G + 2 * (size_t)t;
+    const size_t M = round_up_sz(vb * T, kTileMN);        // rows padded so tile loads never need a clamp
+    const size_t e = lay.elem_bytes, f = sizeof(float);
+    size_t cur = 0;
+    w->x = carve(cur, f * M * lay.D);
+    w->xn = carve(cur, e * M * lay.Kd);
+    w->qkv = carve(cur, e * M * 3 * lay.D);
+    w->y = carve(cur, e * M * lay.Kd);
+    w->h = carve(cur, e * M * lay.Kh);
+    const size_t na = (size_t)batch * t * lay.act;
+    w->den = carve(cur, f * na); w->x2 = carve(cur, f * na); w->d1 = carve(cur, f * na);
+    w->sig = carve(cur, f * batch);
+    w->fused = carve(cur, fused_workspace_bytes(lay, (int)vb, (int)T, precision));
+    w->total = cur;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling hooks
+// ---------------------------------------------------------------------------------------------
+static std::mutex g_prof_mu;
+static int g_prof_site = 0;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static std::vector<hipEvent_t> g_prof_free;
+static hipEvent_t g_prof_open = nullptr;
+
+static hipEvent_t prof_get_event() {
+    if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void profile_begin(int site, hipStream_t s) {
+    if (g_prof_site != site) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEvent_t e = prof_get_event();
+    if (!e) return;
+    (void)hipEventRecord(e, s);
+    g_prof_open = e;
+}
+
+void profile_end(int site, hipStream_t s) {
+    if (g_prof_site != site) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_open) return;
+    hipEvent_t e = prof_get_event();
+    if (!e) return;
+    (void)hipEventRecord(e, s);
+    g_prof_events.emplace_back(g_prof_open, e);
+    g_prof_open = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one forward of the score network (unfused generic path)
+// ---------------------------------------------------------------------------------------------
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return BESO_ERR_HIP; } while (0)
+
+static int forward_generic(const Layout& lay, const Workspace& ws, const char* packed, int precision,
+                           const FwdArgs& a, char* wsp, hipStream_t s) {
+    float* x = (float*)(wsp + ws.x);
+    void* xn = wsp + ws.xn; void* qkv = wsp + ws.qkv; void* y = wsp + ws.y; void* h = wsp + ws.h;
+    const int M = a.vbatch * a.T;
+    auto F = [&](size_t off) { return (const float*)(packed + off); };
+    profile_begin(BESO_SITE_EMBED, s);
+    HIP_TRY(launch_embed(lay, packed, a, x, s));
+    profile_end(BESO_SITE_EMBED, s);
+    for (int l = 0; l < lay.L; ++l) {
+        const LayerOff& o = lay.layer[l];
+        profile_begin(BESO_SITE_LAYERNORM, s);
+        HIP_TRY(launch_layernorm(x, F(o.ln1_w), F(o.ln1_b), xn, M, lay.D, lay.Kd, precision, s));
+        profile_end(BESO_SITE_LAYERNORM, s);
+        profile_begin(BESO_SITE_GEMM_QKV, s);
+        HIP_TRY(launch_gemm(precision, EPI_BIAS_STORE, xn, lay.Kd, packed + o.w_qkv, lay.Kd, F(o.b_qkv), qkv,
+                            3 * lay.D, 3 * lay.D, M, lay.Nqkv, lay.Kd, s));
+        profile_end(BESO_SITE_GEMM_QKV, s);
+        profile_begin(BESO_SITE_ATTENTION, s);
+        HIP_TRY(launch_attention(qkv, y, a.vbatch, a.T, lay.D, lay.H, lay.Kd, precision, s));
+        profile_end(BESO_SITE_ATTENTION, s);
+        profile_begin(BESO_SITE_GEMM_PROJ, s);
+        HIP_TRY(launch_gemm(precision, EPI_BIAS_RESID, y, lay.Kd, packed + o.w_proj, lay.Kd, F(o.b_proj), x, lay.D,
+                            lay.D, M, lay.Nd, lay.Kd, s));
+        profile_end(BESO_SITE_GEMM_PROJ, s);
+        HIP_TRY(launch_layernorm(x, F(o.ln2_w), F(o.ln2_b), xn, M, lay.D, lay.Kd, precision, s));
+        profile_begin(BESO_SITE_GEMM_FC1, s);
+        HIP_TRY(launch_gemm(precision, EPI_BIAS_GELU_STORE, xn, lay.Kd, packed + o.w_fc1, lay.Kd, F(o.b_fc1), h,
+                            lay.Kh, lay.Kh, M, lay.Nh, lay.Kd, s));
+        profile_end(BESO_SITE_GEMM_FC1, s);
+        profile_begin(BESO_SITE_GEMM_FC2, s);
+        HIP_TRY(launch_gemm(precision, EPI_BIAS_RESID, h, lay.Kh, packed + o.w_fc2, lay.Kh, F(o.b_fc2), x, lay.D,
+                            lay.D, M, lay.Nd, lay.Kh, s));
+        profile_end(BESO_SITE_GEMM_FC2, s);
+    }
+    profile_begin(BESO_SITE_HEAD, s);
+    HIP_TRY(launch_head(lay, packed, a, x, s));
+    profile_end(BESO_SITE_HEAD, s);
+    return BESO_OK;
+}
+
+static int forward(const beso_config* cfg, const void* packed, int precision, const float* state,
+                   const float* action, const float* goal, const float* sigma, float* out, int batch, int t,
+                   int flags, float cond_lambda, int precondition, void* workspace, size_t workspace_bytes,
+                   hipStream_t s) {
+    int st = validate_config(cfg);
+    if (st != BESO_OK) return st;
+    if (precision == BESO_PREC_BF16X3) return BESO_ERR_UNSUPPORTED;
+    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32) return BESO_ERR_BAD_ARG;
+    if (batch < 1 || t < 1 || t > cfg->obs_seq_len) return BESO_ERR_BAD_SHAPE;
+    if (!packed || !state || !action || !sigma || !out || !workspace) return BESO_ERR_BAD_ARG;
+    if (cfg->goal_seq_len > 0 && !goal) return BESO_ERR_BAD_ARG;
+    if (flags & ~BESO_FLAG_UNCOND) return BESO_ERR_BAD_ARG;
+    Layout lay;
+    if (!make_layout(cfg, precision, &lay)) return BESO_ERR_BAD_CONFIG;
+    // ClassifierFreeSampleModel (classifier_free_sampler.py:35-49)
+    bool uncond = (flags & BESO_FLAG_UNCOND) != 0;
+    bool two = false;
+    if (precondition && !uncond) {
+        if (cond_lambda == 0.f) uncond = true;
+        else if (cond_lambda != 1.f) two = true;
+    }
+    Workspace ws;
+    if (!make_workspace(cfg, lay, batch, t, precision, two ? 1 : 0, &ws)) return BESO_ERR_BAD_SHAPE;
+    if (workspace_bytes < ws.total) return BESO_ERR_WORKSPACE;
+    FwdArgs a;
+    a.state = state; a.action = action; a.goal = goal; a.sigma = sigma; a.out = out;
+    a.batch = batch; a.vbatch = two ? 2 * batch : batch; a.t = t; a.T = 1 + lay.G + 2 * t;
+    a.precondition = precondition;
+    a.uncond_from = two ? batch : (uncond ? 0 : a.vbatch);
+    a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
+    profile_begin(BESO_SITE_FORWARD, s);
+    int r;
+    if (fused_supported(lay, a, precision))
+        r = forward_fused(lay, ws, (const char*)packed, precision, a, (char*)workspace, s);
+    else
+        r = forward_generic(lay, ws, (const char*)packed, precision, a, (char*)workspace, s);
+    profile_end(BESO_SITE_FORWARD, s);
+    return r;
+}
+
+}  // namespace beso
+
+using namespace beso;
+
+extern "C" {
+
+const char* beso_version(void) { return "beso_hip 0.1 (gfx950)"; }
+
+const char* beso_status_string(int st) {
+    switch (st) {
+        case BESO_OK: return "ok";
+        case BESO_ERR_BAD_CONFIG: return "bad model config";
+        case BESO_ERR_BAD_SHAPE: return "bad shape (batch/t out of range; t must be <= obs_seq_len)";
+        case BESO_ERR_BAD_ARG: return "bad argument (null pointer or unknown enum)";
+        case BESO_ERR_WORKSPACE: return "workspace or packed buffer too small";
+        case BESO_ERR_UNSUPPORTED: return "unsupported configuration";
+        case BESO_ERR_HIP: return "HIP runtime error";
+        default: return "unknown status";
+    }
+}
+
+int beso_num_params(const beso_config* cfg) {
+    if (validate_config(cfg) != BESO_OK) return 0;
+    return 3 + 16 * cfg->n_layers + 6 + (cfg->linear_output ? 2 : 4);
+}
+
+size_t beso_packed_bytes(const beso_config* cfg, int precision) {
+    Layout lay;
+    if (!make_layout(cfg, precision, &lay)) return 0;
+    return lay.total;
+}
+
+int beso_pack_weights(const beso_config* cfg, const float* const* p, int n_params, void* packed_v,
+                      size_t packed_bytes, int precision, void* stream) {
+    int st = validate_config(cfg);
+    if (st != BESO_OK) return st;
+    if (precision == BESO_PREC_BF16X3) return BESO_ERR_UNSUPPORTED;
+    Layout lay;
+    if (!make_layout(cfg, precision, &lay)) return BESO_ERR_BAD_ARG;
+    if (!p || !packed_v) return BESO_ERR_BAD_ARG;
+    if (n_params != beso_num_params(cfg)) return BESO_ERR_BAD_ARG;
+    for (int i = 0; i < n_params; ++i) if (!p[i]) return BESO_ERR_BAD_ARG;
+    if (packed_bytes < lay.total) return BESO_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* pk = (char*)packed_v;
+    const int D = lay.D;
+    int i = 0;
+    // fp32 sections: precision -1
+#define PACK32(off, rows, cols, rp, cp) HIP_TRY(launch_pack_matrix(p[i++], rows, cols, pk + (off), rp, cp, -1, s))
+#define PACKW(src, off, rows, cols, rp, cp) HIP_TRY(launch_pack_matrix(src, rows, cols, pk + (off), rp, cp, precision, s))
+    PACK32(lay.pos_emb, lay.seq_size, D, lay.seq_size, D);
+    PACK32(lay.tok_w, D, lay.obs, D, lay.obs);
+    PACK32(lay.tok_b, 1, D, 1, D);
+    for (int l = 0; l < lay.L; ++l) {
+        const LayerOff& o = lay.layer[l];
+        PACK32(o.ln1_w, 1, D, 1, D); PACK32(o.ln1_b, 1, D, 1, D);
+        PACK32(o.ln2_w, 1, D, 1, D); PACK32(o.ln2_b, 1, D, 1, D);
+        // reference order: key, query, value, proj (score_gpts.py:33-39).  Fused rows: [q | k | v].
+        const float *kw = p[i], *kb = p[i + 1], *qw = p[i + 2], *qb = p[i + 3], *vw = p[i + 4], *vb = p[i + 5];
+        const float *pw = p[i + 6], *pb = p[i + 7];
+        i += 8;
+        const size_t e = lay.elem_bytes;
+        // zero the whole padded operand first (rows 3D..Nqkv), then drop q,k,v in
+        HIP_TRY(hipMemsetAsync(pk + o.w_qkv, 0, e * lay.Nqkv * lay.Kd, s));
+        HIP_TRY(hipMemsetAsync(pk + o.b_qkv, 0, sizeof(float) * lay.Nqkv, s));
+        PACKW(qw, o.w_qkv, D, D, D, lay.Kd);
+        PACKW(kw, o.w_qkv + e * (size_t)D * lay.Kd, D, D, D, lay.Kd);
+        PACKW(vw, o.w_qkv + e * (size_t)2 * D * lay.Kd, D, D, D, lay.Kd);
+        HIP_TRY(launch_pack_matrix(qb, 1, D, pk + o.b_qkv, 1, D, -1, s));
+        HIP_TRY(launch_pack_matrix(kb, 1, D, pk + o.b_qkv + sizeof(float) * D, 1, D, -1, s));
+        HIP_TRY(launch_pack_matrix(vb, 1, D, pk + o.b_qkv + sizeof(float) * 2 * D, 1, D, -1, s));
+        PACKW(pw, o.w_proj, D, D, lay.Nd, lay.Kd);
+        HIP_TRY(launch_pack_matrix(pb, 1, D, pk + o.b_proj, 1, lay.Nd, -1, s));
+        const float *f1w = p[i], *f1b = p[i + 1], *f2w = p[i + 2], *f2b = p[i + 3];
+        i += 4;
+        PACKW(f1w, o.w_fc1, 4 * D, D, lay.Nh, lay.Kd);
+        HIP_TRY(launch_pack_matrix(f1b, 1, 4 * D, pk + o.b_fc1, 1, lay.Nh, -1, s));
+        PACKW(f2w, o.w_fc2, D, 4 * D, lay.Nd, lay.Kh);
+        HIP_TRY(launch_pack_matrix(f2b, 1, D, pk + o.b_fc2, 1, lay.Nd, -1, s));
+    }
+    PACK32(lay.lnf_w, 1, D, 1, D); PACK32(lay.lnf_b, 1, D, 1, D);
+    PACK32(lay.sig_w, 1, D, 1, D); PACK32(lay.sig_b, 1, D, 1, D);          // sigma_emb.weight is [D,1]
+    PACK32(lay.act_w, D, lay.act, D, lay.act); PACK32(lay.act_b, 1, D, 1, D);
+    if (lay.linear_output) {
+        PACK32(lay.head_w0, lay.act, D, lay.act, D); PACK32(lay.head_b0, 1, lay.act, 1, lay.act);
+    } else {
+        PACK32(lay.head_w0, kHeadHidden, D, kHeadHidden, D); PACK32(lay.head_b0, 1, kHeadHidden, 1, kHeadHidden);
+        PACK32(lay.head_w1, lay.act, kHeadHidden, lay.act, kHeadHidden); PACK32(lay.head_b1, 1, lay.act, 1, lay.act);
+    }
+#undef PACK32
+#undef PACKW
+    if (i != n_params) return BESO_ERR_BAD_ARG;
+    return fused_pack(lay, p, pk, precision, s);
+}
+
+size_t beso_workspace_bytes(const beso_config* cfg, int batch, int t, int precision, int cfg_guidance) {
+    Layout lay;
+    Workspace ws;
+    if (!make_layout(cfg, precision, &lay)) return 0;
+    if (!make_workspace(cfg, lay, batch, t, precision, cfg_guidance, &ws)) return 0;
+    return ws.total;
+}
+
+int beso_score_fwd(const beso_config* cfg, const void* packed, int precision, const float* state,
+                   const float* action, const float* goal, const float* sigma, float* out, int batch, int t,
+                   int flags, void* workspace, size_t workspace_bytes, void* stream) {
+    return forward(cfg, packed, precision, state, action, goal, sigma, out, batch, t, flags, 1.0f, 0, workspace,
+                   workspace_bytes, (hipStream_t)stream);
+}
+
+int beso_denoise_fwd(const beso_config* cfg, const void* packed, int precision, const float* state,
+                     const float* action, const float* goal, const float* sigma, float* out, int batch, int t,
+                     int flags, float cond_lambda, void* workspace, size_t workspace_bytes, void* stream) {
+    return forward(cfg, packed, precision, state, action, goal, sigma, out, batch, t, flags, cond_lambda, 1,
+                   workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int beso_sampler_step(int mode, float* out, float* aux, const float* x, const float* x2, const float* den,
+                      float c0, float c1, size_t n, void* stream) {
+    if (mode < BESO_STEP_DDIM || mode > BESO_STEP_HEUN_CORRECT || !out || !x || !den) return BESO_ERR_BAD_ARG;
+    if ((mode == BESO_STEP_HEUN_PREDICT || mode == BESO_STEP_HEUN_CORRECT) && !aux) return BESO_ERR_BAD_ARG;
+    if (mode == BESO_STEP_HEUN_CORRECT && !x2) return BESO_ERR_BAD_ARG;
+    if (n == 0) return BESO_OK;
+    HIP_TRY(launch_sampler_step(mode, out, aux, x, x2, den, c0, c1, n, (hipStream_t)stream));
+    return BESO_OK;
+}
+
+int beso_sample(const beso_config* cfg, const void* packed, int precision, int sampler, const float* state,
+                const float* goal, float* x, int batch, int t, const float* sigmas, int n_sigmas,
+                float cond_lambda, void* workspace, size_t workspace_bytes, void* stream) {
+    int st = validate_config(cfg);
+    if (st != BESO_OK) return st;
+    if (sampler < BESO_SAMPLER_DDIM || sampler > BESO_SAMPLER_HEUN) return BESO_ERR_BAD_ARG;
+    if (!sigmas || n_sigmas < 2 || !x || !workspace) return BESO_ERR_BAD_ARG;
+    if (batch < 1 || t < 1 || t > cfg->obs_seq_len) return BESO_ERR_BAD_SHAPE;
+    if (precision == BESO_PREC_BF16X3) return BESO_ERR_UNSUPPORTED;
+    Layout lay;
+    Workspace ws;
+    if (!make_layout(cfg, precision, &lay)) return BESO_ERR_BAD_ARG;
+    const int two = (cond_lambda != 0.f && cond_lambda != 1.f) ? 1 : 0;
+    if (!make_workspace(cfg, lay, batch, t, precision, two, &ws)) return BESO_ERR_BAD_SHAPE;
+    if (workspace_bytes < ws.total) return BESO_ERR_WORKSPACE;
+    for (int i = 0; i + 1 < n_sigmas; ++i) if (!(sigmas[i] > 0.f)) return BESO_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    char* wsp = (char*)workspace;
+    float* den = (float*)(wsp + ws.den);
+    float* x2 = (float*)(wsp + ws.x2);
+    float* d1 = (float*)(wsp + ws.d1);
+    float* sig = (float*)(wsp + ws.sig);
+    const size_t n = (size_t)batch * t * lay.act;
+    auto fill_sigma = [&](float v) -> hipError_t {
+        uint32_t bits; memcpy(&bits, &v, 4);
+        return hipMemsetD32Async((hipDeviceptr_t)sig, (int)bits, (size_t)batch, s);
+    };
+    for (int i = 0; i + 1 < n_sigmas; ++i) {
+        const float si = sigmas[i], sn = sigmas[i + 1];
+        HIP_TRY(fill_sigma(si));
+        st = beso_denoise_fwd(cfg, packed, precision, state, x, goal, sig, den, batch, t, 0, cond_lambda, workspace,
+                              workspace_bytes, stream);
+        if (st != BESO_OK) return st;
+        if (sampler == BESO_SAMPLER_DDIM) {
+            // t = -log(sigma); h = t_next - t; x = (sigma_fn(t_next)/sigma_fn(t))*x - expm1(-h)*den  (gc_sampling.py:921-923)
+            const float tt = -logf(si), tn = -logf(sn);      // sn == 0 -> tn = +inf -> x = den exactly
+            const float h = tn - tt;
+            const float c0 = expf(-tn) / expf(-tt), c1 = expm1f(-h);
+            HIP_TRY(launch_sampler_step(BESO_STEP_DDIM, x, nullptr, x, nullptr, den, c0, c1, n, s));
+        } else if (sampler == BESO_SAMPLER_EULER || sn == 0.f) {
+            // gamma = 0: sigma_hat = sigma_i; d = (x - den)/sigma_hat; x += d*(sigma_next - sigma_hat)  (:205-210, :301-303)
+            HIP_TRY(launch_sampler_step(BESO_STEP_EULER, x, nullptr, x, nullptr, den, si, sn - si, n, s));
+        } else {
+            // Heun: predictor, second evaluation at sigma_{i+1}, trapezoid corrector (:304-310)
+            HIP_TRY(launch_sampler_step(BESO_STEP_HEUN_PREDICT, x2, d1, x, nullptr, den, si, sn - si, n, s));
+            HIP_TRY(fill_sigma(sn));
+            st = beso_denoise_fwd(cfg, packed, precision, state, x2, goal, sig, den, batch, t, 0, cond_lambda,
+                                  workspace, workspace_bytes, stream);
+            if (st != BESO_OK) return st;
+            HIP_TRY(launch_sampler_step(BESO_STEP_HEUN_CORRECT, x, d1, x, x2, den, sn, sn - si, n, s));
+        }
+    }
+    return BESO_OK;
+}
+
+void beso_profile_enable(int site) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_site = site;
+}
+
+int beso_profile_read(double* total_ms, int* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double tot = 0.0;
+    int n = 0;
+    for (auto& pr : g_prof_events) {
+        if (hipEventSynchronize(pr.second) != hipSuccess) return BESO_ERR_HIP;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { tot += ms; ++n; }
+        g_prof_free.push_back(pr.first);
+        g_prof_free.push_back(pr.second);
+    }
+    g_prof_events.clear();
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return BESO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// Internal definitions shared by the HIP translation units of libbeso_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/beso_hip.h"
+
+namespace beso {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+constexpr int kWave = 64;
+constexpr int kTileMN = 128;   // generic GEMM block tile (M and N)
+constexpr int kTileKBytes = 128;  // bytes of K per LDS row per stage (64 bf16 / 32 fp32)
+constexpr int kHeadHidden = 100;  // action_pred hidden width when linear_output is False (score_gpts.py:187)
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+// bf16 <-> fp32, round-to-nearest-even
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+template <typename T> struct Act;
+template <> struct Act<uint16_t> {            // bf16 activations / GEMM operands
+    static constexpr int kPerChunk = 8;        // elements per 16-byte chunk
+    __device__ static __forceinline__ uint16_t from(float f) { return f2bf(f); }
+    __device__ static __forceinline__ float to(uint16_t v) { return bf2f(v); }
+};
+template <> struct Act<float> {
+    static constexpr int kPerChunk = 4;
+    __device__ static __forceinline__ float from(float f) { return f; }
+    __device__ static __forceinline__ float to(float v) { return v; }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed-weight image.  Offsets in bytes from the start of the image; every section 256-B aligned.
+// GEMM operands are [Np][Kp] (torch Linear layout = B^T, k contiguous), Np = ceil128(N),
+// Kp = ceil64(K), zero padded, element type = bf16 or fp32 by precision.
+// ---------------------------------------------------------------------------------------------
+struct LayerOff {
+    size_t ln1_w, ln1_b, ln2_w, ln2_b;   // fp32 [D]
+    size_t b_qkv, b_proj, b_fc1, b_fc2;  // fp32 [Np]
+    size_t w_qkv, w_proj, w_fc1, w_fc2;  // elem [Np][Kp]
+};
+
+constexpr int kMaxLayers = 32;
+
+struct Layout {
+    int D, H, hd, L, G, W, obs, act, seq_size, linear_output;
+    int Kd, Kh;          // padded K of D and 4D
+    int Nqkv, Nd, Nh;    // padded N of 3D, D, 4D
+    int elem_bytes;      // 2 (bf16, bf16x3) or 4 (fp32)
+    size_t pos_emb, tok_w, tok_b, sig_w, sig_b, act_w, act_b, lnf_w, lnf_b;
+    size_t head_w0, head_b0, head_w1, head_b1;   // linear_output: w0=[act,D], b0=[act]; else Linear(D,100),Linear(100,act)
+    LayerOff layer[kMaxLayers];
+    size_t fused;        // image of the fused path (fused.hip), 0 bytes when unsupported
+    size_t total;
+};
+
+// Workspace carve-up for one forward over Mtok = Bv*T tokens.
+struct Workspace {
+    size_t x;      // fp32 [Mtok][D]       residual stream
+    size_t xn;     // elem [Mtok][Kd]      LayerNorm output (GEMM operand)
+    size_t qkv;    // elem [Mtok][3D]
+    size_t y;      // elem [Mtok][Kd]      attention output
+    size_t h;      // elem [Mtok][Kh]      MLP hidden
+    size_t den;    // fp32 [B][t][act]     denoised (sampler scratch)
+    size_t x2;     // fp32 [B][t][act]     Heun predictor state
+    size_t d1;     // fp32 [B][t][act]     Heun first derivative d
+    size_t sig;    // fp32 [B]             per-step sigma vector of beso_sample
+    size_t fused;  // scratch of the fused path
+    size_t total;
+};
+
+int  validate_config(const beso_config* cfg);
+bool make_layout(const beso_config* cfg, int precision, Layout* out);
+bool make_workspace(const beso_config* cfg, const Layout& lay, int batch, int t, int precision,
+                    int cfg_guidance, Workspace* out);
+
+// ---- kernel launchers (each enqueues on `s`, returns hipError_t) -------------------------------
+struct FwdArgs {
+    const float* state; const float* action; const float* goal; const float* sigma;
+    float* out;
+    int batch;        // real batch B
+    int vbatch;       // virtual batch: B or 2B (classifier-free guidance)
+    int t;            // observations in the window
+    int T;            // tokens per sample
+    int precondition; // 1: GCDenoiser (c_in / c_out / c_skip), 0: raw inner model
+    int uncond_from;  // virtual samples >= uncond_from use zero goals
+    float cond_lambda;
+    float sigma_data;
+};
+
+hipError_t launch_pack_matrix(const float* src, int rows, int cols, void* dst, int rows_p,
+                              int cols_p, int precision, hipStream_t s);
+hipError_t launch_embed(const Layout& lay, const char* packed, const FwdArgs& a, float* x, hipStream_t s);
+hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int rows,
+                            int D, int ld_out, int precision, hipStream_t s);
+hipError_t launch_attention(const void* qkv, void* y, int vbatch, int T, int D, int H, int ld_y,
+                            int precision, hipStream_t s);
+hipError_t launch_head(const Layout& lay, const char* packed, const FwdArgs& a, const float* x, hipStream_t s);
+enum { EPI_BIAS_STORE = 0, EPI_BIAS_GELU_STORE = 1, EPI_BIAS_RESID = 2 };
+hipError_t launch_gemm(int precision, int epi, const void* A, int lda, const void* Wt, int ldw,
+                       const float* bias, void* out, int ldo,
+                       int n_store, int M, int Np, int Kp, hipStream_t s);
+hipError_t launch_sampler_step(int mode, float* out, float* aux, const float* x, const float* x2, const float* den,
+                               float c0, float c1, size_t n, hipStream_t s);
+
+// profile hooks (api.hip)
+void profile_begin(int site, hipStream_t s);
+void profile_end(int site, hipStream_t s);
+
+}  // namespace beso

@@ -1,0 +1,305 @@
+// Memory-bound kernels of the score network: weight packing, token embedding (K1), LayerNorm,
+// final-LN + action head + un-precondition (K7) and the sampler update (K8).
+// Reference semantics: score_gpts.py:272-358, score_wrappers.py:31-96, gc_sampling.py.
+#include "common.h"
+
+namespace beso {
+
+// -----------------------------------------------------------------------------------------------
+// K0: dst[rows_p][cols_p] <- src[rows][cols], converted to the GEMM operand type, zero padded.
+// -----------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void pack_matrix_kernel(const float* __restrict__ src, int rows, int cols, E* __restrict__ dst,
+                                   int rows_p, int cols_p) {
+    size_t n = (size_t)rows_p * cols_p;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / cols_p), c = (int)(i % cols_p);
+        float v = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+        dst[i] = Act<E>::from(v);
+    }
+}
+
+hipError_t launch_pack_matrix(const float* src, int rows, int cols, void* dst, int rows_p, int cols_p,
+                              int precision, hipStream_t s) {
+    size_t n = (size_t)rows_p * cols_p;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    if (precision == -1 || precision == BESO_PREC_FP32)   // -1: always-fp32 sections (biases, LN, embeddings)
+        hipLaunchKernelGGL(pack_matrix_kernel<float>, dim3(grid), dim3(256), 0, s, src, rows, cols, (float*)dst,
+                           rows_p, cols_p);
+    else
+        hipLaunchKernelGGL(pack_matrix_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, src, rows, cols,
+                           (uint16_t*)dst, rows_p, cols_p);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// K1: precondition + embed + assemble  -> x[vbatch][T][D]  (fp32 residual stream)
+//   token 0            : sigma_emb(log(sigma)/4)                         score_gpts.py:284-286
+//   tokens 1..G        : tok_emb(goal_g) + pos[g]     (zeros in if uncond) :301-306,322
+//   token G+1+2i       : tok_emb(state_i) + pos[G+i]                      :305,323
+//   token G+2+2i       : action_emb(action_i * c_in) + pos[G+i]           :307,325; score_wrappers.py:96
+// One block per token row, one thread per output feature.
+// -----------------------------------------------------------------------------------------------
+__global__ void embed_kernel(const float* __restrict__ state, const float* __restrict__ action,
+                             const float* __restrict__ goal, const float* __restrict__ sigma,
+                             const float* __restrict__ pos, const float* __restrict__ tok_w,
+                             const float* __restrict__ tok_b, const float* __restrict__ sig_w,
+                             const float* __restrict__ sig_b, const float* __restrict__ act_w,
+                             const float* __restrict__ act_b, float* __restrict__ x, int B, int t, int T, int G,
+                             int D, int obs, int act, int precondition, int uncond_from, float sigma_data) {
+    extern __shared__ float in_vec[];   // the input vector of this token
+    int row = blockIdx.x;               // vb*T + j
+    int vb = row / T, j = row % T;
+    int b = vb % B;
+    float sg = sigma[b];
+    int kind, len = 0, posrow = -1;     // kind 0 sigma, 1 goal/state (tok_emb), 2 action
+    const float* src = nullptr;
+    float scale = 1.f;
+    if (j == 0) {
+        kind = 0;
+    } else if (j <= G) {
+        kind = 1; len = obs; posrow = j - 1;
+        src = (vb >= uncond_from) ? nullptr : goal + ((size_t)b * G + (j - 1)) * obs;
+    } else {
+        int idx = j - G - 1, i = idx >> 1;
+        posrow = G + i;
+        if ((idx & 1) == 0) { kind = 1; len = obs; src = state + ((size_t)b * t + i) * obs; }
+        else {
+            kind = 2; len = act; src = action + ((size_t)b * t + i) * act;
+            if (precondition) scale = 1.0f / sqrtf(sg * sg + sigma_data * sigma_data);   // c_in
+        }
+    }
+    for (int c = threadIdx.x; c < len; c += blockDim.x) in_vec[c] = src ? src[c] * scale : 0.f;
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float v;
+        if (kind == 0) {
+            v = sig_w[d] * (logf(sg) / 4.0f) + sig_b[d];
+        } else {
+            const float* w = (kind == 1 ? tok_w : act_w) + (size_t)d * len;
+            float acc = 0.f;
+            for (int c = 0; c < len; ++c) acc = fmaf(in_vec[c], w[c], acc);
+            v = acc + (kind == 1 ? tok_b[d] : act_b[d]) + pos[(size_t)posrow * D + d];
+        }
+        x[(size_t)row * D + d] = v;
+    }
+}
+
+hipError_t launch_embed(const Layout& lay, const char* packed, const FwdArgs& a, float* x, hipStream_t s) {
+    int rows = a.vbatch * a.T;
+    int threads = lay.D >= 256 ? 256 : round_up(lay.D, 64);
+    size_t shmem = sizeof(float) * (size_t)(lay.obs > lay.act ? lay.obs : lay.act);
+    auto P = [&](size_t off) { return (const float*)(packed + off); };
+    hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(threads), shmem, s, a.state, a.action, a.goal, a.sigma,
+                       P(lay.pos_emb), P(lay.tok_w), P(lay.tok_b), P(lay.sig_w), P(lay.sig_b), P(lay.act_w),
+                       P(lay.act_b), x, a.batch, a.t, a.T, lay.G, lay.D, lay.obs, lay.act, a.precondition,
+                       a.uncond_from, a.sigma_data);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// LayerNorm (eps 1e-5, biased variance, affine): fp32 row -> GEMM operand row (zero padded to ld_out).
+// One wave per row; the row lives in registers (D <= 64*kMaxPerLane).
+// -----------------------------------------------------------------------------------------------
+constexpr int kLnMaxPerLane = 16;
+
+template <typename E>
+__global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                 const float* __restrict__ b, E* __restrict__ out, int rows, int D, int ld_out) {
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    if (wave >= rows) return;
+    const float* xr = x + (size_t)wave * D;
+    float v[kLnMaxPerLane];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        int c = lane + i * 64;
+        v[i] = (c < D) ? xr[c] : 0.f;
+        sum += v[i];
+    }
+    float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        int c = lane + i * 64;
+        float d = (c < D) ? v[i] - mean : 0.f;
+        sq = fmaf(d, d, sq);
+    }
+    float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + 1e-5f);
+    E* o = out + (size_t)wave * ld_out;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        int c = lane + i * 64;
+        if (c < D) o[c] = Act<E>::from((v[i] - mean) * rstd * w[c] + b[c]);
+        else if (c < ld_out) o[c] = Act<E>::from(0.f);
+    }
+}
+
+hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int rows, int D,
+                            int ld_out, int precision, hipStream_t s) {
+    int waves_per_block = 4;
+    int grid = (rows + waves_per_block - 1) / waves_per_block;
+    if (precision == BESO_PREC_FP32)
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, s, x, w, b, (float*)out, rows, D,
+                           ld_out);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, x, w, b, (uint16_t*)out,
+                           rows, D, ld_out);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// K7: ln_f on the action-token rows only (score_gpts.py:341-353), action_pred (:354), then
+// D_theta = F*c_out + action*c_skip (score_wrappers.py:96) and the classifier-free combination
+// out_u + lambda*(out_c - out_u) (classifier_free_sampler.py:49).  One wave per (sample, step).
+// -----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float head_row(const float* __restrict__ xr, const float* __restrict__ lnw,
+                                         const float* __restrict__ lnb, const float* __restrict__ w0,
+                                         const float* __restrict__ b0, const float* __restrict__ w1,
+                                         const float* __restrict__ b1, int D, int act, int linear_output,
+                                         int lane, float* hid /* LDS scratch [kHeadHidden] per wave */) {
+    // returns pred[lane] (lanes >= act return 0)
+    float mine = 0.f;
+    float v[kLnMaxPerLane];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        int c = lane + i * 64;
+        v[i] = (c < D) ? xr[c] : 0.f;
+        sum += v[i];
+    }
+    float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        int c = lane + i * 64;
+        float d = (c < D) ? v[i] - mean : 0.f;
+        sq = fmaf(d, d, sq);
+    }
+    float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        int c = lane + i * 64;
+        v[i] = (c < D) ? (v[i] - mean) * rstd * lnw[c] + lnb[c] : 0.f;
+    }
+    if (linear_output) {
+        for (int o = 0; o < act; ++o) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < kLnMaxPerLane; ++i) {
+                int c = lane + i * 64;
+                if (c < D) acc = fmaf(v[i], w0[(size_t)o * D + c], acc);
+            }
+            float r = wave_sum(acc) + b0[o];
+            if (lane == o) mine = r;
+        }
+    } else {
+        for (int o = 0; o < kHeadHidden; ++o) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < kLnMaxPerLane; ++i) {
+                int c = lane + i * 64;
+                if (c < D) acc = fmaf(v[i], w0[(size_t)o * D + c], acc);
+            }
+            float z = wave_sum(acc) + b0[o];
+            if (lane == 0) hid[o] = z / (1.0f + expf(-z));   // SiLU
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int o = 0; o < act; ++o) {
+            float acc = 0.f;
+            for (int c = lane; c < kHeadHidden; c += 64) acc = fmaf(hid[c], w1[(size_t)o * kHeadHidden + c], acc);
+            float r = wave_sum(acc) + b1[o];
+            if (lane == o) mine = r;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return mine;
+}
+
+__global__ void head_kernel(const float* __restrict__ x, const float* __restrict__ action,
+                            const float* __restrict__ sigma, const float* __restrict__ lnw,
+                            const float* __restrict__ lnb, const float* __restrict__ w0,
+                            const float* __restrict__ b0, const float* __restrict__ w1,
+                            const float* __restrict__ b1, float* __restrict__ out, int B, int vbatch, int t, int T,
+                            int G, int D, int act, int linear_output, int precondition, float cond_lambda,
+                            float sigma_data) {
+    __shared__ float hid_all[4][kHeadHidden];
+    int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int item = blockIdx.x * 4 + wid;           // b*t + i
+    if (item >= B * t) return;
+    int b = item / t, i = item % t;
+    int j = G + 2 + 2 * i;                     // action token of step i
+    float fc = head_row(x + ((size_t)b * T + j) * D, lnw, lnb, w0, b0, w1, b1, D, act, linear_output, lane,
+                        hid_all[wid]);
+    bool two = vbatch > B;
+    float fu = 0.f;
+    if (two)
+        fu = head_row(x + ((size_t)(b + B) * T + j) * D, lnw, lnb, w0, b0, w1, b1, D, act, linear_output, lane,
+                      hid_all[wid]);
+    if (lane < act) {
+        float sg = sigma[b];
+        float a = action[((size_t)b * t + i) * act + lane];
+        float c_skip = 0.f, c_out = 1.f;
+        if (precondition) {
+            float sd2 = sigma_data * sigma_data;
+            c_skip = sd2 / (sg * sg + sd2);
+            c_out = sg * sigma_data / sqrtf(sg * sg + sd2);
+        }
+        float oc = fc * c_out + a * c_skip;
+        float r = oc;
+        if (two) {
+            float ou = fu * c_out + a * c_skip;
+            r = ou + cond_lambda * (oc - ou);
+        }
+        out[((size_t)b * t + i) * act + lane] = r;
+    }
+}
+
+hipError_t launch_head(const Layout& lay, const char* packed, const FwdArgs& a, const float* x, hipStream_t s) {
+    auto P = [&](size_t off) { return (const float*)(packed + off); };
+    int items = a.batch * a.t;
+    hipLaunchKernelGGL(head_kernel, dim3((items + 3) / 4), dim3(256), 0, s, x, a.action, a.sigma, P(lay.lnf_w),
+                       P(lay.lnf_b), P(lay.head_w0), P(lay.head_b0), P(lay.head_w1), P(lay.head_b1), a.out,
+                       a.batch, a.vbatch, a.t, a.T, lay.G, lay.D, lay.act, lay.linear_output,
+                       a.precondition, a.cond_lambda, a.sigma_data);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------
+// K8: sampler update, in the reference's operation order (gc_sampling.py:205-210,296-310,921-923)
+// -----------------------------------------------------------------------------------------------
+__global__ void sampler_step_kernel(int mode, float* __restrict__ out, float* __restrict__ aux,
+                                    const float* __restrict__ x, const float* __restrict__ x2,
+                                    const float* __restrict__ den, float c0, float c1, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float xv = x[i], dv = den[i], r;
+        if (mode == BESO_STEP_DDIM) {
+            r = c0 * xv - c1 * dv;
+        } else if (mode == BESO_STEP_EULER) {
+            float d = (xv - dv) / c0;
+            r = xv + d * c1;
+        } else if (mode == BESO_STEP_HEUN_PREDICT) {
+            float d = (xv - dv) / c0;
+            aux[i] = d;
+            r = xv + d * c1;
+        } else {
+            float d2 = (x2[i] - dv) / c0;
+            r = xv + ((aux[i] + d2) / 2.0f) * c1;
+        }
+        out[i] = r;
+    }
+}
+
+hipError_t launch_sampler_step(int mode, float* out, float* aux, const float* x, const float* x2, const float* den,
+                               float c0, float c1, size_t n, hipStream_t s) {
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(sampler_step_kernel, dim3(grid), dim3(256), 0, s, mode, out, aux, x, x2, den, c0, c1, n);
+    return hipGetLastError();
+}
+
+}  // namespace beso

@@ -1,0 +1,14 @@
+// Fused score-network path (kernels specialised for the shipped model shapes).  See fused.hip.
+#pragma once
+#include "common.h"
+
+namespace beso {
+
+size_t fused_packed_bytes(const Layout& lay, int precision);
+size_t fused_workspace_bytes(const Layout& lay, int vbatch, int T, int precision);
+int    fused_pack(const Layout& lay, const float* const* params, char* packed, int precision, hipStream_t s);
+bool   fused_supported(const Layout& lay, const FwdArgs& a, int precision);
+int    forward_fused(const Layout& lay, const Workspace& ws, const char* packed, int precision, const FwdArgs& a,
+                     char* wsp, hipStream_t s);
+
+}  // namespace beso

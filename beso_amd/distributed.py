@@ -1,0 +1,115 @@
+"""Data-parallel plumbing: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).
+
+Inference shards the batch and needs no collective.  The training step has exactly one exchange:
+the all-reduce of the score-matching gradients.  Gradients are reduced as ONE flat
+fp32 bucket (9.4 M values = 37.5 MB for the kitchen model): on the fully connected xGMI mesh RCCL
+splits a single large all-reduce over all seven links, which beats many per-tensor collectives that
+are each latency bound.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def init_from_env(backend: Optional[str] = None) -> bool:
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1 or (dist.is_available() and dist.is_initialized()):
+        return ws > 1
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=ws)
+    return True
+
+
+def shard_range(total: int, n_shards: int, index: int):
+    """[lo, hi) of shard ``index`` when ``total`` independent samples are split over ``n_shards``
+    ranks (remainder spread over the first ranks)."""
+    base, rem = divmod(total, n_shards)
+    lo = index * base + min(index, rem)
+    return lo, lo + base + (1 if index < rem else 0)
+
+
+class GradientBucket:
+    """Flat fp32 gradient bucket for the C1 all-reduce.  ``sync(params)`` averages ``p.grad`` over the
+    ranks in place; with ``async_op=True`` the caller overlaps the collective with other work and
+    calls ``wait()`` before the optimizer step."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._work = None
+
+    def _pack(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+
+    def _unpack(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = self.flat[off:off + n].view_as(p).clone()
+            else:
+                p.grad.copy_(self.flat[off:off + n].view_as(p))
+            off += n
+
+    def sync(self, async_op: bool = False):
+        if not is_distributed():
+            return None
+        self._pack()
+        self.flat.div_(world_size())            # mean over the GLOBAL batch (score_wrappers.py:79)
+        self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        if not async_op:
+            self._unpack()
+        return self._work
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+            self._unpack()
+
+
+def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0) -> None:
+    """C2: make every replica start from rank ``src``'s weights (one flat broadcast)."""
+    if not is_distributed():
+        return
+    params = list(params)
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    dist.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))
+            off += n

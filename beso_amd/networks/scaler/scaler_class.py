@@ -1,0 +1,67 @@
+"""Boundary plumbing: z-score scaler of observations / actions with the action bounds the agent
+clips to (reference: beso/networks/scaler/scaler_class.py:11-166).  Elementwise host-side torch;
+the workspace normally builds the reference's own Scaler -- any object with this surface works."""
+import numpy as np
+import torch
+
+
+class Scaler:
+    def __init__(self, x_data, y_data, scale_data: bool, device: str):
+        self.scale_data = scale_data
+        self.device = device
+        if isinstance(x_data, torch.Tensor):
+            x_data, y_data = x_data.detach().cpu().numpy(), y_data.detach().cpu().numpy()
+        if x_data.ndim == 3:
+            x_data = x_data.reshape(-1, x_data.shape[-1])
+            y_data = y_data.reshape(-1, y_data.shape[-1])
+        elif x_data.ndim not in (2, 4):
+            raise ValueError('not implemented yet!')
+        dev = lambda a: torch.from_numpy(a).to(device)       # noqa: E731
+        self.x_mean, self.x_std = dev(x_data.mean(0)), dev(x_data.std(0))
+        self.y_mean, self.y_std = dev(y_data.mean(0)), dev(y_data.std(0))
+        self.x_max, self.x_min = dev(x_data.max(0)), dev(x_data.min(0))
+        self.y_max, self.y_min = dev(y_data.max(0)), dev(y_data.min(0))
+        self.y_bounds = np.zeros((2, y_data.shape[-1]))
+        self.x_bounds = np.zeros((2, x_data.shape[-1]))
+        if scale_data:
+            self.y_bounds[0] = (y_data.min(0) - y_data.mean(0)) / (y_data.std(0) + 1e-12)
+            self.y_bounds[1] = (y_data.max(0) - y_data.mean(0)) / (y_data.std(0) + 1e-12)
+            self.x_bounds[0] = (x_data.min(0) - x_data.mean(0)) / (x_data.std(0) + 1e-12)
+            self.x_bounds[1] = (x_data.max(0) - x_data.mean(0)) / (x_data.std(0) + 1e-12)
+        else:
+            self.y_bounds[0], self.y_bounds[1] = y_data.min(0), y_data.max(0)
+            self.x_bounds[0], self.x_bounds[1] = x_data.min(0), x_data.max(0)
+        self.y_bounds_tensor = torch.from_numpy(self.y_bounds).to(device)
+        self.x_bounds_tensor = torch.from_numpy(self.x_bounds).to(device)
+        self.tensor_y_bounds = self.y_bounds_tensor
+
+    @torch.no_grad()
+    def scale_input(self, x):
+        x = x.to(self.device)
+        if x.shape[-1] == 7 and len(self.x_mean) == 30:      # one-hot kitchen goals pass through
+            return x
+        if self.scale_data:
+            return ((x - self.x_mean) / (self.x_std + 1e-12)).to(torch.float32)
+        return x
+
+    @torch.no_grad()
+    def scale_output(self, y):
+        y = y.to(self.device)
+        if self.scale_data:
+            return ((y - self.y_mean) / (self.y_std + 1e-12)).to(torch.float32)
+        return y
+
+    @torch.no_grad()
+    def inverse_scale_input(self, x):
+        return x * (self.x_std + 1e-12) + self.x_mean if self.scale_data else x
+
+    @torch.no_grad()
+    def inverse_scale_output(self, y):
+        y = y.to(self.device)
+        return y * (self.y_std + 1e-12) + self.y_mean if self.scale_data else y
+
+    @torch.no_grad()
+    def clip_action(self, y):
+        """Clamp to 1.1 x the data bounds (scaler_class.py:162-166)."""
+        lo, hi = self.y_bounds_tensor[0] * 1.1, self.y_bounds_tensor[1] * 1.1
+        return torch.clamp(y, lo, hi).to(self.device).to(torch.float32)

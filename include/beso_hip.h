@@ -1,0 +1,152 @@
+/*
+ * beso_hip.h -- C ABI of libbeso_hip.so: the MI355X (gfx950) implementation of BESO's
+ * score-denoising hot path.
+ *
+ * The reference (intuitive-robots/beso) is pure Python/PyTorch and has no FFI of its own; the
+ * boundary below is what a binding for this path would bind.  Each entry point names the
+ * reference interface it replaces (file:line relative to the reference checkout):
+ *
+ *   beso_pack_weights   <- GCDenoiser.state_dict() / load_state_dict   beso_agent.py:458-476
+ *   beso_score_fwd      <- DiffusionGPT.forward                        k_diffusion/score_gpts.py:272-358
+ *   beso_denoise_fwd    <- GCDenoiser.forward                          k_diffusion/score_wrappers.py:81-96
+ *                          (+ ClassifierFreeSampleModel.forward        k_diffusion/classifier_free_sampler.py:35-49)
+ *   beso_sampler_step   <- the per-step update of sample_ddim/_euler/_heun
+ *                                                                      k_diffusion/gc_sampling.py:205-210,296-310,921-923
+ *   beso_sample         <- sample_ddim / sample_euler / sample_heun    k_diffusion/gc_sampling.py:167-213,259-314,895-924
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes.  No torch types.  `stream` is a hipStream_t passed as void*.
+ *   - every tensor is device memory, contiguous, fp32, owned by the caller.  The library never
+ *     allocates or frees device memory and never synchronises the stream; work is enqueued on
+ *     `stream` and the call returns.
+ *   - return value: 0 = ok, negative = error (see beso_status_string).  Bad shapes and unsupported
+ *     configurations are rejected before anything is enqueued.
+ *   - thread-safety: calls on distinct workspaces/streams are independent; a workspace must not be
+ *     shared by concurrent calls.
+ */
+#ifndef BESO_HIP_H
+#define BESO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* DiffusionGPT.__init__ kwargs that shape the computation (score_gpts.py:121-139) + GCDenoiser.sigma_data. */
+typedef struct beso_config {
+    int32_t obs_dim;        /* state_dim                                                      */
+    int32_t act_dim;        /* action_dim                                                     */
+    int32_t embed_dim;      /* D                                                              */
+    int32_t n_layers;       /* L                                                              */
+    int32_t n_heads;        /* H,  D % H == 0                                                 */
+    int32_t goal_seq_len;   /* G actually used: 0 when goal_conditioned is False (:143-144)   */
+    int32_t obs_seq_len;    /* W (window_size); block_size = G + 2W + 1 (:148)                */
+    int32_t linear_output;  /* 1: action_pred = Linear(D, act); 0: Linear(D,100)-SiLU-Linear  */
+    float   sigma_data;     /* GCDenoiser.sigma_data (score_wrappers.py:29)                   */
+} beso_config;
+
+/* arithmetic of the GEMMs (everything else -- residual stream, LayerNorm, softmax, GELU,
+ * preconditioning, sampler update -- is fp32 in every mode) */
+enum {
+    BESO_PREC_BF16 = 0,   /* bf16 MFMA inputs, fp32 accumulate: throughput mode                 */
+    BESO_PREC_FP32 = 1,   /* fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32: parity mode  */
+    BESO_PREC_BF16X3 = 2  /* split-bf16 (hi*hi + hi*lo + lo*hi), fp32-class accuracy            */
+};
+
+/* beso_denoise_fwd / beso_score_fwd flags */
+enum {
+    BESO_FLAG_UNCOND = 1  /* DiffusionGPT.forward(uncond=True): goals := 0 (score_gpts.py:301-302) */
+};
+
+/* sampler ids for beso_sample / beso_sampler_step */
+enum {
+    BESO_SAMPLER_DDIM = 0,   /* gc_sampling.py:895-924 */
+    BESO_SAMPLER_EULER = 1,  /* gc_sampling.py:167-213, s_churn = 0 */
+    BESO_SAMPLER_HEUN = 2    /* gc_sampling.py:259-314, s_churn = 0 */
+};
+
+/* status codes */
+enum {
+    BESO_OK = 0,
+    BESO_ERR_BAD_CONFIG = -1,      /* config fields out of range / D % H != 0                      */
+    BESO_ERR_BAD_SHAPE = -2,       /* batch < 1, t < 1, t > obs_seq_len (score_gpts.py:282)         */
+    BESO_ERR_BAD_ARG = -3,         /* null pointer, unknown precision / sampler / flag              */
+    BESO_ERR_WORKSPACE = -4,       /* workspace or packed buffer too small                          */
+    BESO_ERR_UNSUPPORTED = -5,     /* configuration this build has no kernel for                    */
+    BESO_ERR_HIP = -6              /* a HIP runtime call failed (hipGetLastError has the detail)     */
+};
+
+const char* beso_version(void);
+const char* beso_status_string(int status);
+
+/* Number of parameter tensors, in the order of the reference module's named_parameters():
+ * pos_emb, tok_emb.{weight,bias}, per block {ln1,ln2}.{weight,bias}, attn.{key,query,value,proj}.{weight,bias},
+ * mlp.{0,2}.{weight,bias}; ln_f.{weight,bias}, sigma_emb.{weight,bias}, action_emb.{weight,bias},
+ * action_pred[.0/.2].{weight,bias}.  Linear weights are torch layout [out, in], fp32.            */
+int beso_num_params(const beso_config* cfg);
+
+/* Size of the packed-weight image for `precision`, in bytes (0 on bad config). */
+size_t beso_packed_bytes(const beso_config* cfg, int precision);
+
+/* Re-lay the fp32 parameters (host array `params` of `n_params` DEVICE pointers, order above) into
+ * the kernel-ready image `packed` (device, >= beso_packed_bytes): fused QKV rows, bf16 (or fp32)
+ * GEMM operands zero-padded to the MFMA tile grid.  Call again whenever a parameter changes
+ * (optimizer step, EMA swap, load_state_dict).                                                   */
+int beso_pack_weights(const beso_config* cfg, const float* const* params, int n_params,
+                      void* packed, size_t packed_bytes, int precision, void* stream);
+
+/* Scratch needed by one forward over `batch` samples with `t` observations in the window
+ * (T = 1 + G + 2t tokens each).  `cfg_guidance` != 0 doubles the token count (cond + uncond).    */
+size_t beso_workspace_bytes(const beso_config* cfg, int batch, int t, int precision, int cfg_guidance);
+
+/* DiffusionGPT.forward (eval mode): out[batch,t,act] = F(states[batch,t,obs], actions[batch,t,act],
+ * goals[batch,G,obs], sigma[batch]).  No preconditioning.                                        */
+int beso_score_fwd(const beso_config* cfg, const void* packed, int precision,
+                   const float* state, const float* action, const float* goal, const float* sigma,
+                   float* out, int batch, int t, int flags,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* GCDenoiser.forward: out = F(state, action*c_in, goal, sigma)*c_out + action*c_skip.
+ * cond_lambda reproduces ClassifierFreeSampleModel: 1 -> conditional only, 0 -> unconditional only,
+ * otherwise out_u + cond_lambda*(out_c - out_u) evaluated as ONE 2*batch pass.                    */
+int beso_denoise_fwd(const beso_config* cfg, const void* packed, int precision,
+                     const float* state, const float* action, const float* goal, const float* sigma,
+                     float* out, int batch, int t, int flags, float cond_lambda,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* One sampler update, elementwise over n fp32 values, in the reference's operation order:
+ *   BESO_STEP_DDIM         out = c0*x - c1*den              c0 = sigma_fn(t_next)/sigma_fn(t), c1 = expm1(-h)   gc_sampling.py:921-923
+ *   BESO_STEP_EULER        d = (x - den)/c0; out = x + d*c1                 c0 = sigma_hat, c1 = dt              :205-210
+ *   BESO_STEP_HEUN_PREDICT d = (x - den)/c0; aux = d; out = x + d*c1        (out = action_2)                     :296-305
+ *   BESO_STEP_HEUN_CORRECT d2 = (x2 - den)/c0; out = x + ((aux + d2)/2)*c1  c0 = sigma_{i+1}                     :306-310
+ * out may alias x.  x2 / aux may be NULL for the modes that do not use them.                     */
+enum { BESO_STEP_DDIM = 0, BESO_STEP_EULER = 1, BESO_STEP_HEUN_PREDICT = 2, BESO_STEP_HEUN_CORRECT = 3 };
+int beso_sampler_step(int mode, float* out, float* aux, const float* x, const float* x2, const float* den,
+                      float c0, float c1, size_t n, void* stream);
+
+/* A whole sampling loop: x[batch,t,act] holds x_T on entry and the sample on return.
+ * `sigmas` is a HOST array of n_sigmas values, the last one 0 (get_sigmas_*: gc_sampling.py:26-44).
+ * No host synchronisation inside: all n_sigmas-1 steps are enqueued back to back.                */
+int beso_sample(const beso_config* cfg, const void* packed, int precision, int sampler,
+                const float* state, const float* goal, float* x, int batch, int t,
+                const float* sigmas, int n_sigmas, float cond_lambda,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* Timing hooks for bench.py: HIP events are recorded on the launch stream around every launch of
+ * the selected launch site while enabled (site 0 = off).  beso_profile_read synchronises the
+ * recorded events, returns their summed elapsed time and count, and clears them.               */
+enum {
+    BESO_SITE_OFF = 0, BESO_SITE_GEMM_QKV = 1, BESO_SITE_GEMM_PROJ = 2, BESO_SITE_GEMM_FC1 = 3,
+    BESO_SITE_GEMM_FC2 = 4, BESO_SITE_ATTENTION = 5, BESO_SITE_LAYERNORM = 6, BESO_SITE_EMBED = 7,
+    BESO_SITE_HEAD = 8, BESO_SITE_FORWARD = 9 /* one whole score-net forward */,
+    BESO_SITE_FUSED_LAYER = 10 /* fused per-layer kernel (fused path) */
+};
+void beso_profile_enable(int site);
+int  beso_profile_read(double* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BESO_HIP_H */

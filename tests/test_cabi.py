@@ -1,0 +1,103 @@
+"""C-ABI checks that need no GPU: the shared library loads, exports every symbol that
+include/beso_hip.h declares, and rejects bad configs / shapes before touching the device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from beso_amd import _lib
+from beso_amd.runtime import ScoreNetShape
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from beso_amd.build import build
+    build(verbose=False)
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "beso_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(beso_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 12
+    assert sorted(_lib.EXPORTS) == names, "binding list and header disagree"
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_version_and_status_strings(lib):
+    assert b"gfx950" in lib.beso_version()
+    assert lib.beso_status_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5, -6):
+        assert lib.beso_status_string(code) not in (b"ok", b"unknown status")
+
+
+def test_sizes_for_shipped_shapes(lib):
+    kitchen = ScoreNetShape(30, 9, 360, 6, 6, 2, 4, True, 0.5).c_struct()
+    assert lib.beso_num_params(C.byref(kitchen)) == 107           # 113 state_dict entries - 6 mask buffers
+    bf16 = lib.beso_packed_bytes(C.byref(kitchen), _lib.PREC_BF16)
+    fp32 = lib.beso_packed_bytes(C.byref(kitchen), _lib.PREC_FP32)
+    assert 18_000_000 < bf16 < fp32 < 90_000_000
+    ws1 = lib.beso_workspace_bytes(C.byref(kitchen), 4096, 4, _lib.PREC_BF16, 0)
+    ws2 = lib.beso_workspace_bytes(C.byref(kitchen), 4096, 4, _lib.PREC_BF16, 1)
+    assert 0 < ws1 < ws2 < 4 * ws1
+    # t outside [1, W] is a shape error (score_gpts.py:282), reported as size 0 here
+    assert lib.beso_workspace_bytes(C.byref(kitchen), 4, 5, _lib.PREC_BF16, 0) == 0
+    assert lib.beso_workspace_bytes(C.byref(kitchen), 0, 4, _lib.PREC_BF16, 0) == 0
+
+
+def test_bad_config_is_rejected(lib):
+    bad = ScoreNetShape(30, 9, 361, 6, 6, 2, 4, True, 0.5).c_struct()    # D % H != 0
+    assert lib.beso_num_params(C.byref(bad)) == 0
+    assert lib.beso_packed_bytes(C.byref(bad), _lib.PREC_BF16) == 0
+    st = lib.beso_denoise_fwd(C.byref(bad), None, 0, None, None, None, None, None, 1, 1, 0, 1.0, None, 0, None)
+    assert st == -1
+    with pytest.raises(ValueError):
+        _lib.check(st, "denoise")
+
+
+def test_null_and_shape_errors_do_not_touch_the_device(lib):
+    cfg = ScoreNetShape(7, 3, 48, 2, 6, 2, 3, True, 0.5).c_struct()
+    one = C.c_void_p(16)
+    # t > obs_seq_len
+    st = lib.beso_denoise_fwd(C.byref(cfg), one, 0, one, one, one, one, one, 2, 9, 0, 1.0, one, 1 << 30, None)
+    assert st == -2
+    # null pointers
+    st = lib.beso_denoise_fwd(C.byref(cfg), None, 0, one, one, one, one, one, 2, 2, 0, 1.0, one, 1 << 30, None)
+    assert st == -3
+    # unknown precision / flag / sampler
+    assert lib.beso_denoise_fwd(C.byref(cfg), one, 7, one, one, one, one, one, 2, 2, 0, 1.0, one, 1 << 30, None) == -3
+    assert lib.beso_denoise_fwd(C.byref(cfg), one, 0, one, one, one, one, one, 2, 2, 8, 1.0, one, 1 << 30, None) == -3
+    sig = (C.c_float * 3)(1.0, 0.5, 0.0)
+    assert lib.beso_sample(C.byref(cfg), one, 0, 9, one, one, one, 2, 2, sig, 3, 1.0, one, 1 << 30, None) == -3
+    # workspace too small
+    st = lib.beso_denoise_fwd(C.byref(cfg), one, 0, one, one, one, one, one, 2, 2, 0, 1.0, one, 16, None)
+    assert st == -4
+    with pytest.raises(_lib.BesoHipError):
+        _lib.check(st)
+    # sampler step argument checks
+    assert lib.beso_sampler_step(9, one, None, one, None, one, 1.0, 1.0, 4, None) == -3
+    assert lib.beso_sampler_step(_lib.STEP_HEUN_CORRECT, one, one, one, None, one, 1.0, 1.0, 4, None) == -3
+    assert lib.beso_sampler_step(_lib.STEP_DDIM, one, None, one, None, one, 1.0, 1.0, 0, None) == 0
+
+
+def test_product_path_has_no_cpu_fallback():
+    """CPU tensors must raise, not silently compute somewhere else."""
+    import torch
+    from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
+    from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser
+    inner = DiffusionGPT(state_dim=7, device="cpu", goal_conditioned=True, action_dim=3, embed_dim=48,
+                         embed_pdrob=0, attn_pdrop=0, resid_pdrop=0, n_layers=2, n_heads=6, goal_seq_len=2,
+                         obs_seq_len=3, sigma_vocab_size=3, time_embedding_fn=None, linear_output=True)
+    m = GCDenoiser(inner, sigma_data=0.5).eval()
+    s, a, g = torch.zeros(2, 3, 7), torch.zeros(2, 3, 3), torch.zeros(2, 2, 7)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="GPU"):
+        m(s, a, g, torch.ones(2))

@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference interface, checked on CPU.  The score network itself is
+replaced by an oracle-backed callable here (the samplers and the agent accept any
+``model(state, action, goal, sigma)``); the HIP network is checked in the ``-m gpu`` tests."""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import beso_oracle as O
+from conftest import load_golden, weights_from_fixture, rel_err
+
+from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+from beso_amd.agents.diffusion_agents.k_diffusion import utils as kutils
+from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
+from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser
+from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
+from beso_amd.agents.diffusion_agents.beso_agent import BesoAgent
+from beso_amd.agents.input_encoders.obs_encoder import NoEncoder
+from beso_amd.networks.ema_helper.ema import ExponentialMovingAverage
+from beso_amd.networks.scaler.scaler_class import Scaler
+from beso_amd._instantiate import instantiate
+
+
+class OracleModel(torch.nn.Module):
+    """tests-only stand-in for the score network: evaluates the CPU oracle."""
+
+    def __init__(self, w, cfg, cond_lambda=None):
+        super().__init__()
+        self.w, self.cfg, self.cond_lambda = w, cfg, cond_lambda
+        self.dummy = torch.nn.Parameter(torch.zeros(1))      # optimizers refuse an empty parameter list
+
+    def forward(self, state, action, goal, sigma, uncond=False, **kw):
+        s, a, g, sg = (t.detach().cpu().numpy() for t in (state, action, goal, sigma))
+        if self.cond_lambda is None:
+            out = O.denoise(self.w, self.cfg, s, a, g, sg, uncond=uncond)
+        else:
+            out = O.denoise_cfg(self.w, self.cfg, s, a, g, sg, self.cond_lambda)
+        return torch.from_numpy(np.ascontiguousarray(out))
+
+    def get_params(self):
+        return self.parameters()
+
+
+def make_module(cfg: O.ScoreGPTConfig, **kw):
+    inner = functools.partial(
+        DiffusionGPT, state_dim=cfg.obs_dim, device="cpu", goal_conditioned=cfg.goal_conditioned,
+        action_dim=cfg.act_dim, embed_dim=cfg.embed_dim, embed_pdrob=0.0, attn_pdrop=kw.get("attn_pdrop", 0.0),
+        resid_pdrop=0.0, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=cfg.goal_seq_len,
+        obs_seq_len=cfg.obs_seq_len, sigma_vocab_size=3, time_embedding_fn=None,
+        goal_drop=kw.get("goal_drop", 0.0), linear_output=cfg.linear_output)
+    return GCDenoiser(inner, sigma_data=cfg.sigma_data)
+
+
+def load_weights(module, w):
+    sd = module.state_dict()
+    for k, v in w.items():
+        assert k in sd, k
+        sd[k] = torch.from_numpy(v.copy())
+    module.load_state_dict(sd)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["kitchen", "block_push", "tiny", "tiny_mlp_head", "tiny_nogoal"])
+def test_module_has_the_reference_parameter_layout(name):
+    cfg = O.CONFIGS[name]
+    m = make_module(cfg)
+    shapes = O.param_shapes(cfg)          # the reference's named_parameters() order (asserted in make_fixtures.py)
+    assert [n for n, _ in m.named_parameters()] == [n for n, _ in shapes]
+    assert [tuple(p.shape) for _, p in m.named_parameters()] == [s for _, s in shapes]
+    masks = [k for k in m.state_dict() if k.endswith("attn.mask")]
+    assert len(masks) == cfg.n_layers and len(m.state_dict()) == len(shapes) + cfg.n_layers
+    assert m.state_dict()[masks[0]].shape == (1, 1, cfg.block_size, cfg.block_size)
+    assert list(m.get_params()) == list(m.inner_model.parameters())
+
+
+def test_autograd_training_forward_matches_reference_vectors():
+    """The differentiable evaluation used by train_step reproduces the reference's forward, loss and
+    parameter gradients (tiny_loss.npz was produced by the reference's loss.backward())."""
+    fx = load_golden("tiny_loss.npz")
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    m = make_module(cfg)
+    load_weights(m, w)
+    m.train()
+    T = lambda k: torch.from_numpy(fx[k].copy())        # noqa: E731
+    loss = m.loss(T("state"), T("action"), T("goal"), T("noise"), T("sigma"))
+    assert abs(loss.item() - float(fx["loss"])) < 2e-6 * abs(float(fx["loss"]))
+    loss.backward()
+    for n, p in m.named_parameters():
+        assert abs(p.grad.norm().item() - float(fx["gnorm::" + n])) <= 2e-4 * float(fx["gnorm::" + n]) + 1e-9, n
+        np.testing.assert_allclose(p.grad.reshape(-1)[:8].numpy(), fx["gslice::" + n], rtol=2e-3, atol=1e-7)
+    fwd = load_golden("tiny_forward.npz")
+    w2 = weights_from_fixture(fwd)
+    load_weights(m, w2)
+    m.eval()
+    for t in fwd["ts"]:
+        p = f"t{int(t)}::"
+        x = m.inner_model._forward_autograd(*(torch.from_numpy(fwd[p + k].copy()) for k in ("state", "action", "goal", "sigma")), False)
+        assert rel_err(x.detach().numpy(), fwd[p + "inner"]) < 2e-5
+
+
+def test_schedules_match_reference():
+    fx = load_golden("schedules.npz")
+    fns = {"exponential": lambda n: ks.get_sigmas_exponential(n, 0.005, 1.0),
+           "linear": lambda n: ks.get_sigmas_linear(n, 0.005, 1.0),
+           "karras": lambda n: ks.get_sigmas_karras(n, 0.005, 1.0, 5.0),
+           "polyexponential": lambda n: ks.get_sigmas_polyexponential(n, 0.005, 1.0),
+           "vp": lambda n: ks.get_sigmas_vp(n), "ve": lambda n: ks.get_sigmas_ve(n, 0.005, 1.0),
+           "cosine_beta": lambda n: ks.cosine_beta_schedule(n)}
+    for key, ref in fx.items():
+        name, n = key.rsplit("_", 1)
+        np.testing.assert_array_equal(fns[name](int(n)).numpy(), ref, err_msg=key)
+
+
+@pytest.mark.parametrize("fixture,cfg_name", [("kitchen_samplers.npz", "kitchen"),
+                                              ("block_push_heun_cfg.npz", "block_push")])
+def test_generic_sampler_loops_match_reference(fixture, cfg_name):
+    fx = load_golden(fixture)
+    cfg = O.CONFIGS[cfg_name]
+    w = O.make_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    lam = float(fx["cond_lambda"])
+    model = OracleModel(w, cfg, None if lam < 0 else lam)
+    fns = {"ddim": ks.sample_ddim, "euler": ks.sample_euler, "heun": ks.sample_heun, "dpmpp_2m": ks.sample_dpmpp_2m,
+           "dpm": ks.sample_dpm_2, "dpmpp_2s": ks.sample_dpmpp_2s}
+    T = lambda k: torch.from_numpy(fx[k].copy())        # noqa: E731
+    for key in sorted(k[:-5] for k in fx if k.endswith("::out")):
+        n = int(key.split("_")[-2])
+        if n > 10:
+            continue                                    # the 50-step case is covered by the oracle test
+        sampler = key[: key.index(f"_{n}_")]
+        out = fns[sampler](model, T("state"), T("x_t"), T("goal"), torch.from_numpy(fx[key + "::sigmas"]), disable=True)
+        assert rel_err(out.numpy(), fx[key + "::out"]) < 5e-5, key
+
+
+def test_euler_ancestral_consumes_the_same_random_stream_as_the_reference():
+    fx = load_golden("tiny_euler_ancestral.npz")
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=int(fx["seed"]), std=0.02)
+    torch.manual_seed(4321)
+    out = ks.sample_euler_ancestral(OracleModel(w, cfg), *(torch.from_numpy(fx[k].copy()) for k in ("state", "x_t", "goal")),
+                                    torch.from_numpy(fx["sigmas"]), disable=True)
+    assert rel_err(out.numpy(), fx["out"]) < 2e-5
+
+
+def test_cfg_wrapper_semantics():
+    fx = load_golden("block_push_cfg.npz")
+    cfg = O.BLOCK_PUSH
+    w = O.make_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    T = lambda k: torch.from_numpy(fx[k].copy())        # noqa: E731
+    for lam in fx["lambdas"]:
+        m = ClassifierFreeSampleModel(OracleModel(w, cfg), float(lam))
+        out = m(T("state"), T("action"), T("goal"), T("sigma"))
+        assert rel_err(out.numpy(), fx[f"lam{float(lam)}"]) < 2e-5
+
+
+def test_sigma_density_matches_reference():
+    fx = load_golden("tiny_loss.npz")
+    torch.manual_seed(7)
+    s = kutils.rand_log_logistic((64,), loc=np.log(0.5), scale=0.5, min_value=0.005, max_value=1.0)
+    np.testing.assert_allclose(s.numpy(), fx["loglogistic::sigma"], rtol=1e-6)
+    assert kutils.append_dims(torch.ones(3), 3).shape == (3, 1, 1)
+    with pytest.raises(ValueError):
+        kutils.append_dims(torch.ones(3, 1, 1), 2)
+
+
+def test_ema_rule():
+    p = [torch.nn.Parameter(torch.ones(4, 3)), torch.nn.Parameter(torch.zeros(5))]
+    ema = ExponentialMovingAverage(p, 0.999, "cpu")
+    with torch.no_grad():
+        p[0].mul_(3.0)
+        p[1].add_(2.0)
+    ema.update(p)                                        # decay = min(0.999, 2/11)
+    d = 2 / 11
+    np.testing.assert_allclose(ema.shadow_params[0].numpy(), 1 - (1 - d) * (1 - 3.0), rtol=1e-6)
+    np.testing.assert_allclose(ema.shadow_params[1].numpy(), 0 - (1 - d) * (0 - 2.0), rtol=1e-6)
+    ema.store(p)
+    ema.copy_to(p)
+    np.testing.assert_allclose(p[1].detach().numpy(), ema.shadow_params[1].numpy())
+    ema.restore(p)
+    np.testing.assert_allclose(p[1].detach().numpy(), 2.0)
+    with pytest.raises(ValueError):
+        ExponentialMovingAverage(p, 1.5)
+
+
+def test_instantiate_shim():
+    enc = instantiate({"_target_": "beso_amd.agents.input_encoders.obs_encoder.NoEncoder", "_recursive_": False,
+                       "device": "cpu", "state_modality": "observation", "goal_modality": "goal_observation"})
+    assert isinstance(enc, NoEncoder)
+    assert instantiate(functools.partial(dict, a=1), b=2) == {"a": 1, "b": 2}
+    with pytest.raises(TypeError):
+        instantiate(3)
+
+
+# ------------------------------------------------------------------------------------------------
+def build_agent(cfg, model_factory, device="cpu", sampler="ddim"):
+    return BesoAgent(
+        model=model_factory,
+        input_encoder=functools.partial(NoEncoder, device=device, state_modality="observation",
+                                        goal_modality="goal_observation"),
+        optimization=lambda params: torch.optim.AdamW(params, lr=1e-4),
+        device=device, obs_modalities=["observation"], goal_modalities=["goal_observation"],
+        target_modality="action", max_train_steps=10, max_epochs=1, train_method="steps", eval_every_n_steps=5,
+        use_ema=True, goal_conditioned=True, pred_last_action_only=False, rho=5.0, num_sampling_steps=3,
+        lr_scheduler=lambda optimizer: torch.optim.lr_scheduler.StepLR(optimizer, 100, 0.99),
+        sampler_type=sampler, sigma_data=cfg.sigma_data, sigma_min=0.005, sigma_max=1.0,
+        sigma_sample_density_type="loglogistic", sigma_sample_density_mean=-0.6, sigma_sample_density_std=1.6,
+        decay=0.999, update_ema_every_n_steps=1, window_size=cfg.obs_seq_len, goal_window_size=cfg.goal_seq_len)
+
+
+def run_agent_trace(agent, fx, device="cpu"):
+    """Replays tiny_agent_trace.npz: returns max relative error of the predicted actions."""
+    agent.get_scaler(Scaler(fx["x_data"], fx["y_data"], True, device))
+    agent.set_bounds(agent.scaler)
+    agent.reset()
+    goal = torch.from_numpy(fx["goal"].copy())
+    worst = 0.0
+    for c in range(int(fx["n_calls"])):
+        noise = torch.from_numpy(fx[f"call{c}::noise"])
+        real_randn = torch.randn
+        try:   # inject the x_T draw the reference made (beso_agent.py:357); RNG parity is by injection
+            torch.randn = lambda *a, **k: noise.to(k.get("device", "cpu")).clone()
+            pred = agent.predict({"observation": torch.from_numpy(fx[f"call{c}::obs"].copy()),
+                                  "goal_observation": goal}, new_sampler_type="ddim", new_sampling_steps=3,
+                                 get_mean=None, extra_args={}, noise_scheduler="exponential")
+        finally:
+            torch.randn = real_randn
+        assert tuple(pred.shape) == tuple(fx[f"call{c}::pred_shape"]), (c, pred.shape)   # [1,1,act] then [1,act]
+        worst = max(worst, rel_err(pred.detach().cpu().numpy(), fx[f"call{c}::pred"]))
+    return worst
+
+
+def test_agent_predict_trace_matches_reference():
+    fx = load_golden("tiny_agent_trace.npz")
+    cfg = O.TINY
+    w = weights_from_fixture(fx)
+    agent = build_agent(cfg, lambda: OracleModel(w, cfg))
+    assert run_agent_trace(agent, fx) < 5e-5
+    assert len(agent.obs_context) == cfg.obs_seq_len and len(agent.action_context) == cfg.obs_seq_len - 1
+    agent.reset()
+    assert len(agent.obs_context) == 0 and len(agent.action_context) == 0
+
+
+def test_agent_surface_and_error_conventions():
+    cfg = O.TINY
+    agent = build_agent(cfg, lambda: OracleModel(O.make_weights(cfg), cfg))
+    with pytest.raises(ValueError, match="sampler"):
+        agent.sample_loop(torch.tensor([1.0, 0.0]), torch.zeros(1, 1, 3), torch.zeros(1, 1, 7), torch.zeros(1, 2, 7), "nope")
+    with pytest.raises(ValueError):
+        agent.get_noise_schedule(3, "nope")
+    with pytest.raises(KeyError):      # non-empty extra_args must carry both keys (beso_agent.py:408-410)
+        agent.sample_loop(torch.tensor([1.0, 0.0]), torch.zeros(1, 1, 3), torch.zeros(1, 1, 7), torch.zeros(1, 2, 7),
+                          "ddim", {"s_churn": 1})
+    for kind in ("loglogistic", "lognormal", "loguniform", "uniform", "v-diffusion"):
+        agent.sigma_sample_density_type = kind
+        s = agent.make_sample_density()(shape=(16,), device="cpu")
+        assert s.shape == (16,) and bool((s > 0).all())
+    agent.sigma_sample_density_type = "nope"
+    with pytest.raises(ValueError):
+        agent.make_sample_density()
+    for name in ("karras", "exponential", "vp", "linear", "cosine_beta", "ve", "iddpm"):
+        sig = agent.get_noise_schedule(5, name)
+        assert sig.shape == (6,) and float(sig[-1]) == 0.0
+
+
+def test_train_step_and_checkpoint_roundtrip(tmp_path):
+    """train_step (autograd path), EMA update, store_model_weights / load_pretrained_model formats
+    (model_state_dict.pth = EMA weights, non_ema_model_state_dict.pth = raw: beso_agent.py:466-476)."""
+    cfg = O.TINY
+    agent = build_agent(cfg, lambda: make_module(cfg, attn_pdrop=0.1, goal_drop=0.1))
+    rng = np.random.default_rng(0)
+    x_data = rng.standard_normal((40, cfg.obs_dim)).astype(np.float32)
+    y_data = rng.uniform(-1, 1, (40, cfg.act_dim)).astype(np.float32)
+    agent.get_scaler(Scaler(x_data, y_data, True, "cpu"))
+    batch = {"observation": torch.randn(8, cfg.obs_seq_len, cfg.obs_dim),
+             "goal_observation": torch.randn(8, cfg.goal_seq_len, cfg.obs_dim),
+             "action": torch.rand(8, cfg.obs_seq_len, cfg.act_dim) * 2 - 1}
+    before = [p.detach().clone() for p in agent.model.parameters()]
+    l0 = agent.train_step(batch)
+    assert np.isfinite(l0) and agent.steps == 1 and agent.ema_helper.num_updates == 1
+    assert any(not torch.equal(a, b) for a, b in zip(before, agent.model.parameters()))
+    agent.working_dir = str(tmp_path)
+    agent.store_model_weights(str(tmp_path))
+    ema_sd = torch.load(tmp_path / "model_state_dict.pth")
+    raw_sd = torch.load(tmp_path / "non_ema_model_state_dict.pth")
+    assert list(ema_sd) == list(agent.model.state_dict()) == list(raw_sd)
+    k = "inner_model.tok_emb.weight"
+    assert torch.equal(raw_sd[k], agent.model.state_dict()[k])
+    assert torch.allclose(ema_sd[k], agent.ema_helper.shadow_params[1]) and not torch.equal(ema_sd[k], raw_sd[k])
+    agent2 = build_agent(cfg, lambda: make_module(cfg))
+    agent2.load_pretrained_model(str(tmp_path))
+    assert torch.equal(agent2.model.state_dict()[k], ema_sd[k])
+    assert torch.equal(agent2.ema_helper.shadow_params[1], ema_sd[k])
