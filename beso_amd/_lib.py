@@ -18,7 +18,7 @@ SITES = {"off": 0, "gemm_qkv": 1, "gemm_proj": 2, "gemm_fc1": 3, "gemm_fc2": 4, 
          "layernorm": 6, "embed": 7, "head": 8, "forward": 9, "fused_layer": 10}
 
 # every symbol include/beso_hip.h declares (tests check that the library exports all of them)
-EXPORTS = ["beso_version", "beso_status_string", "beso_num_params", "beso_packed_bytes", "beso_pack_weights",
+EXPORTS = ["beso_version", "beso_status_string", "beso_last_error", "beso_num_params", "beso_packed_bytes", "beso_pack_weights",
            "beso_workspace_bytes", "beso_score_fwd", "beso_denoise_fwd", "beso_sampler_step", "beso_sample",
            "beso_profile_enable", "beso_profile_read"]
 
@@ -46,6 +46,11 @@ def load() -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
+        # torch bundles its own libamdhip64.so.7; it must be the HIP runtime of the process BEFORE this
+        # library is mapped, so that both resolve to the same runtime instance (streams and device
+        # pointers are handed across).  Loading ours first would pull in /opt/rocm's copy as a second
+        # runtime and every launch on a torch stream would fail.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise BesoHipError(
                 f"{LIB_PATH} not found: build it with `python -m beso_amd.build` (hipcc, gfx950). "
@@ -57,6 +62,8 @@ def load() -> C.CDLL:
         lib.beso_version.argtypes = []
         lib.beso_status_string.restype = C.c_char_p
         lib.beso_status_string.argtypes = [i32]
+        lib.beso_last_error.restype = C.c_char_p
+        lib.beso_last_error.argtypes = []
         lib.beso_num_params.restype = i32
         lib.beso_num_params.argtypes = [cfgp]
         lib.beso_packed_bytes.restype = sz
@@ -92,4 +99,6 @@ def check(status: int, what: str = "") -> None:
     text = f"beso_hip: {what + ': ' if what else ''}{msg} (status {status})"
     if status in (-1, -2, -3, -5):
         raise ValueError(text)
+    if status == -6:
+        text += ": " + load().beso_last_error().decode()
     raise BesoHipError(text)

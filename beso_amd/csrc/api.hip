@@ -3,6 +3,7 @@
 // enqueued on the caller's stream.
 #include <math.h>
 #include <string.h>
+#include <stdio.h>
 #include <vector>
 #include <mutex>
 #include "common.h"
@@ -129,10 +130,15 @@ void profile_end(int site, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // one forward of the score network (unfused generic path)
 // ---------------------------------------------------------------------------------------------
-#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return BESO_ERR_HIP; } while (0)
+static thread_local char g_last_error[256] = "";
+static int record_hip_error(hipError_t e, const char* what, int line) {
+    snprintf(g_last_error, sizeof(g_last_error), "%s (%d) from `%s` at api.hip:%d", hipGetErrorName(e), (int)e, what, line);
+    return BESO_ERR_HIP;
+}
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return record_hip_error(_e, #expr, __LINE__); } while (0)
 
 static int forward_generic(const Layout& lay, const Workspace& ws, const char* packed, int precision,
-                           const FwdArgs& a, char* wsp, hipStream_t s) {
+                           const FwdArgs& a, char* wsp, hipStream_t s, bool fused_mlp) {
     float* x = (float*)(wsp + ws.x);
     void* xn = wsp + ws.xn; void* qkv = wsp + ws.qkv; void* y = wsp + ws.y; void* h = wsp + ws.h;
     const int M = a.vbatch * a.T;
@@ -156,6 +162,14 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
         HIP_TRY(launch_gemm(precision, EPI_BIAS_RESID, y, lay.Kd, packed + o.w_proj, lay.Kd, F(o.b_proj), x, lay.D,
                             lay.D, M, lay.Nd, lay.Kd, s));
         profile_end(BESO_SITE_GEMM_PROJ, s);
+        if (fused_mlp) {
+            // LN2 + FC1 + GELU + FC2 + residual as one kernel, hidden activations never leave the CU
+            profile_begin(BESO_SITE_FUSED_LAYER, s);
+            int st = fused_mlp_block(lay, packed, l, x, M, s);
+            profile_end(BESO_SITE_FUSED_LAYER, s);
+            if (st != BESO_OK) return st;
+            continue;
+        }
         HIP_TRY(launch_layernorm(x, F(o.ln2_w), F(o.ln2_b), xn, M, lay.D, lay.Kd, precision, s));
         profile_begin(BESO_SITE_GEMM_FC1, s);
         HIP_TRY(launch_gemm(precision, EPI_BIAS_GELU_STORE, xn, lay.Kd, packed + o.w_fc1, lay.Kd, F(o.b_fc1), h,
@@ -203,11 +217,8 @@ static int forward(const beso_config* cfg, const void* packed, int precision, co
     a.uncond_from = two ? batch : (uncond ? 0 : a.vbatch);
     a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
     profile_begin(BESO_SITE_FORWARD, s);
-    int r;
-    if (fused_supported(lay, a, precision))
-        r = forward_fused(lay, ws, (const char*)packed, precision, a, (char*)workspace, s);
-    else
-        r = forward_generic(lay, ws, (const char*)packed, precision, a, (char*)workspace, s);
+    int r = forward_generic(lay, ws, (const char*)packed, precision, a, (char*)workspace, s,
+                            fused_supported(lay, a, precision));
     profile_end(BESO_SITE_FORWARD, s);
     return r;
 }
@@ -219,6 +230,8 @@ using namespace beso;
 extern "C" {
 
 const char* beso_version(void) { return "beso_hip 0.1 (gfx950)"; }
+
+const char* beso_last_error(void) { return g_last_error; }
 
 const char* beso_status_string(int st) {
     switch (st) {

@@ -21,6 +21,7 @@ __global__ void pack_matrix_kernel(const float* __restrict__ src, int rows, int 
 
 hipError_t launch_pack_matrix(const float* src, int rows, int cols, void* dst, int rows_p, int cols_p,
                               int precision, hipStream_t s) {
+    (void)hipGetLastError();   // clear any stale error left by other runtime users in this thread
     size_t n = (size_t)rows_p * cols_p;
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;
@@ -88,6 +89,7 @@ __global__ void embed_kernel(const float* __restrict__ state, const float* __res
 }
 
 hipError_t launch_embed(const Layout& lay, const char* packed, const FwdArgs& a, float* x, hipStream_t s) {
+    (void)hipGetLastError();   // clear any stale error left by other runtime users in this thread
     int rows = a.vbatch * a.T;
     int threads = lay.D >= 256 ? 256 : round_up(lay.D, 64);
     size_t shmem = sizeof(float) * (size_t)(lay.obs > lay.act ? lay.obs : lay.act);
@@ -140,6 +142,7 @@ __global__ void layernorm_kernel(const float* __restrict__ x, const float* __res
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int rows, int D,
                             int ld_out, int precision, hipStream_t s) {
+    (void)hipGetLastError();   // clear any stale error left by other runtime users in this thread
     int waves_per_block = 4;
     int grid = (rows + waves_per_block - 1) / waves_per_block;
     if (precision == BESO_PREC_FP32)
@@ -259,6 +262,7 @@ __global__ void head_kernel(const float* __restrict__ x, const float* __restrict
 }
 
 hipError_t launch_head(const Layout& lay, const char* packed, const FwdArgs& a, const float* x, hipStream_t s) {
+    (void)hipGetLastError();   // clear any stale error left by other runtime users in this thread
     auto P = [&](size_t off) { return (const float*)(packed + off); };
     int items = a.batch * a.t;
     hipLaunchKernelGGL(head_kernel, dim3((items + 3) / 4), dim3(256), 0, s, x, a.action, a.sigma, P(lay.lnf_w),
@@ -295,6 +299,7 @@ __global__ void sampler_step_kernel(int mode, float* __restrict__ out, float* __
 
 hipError_t launch_sampler_step(int mode, float* out, float* aux, const float* x, const float* x2, const float* den,
                                float c0, float c1, size_t n, hipStream_t s) {
+    (void)hipGetLastError();   // clear any stale error left by other runtime users in this thread
     int grid = (int)((n + 255) / 256);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;

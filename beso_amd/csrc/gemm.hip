@@ -129,6 +129,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const E* __restrict__ A, i
 template <typename E>
 static hipError_t launch_e(int epi, const void* A, int lda, const void* Wt, int ldw, const float* bias, void* out,
                            int ldo, int n_store, int M, int Np, int Kp, hipStream_t s) {
+    (void)hipGetLastError();
+    (void)hipGetLastError();   // clear any stale error left by other runtime users in this thread
     int nt_n = Np / kTileMN, nt_m = (M + kTileMN - 1) / kTileMN;
     dim3 grid(nt_n * nt_m), block(256);
     switch (epi) {
@@ -152,6 +154,7 @@ static hipError_t launch_e(int epi, const void* A, int lda, const void* Wt, int 
 
 hipError_t launch_gemm(int precision, int epi, const void* A, int lda, const void* Wt, int ldw, const float* bias,
                        void* out, int ldo, int n_store, int M, int Np, int Kp, hipStream_t s) {
+    (void)hipGetLastError();   // clear any stale error left by other runtime users in this thread
     if (precision == BESO_PREC_FP32) return launch_e<float>(epi, A, lda, Wt, ldw, bias, out, ldo, n_store, M, Np, Kp, s);
     return launch_e<uint16_t>(epi, A, lda, Wt, ldw, bias, out, ldo, n_store, M, Np, Kp, s);
 }

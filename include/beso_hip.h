@@ -80,6 +80,8 @@ enum {
 
 const char* beso_version(void);
 const char* beso_status_string(int status);
+/* Detail of the last BESO_ERR_HIP on the calling thread (HIP error name and the failing call). */
+const char* beso_last_error(void);
 
 /* Number of parameter tensors, in the order of the reference module's named_parameters():
  * pos_emb, tok_emb.{weight,bias}, per block {ln1,ln2}.{weight,bias}, attn.{key,query,value,proj}.{weight,bias},

@@ -215,7 +215,9 @@ def test_sampler_properties_block_push_2048():
     from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
     from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
     cfg = O.BLOCK_PUSH
-    m = make_module(cfg, O.make_weights(cfg, seed=7, std=0.05), "bf16")
+    # fp32 mode: bf16 rounding makes the network discontinuous at the 1e-3 level, so "same loop, two
+    # drivers" is only an equality at fp32 round-off in the exact mode
+    m = make_module(cfg, O.make_weights(cfg, seed=7, std=0.05), "fp32")
     model = ClassifierFreeSampleModel(m, 2.0)
     B = 2048
     s, g, x = (G(v) for v in O.make_inputs(cfg, B, seed=3))
