@@ -138,7 +138,7 @@ static int record_hip_error(hipError_t e, const char* what, int line) {
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return record_hip_error(_e, #expr, __LINE__); } while (0)
 
 static int forward_generic(const Layout& lay, const Workspace& ws, const char* packed, int precision,
-                           const FwdArgs& a, char* wsp, hipStream_t s, bool fused_mlp) {
+                           const FwdArgs& a, char* wsp, hipStream_t s, int fused) {
     float* x = (float*)(wsp + ws.x);
     void* xn = wsp + ws.xn; void* qkv = wsp + ws.qkv; void* y = wsp + ws.y; void* h = wsp + ws.h;
     const int M = a.vbatch * a.T;
@@ -146,7 +146,14 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
     profile_begin(BESO_SITE_EMBED, s);
     HIP_TRY(launch_embed(lay, packed, a, x, s));
     profile_end(BESO_SITE_EMBED, s);
-    for (int l = 0; l < lay.L; ++l) {
+    if (fused == 2) {
+        // all transformer layers as ONE launch: the residual tile of 8 samples stays in registers
+        profile_begin(BESO_SITE_FUSED_LAYER, s);
+        int st = fused_layers(lay, packed, 0, lay.L, x, a.vbatch, a.T, s);
+        profile_end(BESO_SITE_FUSED_LAYER, s);
+        if (st != BESO_OK) return st;
+    }
+    for (int l = 0; l < (fused == 2 ? 0 : lay.L); ++l) {
         const LayerOff& o = lay.layer[l];
         profile_begin(BESO_SITE_LAYERNORM, s);
         HIP_TRY(launch_layernorm(x, F(o.ln1_w), F(o.ln1_b), xn, M, lay.D, lay.Kd, precision, s));
@@ -162,7 +169,7 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
         HIP_TRY(launch_gemm(precision, EPI_BIAS_RESID, y, lay.Kd, packed + o.w_proj, lay.Kd, F(o.b_proj), x, lay.D,
                             lay.D, M, lay.Nd, lay.Kd, s));
         profile_end(BESO_SITE_GEMM_PROJ, s);
-        if (fused_mlp) {
+        if (fused == 1) {
             // LN2 + FC1 + GELU + FC2 + residual as one kernel, hidden activations never leave the CU
             profile_begin(BESO_SITE_FUSED_LAYER, s);
             int st = fused_mlp_block(lay, packed, l, x, M, s);
@@ -218,7 +225,7 @@ static int forward(const beso_config* cfg, const void* packed, int precision, co
     a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
     profile_begin(BESO_SITE_FORWARD, s);
     int r = forward_generic(lay, ws, (const char*)packed, precision, a, (char*)workspace, s,
-                            fused_supported(lay, a, precision));
+                            fused_level(lay, a, precision));
     profile_end(BESO_SITE_FORWARD, s);
     return r;
 }

@@ -1,19 +1,26 @@
 // Fused score-network path for the shipped model shapes (bf16 MFMA inputs, fp32 everything else).
 //
-// MLP block  x <- x + W2 * GELU(W1 * LN2(x) + b1) + b2   (score_gpts.py:105-114)  as ONE kernel:
-//   * a workgroup = 8 waves (2 per SIMD, <= 256 VGPRs) owns a tile of NTT*16 tokens; the fp32 residual
-//     tile lives in MFMA accumulators for the whole kernel, split across the waves BY FEATURE
-//     (wave w owns output-feature row tiles [w*RPW, (w+1)*RPW));
-//   * everything is computed transposed, Y^T = W^T X^T: weights are the MFMA A operand (rows =
-//     output features) and are read straight from L2 into registers in a pre-packed fragment order
-//     (1 KiB per wave-instruction, lane-linear), activations are the B operand (columns = tokens);
+// Structure (all kernels here share it):
+//   * a workgroup = 8 waves (2 per SIMD, <= 256 VGPRs) owns a tile of NTT*16 = 96 token slots; the fp32
+//     residual stream of the tile lives in MFMA accumulators, split across the waves BY FEATURE
+//     (wave w owns output-feature row tiles [w*RPW, (w+1)*RPW)), for the whole kernel;
+//   * every GEMM is computed transposed, Y^T = W^T X^T: weights are the MFMA A operand (rows = output
+//     features), read straight from L2 into registers in a pre-packed fragment order (1 KiB per
+//     wave-instruction, lane-linear); activations are the B operand (columns = tokens);
 //   * the D(col = token, row = 4*(lane>>4)+reg) accumulator layout of one GEMM IS the B-operand layout
 //     of the next one up to a permutation of the contraction index, and the weights are packed with
-//     that permutation (slot (g,j) of k-step kk <-> index 32kk + 16(j>>2) + 4g + (j&3)); so the GELU
-//     output goes accumulator -> v_cvt_pk_bf16_f32 -> B fragment with no transpose;
-//   * LN2's gamma/beta are folded into W1/b1 at pack time, the kernel only normalises;
-//   * LayerNorm statistics and the B fragments (normalised x, GELU(h)) are exchanged between the
-//     waves through LDS in lane-linear 1 KiB fragments (conflict-free ds_read_b128 / ds_write_b128).
+//     that permutation (slot (g,j) of k-step kk <-> index 32kk + 16(j>>2) + 4g + (j&3)); so e.g. the
+//     GELU output goes accumulator -> v_cvt_pk_bf16_f32 -> B fragment with no transpose;
+//   * LayerNorm gamma/beta are folded into the following Linear at pack time; kernels only normalise;
+//   * B fragments (normalised x, GELU(h), attention output) and the LayerNorm partial sums are
+//     exchanged between the waves through LDS in lane-linear 1 KiB fragments (conflict-free b128).
+//
+// Kernels:
+//   mlp_block_kernel   x <- x + W2 GELU(W1 LN2(x) + b1) + b2                       (score_gpts.py:105-114)
+//   layers_kernel      for l in [l0, l1): x <- x + proj(attn(LN1 x)); x <- x + mlp(LN2 x)   (:50-115)
+//                      attention per head: QKV_h GEMM -> q,k,v (bf16) in LDS -> scores with
+//                      v_dot2_f32_bf16, causal softmax, P.V on the VALU -> y_h^T B fragments -> the
+//                      head's slice of the out-projection accumulated into the residual.
 #include "fused.h"
 
 namespace beso {
@@ -24,30 +31,53 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 namespace {
 
 constexpr int kWaves = 8;
-constexpr int kChunkTiles = 2 * kWaves;     // hidden row tiles per chunk: 2 per wave = one FC2 k-step per wave
+constexpr int kChunkTiles = 2 * kWaves;   // hidden row tiles per MLP chunk: 2 per wave = one FC2 k-step per wave
+constexpr int kNTT = 6;                   // token tiles (16 tokens) per workgroup
+constexpr int kMT = kNTT * 16;            // 96 token slots
+constexpr int kSPW = 8;                   // samples per workgroup in layers_kernel
+constexpr int kHDP = 64;                  // padded head dim of the attention phase
+constexpr int kQKVRow = kHDP + 4;         // bf16 elements per q/k/v row in LDS (+4: conflict-free 8-byte writes)
 
 struct FusedDims {
-    int D, FT, RPW, KS, HT, NCH, KS2p;   // features, feature tiles, row tiles per wave, k-steps of D,
-                                          // hidden row tiles, hidden chunks, padded hidden k-steps
-    size_t w1_bytes, b1_bytes, w2_bytes, b2_bytes, layer_bytes;
+    int D, FT, RPW, KS, HT, NCH, KS2p, H, hd;
+    bool attn;                            // attention phase available (hd <= 64 and 8*block_size <= 96)
+    // per-layer image: [w1 | b1 | w2 | b2 | wqkv | bqkv | wproj | bproj]
+    size_t w1_bytes, b1_bytes, w2_bytes, b2_bytes, wqkv_bytes, bqkv_bytes, wproj_bytes, bproj_bytes, layer_bytes;
+    size_t o_b1, o_w2, o_b2, o_wqkv, o_bqkv, o_wproj, o_bproj;
 };
 
 bool fused_dims(const Layout& lay, FusedDims* d) {
     d->D = lay.D;
+    d->H = lay.H;
+    d->hd = lay.hd;
     if (lay.D % 8 != 0) return false;
     d->FT = (lay.D + 15) / 16;
     d->RPW = (d->FT + kWaves - 1) / kWaves;
     d->KS = (lay.D + 31) / 32;
-    if (2 * d->KS < d->FT) return false;
-    d->HT = (4 * lay.D) / 16;
+    if (2 * d->KS < d->FT || (d->KS & 1)) return false;
     if ((4 * lay.D) % 32 != 0) return false;
+    d->HT = (4 * lay.D) / 16;
     d->NCH = (d->HT + kChunkTiles - 1) / kChunkTiles;
     d->KS2p = d->NCH * kWaves;
-    d->w1_bytes = round_up_sz((size_t)d->NCH * kChunkTiles * d->KS * 1024, 256);
+    const int T = 1 + lay.G + 2 * lay.W;
+    d->attn = lay.hd <= kHDP && lay.hd % 4 == 0 && kSPW * T <= kMT;
+    const size_t rt2 = (size_t)d->RPW * kWaves;
+    d->w1_bytes = (size_t)d->NCH * kChunkTiles * d->KS * 1024;
     d->b1_bytes = round_up_sz((size_t)d->NCH * kChunkTiles * 16 * sizeof(float), 256);
-    d->w2_bytes = round_up_sz((size_t)d->RPW * kWaves * d->KS2p * 1024, 256);
-    d->b2_bytes = round_up_sz((size_t)d->RPW * kWaves * 16 * sizeof(float), 256);
-    d->layer_bytes = d->w1_bytes + d->b1_bytes + d->w2_bytes + d->b2_bytes;
+    d->w2_bytes = rt2 * d->KS2p * 1024;
+    d->b2_bytes = round_up_sz(rt2 * 16 * sizeof(float), 256);
+    d->wqkv_bytes = d->attn ? (size_t)lay.H * 12 * d->KS * 1024 : 0;
+    d->bqkv_bytes = d->attn ? round_up_sz((size_t)lay.H * 3 * kHDP * sizeof(float), 256) : 0;
+    d->wproj_bytes = d->attn ? rt2 * (2 * lay.H) * 1024 : 0;
+    d->bproj_bytes = d->attn ? round_up_sz(rt2 * 16 * sizeof(float), 256) : 0;
+    d->o_b1 = d->w1_bytes;
+    d->o_w2 = d->o_b1 + d->b1_bytes;
+    d->o_b2 = d->o_w2 + d->w2_bytes;
+    d->o_wqkv = d->o_b2 + d->b2_bytes;
+    d->o_bqkv = d->o_wqkv + d->wqkv_bytes;
+    d->o_wproj = d->o_bqkv + d->bqkv_bytes;
+    d->o_bproj = d->o_wproj + d->wproj_bytes;
+    d->layer_bytes = d->o_bproj + d->bproj_bytes;
     return true;
 }
 
@@ -57,9 +87,9 @@ bool shape_has_kernel(const FusedDims& d) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// pack kernels
+// pack kernels.  A-operand fragment order:
+//   dst[((R*kt + kk)*64 + lane)*8 + j] = bf16( M[16R + (lane&15)][32kk + 16(j>>2) + 4(lane>>4) + (j&3)] )
 // ---------------------------------------------------------------------------------------------
-// dst[((R*kt + kk)*64 + lane)*8 + j] = bf16( src[16R + (lane&15)][32kk + 16(j>>2) + 4(lane>>4) + (j&3)] * colscale[col] )
 __global__ void pack_mfma_a_kernel(const float* __restrict__ src, int rows, int cols, const float* __restrict__ colscale,
                                    uint16_t* __restrict__ dst, int rt, int kt) {
     size_t total = (size_t)rt * kt * 512;
@@ -74,6 +104,65 @@ __global__ void pack_mfma_a_kernel(const float* __restrict__ src, int rows, int 
             v = src[(size_t)r * cols + c];
             if (colscale) v *= colscale[c];
         }
+        dst[i] = f2bf(v);
+    }
+}
+
+// q/k/v weights of all heads: tile index = (h*3 + part)*4 + R4, rows of head h padded hd -> 64;
+// LayerNorm-1 gamma folded in.  part 0 = query, 1 = key, 2 = value.
+__global__ void pack_qkv_kernel(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+                                const float* __restrict__ gamma, uint16_t* __restrict__ dst, int D, int H, int hd,
+                                int kt) {
+    size_t total = (size_t)H * 12 * kt * 512;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        size_t tile = i >> 9;
+        int kk = (int)(tile % kt);
+        int rt = (int)(tile / kt);               // (h*3 + part)*4 + R4
+        int R4 = rt & 3, part = (rt >> 2) % 3, h = rt / 12;
+        int d = 16 * R4 + (lane & 15);
+        int c = 32 * kk + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+        float v = 0.f;
+        if (d < hd && c < D) {
+            const float* w = part == 0 ? wq : (part == 1 ? wk : wv);
+            v = w[(size_t)(h * hd + d) * D + c] * gamma[c];
+        }
+        dst[i] = f2bf(v);
+    }
+}
+
+// out[(h*3 + part)*64 + d] = b_part[h*hd + d] + sum_c W_part[h*hd + d][c] * beta[c]   (0 for d >= hd)
+__global__ void fold_qkv_bias_kernel(const float* __restrict__ wq, const float* __restrict__ wk,
+                                     const float* __restrict__ wv, const float* __restrict__ bq,
+                                     const float* __restrict__ bk, const float* __restrict__ bv,
+                                     const float* __restrict__ beta, float* __restrict__ out, int D, int H, int hd) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * 3 * kHDP) return;
+    int d = i % kHDP, part = (i / kHDP) % 3, h = i / (3 * kHDP);
+    float acc = 0.f;
+    if (d < hd) {
+        const float* w = part == 0 ? wq : (part == 1 ? wk : wv);
+        const float* b = part == 0 ? bq : (part == 1 ? bk : bv);
+        const int r = h * hd + d;
+        acc = b[r];
+        for (int c = 0; c < D; ++c) acc = fmaf(w[(size_t)r * D + c], beta[c], acc);
+    }
+    out[i] = acc;
+}
+
+// out-projection: k-step (2h + kk) covers head h, head dims 32kk .. 32kk+31 (zero for d >= hd)
+__global__ void pack_proj_kernel(const float* __restrict__ wp, uint16_t* __restrict__ dst, int D, int H, int hd, int rt) {
+    const int kt = 2 * H;
+    size_t total = (size_t)rt * kt * 512;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        size_t tile = i >> 9;
+        int kk = (int)(tile % kt), R = (int)(tile / kt);
+        int o = 16 * R + (lane & 15);
+        int h = kk >> 1;
+        int d = 32 * (kk & 1) + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+        float v = 0.f;
+        if (o < D && d < hd) v = wp[(size_t)o * D + h * hd + d];
         dst[i] = f2bf(v);
     }
 }
@@ -99,21 +188,25 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
 }
 
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+
 // exact-erf GELU (nn.GELU() default).  erf by Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7:
-// 2 transcendentals (rcp, exp2) + ~11 plain VALU ops.
+// GELU(v) = max(v,0) - |v| * q,  q = 0.5 * poly(t) * exp(-v^2/2),  t = 1/(1 + p|v|/sqrt2)
 __device__ __forceinline__ float gelu_fast(float v) {
-    const float x = v * 0.70710678118654752440f;
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
+    const float av = fabsf(v);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, av, 1.0f));
+    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
     p *= t;
-    const float e = __builtin_amdgcn_exp2f(x * x * -1.4426950408889634f);   // exp(-x^2)
-    const float erf_abs = fmaf(-p, e, 1.0f);
-    const float erf_v = copysignf(erf_abs, x);
-    return 0.5f * v * (1.0f + erf_v);
+    const float e = __builtin_amdgcn_exp2f(v * (v * -0.72134752044448170368f));   // exp(-v^2/2)
+    return fmaf(-av, p * e, fmaxf(v, 0.f));
 }
 
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
@@ -122,190 +215,452 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// MLP block kernel.  RPW: output-feature row tiles per wave; KS: k-steps (32 wide) over D;
-// NTT: token tiles (16 tokens) per workgroup.
-// LDS: xnT [NTT][KS] KiB | hT [NTT][8] KiB | red [2][8][NTT*16] floats
+// One GEMM phase of the transposed formulation:  acc[r][t] += sum_kk A(r,kk) * B(t,kk)
+//   A(r,kk) = a[r*a_rs + kk*64]    weights, L2 -> registers (pointer already offset by the lane)
+//   B(t,kk) = b[t*b_ts + kk*b_ks]  activations, LDS -> registers (pointer already offset by the lane)
+// Two k-steps per iteration with named even/odd weight-fragment registers; the loads that refill a
+// register set are issued right behind the MFMAs that consumed it, so weight fragments are ~1.5
+// k-steps and LDS fragments half a k-step ahead of their use without copies.  The sched_barriers pin that order
+// (left alone, the scheduler sinks the loads next to their consumers and serialises on vmcnt(0)).
+// aE/aO must already hold k-steps 0 and 1 (prefetch_a), which lets the caller issue them early.
+// ksteps must be even.
 // ---------------------------------------------------------------------------------------------
-template <int RPW, int KS, int NTT>
-__global__ __launch_bounds__(512, 2) void mlp_block_kernel(float* __restrict__ x, const u32x4* __restrict__ w1p,
-                                                           const float* __restrict__ b1f,
-                                                           const u32x4* __restrict__ w2p,
-                                                           const float* __restrict__ b2p, int M, int D, int HT,
-                                                           int KS2p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    u32x4* xnT = (u32x4*)lds;                                   // [(t*KS + kk)*64 + lane]
-    u32x4* hT = (u32x4*)(lds + (size_t)NTT * KS * 1024);        // [(t*8 + kl)*64 + lane]
-    float* red = (float*)(lds + (size_t)NTT * (KS + 8) * 1024);  // [2][8][NTT*16]
-    constexpr int MT = NTT * 16;
+template <int R>
+__device__ __forceinline__ void prefetch_a(u32x4 (&aE)[R], u32x4 (&aO)[R], const u32x4* __restrict__ a, int a_rs) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { aE[r] = a[(size_t)r * a_rs]; aO[r] = a[(size_t)r * a_rs + 64]; }
+}
 
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * MT;
+template <int R, int NT>
+__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], u32x4 (&aO)[R],
+                                           const u32x4* __restrict__ a, int a_rs, const u32x4* b, int b_ts,
+                                           int b_ks, int ksteps) {
+    // ONE set of B fragments: each half of it is refilled for the next k-step as soon as the MFMAs that
+    // read it have been issued (prefetch distance = half a k-step of MFMAs, enough for LDS latency).
+    constexpr int H1 = (NT + 1) / 2;
+    u32x4 bf[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bf[t] = b[t * b_ts];
+    for (int kk = 0; kk < ksteps; kk += 2) {
+        // ---- k-step kk (even fragments)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < H1; ++t)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aE[r], bf[t], acc[r][t]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < H1; ++t) bf[t] = b[t * b_ts + (kk + 1) * b_ks];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = H1; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aE[r], bf[t], acc[r][t]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = H1; t < NT; ++t) bf[t] = b[t * b_ts + (kk + 1) * b_ks];
+        if (kk + 2 < ksteps) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) aE[r] = a[(size_t)r * a_rs + (kk + 2) * 64];
+        }
+        // ---- k-step kk+1 (odd fragments)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < H1; ++t)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aO[r], bf[t], acc[r][t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 2 < ksteps) {
+#pragma unroll
+            for (int t = 0; t < H1; ++t) bf[t] = b[t * b_ts + (kk + 2) * b_ks];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = H1; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aO[r], bf[t], acc[r][t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 2 < ksteps) {
+#pragma unroll
+            for (int t = H1; t < NT; ++t) bf[t] = b[t * b_ts + (kk + 2) * b_ks];
+        }
+        if (kk + 3 < ksteps) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) aO[r] = a[(size_t)r * a_rs + (kk + 3) * 64];
+        }
+    }
+}
 
-    // ---- residual slice -> accumulators
-    f32x4 acc[RPW][NTT];
+// ---------------------------------------------------------------------------------------------
+// shared pieces of the kernels
+// ---------------------------------------------------------------------------------------------
+struct LdsMap {            // byte offsets inside the dynamic LDS block
+    int xnT, u, red, tab, total;
+};
+__host__ __device__ constexpr LdsMap lds_map(int KS) {
+    // u is the phase-local region: attention (q/k/v 3*96*68*2 = 39168 | probs 8*16*16*4 = 8192 | yT 12288)
+    // or MLP (hT 6*8 KiB = 49152)
+    LdsMap m{};
+    m.xnT = 0;
+    m.u = kNTT * KS * 1024;
+    m.red = m.u + 59648;
+    m.tab = m.red + 2 * kWaves * kMT * 4;
+    m.total = m.tab + 512;
+    return m;
+}
+
+template <int RPW>
+struct Tile {
+    f32x4 acc[RPW][kNTT];
     bool fvalid[RPW];
+};
+
+template <int RPW>
+__device__ __forceinline__ void load_x_tile(Tile<RPW>& T, const float* __restrict__ x, int D, int m0, int m_end,
+                                            int w, int n, int g) {
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int f0 = 16 * (w * RPW + i) + 4 * g;
-        fvalid[i] = f0 < D;
+        T.fvalid[i] = f0 < D;
 #pragma unroll
-        for (int t = 0; t < NTT; ++t) {
+        for (int t = 0; t < kNTT; ++t) {
             const int tok = m0 + t * 16 + n;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (fvalid[i] && tok < M) v = *(const f32x4*)(x + (size_t)tok * D + f0);
-            acc[i][t] = v;
+            if (T.fvalid[i] && tok < m_end) v = *(const f32x4*)(x + (size_t)tok * D + f0);
+            T.acc[i][t] = v;
         }
     }
+}
 
-    // ---- LayerNorm statistics (two-pass, fp32), partial sums exchanged through LDS
-    float mean[NTT], rstd[NTT];
+template <int RPW>
+__device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restrict__ x, int D, int m0, int m_end,
+                                             int w, int n, int g) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int f0 = 16 * (w * RPW + i) + 4 * g;
+        if (!T.fvalid[i]) continue;
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) {
+            const int tok = m0 + t * 16 + n;
+            if (tok < m_end) *(f32x4*)(x + (size_t)tok * D + f0) = T.acc[i][t];
+        }
+    }
+}
+
+// LayerNorm without affine (gamma/beta are folded into the consumer): two-pass fp32 statistics over the
+// feature slices of all 8 waves, then (x - mean) * rstd as bf16 B fragments into xnT.  Ends with a
+// barrier; `bias` (the residual-add bias of the block's last Linear) is added to the residual after
+// the normalised copy has been taken.
+template <int RPW, int KS>
+__device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float* red, int D, int w, int lane,
+                                                 const float* __restrict__ bias) {
+    const int n = lane & 15, g = lane >> 4;
+    float mean[kNTT], rstd[kNTT];
     const float invD = 1.0f / (float)D;
 #pragma unroll
-    for (int t = 0; t < NTT; ++t) {
+    for (int t = 0; t < kNTT; ++t) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) s += (acc[i][t][0] + acc[i][t][1]) + (acc[i][t][2] + acc[i][t][3]);
+        for (int i = 0; i < RPW; ++i) s += (T.acc[i][t][0] + T.acc[i][t][1]) + (T.acc[i][t][2] + T.acc[i][t][3]);
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
-        if (g == 0) red[(0 * kWaves + w) * MT + t * 16 + n] = s;
+        if (g == 0) red[(0 * kWaves + w) * kMT + t * 16 + n] = s;
     }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < NTT; ++t) {
+    for (int t = 0; t < kNTT; ++t) {
         float s = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < kWaves; ++ww) s += red[(0 * kWaves + ww) * MT + t * 16 + n];
+        for (int ww = 0; ww < kWaves; ++ww) s += red[(0 * kWaves + ww) * kMT + t * 16 + n];
         mean[t] = s * invD;
     }
 #pragma unroll
-    for (int t = 0; t < NTT; ++t) {
+    for (int t = 0; t < kNTT; ++t) {
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-            if (fvalid[i]) {
+            if (T.fvalid[i]) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = acc[i][t][r] - mean[t]; q = fmaf(d, d, q); }
+                for (int r = 0; r < 4; ++r) { const float d = T.acc[i][t][r] - mean[t]; q = fmaf(d, d, q); }
             }
         }
         q += __shfl_xor(q, 16, 64);
         q += __shfl_xor(q, 32, 64);
-        if (g == 0) red[(1 * kWaves + w) * MT + t * 16 + n] = q;
+        if (g == 0) red[(1 * kWaves + w) * kMT + t * 16 + n] = q;
     }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < NTT; ++t) {
+    for (int t = 0; t < kNTT; ++t) {
         float q = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < kWaves; ++ww) q += red[(1 * kWaves + ww) * MT + t * 16 + n];
+        for (int ww = 0; ww < kWaves; ++ww) q += red[(1 * kWaves + ww) * kMT + t * 16 + n];
         rstd[t] = 1.0f / sqrtf(q * invD + 1e-5f);
     }
-
-    // ---- normalised x as bf16 B fragments -> LDS; then add the FC2 bias to the residual
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int Rf = w * RPW + i;
         if ((Rf >> 1) < KS) {
 #pragma unroll
-            for (int t = 0; t < NTT; ++t) {
+            for (int t = 0; t < kNTT; ++t) {
                 uint2 pk = make_uint2(0u, 0u);
-                if (fvalid[i]) {
+                if (T.fvalid[i]) {
                     const float a = rstd[t], b = -mean[t] * rstd[t];
-                    pk.x = pack_bf16x2(fmaf(acc[i][t][0], a, b), fmaf(acc[i][t][1], a, b));
-                    pk.y = pack_bf16x2(fmaf(acc[i][t][2], a, b), fmaf(acc[i][t][3], a, b));
+                    pk.x = pack_bf16x2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
+                    pk.y = pack_bf16x2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
                 }
                 uint2* dst = (uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane) + (Rf & 1);
                 *dst = pk;
             }
         }
-        const f32x4 bias = *(const f32x4*)(b2p + 16 * Rf + 4 * g);
+        const f32x4 bv = *(const f32x4*)(bias + 16 * Rf + 4 * g);
 #pragma unroll
-        for (int t = 0; t < NTT; ++t) acc[i][t] += bias;
+        for (int t = 0; t < kNTT; ++t) T.acc[i][t] += bv;
     }
     __syncthreads();
+}
 
-    // ---- hidden chunks: FC1 (+bias, GELU) -> hT -> FC2 accumulate
+// MLP phase (xnT holds LN2(x) fragments on entry): hidden chunks of 16 row tiles, FC1 (+bias, GELU) ->
+// hT -> FC2 accumulated into the residual.  The first weight fragments of each GEMM phase are issued
+// one phase early (FC2's before the GELU, the next chunk's FC1 before the FC2 loop).
+template <int RPW, int KS>
+__device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
+                                          const float* __restrict__ b1f, const u32x4* __restrict__ w2p, int HT,
+                                          int KS2p, int w, int lane) {
+    const int g = lane >> 4;
     const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
+    u32x4 a1E[2], a1O[2];
+    prefetch_a<2>(a1E, a1O, w1p + (size_t)(2 * w) * KS * 64 + lane, KS * 64);
     for (int c = 0; c < n_chunks; ++c) {
         const int tiles_here = min(kChunkTiles, HT - c * kChunkTiles);
-        if (2 * w < tiles_here) {
-            const int R0 = c * kChunkTiles + 2 * w;
-            f32x4 h0[NTT], h1[NTT];
+        const bool fc1_active = 2 * w < tiles_here;
+        const int R0 = c * kChunkTiles + 2 * w;
+        f32x4 h[2][kNTT];
+        if (fc1_active) {
             const f32x4 bias0 = *(const f32x4*)(b1f + 16 * R0 + 4 * g);
             const f32x4 bias1 = *(const f32x4*)(b1f + 16 * (R0 + 1) + 4 * g);
 #pragma unroll
-            for (int t = 0; t < NTT; ++t) { h0[t] = bias0; h1[t] = bias1; }
-            const u32x4* a0p = w1p + (size_t)R0 * KS * 64 + lane;
-            const u32x4* a1p = a0p + (size_t)KS * 64;
+            for (int t = 0; t < kNTT; ++t) { h[0][t] = bias0; h[1][t] = bias1; }
+            gemm_phase<2, kNTT>(h, a1E, a1O, w1p + (size_t)R0 * KS * 64 + lane, KS * 64, xnT + lane, KS * 64, 64, KS);
+        }
+        u32x4 a2E[RPW], a2O[RPW];
+        const u32x4* a2 = w2p + ((size_t)(w * RPW) * KS2p + c * kWaves) * 64 + lane;
+        prefetch_a<RPW>(a2E, a2O, a2, KS2p * 64);
+        if (fc1_active) {
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const u32x4 a0 = a0p[kk * 64];
-                const u32x4 a1 = a1p[kk * 64];
-#pragma unroll
-                for (int t = 0; t < NTT; ++t) {
-                    const u32x4 b = xnT[((size_t)t * KS + kk) * 64 + lane];
-                    h0[t] = mfma_bf16(a0, b, h0[t]);
-                    h1[t] = mfma_bf16(a1, b, h1[t]);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < NTT; ++t) {
+            for (int t = 0; t < kNTT; ++t) {
                 u32x4 hb;
-                hb[0] = pack_bf16x2(gelu_fast(h0[t][0]), gelu_fast(h0[t][1]));
-                hb[1] = pack_bf16x2(gelu_fast(h0[t][2]), gelu_fast(h0[t][3]));
-                hb[2] = pack_bf16x2(gelu_fast(h1[t][0]), gelu_fast(h1[t][1]));
-                hb[3] = pack_bf16x2(gelu_fast(h1[t][2]), gelu_fast(h1[t][3]));
+                hb[0] = pack_bf16x2(gelu_fast(h[0][t][0]), gelu_fast(h[0][t][1]));
+                hb[1] = pack_bf16x2(gelu_fast(h[0][t][2]), gelu_fast(h[0][t][3]));
+                hb[2] = pack_bf16x2(gelu_fast(h[1][t][0]), gelu_fast(h[1][t][1]));
+                hb[3] = pack_bf16x2(gelu_fast(h[1][t][2]), gelu_fast(h[1][t][3]));
                 hT[((size_t)t * kWaves + w) * 64 + lane] = hb;
             }
         }
         __syncthreads();
-        const int ksteps = tiles_here >> 1;
-        for (int kl = 0; kl < ksteps; ++kl) {
-            u32x4 a[RPW];
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) a[i] = w2p[((size_t)(w * RPW + i) * KS2p + (c * kWaves + kl)) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < NTT; ++t) {
-                const u32x4 b = hT[((size_t)t * kWaves + kl) * 64 + lane];
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) acc[i][t] = mfma_bf16(a[i], b, acc[i][t]);
-            }
-        }
+        if (c + 1 < n_chunks)
+            prefetch_a<2>(a1E, a1O, w1p + (size_t)(R0 + kChunkTiles) * KS * 64 + lane, KS * 64);
+        // k-steps are consumed in pairs; an odd tail reads a stale (finite) hT slot against zero weights
+        gemm_phase<RPW, kNTT>(T.acc, a2E, a2O, a2, KS2p * 64, hT + lane, kWaves * 64, 64,
+                              ((tiles_here >> 1) + 1) & ~1);
         __syncthreads();
-    }
-
-    // ---- residual tile back to HBM
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int f0 = 16 * (w * RPW + i) + 4 * g;
-        if (!fvalid[i]) continue;
-#pragma unroll
-        for (int t = 0; t < NTT; ++t) {
-            const int tok = m0 + t * 16 + n;
-            if (tok < M) *(f32x4*)(x + (size_t)tok * D + f0) = acc[i][t];
-        }
     }
 }
 
-constexpr int kNTT = 6;   // 96 tokens per workgroup
+// Attention phase (xnT holds LN1(x) fragments on entry).  Tokens of the tile are in natural order:
+// slot = sample*Tn + position, n_samples*Tn valid slots.
+template <int RPW, int KS>
+__device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsigned char* u, const uint8_t* tab,
+                                           const u32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
+                                           const u32x4* __restrict__ wproj, int H, int hd, int Tn, int n_samples,
+                                           int w, int lane) {
+    const int n = lane & 15, g = lane >> 4;
+    const int tid = w * 64 + lane;
+    uint16_t* qkv = (uint16_t*)u;                         // [3][96][kQKVRow] bf16
+    float* probs = (float*)(u + 39168);                   // [8][16][16]
+    u32x4* yT = (u32x4*)(u + 39168 + 8192);               // [(t*2 + kk)*64 + lane]
+    const int wa = w & 3, wb = w >> 2;                    // QKV split: row tiles 3wa..3wa+2 x token tiles 3wb..3wb+2
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int NP = Tn * (Tn + 1) / 2;
+    const int n_valid = n_samples * Tn;
+
+    for (int h = 0; h < H; ++h) {
+        // ---- q, k, v of head h for all tokens of the tile
+        {
+            f32x4 qa[3][3];
+            u32x4 aE[3], aO[3];
+            const u32x4* a = wqkv + ((size_t)(h * 12 + 3 * wa) * KS) * 64 + lane;
+            prefetch_a<3>(aE, aO, a, KS * 64);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const f32x4 bv = *(const f32x4*)(bqkv + (h * 12 + 3 * wa + i) * 16 + 4 * g);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) qa[i][t] = bv;
+            }
+            gemm_phase<3, 3>(qa, aE, aO, a, KS * 64, xnT + (size_t)(3 * wb) * KS * 64 + lane, KS * 64, 64, KS);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int rt = 3 * wa + i, part = rt >> 2, d0 = (rt & 3) * 16 + 4 * g;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int tok = (3 * wb + t) * 16 + n;
+                    uint2 pk;
+                    pk.x = pack_bf16x2(qa[i][t][0], qa[i][t][1]);
+                    pk.y = pack_bf16x2(qa[i][t][2], qa[i][t][3]);
+                    *(uint2*)(qkv + ((size_t)part * kMT + tok) * kQKVRow + d0) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- scores: one (sample, i, j<=i) pair per thread, 64-wide dot product with v_dot2_f32_bf16
+        for (int pi = tid; pi < n_samples * NP; pi += kWaves * 64) {
+            const int s = pi / NP, pr = pi - s * NP;
+            const int i = tab[2 * pr], j = tab[2 * pr + 1];
+            const uint2* qr = (const uint2*)(qkv + ((size_t)0 * kMT + s * Tn + i) * kQKVRow);
+            const uint2* kr = (const uint2*)(qkv + ((size_t)1 * kMT + s * Tn + j) * kQKVRow);
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < kHDP / 4; ++c) {
+                const uint2 qv = qr[c], kv = kr[c];
+                d0 = dot2_bf16(qv.x, kv.x, d0);
+                d1 = dot2_bf16(qv.y, kv.y, d1);
+            }
+            probs[(s * 16 + i) * 16 + j] = (d0 + d1) * scale;
+        }
+        __syncthreads();
+        // ---- causal softmax, one (sample, i) row per thread
+        if (tid < n_valid) {
+            const int s = tid / Tn, i = tid - s * Tn;
+            float* row = probs + (s * 16 + i) * 16;
+            float m = row[0];
+            for (int j = 1; j <= i; ++j) m = fmaxf(m, row[j]);
+            float sum = 0.f;
+            for (int j = 0; j <= i; ++j) { const float e = expf(row[j] - m); row[j] = e; sum += e; }
+            const float inv = 1.0f / sum;
+            for (int j = 0; j <= i; ++j) row[j] *= inv;
+        }
+        __syncthreads();
+        // ---- y = P V: one B fragment (token, k-step, lane group) = 8 head dims per work item
+        for (int it = tid; it < n_valid * 8; it += kWaves * 64) {
+            const int tok = it >> 3, kk = (it >> 2) & 1, gg = it & 3;
+            const int s = tok / Tn, i = tok - s * Tn;
+            const float* prow = probs + (s * 16 + i) * 16;
+            const uint16_t* vb = qkv + ((size_t)2 * kMT + s * Tn) * kQKVRow + 32 * kk + 4 * gg;
+            float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j <= i; ++j) {
+                const float p = prow[j];
+                const uint2 v0 = *(const uint2*)(vb + (size_t)j * kQKVRow);
+                const uint2 v1 = *(const uint2*)(vb + (size_t)j * kQKVRow + 16);
+                o[0] = fmaf(p, bf16_lo(v0.x), o[0]); o[1] = fmaf(p, bf16_hi(v0.x), o[1]);
+                o[2] = fmaf(p, bf16_lo(v0.y), o[2]); o[3] = fmaf(p, bf16_hi(v0.y), o[3]);
+                o[4] = fmaf(p, bf16_lo(v1.x), o[4]); o[5] = fmaf(p, bf16_hi(v1.x), o[5]);
+                o[6] = fmaf(p, bf16_lo(v1.y), o[6]); o[7] = fmaf(p, bf16_hi(v1.y), o[7]);
+            }
+            u32x4 yb;
+            yb[0] = pack_bf16x2(o[0], o[1]); yb[1] = pack_bf16x2(o[2], o[3]);
+            yb[2] = pack_bf16x2(o[4], o[5]); yb[3] = pack_bf16x2(o[6], o[7]);
+            yT[((size_t)(tok >> 4) * 2 + kk) * 64 + (gg << 4) + (tok & 15)] = yb;
+        }
+        __syncthreads();
+        // ---- the head's slice of the out-projection, accumulated into the residual
+        {
+            u32x4 aE[RPW], aO[RPW];
+            const u32x4* a = wproj + ((size_t)(w * RPW) * (2 * H) + 2 * h) * 64 + lane;
+            prefetch_a<RPW>(aE, aO, a, 2 * H * 64);
+            gemm_phase<RPW, kNTT>(T.acc, aE, aO, a, 2 * H * 64, yT + lane, 2 * 64, 64, 2);
+        }
+        // no barrier needed here: the next writes to qkv/probs/yT happen behind the next head's barriers
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+template <int RPW, int KS>
+__global__ __launch_bounds__(512, 2) void mlp_block_kernel(float* __restrict__ x, const char* __restrict__ lw,
+                                                           FusedDims d, int M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr LdsMap L = lds_map(KS);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * kMT;
+    Tile<RPW> T;
+    load_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
+    layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane, (const float*)(lw + d.o_b2));
+    mlp_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
+                       (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane);
+    store_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
+}
+
+// Whole transformer layers [l0, l1) over the tile's 8 samples; x stays in registers in between.
+template <int RPW, int KS>
+__global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, const char* __restrict__ lw0,
+                                                        FusedDims d, int l0, int l1, int n_samples_total, int Tn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr LdsMap L = lds_map(KS);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int s0 = blockIdx.x * kSPW;
+    const int n_samples = min(kSPW, n_samples_total - s0);
+    const int m0 = s0 * Tn, m_end = m0 + n_samples * Tn;
+    uint8_t* tab = (uint8_t*)(lds + L.tab);
+    // (i, j) of the causal pairs, j <= i
+    for (int pr = threadIdx.x; pr < Tn * (Tn + 1) / 2; pr += blockDim.x) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= pr) ++i;
+        tab[2 * pr] = (uint8_t)i;
+        tab[2 * pr + 1] = (uint8_t)(pr - i * (i + 1) / 2);
+    }
+    // the attention-output fragments of padding tokens are never written: make them finite once
+    for (int i = threadIdx.x; i < kNTT * 2 * 64; i += blockDim.x) ((u32x4*)(lds + L.u + 39168 + 8192))[i] = u32x4{0, 0, 0, 0};
+    Tile<RPW> T;
+    load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
+    for (int l = l0; l < l1; ++l) {
+        const char* lw = lw0 + (size_t)l * d.layer_bytes;
+        layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+                                  (const float*)(lw + d.o_bproj));
+        attn_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), lds + L.u, tab, (const u32x4*)(lw + d.o_wqkv),
+                            (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.H, d.hd, Tn, n_samples, w,
+                            lane);
+        layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+                                  (const float*)(lw + d.o_b2));
+        mlp_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
+                           (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane);
+    }
+    store_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
+}
+
+template <typename K>
+hipError_t ensure_lds(K kernel, size_t bytes, bool* done) {
+    if (*done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) *done = true;
+    return e;
+}
 
 template <int RPW, int KS>
-hipError_t launch_mlp_block(float* x, const char* base, const FusedDims& d, int M, hipStream_t s) {
-    const size_t lds_bytes = (size_t)kNTT * (KS + 8) * 1024 + 2 * kWaves * kNTT * 16 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_block_kernel<RPW, KS, kNTT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const int grid = (M + kNTT * 16 - 1) / (kNTT * 16);
+hipError_t launch_mlp_block(float* x, const char* lw, const FusedDims& d, int M, hipStream_t s) {
+    constexpr LdsMap L = lds_map(KS);
+    static bool attr = false;
+    hipError_t e = ensure_lds(mlp_block_kernel<RPW, KS>, L.total, &attr);
+    if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((mlp_block_kernel<RPW, KS, kNTT>), dim3(grid), dim3(512), lds_bytes, s, x,
-                       (const u32x4*)base, (const float*)(base + d.w1_bytes),
-                       (const u32x4*)(base + d.w1_bytes + d.b1_bytes),
-                       (const float*)(base + d.w1_bytes + d.b1_bytes + d.w2_bytes), M, d.D, d.HT, d.KS2p);
+    hipLaunchKernelGGL((mlp_block_kernel<RPW, KS>), dim3((M + kMT - 1) / kMT), dim3(512), L.total, s, x, lw, d, M);
+    return hipGetLastError();
+}
+
+template <int RPW, int KS>
+hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
+                         hipStream_t s) {
+    constexpr LdsMap L = lds_map(KS);
+    static bool attr = false;
+    hipError_t e = ensure_lds(layers_kernel<RPW, KS>, L.total, &attr);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((layers_kernel<RPW, KS>), dim3((n_samples + kSPW - 1) / kSPW), dim3(512), L.total, s, x, lw0, d,
+                       l0, l1, n_samples, Tn);
     return hipGetLastError();
 }
 
@@ -330,26 +685,44 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
         // parameter order (include/beso_hip.h): 3 leading tensors, then 16 per block:
         // ln1.w ln1.b ln2.w ln2.b key.w key.b query.w query.b value.w value.b proj.w proj.b fc1.w fc1.b fc2.w fc2.b
         const float* const* q = p + 3 + 16 * l;
-        const float *ln2w = q[2], *ln2b = q[3], *f1w = q[12], *f1b = q[13], *f2w = q[14], *f2b = q[15];
+        const float *ln1w = q[0], *ln1b = q[1], *ln2w = q[2], *ln2b = q[3];
+        const float *kw = q[4], *kb = q[5], *qw = q[6], *qb = q[7], *vw = q[8], *vb = q[9], *pw = q[10], *pb = q[11];
+        const float *f1w = q[12], *f1b = q[13], *f2w = q[14], *f2b = q[15];
         char* base = packed + lay.fused + (size_t)l * d.layer_bytes;
         const int rt1 = d.NCH * kChunkTiles, rt2 = d.RPW * kWaves;
         (void)hipGetLastError();
         hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, f1w, 4 * D, D, ln2w, (uint16_t*)base, rt1,
                            d.KS);
         hipLaunchKernelGGL(fold_bias_kernel, dim3((rt1 * 16 + 255) / 256), dim3(256), 0, s, f1w, f1b, ln2b,
-                           (float*)(base + d.w1_bytes), 4 * D, D, rt1 * 16);
+                           (float*)(base + d.o_b1), 4 * D, D, rt1 * 16);
         hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, f2w, D, 4 * D, (const float*)nullptr,
-                           (uint16_t*)(base + d.w1_bytes + d.b1_bytes), rt2, d.KS2p);
+                           (uint16_t*)(base + d.o_w2), rt2, d.KS2p);
         FTRY(hipGetLastError());
-        FTRY(launch_pack_matrix(f2b, 1, D, base + d.w1_bytes + d.b1_bytes + d.w2_bytes, 1, rt2 * 16, -1, s));
+        FTRY(launch_pack_matrix(f2b, 1, D, base + d.o_b2, 1, rt2 * 16, -1, s));
+        if (d.attn) {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(pack_qkv_kernel, dim3(1024), dim3(256), 0, s, qw, kw, vw, ln1w,
+                               (uint16_t*)(base + d.o_wqkv), D, lay.H, lay.hd, d.KS);
+            hipLaunchKernelGGL(fold_qkv_bias_kernel, dim3((lay.H * 3 * kHDP + 255) / 256), dim3(256), 0, s, qw, kw, vw,
+                               qb, kb, vb, ln1b, (float*)(base + d.o_bqkv), D, lay.H, lay.hd);
+            hipLaunchKernelGGL(pack_proj_kernel, dim3(512), dim3(256), 0, s, pw, (uint16_t*)(base + d.o_wproj), D, lay.H,
+                               lay.hd, rt2);
+            FTRY(hipGetLastError());
+            FTRY(launch_pack_matrix(pb, 1, D, base + d.o_bproj, 1, rt2 * 16, -1, s));
+        }
     }
     return BESO_OK;
 }
 
-bool fused_supported(const Layout& lay, const FwdArgs&, int precision) {
+// 0: no fused kernel, 1: MLP block only, 2: whole layers
+int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     FusedDims d;
-    return precision == BESO_PREC_BF16 && lay.fused != lay.total && fused_dims(lay, &d) && shape_has_kernel(d);
+    if (precision != BESO_PREC_BF16 || lay.fused == lay.total || !fused_dims(lay, &d) || !shape_has_kernel(d)) return 0;
+    if (d.attn && d.RPW == 3 && d.KS == 12 && kSPW * a.T <= kMT) return 2;
+    return 1;
 }
+
+bool fused_supported(const Layout& lay, const FwdArgs& a, int precision) { return fused_level(lay, a, precision) > 0; }
 
 int fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, int M, hipStream_t s) {
     FusedDims d;
@@ -362,8 +735,19 @@ int fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, 
     return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
+int fused_layers(const Layout& lay, const char* packed, int l0, int l1, float* x, int n_samples, int Tn,
+                 hipStream_t s) {
+    FusedDims d;
+    if (!fused_dims(lay, &d) || !d.attn) return BESO_ERR_UNSUPPORTED;
+    const char* base = packed + lay.fused;
+    hipError_t e;
+    if (d.RPW == 3 && d.KS == 12) e = launch_layers<3, 12>(x, base, d, l0, l1, n_samples, Tn, s);
+    else return BESO_ERR_UNSUPPORTED;
+    return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
 int forward_fused(const Layout&, const Workspace&, const char*, int, const FwdArgs&, char*, hipStream_t) {
-    return BESO_ERR_UNSUPPORTED;   // orchestration lives in api.hip (forward_generic with use_fused_mlp)
+    return BESO_ERR_UNSUPPORTED;   // orchestration lives in api.hip
 }
 
 }  // namespace beso
