@@ -36,7 +36,8 @@ def _deps_mtime() -> float:
 def _compile(unit: str) -> str:
     src = os.path.join(CSRC, unit + ".hip")
     obj = os.path.join(OBJDIR, unit + ".o")
-    cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+    extra = os.environ.get("BESO_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [_hipcc(), *FLAGS, *extra, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {unit}:\n{r.stdout}\n{r.stderr}")

@@ -414,6 +414,8 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
     return BESO_OK;
 }
 
+void beso_debug_set_stamps(void* device_buf, int capacity_u64) { fused_set_stamps(device_buf, capacity_u64); }
+
 void beso_profile_enable(int site) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_site = site;

@@ -12,6 +12,7 @@ int    fused_level(const Layout& lay, const FwdArgs& a, int precision);   // 0 n
 int    fused_layers(const Layout& lay, const char* packed, int l0, int l1, float* x, int n_samples, int Tn,
                     hipStream_t s);
 int    fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, int M, hipStream_t s);
+void   fused_set_stamps(void* buf, int cap);
 int    forward_fused(const Layout& lay, const Workspace& ws, const char* packed, int precision, const FwdArgs& a,
                      char* wsp, hipStream_t s);
 

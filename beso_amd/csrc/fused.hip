@@ -27,6 +27,7 @@ namespace beso {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 namespace {
 
@@ -36,7 +37,9 @@ constexpr int kNTT = 6;                   // token tiles (16 tokens) per workgro
 constexpr int kMT = kNTT * 16;            // 96 token slots
 constexpr int kSPW = 8;                   // samples per workgroup in layers_kernel
 constexpr int kHDP = 64;                  // padded head dim of the attention phase
-constexpr int kQKVRow = kHDP + 4;         // bf16 elements per q/k/v row in LDS (+4: conflict-free 8-byte writes)
+constexpr int kQKVRow = kHDP + 8;         // bf16 elements per q/k/v row in LDS: 144 B, 16-B aligned, conflict-free b128 reads
+constexpr int kQKVRows = kMT + 8;         // rows per part: a sample's 16-row MFMA window may run 8 rows past the last slot
+constexpr int kQKVBytes = 3 * kQKVRows * kQKVRow * 2;   // 44928
 
 struct FusedDims {
     int D, FT, RPW, KS, HT, NCH, KS2p, H, hd;
@@ -90,13 +93,18 @@ bool shape_has_kernel(const FusedDims& d) {
 // pack kernels.  A-operand fragment order:
 //   dst[((R*kt + kk)*64 + lane)*8 + j] = bf16( M[16R + (lane&15)][32kk + 16(j>>2) + 4(lane>>4) + (j&3)] )
 // ---------------------------------------------------------------------------------------------
+// Fragment (R, kk) lives at tile index ((R/grp)*kt + kk)*grp + R%grp: the `grp` row tiles a workgroup
+// consumes together in one k-step are contiguous (grp KiB), so a k-step's loads of all 8 waves spread
+// over the L2 channels instead of striding by a whole row of k-steps.
 __global__ void pack_mfma_a_kernel(const float* __restrict__ src, int rows, int cols, const float* __restrict__ colscale,
-                                   uint16_t* __restrict__ dst, int rt, int kt) {
+                                   uint16_t* __restrict__ dst, int rt, int kt, int grp) {
     size_t total = (size_t)rt * kt * 512;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
         size_t tile = i >> 9;
-        int kk = (int)(tile % kt), R = (int)(tile / kt);
+        int rin = (int)(tile % grp);
+        int kk = (int)((tile / grp) % kt);
+        int R = (int)(tile / ((size_t)grp * kt)) * grp + rin;
         int r = 16 * R + (lane & 15);
         int c = 32 * kk + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
         float v = 0.f;
@@ -116,10 +124,11 @@ __global__ void pack_qkv_kernel(const float* __restrict__ wq, const float* __res
     size_t total = (size_t)H * 12 * kt * 512;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        size_t tile = i >> 9;
-        int kk = (int)(tile % kt);
-        int rt = (int)(tile / kt);               // (h*3 + part)*4 + R4
-        int R4 = rt & 3, part = (rt >> 2) % 3, h = rt / 12;
+        size_t tile = i >> 9;                    // (h*kt + kk)*12 + rt12
+        int rt12 = (int)(tile % 12);
+        int kk = (int)((tile / 12) % kt);
+        int h = (int)(tile / ((size_t)12 * kt));
+        int R4 = rt12 & 3, part = rt12 >> 2;
         int d = 16 * R4 + (lane & 15);
         int c = 32 * kk + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
         float v = 0.f;
@@ -156,8 +165,8 @@ __global__ void pack_proj_kernel(const float* __restrict__ wp, uint16_t* __restr
     size_t total = (size_t)rt * kt * 512;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        size_t tile = i >> 9;
-        int kk = (int)(tile % kt), R = (int)(tile / kt);
+        size_t tile = i >> 9;                    // kk*rt + R
+        int R = (int)(tile % rt), kk = (int)(tile / rt);
         int o = 16 * R + (lane & 15);
         int h = kk >> 1;
         int d = 32 * (kk & 1) + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
@@ -216,7 +225,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
 
 // ---------------------------------------------------------------------------------------------
 // One GEMM phase of the transposed formulation:  acc[r][t] += sum_kk A(r,kk) * B(t,kk)
-//   A(r,kk) = a[r*a_rs + kk*64]    weights, L2 -> registers (pointer already offset by the lane)
+//   A(r,kk) = a[r*64 + kk*a_ks]    weights, L2 -> registers (pointer already offset by the lane)
 //   B(t,kk) = b[t*b_ts + kk*b_ks]  activations, LDS -> registers (pointer already offset by the lane)
 // Two k-steps per iteration with named even/odd weight-fragment registers; the loads that refill a
 // register set are issued right behind the MFMAs that consumed it, so weight fragments are ~1.5
@@ -226,14 +235,14 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
 // ksteps must be even.
 // ---------------------------------------------------------------------------------------------
 template <int R>
-__device__ __forceinline__ void prefetch_a(u32x4 (&aE)[R], u32x4 (&aO)[R], const u32x4* __restrict__ a, int a_rs) {
+__device__ __forceinline__ void prefetch_a(u32x4 (&aE)[R], u32x4 (&aO)[R], const u32x4* __restrict__ a, int a_ks) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) { aE[r] = a[(size_t)r * a_rs]; aO[r] = a[(size_t)r * a_rs + 64]; }
+    for (int r = 0; r < R; ++r) { aE[r] = a[r * 64]; aO[r] = a[r * 64 + a_ks]; }
 }
 
 template <int R, int NT>
 __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], u32x4 (&aO)[R],
-                                           const u32x4* __restrict__ a, int a_rs, const u32x4* b, int b_ts,
+                                           const u32x4* __restrict__ a, int a_ks, const u32x4* b, int b_ts,
                                            int b_ks, int ksteps) {
     // ONE set of B fragments: each half of it is refilled for the next k-step as soon as the MFMAs that
     // read it have been issued (prefetch distance = half a k-step of MFMAs, enough for LDS latency).
@@ -261,7 +270,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
         for (int t = H1; t < NT; ++t) bf[t] = b[t * b_ts + (kk + 1) * b_ks];
         if (kk + 2 < ksteps) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) aE[r] = a[(size_t)r * a_rs + (kk + 2) * 64];
+            for (int r = 0; r < R; ++r) aE[r] = a[r * 64 + (kk + 2) * a_ks];
         }
         // ---- k-step kk+1 (odd fragments)
         __builtin_amdgcn_sched_barrier(0);
@@ -286,7 +295,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
         }
         if (kk + 3 < ksteps) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) aO[r] = a[(size_t)r * a_rs + (kk + 3) * 64];
+            for (int r = 0; r < R; ++r) aO[r] = a[r * 64 + (kk + 3) * a_ks];
         }
     }
 }
@@ -298,8 +307,7 @@ struct LdsMap {            // byte offsets inside the dynamic LDS block
     int xnT, u, red, tab, total;
 };
 __host__ __device__ constexpr LdsMap lds_map(int KS) {
-    // u is the phase-local region: attention (q/k/v 3*96*68*2 = 39168 | probs 8*16*16*4 = 8192 | yT 12288)
-    // or MLP (hT 6*8 KiB = 49152)
+    // u is the phase-local region: attention (q/k/v 3*104*72*2 = 44928 | yT 12288) or MLP (hT 6*8 KiB = 49152)
     LdsMap m{};
     m.xnT = 0;
     m.u = kNTT * KS * 1024;
@@ -307,6 +315,24 @@ __host__ __device__ constexpr LdsMap lds_map(int KS) {
     m.tab = m.red + 2 * kWaves * kMT * 4;
     m.total = m.tab + 512;
     return m;
+}
+
+// Optional phase timing (development aid): when a stamp buffer is installed (beso_debug_set_stamps),
+// thread 0 of workgroup 0 appends {phase id, s_memtime} pairs.
+#ifndef BESO_FUSED_STAMPS
+#define BESO_FUSED_STAMPS 0          // build with -DBESO_FUSED_STAMPS=1 for tools/phase_stamps.py
+#endif
+struct Stamps {
+    unsigned long long* buf;
+    int cap;
+    int n;
+};
+__device__ __forceinline__ void stamp(Stamps& st, int id) {
+    if (BESO_FUSED_STAMPS && st.buf && blockIdx.x == 0 && threadIdx.x == 0 && st.n + 2 <= st.cap) {
+        st.buf[st.n] = (unsigned long long)id;
+        st.buf[st.n + 1] = __builtin_amdgcn_s_memtime();
+        st.n += 2;
+    }
 }
 
 template <int RPW>
@@ -353,7 +379,10 @@ __device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restri
 // the normalised copy has been taken.
 template <int RPW, int KS>
 __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float* red, int D, int w, int lane,
-                                                 const float* __restrict__ bias) {
+                                                 const float* __restrict__ bias, Stamps& st) {
+    // `lane` is made opaque at the top of every phase: otherwise the per-lane address arithmetic of ALL
+    // phases is hoisted out of the layer loop and kept live across it (46 spilled VGPRs).
+    asm volatile("" : "+v"(lane));
     const int n = lane & 15, g = lane >> 4;
     float mean[kNTT], rstd[kNTT];
     const float invD = 1.0f / (float)D;
@@ -366,7 +395,9 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         s += __shfl_xor(s, 32, 64);
         if (g == 0) red[(0 * kWaves + w) * kMT + t * 16 + n] = s;
     }
+    stamp(st, 30);
     __syncthreads();
+    stamp(st, 31);
 #pragma unroll
     for (int t = 0; t < kNTT; ++t) {
         float s = 0.f;
@@ -388,7 +419,9 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         q += __shfl_xor(q, 32, 64);
         if (g == 0) red[(1 * kWaves + w) * kMT + t * 16 + n] = q;
     }
+    stamp(st, 32);
     __syncthreads();
+    stamp(st, 33);
 #pragma unroll
     for (int t = 0; t < kNTT; ++t) {
         float q = 0.f;
@@ -416,6 +449,7 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
 #pragma unroll
         for (int t = 0; t < kNTT; ++t) T.acc[i][t] += bv;
     }
+    stamp(st, 34);
     __syncthreads();
 }
 
@@ -425,11 +459,13 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
 template <int RPW, int KS>
 __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
                                           const float* __restrict__ b1f, const u32x4* __restrict__ w2p, int HT,
-                                          int KS2p, int w, int lane) {
+                                          int KS2p, int w, int lane, Stamps& st) {
+    asm volatile("" : "+v"(lane));
     const int g = lane >> 4;
     const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
     u32x4 a1E[2], a1O[2];
-    prefetch_a<2>(a1E, a1O, w1p + (size_t)(2 * w) * KS * 64 + lane, KS * 64);
+    // w1p: [chunk][kk][16 row tiles]; w2p: [kk2][8*RPW row tiles]
+    prefetch_a<2>(a1E, a1O, w1p + (size_t)(2 * w) * 64 + lane, kChunkTiles * 64);
     for (int c = 0; c < n_chunks; ++c) {
         const int tiles_here = min(kChunkTiles, HT - c * kChunkTiles);
         const bool fc1_active = 2 * w < tiles_here;
@@ -440,11 +476,13 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
             const f32x4 bias1 = *(const f32x4*)(b1f + 16 * (R0 + 1) + 4 * g);
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) { h[0][t] = bias0; h[1][t] = bias1; }
-            gemm_phase<2, kNTT>(h, a1E, a1O, w1p + (size_t)R0 * KS * 64 + lane, KS * 64, xnT + lane, KS * 64, 64, KS);
+            gemm_phase<2, kNTT>(h, a1E, a1O, w1p + ((size_t)c * KS * kChunkTiles + 2 * w) * 64 + lane, kChunkTiles * 64,
+                                xnT + lane, KS * 64, 64, KS);
         }
+        stamp(st, 20);
         u32x4 a2E[RPW], a2O[RPW];
-        const u32x4* a2 = w2p + ((size_t)(w * RPW) * KS2p + c * kWaves) * 64 + lane;
-        prefetch_a<RPW>(a2E, a2O, a2, KS2p * 64);
+        const u32x4* a2 = w2p + ((size_t)(c * kWaves) * (kWaves * RPW) + w * RPW) * 64 + lane;
+        prefetch_a<RPW>(a2E, a2O, a2, kWaves * RPW * 64);
         if (fc1_active) {
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) {
@@ -456,47 +494,49 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
                 hT[((size_t)t * kWaves + w) * 64 + lane] = hb;
             }
         }
+        stamp(st, 21);
         __syncthreads();
+        stamp(st, 22);
         if (c + 1 < n_chunks)
-            prefetch_a<2>(a1E, a1O, w1p + (size_t)(R0 + kChunkTiles) * KS * 64 + lane, KS * 64);
+            prefetch_a<2>(a1E, a1O, w1p + ((size_t)(c + 1) * KS * kChunkTiles + 2 * w) * 64 + lane, kChunkTiles * 64);
         // k-steps are consumed in pairs; an odd tail reads a stale (finite) hT slot against zero weights
-        gemm_phase<RPW, kNTT>(T.acc, a2E, a2O, a2, KS2p * 64, hT + lane, kWaves * 64, 64,
+        gemm_phase<RPW, kNTT>(T.acc, a2E, a2O, a2, kWaves * RPW * 64, hT + lane, kWaves * 64, 64,
                               ((tiles_here >> 1) + 1) & ~1);
+        stamp(st, 23);
         __syncthreads();
+        stamp(st, 24);
     }
 }
 
 // Attention phase (xnT holds LN1(x) fragments on entry).  Tokens of the tile are in natural order:
 // slot = sample*Tn + position, n_samples*Tn valid slots.
 template <int RPW, int KS>
-__device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsigned char* u, const uint8_t* tab,
+__device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsigned char* u,
                                            const u32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
                                            const u32x4* __restrict__ wproj, int H, int hd, int Tn, int n_samples,
-                                           int w, int lane) {
+                                           int w, int lane, Stamps& st) {
+    asm volatile("" : "+v"(lane));
     const int n = lane & 15, g = lane >> 4;
-    const int tid = w * 64 + lane;
-    uint16_t* qkv = (uint16_t*)u;                         // [3][96][kQKVRow] bf16
-    float* probs = (float*)(u + 39168);                   // [8][16][16]
-    u32x4* yT = (u32x4*)(u + 39168 + 8192);               // [(t*2 + kk)*64 + lane]
+    uint16_t* qkv = (uint16_t*)u;                         // [3][kQKVRows][kQKVRow] bf16
+    u32x4* yT = (u32x4*)(u + kQKVBytes);                  // [(t*2 + kk)*64 + lane]
     const int wa = w & 3, wb = w >> 2;                    // QKV split: row tiles 3wa..3wa+2 x token tiles 3wb..3wb+2
-    const float scale = 1.0f / sqrtf((float)hd);
-    const int NP = Tn * (Tn + 1) / 2;
-    const int n_valid = n_samples * Tn;
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
 
     for (int h = 0; h < H; ++h) {
+        stamp(st, 10);
         // ---- q, k, v of head h for all tokens of the tile
         {
             f32x4 qa[3][3];
             u32x4 aE[3], aO[3];
-            const u32x4* a = wqkv + ((size_t)(h * 12 + 3 * wa) * KS) * 64 + lane;
-            prefetch_a<3>(aE, aO, a, KS * 64);
+            const u32x4* a = wqkv + ((size_t)h * KS * 12 + 3 * wa) * 64 + lane;     // [head][kk][12 row tiles]
+            prefetch_a<3>(aE, aO, a, 12 * 64);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const f32x4 bv = *(const f32x4*)(bqkv + (h * 12 + 3 * wa + i) * 16 + 4 * g);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) qa[i][t] = bv;
             }
-            gemm_phase<3, 3>(qa, aE, aO, a, KS * 64, xnT + (size_t)(3 * wb) * KS * 64 + lane, KS * 64, 64, KS);
+            gemm_phase<3, 3>(qa, aE, aO, a, 12 * 64, xnT + (size_t)(3 * wb) * KS * 64 + lane, KS * 64, 64, KS);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int rt = 3 * wa + i, part = rt >> 2, d0 = (rt & 3) * 16 + 4 * g;
@@ -506,69 +546,77 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                     uint2 pk;
                     pk.x = pack_bf16x2(qa[i][t][0], qa[i][t][1]);
                     pk.y = pack_bf16x2(qa[i][t][2], qa[i][t][3]);
-                    *(uint2*)(qkv + ((size_t)part * kMT + tok) * kQKVRow + d0) = pk;
+                    *(uint2*)(qkv + ((size_t)part * kQKVRows + tok) * kQKVRow + d0) = pk;
                 }
             }
         }
+        stamp(st, 11);
         __syncthreads();
-        // ---- scores: one (sample, i, j<=i) pair per thread, 64-wide dot product with v_dot2_f32_bf16
-        for (int pi = tid; pi < n_samples * NP; pi += kWaves * 64) {
-            const int s = pi / NP, pr = pi - s * NP;
-            const int i = tab[2 * pr], j = tab[2 * pr + 1];
-            const uint2* qr = (const uint2*)(qkv + ((size_t)0 * kMT + s * Tn + i) * kQKVRow);
-            const uint2* kr = (const uint2*)(qkv + ((size_t)1 * kMT + s * Tn + j) * kQKVRow);
-            float d0 = 0.f, d1 = 0.f;
+        stamp(st, 12);
+        // ---- attention core on the matrix pipe, one sample per wave (score_gpts.py:69-73):
+        //   S^T[j][i] = sum_d K[j][d] Q[i][d]        2 x v_mfma_f32_16x16x32_bf16 (A = K rows, B = Q rows)
+        //   D layout: lane (i = lane&15, g) holds keys j = 4g + r  ->  causal mask, softmax over j =
+        //   in-lane over r + two xor-shuffles over g; the unnormalised probabilities are already the B
+        //   operand (k = 4g..4g+3) of v_mfma_f32_16x16x16_bf16 for
+        //   Y^T[d][i] = sum_j V[j][d] P[i][j]          4 x (A = V^T gathered with 16-bit LDS reads)
+        //   whose D layout is the B fragment of the out-projection (same k permutation as the weights).
+        if (w < n_samples) {
+            const uint16_t* qb = qkv + ((size_t)0 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
+            const uint16_t* kb = qkv + ((size_t)1 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
+            f32x4 sT = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < kHDP / 4; ++c) {
-                const uint2 qv = qr[c], kv = kr[c];
-                d0 = dot2_bf16(qv.x, kv.x, d0);
-                d1 = dot2_bf16(qv.y, kv.y, d1);
+            for (int kk = 0; kk < 2; ++kk)
+                sT = mfma_bf16(*(const u32x4*)(kb + 32 * kk), *(const u32x4*)(qb + 32 * kk), sT);
+            float e[4], m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = (4 * g + r <= n) ? sT[r] * scale_log2e : -INFINITY;     // (q k^T)/sqrt(hd), in log2 units
+                m = fmaxf(m, e[r]);
             }
-            probs[(s * 16 + i) * 16 + j] = (d0 + d1) * scale;
-        }
-        __syncthreads();
-        // ---- causal softmax, one (sample, i) row per thread
-        if (tid < n_valid) {
-            const int s = tid / Tn, i = tid - s * Tn;
-            float* row = probs + (s * 16 + i) * 16;
-            float m = row[0];
-            for (int j = 1; j <= i; ++j) m = fmaxf(m, row[j]);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
             float sum = 0.f;
-            for (int j = 0; j <= i; ++j) { const float e = expf(row[j] - m); row[j] = e; sum += e; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - m); sum += e[r]; }   // exp2(-inf) = 0
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
-            for (int j = 0; j <= i; ++j) row[j] *= inv;
-        }
-        __syncthreads();
-        // ---- y = P V: one B fragment (token, k-step, lane group) = 8 head dims per work item
-        for (int it = tid; it < n_valid * 8; it += kWaves * 64) {
-            const int tok = it >> 3, kk = (it >> 2) & 1, gg = it & 3;
-            const int s = tok / Tn, i = tok - s * Tn;
-            const float* prow = probs + (s * 16 + i) * 16;
-            const uint16_t* vb = qkv + ((size_t)2 * kMT + s * Tn) * kQKVRow + 32 * kk + 4 * gg;
-            float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int j = 0; j <= i; ++j) {
-                const float p = prow[j];
-                const uint2 v0 = *(const uint2*)(vb + (size_t)j * kQKVRow);
-                const uint2 v1 = *(const uint2*)(vb + (size_t)j * kQKVRow + 16);
-                o[0] = fmaf(p, bf16_lo(v0.x), o[0]); o[1] = fmaf(p, bf16_hi(v0.x), o[1]);
-                o[2] = fmaf(p, bf16_lo(v0.y), o[2]); o[3] = fmaf(p, bf16_hi(v0.y), o[3]);
-                o[4] = fmaf(p, bf16_lo(v1.x), o[4]); o[5] = fmaf(p, bf16_hi(v1.x), o[5]);
-                o[6] = fmaf(p, bf16_lo(v1.y), o[6]); o[7] = fmaf(p, bf16_hi(v1.y), o[7]);
+            uint2 pb = make_uint2(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]));
+            const uint16_t* vb = qkv + ((size_t)2 * kQKVRows + w * Tn + 4 * g) * kQKVRow + n;
+            f32x4 y[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 va;
+                va.x = (uint32_t)vb[16 * dt] | ((uint32_t)vb[kQKVRow + 16 * dt] << 16);
+                va.y = (uint32_t)vb[2 * kQKVRow + 16 * dt] | ((uint32_t)vb[3 * kQKVRow + 16 * dt] << 16);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                y[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, va),
+                                                                  __builtin_bit_cast(s16x4, pb), z, 0, 0, 0);
             }
-            u32x4 yb;
-            yb[0] = pack_bf16x2(o[0], o[1]); yb[1] = pack_bf16x2(o[2], o[3]);
-            yb[2] = pack_bf16x2(o[4], o[5]); yb[3] = pack_bf16x2(o[6], o[7]);
-            yT[((size_t)(tok >> 4) * 2 + kk) * 64 + (gg << 4) + (tok & 15)] = yb;
+            if (n < Tn) {
+                const int tok = w * Tn + n;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    u32x4 yb;
+                    yb[0] = pack_bf16x2(y[2 * kk][0] * inv, y[2 * kk][1] * inv);
+                    yb[1] = pack_bf16x2(y[2 * kk][2] * inv, y[2 * kk][3] * inv);
+                    yb[2] = pack_bf16x2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
+                    yb[3] = pack_bf16x2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
+                    yT[((size_t)(tok >> 4) * 2 + kk) * 64 + (g << 4) + (tok & 15)] = yb;
+                }
+            }
         }
+        stamp(st, 16);
         __syncthreads();
+        stamp(st, 17);
         // ---- the head's slice of the out-projection, accumulated into the residual
         {
             u32x4 aE[RPW], aO[RPW];
-            const u32x4* a = wproj + ((size_t)(w * RPW) * (2 * H) + 2 * h) * 64 + lane;
-            prefetch_a<RPW>(aE, aO, a, 2 * H * 64);
-            gemm_phase<RPW, kNTT>(T.acc, aE, aO, a, 2 * H * 64, yT + lane, 2 * 64, 64, 2);
+            const u32x4* a = wproj + ((size_t)(2 * h) * (kWaves * RPW) + w * RPW) * 64 + lane;   // [2h+kk][row tiles]
+            prefetch_a<RPW>(aE, aO, a, kWaves * RPW * 64);
+            gemm_phase<RPW, kNTT>(T.acc, aE, aO, a, kWaves * RPW * 64, yT + lane, 2 * 64, 64, 2);
         }
-        // no barrier needed here: the next writes to qkv/probs/yT happen behind the next head's barriers
+        // no barrier needed here: the next writes to qkv/yT happen behind the next head's barriers
     }
     __syncthreads();
 }
@@ -578,7 +626,8 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
 // ---------------------------------------------------------------------------------------------
 template <int RPW, int KS>
 __global__ __launch_bounds__(512, 2) void mlp_block_kernel(float* __restrict__ x, const char* __restrict__ lw,
-                                                           FusedDims d, int M) {
+                                                           FusedDims d, int M, unsigned long long* stamps, int cap) {
+    Stamps st{stamps, cap, 0};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr LdsMap L = lds_map(KS);
     const int lane = threadIdx.x & 63;
@@ -587,16 +636,18 @@ __global__ __launch_bounds__(512, 2) void mlp_block_kernel(float* __restrict__ x
     const int m0 = blockIdx.x * kMT;
     Tile<RPW> T;
     load_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
-    layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane, (const float*)(lw + d.o_b2));
+    layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane, (const float*)(lw + d.o_b2), st);
     mlp_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
-                       (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane);
+                       (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, st);
     store_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
 }
 
 // Whole transformer layers [l0, l1) over the tile's 8 samples; x stays in registers in between.
 template <int RPW, int KS>
 __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, const char* __restrict__ lw0,
-                                                        FusedDims d, int l0, int l1, int n_samples_total, int Tn) {
+                                                        FusedDims d, int l0, int l1, int n_samples_total, int Tn,
+                                                        unsigned long long* stamps, int cap) {
+    Stamps st{stamps, cap, 0};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr LdsMap L = lds_map(KS);
     const int lane = threadIdx.x & 63;
@@ -605,32 +656,39 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     const int s0 = blockIdx.x * kSPW;
     const int n_samples = min(kSPW, n_samples_total - s0);
     const int m0 = s0 * Tn, m_end = m0 + n_samples * Tn;
-    uint8_t* tab = (uint8_t*)(lds + L.tab);
-    // (i, j) of the causal pairs, j <= i
-    for (int pr = threadIdx.x; pr < Tn * (Tn + 1) / 2; pr += blockDim.x) {
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= pr) ++i;
-        tab[2 * pr] = (uint8_t)i;
-        tab[2 * pr + 1] = (uint8_t)(pr - i * (i + 1) / 2);
+    // LDS that is read but never written by the phases must be finite: the attention-output fragments of
+    // padding tokens, and the 8 q/k/v rows past the last token slot (a sample's 16-row window reaches them)
+    for (int i = threadIdx.x; i < kNTT * 2 * 64; i += blockDim.x) ((u32x4*)(lds + L.u + kQKVBytes))[i] = u32x4{0, 0, 0, 0};
+    for (int i = threadIdx.x; i < 3 * 8 * kQKVRow / 2; i += blockDim.x) {
+        const int part = i / (8 * kQKVRow / 2), rem = i % (8 * kQKVRow / 2);
+        ((uint32_t*)(lds + L.u))[((size_t)part * kQKVRows + kMT) * kQKVRow / 2 + rem] = 0u;
     }
-    // the attention-output fragments of padding tokens are never written: make them finite once
-    for (int i = threadIdx.x; i < kNTT * 2 * 64; i += blockDim.x) ((u32x4*)(lds + L.u + 39168 + 8192))[i] = u32x4{0, 0, 0, 0};
     Tile<RPW> T;
+    stamp(st, 1);
     load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     for (int l = l0; l < l1; ++l) {
         const char* lw = lw0 + (size_t)l * d.layer_bytes;
+        stamp(st, 2);
         layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
-                                  (const float*)(lw + d.o_bproj));
-        attn_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), lds + L.u, tab, (const u32x4*)(lw + d.o_wqkv),
+                                  (const float*)(lw + d.o_bproj), st);
+        stamp(st, 7);
+        attn_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
                             (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.H, d.hd, Tn, n_samples, w,
-                            lane);
+                            lane, st);
+        stamp(st, 3);
         layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
-                                  (const float*)(lw + d.o_b2));
+                                  (const float*)(lw + d.o_b2), st);
+        stamp(st, 6);
         mlp_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
-                           (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane);
+                           (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, st);
     }
+    stamp(st, 4);
     store_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
+    stamp(st, 5);
 }
+
+unsigned long long* g_stamps = nullptr;
+int g_stamps_cap = 0;
 
 template <typename K>
 hipError_t ensure_lds(K kernel, size_t bytes, bool* done) {
@@ -647,7 +705,7 @@ hipError_t launch_mlp_block(float* x, const char* lw, const FusedDims& d, int M,
     hipError_t e = ensure_lds(mlp_block_kernel<RPW, KS>, L.total, &attr);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((mlp_block_kernel<RPW, KS>), dim3((M + kMT - 1) / kMT), dim3(512), L.total, s, x, lw, d, M);
+    hipLaunchKernelGGL((mlp_block_kernel<RPW, KS>), dim3((M + kMT - 1) / kMT), dim3(512), L.total, s, x, lw, d, M, g_stamps, g_stamps_cap);
     return hipGetLastError();
 }
 
@@ -660,7 +718,7 @@ hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, 
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
     hipLaunchKernelGGL((layers_kernel<RPW, KS>), dim3((n_samples + kSPW - 1) / kSPW), dim3(512), L.total, s, x, lw0, d,
-                       l0, l1, n_samples, Tn);
+                       l0, l1, n_samples, Tn, g_stamps, g_stamps_cap);
     return hipGetLastError();
 }
 
@@ -692,11 +750,11 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
         const int rt1 = d.NCH * kChunkTiles, rt2 = d.RPW * kWaves;
         (void)hipGetLastError();
         hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, f1w, 4 * D, D, ln2w, (uint16_t*)base, rt1,
-                           d.KS);
+                           d.KS, kChunkTiles);
         hipLaunchKernelGGL(fold_bias_kernel, dim3((rt1 * 16 + 255) / 256), dim3(256), 0, s, f1w, f1b, ln2b,
                            (float*)(base + d.o_b1), 4 * D, D, rt1 * 16);
         hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, f2w, D, 4 * D, (const float*)nullptr,
-                           (uint16_t*)(base + d.o_w2), rt2, d.KS2p);
+                           (uint16_t*)(base + d.o_w2), rt2, d.KS2p, rt2);
         FTRY(hipGetLastError());
         FTRY(launch_pack_matrix(f2b, 1, D, base + d.o_b2, 1, rt2 * 16, -1, s));
         if (d.attn) {
@@ -744,6 +802,11 @@ int fused_layers(const Layout& lay, const char* packed, int l0, int l1, float* x
     if (d.RPW == 3 && d.KS == 12) e = launch_layers<3, 12>(x, base, d, l0, l1, n_samples, Tn, s);
     else return BESO_ERR_UNSUPPORTED;
     return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+void fused_set_stamps(void* buf, int cap) {
+    g_stamps = (unsigned long long*)buf;
+    g_stamps_cap = cap;
 }
 
 int forward_fused(const Layout&, const Workspace&, const char*, int, const FwdArgs&, char*, hipStream_t) {

@@ -146,6 +146,9 @@ enum {
     BESO_SITE_FUSED_LAYER = 10 /* fused per-layer kernel (fused path) */
 };
 void beso_profile_enable(int site);
+/* Development aid: install a device buffer of `capacity_u64` uint64 slots; workgroup 0 of the fused
+ * kernels appends {phase id, shader clock} pairs to it (NULL / 0 switches it off).               */
+void beso_debug_set_stamps(void* device_buf, int capacity_u64);
 int  beso_profile_read(double* total_ms, int* launches);
 
 #ifdef __cplusplus

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Development aid: per-phase cycle breakdown of the fused layers kernel (workgroup 0, wave 0), from
+the in-kernel s_memtime stamps (beso_debug_set_stamps).  Run on the GPU box."""
+import collections
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import build_model          # noqa: E402
+from beso_amd import _lib              # noqa: E402
+from oracle import beso_oracle as O    # noqa: E402
+
+NAMES = {1: "start", 2: "layer_start", 7: "ln1_done", 10: "head_start", 11: "qkv_gemm+write", 12: "bar_qkv",
+         13: "scores", 14: "softmax(+bar)", 15: "bar_softmax", 16: "pv", 17: "bar_pv", 3: "attn_done(proj..)",
+         6: "ln2_done", 20: "fc1_gemm", 21: "fc2pref+gelu", 22: "bar_gelu", 23: "fc2_gemm", 24: "bar_fc2", 4: "layers_done",
+         5: "stored", 30: "ln_pass1", 31: "ln_bar1", 32: "ln_pass2", 33: "ln_bar2", 34: "ln_write"}
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    dev = "cuda:0"
+    cfg = O.KITCHEN
+    model = build_model(cfg, O.make_weights(cfg, seed=0, std=0.02), "bf16", dev)
+    s, g, a = (torch.from_numpy(v).to(dev) for v in O.make_inputs(cfg, B, seed=1))
+    sig = torch.full((B,), 0.3, device=dev)
+    lib = _lib.load()
+    buf = torch.zeros(4096, dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            model(s, a, g, sig)
+        torch.cuda.synchronize()
+        lib.beso_debug_set_stamps(buf.data_ptr(), buf.numel())
+        model(s, a, g, sig)
+        torch.cuda.synchronize()
+        lib.beso_debug_set_stamps(None, 0)
+    v = buf.cpu().numpy()
+    ids, ts = v[0::2], v[1::2]
+    n = int(np.nonzero(ids)[0].max()) + 1 if ids.any() else 0
+    ids, ts = ids[:n], ts[:n]
+    total = ts[-1] - ts[0]
+    acc = collections.OrderedDict()
+    for k in range(1, n):
+        key = NAMES.get(int(ids[k]), str(ids[k]))
+        acc[key] = acc.get(key, 0) + int(ts[k] - ts[k - 1])
+    print(f"B={B}: {n} stamps, total {total} ticks (s_memtime, 100 MHz => {total / 100:.1f} us)")
+    for k, c in acc.items():
+        print(f"  {k:22s} {c:10d} ticks  {100.0 * c / total:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
