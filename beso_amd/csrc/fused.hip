@@ -204,18 +204,22 @@ __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
 }
 
-// exact-erf GELU (nn.GELU() default).  erf by Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7:
-// GELU(v) = max(v,0) - |v| * q,  q = 0.5 * poly(t) * exp(-v^2/2),  t = 1/(1 + p|v|/sqrt2)
+// GELU(v) = v * Phi(v) with the exact-erf Phi of nn.GELU() (score_gpts.py:107), evaluated without
+// transcendentals:  Phi(v) - 1/2 = vc * P(vc^2),  vc = clamp(v, +-4),  P a degree-6 minimax polynomial
+// fitted to erf (tools/fit_gelu.py): max |error| of GELU over all v is 1.9e-4, an order of magnitude
+// below the bf16 rounding (2^-9 relative) that the result receives next.  11 plain VALU ops; the
+// rcp/exp2 formulation cost 13 ops of which 2 quarter-rate, and VALU issue is what bounds the MLP phase.
 __device__ __forceinline__ float gelu_fast(float v) {
-    const float av = fabsf(v);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, av, 1.0f));
-    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
-    p = fmaf(p, t, 0.5f * 1.421413741f);
-    p = fmaf(p, t, 0.5f * -0.284496736f);
-    p = fmaf(p, t, 0.5f * 0.254829592f);
-    p *= t;
-    const float e = __builtin_amdgcn_exp2f(v * (v * -0.72134752044448170368f));   // exp(-v^2/2)
-    return fmaf(-av, p * e, fmaxf(v, 0.f));
+    const float vc = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);
+    const float s = vc * vc;
+    float p = fmaf(s, 2.277972093e-08f, -1.598515742e-06f);
+    p = fmaf(p, s, 4.795382804e-05f);
+    p = fmaf(p, s, -0.0008139993719f);
+    p = fmaf(p, s, 0.00877231165f);
+    p = fmaf(p, s, -0.06457294506f);
+    p = fmaf(p, s, 0.3978832308f);
+    const float u = vc * p;
+    return fmaf(v, u, 0.5f * v);
 }
 
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
@@ -234,10 +238,32 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
 // aE/aO must already hold k-steps 0 and 1 (prefetch_a), which lets the caller issue them early.
 // ksteps must be even.
 // ---------------------------------------------------------------------------------------------
+#ifndef BESO_FUSED_ABLATE
+#define BESO_FUSED_ABLATE 0          // 1: every weight-fragment load hits the same few KiB (timing experiment only)
+#endif
+#if BESO_FUSED_ABLATE == 1
+#define ABL_KS(x) 0
+#define ABL_PTR(base, off) (base)
+#else
+#define ABL_KS(x) (x)
+#define ABL_PTR(base, off) ((base) + (off))
+#endif
+
+#ifndef BESO_FUSED_WLOAD
+#define BESO_FUSED_WLOAD 0           // 0: plain loads, 1: non-temporal (measured 11 % SLOWER: 1.39 vs 1.26 ms)
+#endif
+__device__ __forceinline__ u32x4 wload(const u32x4* p) {
+#if BESO_FUSED_WLOAD == 1
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 template <int R>
 __device__ __forceinline__ void prefetch_a(u32x4 (&aE)[R], u32x4 (&aO)[R], const u32x4* __restrict__ a, int a_ks) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) { aE[r] = a[r * 64]; aO[r] = a[r * 64 + a_ks]; }
+    for (int r = 0; r < R; ++r) { aE[r] = wload(a + r * 64); aO[r] = wload(a + r * 64 + ABL_KS(a_ks)); }
 }
 
 template <int R, int NT>
@@ -270,7 +296,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
         for (int t = H1; t < NT; ++t) bf[t] = b[t * b_ts + (kk + 1) * b_ks];
         if (kk + 2 < ksteps) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) aE[r] = a[r * 64 + (kk + 2) * a_ks];
+            for (int r = 0; r < R; ++r) aE[r] = wload(a + r * 64 + ABL_KS((kk + 2) * a_ks));
         }
         // ---- k-step kk+1 (odd fragments)
         __builtin_amdgcn_sched_barrier(0);
@@ -295,7 +321,51 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
         }
         if (kk + 3 < ksteps) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) aO[r] = a[r * 64 + (kk + 3) * a_ks];
+            for (int r = 0; r < R; ++r) aO[r] = wload(a + r * 64 + ABL_KS((kk + 3) * a_ks));
+        }
+    }
+}
+
+// Variant for the phases with short k-steps (2-3 row tiles x 3-6 token tiles per wave): a ring of PFA
+// k-steps of weight fragments (refilled PFA k-steps ahead: the L2 round trip is longer than one short
+// k-step of MFMAs) and two sets of B fragments (a whole k-step of LDS prefetch distance).
+// ksteps must be a multiple of PFA, PFA even.
+template <int R, int PFA>
+__device__ __forceinline__ void prefetch_ring(u32x4 (&ar)[PFA][R], const u32x4* __restrict__ a, int a_ks) {
+#pragma unroll
+    for (int p = 0; p < PFA; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r) ar[p][r] = wload(a + r * 64 + ABL_KS(p * a_ks));
+}
+
+template <int R, int NT, int PFA>
+__device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)[PFA][R],
+                                                const u32x4* __restrict__ a, int a_ks, const u32x4* b, int b_ts,
+                                                int b_ks, int ksteps) {
+    static_assert(PFA % 2 == 0, "B fragments alternate between two sets");
+    u32x4 bb[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bb[0][t] = b[t * b_ts];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bb[1][t] = b[t * b_ts + b_ks];
+    for (int k0 = 0; k0 < ksteps; k0 += PFA) {
+#pragma unroll
+        for (int p = 0; p < PFA; ++p) {
+            const int kk = k0 + p;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(ar[p][r], bb[p & 1][t], acc[r][t]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (BESO_FUSED_ABLATE != 2 && kk + 2 < ksteps) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bb[p & 1][t] = b[t * b_ts + (kk + 2) * b_ks];
+            }
+            if (BESO_FUSED_ABLATE != 3 && kk + PFA < ksteps) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) ar[p][r] = wload(a + r * 64 + ABL_KS((kk + PFA) * a_ks));
+            }
         }
     }
 }
@@ -328,9 +398,11 @@ struct Stamps {
     int n;
 };
 __device__ __forceinline__ void stamp(Stamps& st, int id) {
-    if (BESO_FUSED_STAMPS && st.buf && blockIdx.x == 0 && threadIdx.x == 0 && st.n + 2 <= st.cap) {
-        st.buf[st.n] = (unsigned long long)id;
-        st.buf[st.n + 1] = __builtin_amdgcn_s_memtime();
+    // lane 0 of every wave of workgroup 0 records into its own eighth of the buffer
+    if (BESO_FUSED_STAMPS && st.buf && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && st.n + 2 <= st.cap / 8) {
+        unsigned long long* b = st.buf + (size_t)(threadIdx.x >> 6) * (st.cap / 8);
+        b[st.n] = (unsigned long long)id;
+        b[st.n + 1] = __builtin_amdgcn_s_memtime();
         st.n += 2;
     }
 }
@@ -453,9 +525,33 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
     __syncthreads();
 }
 
-// MLP phase (xnT holds LN2(x) fragments on entry): hidden chunks of 16 row tiles, FC1 (+bias, GELU) ->
-// hT -> FC2 accumulated into the residual.  The first weight fragments of each GEMM phase are issued
-// one phase early (FC2's before the GELU, the next chunk's FC1 before the FC2 loop).
+// GELU of one chunk's FC1 accumulators -> packed bf16 B fragments (one FC2 k-step per wave), as a
+// sequence of 6*kNTT... = 48 scalar evaluations that can be issued in slices between MFMAs.
+template <int LO, int HI>
+__device__ __forceinline__ void gelu_slice(const f32x4 (&h)[2][kNTT], float (&gq)[8], u32x4 (&hb)[kNTT]) {
+    // evaluation idx -> token tile idx/8, element idx%8 (0..3: row tile 0 regs, 4..7: row tile 1 regs)
+#pragma unroll
+    for (int idx = LO; idx < HI; ++idx) {
+        const int t = idx >> 3, j = idx & 7;
+        gq[j] = gelu_fast(h[j >> 2][t][j & 3]);
+        asm volatile("" : "+v"(gq[j]));      // keep the evaluation HERE (between the MFMAs), not sunk to its use
+        if (j == 7) {
+            hb[t][0] = pack_bf16x2(gq[0], gq[1]);
+            hb[t][1] = pack_bf16x2(gq[2], gq[3]);
+            hb[t][2] = pack_bf16x2(gq[4], gq[5]);
+            hb[t][3] = pack_bf16x2(gq[6], gq[7]);
+        }
+    }
+}
+
+// MLP phase (xnT holds LN2(x) fragments on entry): hidden chunks of 16 row tiles; per chunk FC1 (+bias)
+// -> GELU -> hT (one FC2 k-step per wave) -> FC2 accumulated into the residual.  Software pipelined
+// so that the VALU work hides under the matrix pipe: the GELU of chunk c is issued in slices of 3
+// evaluations between the MFMAs of FC2(c-1), whose operands (hT(c-1)) are still in LDS; the packed
+// result waits in registers until every wave has finished reading hT(c-1).
+//     FC1(0)
+//     for c:  [FC2(c-1) || GELU(c)]  barrier  hT <- GELU(c)  FC1(c+1)  barrier
+//     FC2(n-1)
 template <int RPW, int KS>
 __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
                                           const float* __restrict__ b1f, const u32x4* __restrict__ w2p, int HT,
@@ -463,49 +559,113 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     asm volatile("" : "+v"(lane));
     const int g = lane >> 4;
     const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
-    u32x4 a1E[2], a1O[2];
+    constexpr int A2KS = kWaves * RPW * 64;                  // u32x4 stride between FC2 k-steps
+    constexpr int H1 = kNTT / 2;
     // w1p: [chunk][kk][16 row tiles]; w2p: [kk2][8*RPW row tiles]
-    prefetch_a<2>(a1E, a1O, w1p + (size_t)(2 * w) * 64 + lane, kChunkTiles * 64);
-    for (int c = 0; c < n_chunks; ++c) {
+    auto fc1_a = [&](int c) { return ABL_PTR(w1p + (size_t)(2 * w) * 64 + lane, (size_t)c * KS * kChunkTiles * 64); };
+    auto fc2_a = [&](int c) { return ABL_PTR(w2p + (size_t)(w * RPW) * 64 + lane, (size_t)(c * kWaves) * (kWaves * RPW) * 64); };
+    constexpr int PF1 = 4;
+    auto fc1 = [&](int c, f32x4 (&h)[2][kNTT], u32x4 (&ar)[PF1][2]) {
+        const int R0 = c * kChunkTiles + 2 * w;
+        const f32x4 bias0 = *(const f32x4*)(b1f + 16 * R0 + 4 * g);
+        const f32x4 bias1 = *(const f32x4*)(b1f + 16 * (R0 + 1) + 4 * g);
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) { h[0][t] = bias0; h[1][t] = bias1; }
+        gemm_phase_ring<2, kNTT, PF1>(h, ar, fc1_a(c), kChunkTiles * 64, xnT + lane, KS * 64, 64, KS);
+    };
+
+    f32x4 h[2][kNTT];
+    u32x4 a1r[PF1][2];
+    u32x4 hb[kNTT];
+    float gq[8];
+    // ---- prologue: FC1(0), GELU(0) (nothing to hide it under yet), hT(0), FC1(1)
+    static_assert(KS % PF1 == 0, "FC1 weight ring");
+    prefetch_ring<2, PF1>(a1r, fc1_a(0), kChunkTiles * 64);
+    fc1(0, h, a1r);                 // rows beyond HT are zero weights + zero bias: harmless for every wave
+    if (n_chunks > 1) prefetch_ring<2, PF1>(a1r, fc1_a(1), kChunkTiles * 64);
+    gelu_slice<0, 8 * kNTT>(h, gq, hb);
+#pragma unroll
+    for (int t = 0; t < kNTT; ++t) hT[((size_t)t * kWaves + w) * 64 + lane] = hb[t];
+    if (n_chunks > 1) fc1(1, h, a1r);
+    stamp(st, 20);
+    __syncthreads();                     // hT(0) complete
+#pragma unroll 1
+    for (int c = 1; c < n_chunks; ++c) {
         const int tiles_here = min(kChunkTiles, HT - c * kChunkTiles);
         const bool fc1_active = 2 * w < tiles_here;
-        const int R0 = c * kChunkTiles + 2 * w;
-        f32x4 h[2][kNTT];
-        if (fc1_active) {
-            const f32x4 bias0 = *(const f32x4*)(b1f + 16 * R0 + 4 * g);
-            const f32x4 bias1 = *(const f32x4*)(b1f + 16 * (R0 + 1) + 4 * g);
+        const int cn = min(c + 1, n_chunks - 1);
+        prefetch_ring<2, PF1>(a1r, fc1_a(cn), kChunkTiles * 64);
+        {
+            // ---- FC2(c-1) (always a full chunk: 8 k-steps) with GELU(c) woven in, fully unrolled
+            const u32x4* a2 = fc2_a(c - 1);
+            const u32x4* b = hT + lane;
+            u32x4 af2[2][RPW], bf[kNTT];               // [k-step parity][row tile]
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) { h[0][t] = bias0; h[1][t] = bias1; }
-            gemm_phase<2, kNTT>(h, a1E, a1O, w1p + ((size_t)c * KS * kChunkTiles + 2 * w) * 64 + lane, kChunkTiles * 64,
-                                xnT + lane, KS * 64, 64, KS);
-        }
-        stamp(st, 20);
-        u32x4 a2E[RPW], a2O[RPW];
-        const u32x4* a2 = w2p + ((size_t)(c * kWaves) * (kWaves * RPW) + w * RPW) * 64 + lane;
-        prefetch_a<RPW>(a2E, a2O, a2, kWaves * RPW * 64);
-        if (fc1_active) {
+            for (int r = 0; r < RPW; ++r) { af2[0][r] = wload(a2 + r * 64); af2[1][r] = wload(a2 + r * 64 + ABL_KS(A2KS)); }
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) {
-                u32x4 hb;
-                hb[0] = pack_bf16x2(gelu_fast(h[0][t][0]), gelu_fast(h[0][t][1]));
-                hb[1] = pack_bf16x2(gelu_fast(h[0][t][2]), gelu_fast(h[0][t][3]));
-                hb[2] = pack_bf16x2(gelu_fast(h[1][t][0]), gelu_fast(h[1][t][1]));
-                hb[3] = pack_bf16x2(gelu_fast(h[1][t][2]), gelu_fast(h[1][t][3]));
-                hT[((size_t)t * kWaves + w) * 64 + lane] = hb;
+            for (int t = 0; t < kNTT; ++t) bf[t] = b[t * kWaves * 64];
+#pragma unroll
+            for (int kk = 0; kk < kWaves; ++kk) {
+#pragma unroll
+                for (int t = 0; t < kNTT; ++t) {
+                    // unit of the weave: RPW MFMAs (48 cycles of matrix pipe) + one GELU evaluation (~14 VALU)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) T.acc[r][t] = mfma_bf16(af2[kk & 1][r], bf[t], T.acc[r][t]);
+                    {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int idx = kk * kNTT + t;             // 8 * 6 = 48 evaluations
+                        const int tt = idx >> 3, j = idx & 7;
+                        gq[j] = gelu_fast(h[j >> 2][tt][j & 3]);
+                        asm volatile("" : "+v"(gq[j]));
+                        if (j == 7) {
+                            hb[tt][0] = pack_bf16x2(gq[0], gq[1]);
+                            hb[tt][1] = pack_bf16x2(gq[2], gq[3]);
+                            hb[tt][2] = pack_bf16x2(gq[4], gq[5]);
+                            hb[tt][3] = pack_bf16x2(gq[6], gq[7]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t == H1 - 1 && kk + 1 < kWaves) {
+#pragma unroll
+                        for (int t2 = 0; t2 < H1; ++t2) bf[t2] = b[t2 * kWaves * 64 + (kk + 1) * 64];
+                    }
+                    if (t == kNTT - 1) {
+                        if (kk + 1 < kWaves) {
+#pragma unroll
+                            for (int t2 = H1; t2 < kNTT; ++t2) bf[t2] = b[t2 * kWaves * 64 + (kk + 1) * 64];
+                        }
+                        if (kk + 2 < kWaves) {
+#pragma unroll
+                            for (int r = 0; r < RPW; ++r) af2[kk & 1][r] = wload(a2 + r * 64 + ABL_KS((kk + 2) * A2KS));
+                        }
+                    }
+                }
             }
         }
         stamp(st, 21);
-        __syncthreads();
+        __syncthreads();                 // every wave is done reading hT(c-1)
         stamp(st, 22);
-        if (c + 1 < n_chunks)
-            prefetch_a<2>(a1E, a1O, w1p + ((size_t)(c + 1) * KS * kChunkTiles + 2 * w) * 64 + lane, kChunkTiles * 64);
-        // k-steps are consumed in pairs; an odd tail reads a stale (finite) hT slot against zero weights
-        gemm_phase<RPW, kNTT>(T.acc, a2E, a2O, a2, kWaves * RPW * 64, hT + lane, kWaves * 64, 64,
-                              ((tiles_here >> 1) + 1) & ~1);
+        if (fc1_active) {
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) hT[((size_t)t * kWaves + w) * 64 + lane] = hb[t];
+        }
+        if (c + 1 < n_chunks) fc1(c + 1, h, a1r);
         stamp(st, 23);
-        __syncthreads();
+        __syncthreads();                 // hT(c) complete
         stamp(st, 24);
     }
+    {
+        // ---- FC2 of the last chunk; k-steps are consumed in pairs: an odd tail reads a stale (finite) hT
+        // slot against zero weights
+        const int c = n_chunks - 1;
+        const int tiles_here = min(kChunkTiles, HT - c * kChunkTiles);
+        u32x4 a2E[RPW], a2O[RPW];
+        prefetch_a<RPW>(a2E, a2O, fc2_a(c), A2KS);
+        gemm_phase<RPW, kNTT>(T.acc, a2E, a2O, fc2_a(c), A2KS, hT + lane, kWaves * 64, 64, ((tiles_here >> 1) + 1) & ~1);
+    }
+    stamp(st, 25);
+    __syncthreads();
 }
 
 // Attention phase (xnT holds LN1(x) fragments on entry).  Tokens of the tile are in natural order:
@@ -527,16 +687,16 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         // ---- q, k, v of head h for all tokens of the tile
         {
             f32x4 qa[3][3];
-            u32x4 aE[3], aO[3];
-            const u32x4* a = wqkv + ((size_t)h * KS * 12 + 3 * wa) * 64 + lane;     // [head][kk][12 row tiles]
-            prefetch_a<3>(aE, aO, a, 12 * 64);
+            u32x4 ar[4][3];
+            const u32x4* a = ABL_PTR(wqkv + (size_t)(3 * wa) * 64 + lane, (size_t)h * KS * 12 * 64);   // [head][kk][12 row tiles]
+            prefetch_ring<3, 4>(ar, a, 12 * 64);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const f32x4 bv = *(const f32x4*)(bqkv + (h * 12 + 3 * wa + i) * 16 + 4 * g);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) qa[i][t] = bv;
             }
-            gemm_phase<3, 3>(qa, aE, aO, a, 12 * 64, xnT + (size_t)(3 * wb) * KS * 64 + lane, KS * 64, 64, KS);
+            gemm_phase_ring<3, 3, 4>(qa, ar, a, 12 * 64, xnT + (size_t)(3 * wb) * KS * 64 + lane, KS * 64, 64, KS);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int rt = 3 * wa + i, part = rt >> 2, d0 = (rt & 3) * 16 + 4 * g;
@@ -612,7 +772,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         // ---- the head's slice of the out-projection, accumulated into the residual
         {
             u32x4 aE[RPW], aO[RPW];
-            const u32x4* a = wproj + ((size_t)(2 * h) * (kWaves * RPW) + w * RPW) * 64 + lane;   // [2h+kk][row tiles]
+            const u32x4* a = ABL_PTR(wproj + (size_t)(w * RPW) * 64 + lane, (size_t)(2 * h) * (kWaves * RPW) * 64);   // [2h+kk][row tiles]
             prefetch_a<RPW>(aE, aO, a, kWaves * RPW * 64);
             gemm_phase<RPW, kNTT>(T.acc, aE, aO, a, kWaves * RPW * 64, yT + lane, 2 * 64, 64, 2);
         }

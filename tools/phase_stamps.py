@@ -16,7 +16,7 @@ from oracle import beso_oracle as O    # noqa: E402
 
 NAMES = {1: "start", 2: "layer_start", 7: "ln1_done", 10: "head_start", 11: "qkv_gemm+write", 12: "bar_qkv",
          13: "scores", 14: "softmax(+bar)", 15: "bar_softmax", 16: "pv", 17: "bar_pv", 3: "attn_done(proj..)",
-         6: "ln2_done", 20: "fc1_gemm", 21: "fc2pref+gelu", 22: "bar_gelu", 23: "fc2_gemm", 24: "bar_fc2", 4: "layers_done",
+         6: "ln2_done", 20: "fc1(0)", 21: "fc2(c-1)||gelu(c)", 22: "bar_a", 23: "hT_write+fc1(c+1)", 24: "bar_b", 25: "fc2(last)", 4: "layers_done",
          5: "stored", 30: "ln_pass1", 31: "ln_bar1", 32: "ln_pass2", 33: "ln_bar2", 34: "ln_write"}
 
 
@@ -28,7 +28,7 @@ def main():
     s, g, a = (torch.from_numpy(v).to(dev) for v in O.make_inputs(cfg, B, seed=1))
     sig = torch.full((B,), 0.3, device=dev)
     lib = _lib.load()
-    buf = torch.zeros(4096, dtype=torch.int64, device=dev)
+    buf = torch.zeros(8 * 2048, dtype=torch.int64, device=dev)
     with torch.no_grad():
         for _ in range(3):
             model(s, a, g, sig)
@@ -37,18 +37,29 @@ def main():
         model(s, a, g, sig)
         torch.cuda.synchronize()
         lib.beso_debug_set_stamps(None, 0)
-    v = buf.cpu().numpy()
-    ids, ts = v[0::2], v[1::2]
-    n = int(np.nonzero(ids)[0].max()) + 1 if ids.any() else 0
-    ids, ts = ids[:n], ts[:n]
-    total = ts[-1] - ts[0]
-    acc = collections.OrderedDict()
-    for k in range(1, n):
-        key = NAMES.get(int(ids[k]), str(ids[k]))
-        acc[key] = acc.get(key, 0) + int(ts[k] - ts[k - 1])
-    print(f"B={B}: {n} stamps, total {total} ticks (s_memtime, 100 MHz => {total / 100:.1f} us)")
-    for k, c in acc.items():
-        print(f"  {k:22s} {c:10d} ticks  {100.0 * c / total:5.1f} %")
+    allv = buf.cpu().numpy().reshape(8, -1)
+    t0 = None
+    for wave in range(8):
+        v = allv[wave]
+        ids, ts = v[0::2], v[1::2]
+        n = int(np.nonzero(ids)[0].max()) + 1 if ids.any() else 0
+        ids, ts = ids[:n], ts[:n]
+        if n == 0:
+            continue
+        total = ts[-1] - ts[0]
+        acc = collections.OrderedDict()
+        for k in range(1, n):
+            key = NAMES.get(int(ids[k]), str(ids[k]))
+            acc[key] = acc.get(key, 0) + int(ts[k] - ts[k - 1])
+        if wave == 0:
+            print(f"B={B}: {n} stamps/wave, wave 0 total {total} cycles")
+            keys = list(acc.keys())
+            table = {k: [] for k in keys}
+        for k in keys:
+            table[k].append(acc.get(k, 0))
+    print(f"  {'phase':22s} " + " ".join(f"   w{w}" for w in range(8)) + "   (kcycles per wave over the whole kernel)")
+    for k in keys:
+        print(f"  {k:22s} " + " ".join(f"{c / 1000:5.0f}" for c in table[k]))
 
 
 if __name__ == "__main__":
