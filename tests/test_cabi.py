@@ -45,7 +45,8 @@ def test_sizes_for_shipped_shapes(lib):
     assert lib.beso_num_params(C.byref(kitchen)) == 107           # 113 state_dict entries - 6 mask buffers
     bf16 = lib.beso_packed_bytes(C.byref(kitchen), _lib.PREC_BF16)
     fp32 = lib.beso_packed_bytes(C.byref(kitchen), _lib.PREC_FP32)
-    assert 18_000_000 < bf16 < fp32 < 90_000_000
+    # bf16 image = generic GEMM operands (bf16) + the fused kernels' fragment-ordered copy
+    assert 18_000_000 < bf16 < 90_000_000 and 37_000_000 < fp32 < 90_000_000
     ws1 = lib.beso_workspace_bytes(C.byref(kitchen), 4096, 4, _lib.PREC_BF16, 0)
     ws2 = lib.beso_workspace_bytes(C.byref(kitchen), 4096, 4, _lib.PREC_BF16, 1)
     assert 0 < ws1 < ws2 < 4 * ws1
