@@ -1,0 +1,126 @@
+"""N > 1 path on CPU: two processes, gloo backend.  Covers the gradient all-reduce of the training
+step (C1), the weight broadcast (C2), batch sharding of the inference path, and that a 2-rank
+train_step equals a single-process step on the concatenated batch."""
+import functools
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_agent(seed):
+    from oracle import beso_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host_logic import build_agent, make_module
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    cfg = O.TINY
+    torch.manual_seed(seed)
+    agent = build_agent(cfg, lambda: make_module(cfg))
+    rng = np.random.default_rng(0)
+    agent.get_scaler(Scaler(rng.standard_normal((40, cfg.obs_dim)).astype(np.float32),
+                            rng.uniform(-1, 1, (40, cfg.act_dim)).astype(np.float32), False, "cpu"))
+    return cfg, agent
+
+
+def _batch(cfg, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"observation": torch.randn(n, cfg.obs_seq_len, cfg.obs_dim, generator=g),
+            "goal_observation": torch.randn(n, cfg.goal_seq_len, cfg.obs_dim, generator=g),
+            "action": torch.rand(n, cfg.obs_seq_len, cfg.act_dim, generator=g) * 2 - 1}
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from beso_amd import distributed as bdist
+    assert bdist.init_from_env("gloo")
+    assert bdist.world_size() == world and bdist.rank() == rank and bdist.is_distributed()
+    # --- C1: flat gradient bucket = mean over ranks
+    p = [torch.nn.Parameter(torch.full((3, 2), float(rank + 1))), torch.nn.Parameter(torch.zeros(5))]
+    p[0].grad = torch.full((3, 2), float(rank + 1))
+    p[1].grad = None                                   # a parameter that received no gradient on this rank
+    bucket = bdist.GradientBucket(p)
+    bucket.sync()
+    assert torch.allclose(p[0].grad, torch.full((3, 2), 1.5)) and torch.allclose(p[1].grad, torch.zeros(5))
+    p[0].grad = torch.full((3, 2), float(10 * (rank + 1)))
+    bucket.sync(async_op=True)
+    bucket.wait()
+    assert torch.allclose(p[0].grad, torch.full((3, 2), 15.0))
+    # --- C2: broadcast makes replicas identical
+    cfg, agent = _make_agent(seed=100 + rank)           # different init per rank on purpose
+    bdist.broadcast_parameters(agent.model.get_params(), src=0)
+    agent.ema_helper.load_shadow_params(agent.model.get_params())
+    flat = torch.cat([q.detach().reshape(-1) for q in agent.model.get_params()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert torch.equal(gathered[0], gathered[1])
+    # --- one data-parallel training step: each rank sees its shard of the global batch
+    full = _batch(cfg, 8, seed=7)
+    lo, hi = bdist.shard_range(8, world, rank)
+    shard = {k: v[lo:hi] for k, v in full.items()}
+    torch.manual_seed(1234)                             # same noise / sigma stream on both ranks ...
+    noise = torch.randn(8, cfg.obs_seq_len, cfg.act_dim)
+    sigma = torch.rand(8) * 0.9 + 0.05
+    real_randn_like, real_density = torch.randn_like, agent.make_sample_density
+    torch.randn_like = lambda t: noise[lo:hi].clone()   # ... sliced like the batch
+    agent.make_sample_density = lambda: (lambda shape, device: sigma[lo:hi].clone())
+    try:
+        loss = agent.train_step(shard)
+    finally:
+        torch.randn_like = real_randn_like
+        agent.make_sample_density = real_density
+    after = torch.cat([q.detach().reshape(-1) for q in agent.model.get_params()])
+    gathered = [torch.zeros_like(after) for _ in range(world)]
+    dist.all_gather(gathered, after)
+    assert torch.equal(gathered[0], gathered[1]), "replicas diverged after the all-reduced step"
+    if rank == 0:
+        torch.save({"params": after, "loss": loss, "noise": noise, "sigma": sigma}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_training_step_matches_single_process(tmp_path):
+    out = str(tmp_path / "dp.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    dp = torch.load(out)
+    # single process, whole batch, same init (rank 0's) and the same noise / sigma
+    sys.path.insert(0, ROOT)
+    cfg, agent = _make_agent(seed=100)
+    full = _batch(cfg, 8, seed=7)
+    real_randn_like = torch.randn_like
+    torch.randn_like = lambda t: dp["noise"].clone()
+    agent.make_sample_density = lambda: (lambda shape, device: dp["sigma"].clone())
+    try:
+        agent.train_step(full)
+    finally:
+        torch.randn_like = real_randn_like
+    single = torch.cat([q.detach().reshape(-1) for q in agent.model.get_params()])
+    # mean of per-shard gradients == gradient of the global mean loss (equal shard sizes); AdamW sees the same grads
+    # (the first AdamW step is lr * g / (|g| + eps): fp32 summation-order noise in g shows up at the 1e-7 level)
+    assert torch.allclose(single, dp["params"], rtol=2e-5, atol=2e-6)
+
+
+def test_shard_range_covers_the_batch():
+    from beso_amd.distributed import shard_range
+    for total in (1, 7, 8, 4096, 4097):
+        for n in (1, 2, 3, 8):
+            spans = [shard_range(total, n, i) for i in range(n)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
