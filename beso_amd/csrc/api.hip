@@ -143,15 +143,18 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
     void* xn = wsp + ws.xn; void* qkv = wsp + ws.qkv; void* y = wsp + ws.y; void* h = wsp + ws.h;
     const int M = a.vbatch * a.T;
     auto F = [&](size_t off) { return (const float*)(packed + off); };
-    profile_begin(BESO_SITE_EMBED, s);
-    HIP_TRY(launch_embed(lay, packed, a, x, s));
-    profile_end(BESO_SITE_EMBED, s);
+    int fused_edges = 0;
     if (fused == 2) {
-        // all transformer layers as ONE launch: the residual tile of 8 samples stays in registers
+        // embed -> all transformer layers -> head as ONE launch: the residual tile of 8 samples never leaves
+        // the CU's registers (shapes whose head cannot be fused store x and run the head kernel)
         profile_begin(BESO_SITE_FUSED_LAYER, s);
-        int st = fused_layers(lay, packed, 0, lay.L, x, a.vbatch, a.T, s);
+        int st = fused_layers(lay, packed, a, x, &fused_edges, s);
         profile_end(BESO_SITE_FUSED_LAYER, s);
         if (st != BESO_OK) return st;
+    } else {
+        profile_begin(BESO_SITE_EMBED, s);
+        HIP_TRY(launch_embed(lay, packed, a, x, s));
+        profile_end(BESO_SITE_EMBED, s);
     }
     for (int l = 0; l < (fused == 2 ? 0 : lay.L); ++l) {
         const LayerOff& o = lay.layer[l];
@@ -187,9 +190,11 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
                             lay.D, M, lay.Nd, lay.Kh, s));
         profile_end(BESO_SITE_GEMM_FC2, s);
     }
-    profile_begin(BESO_SITE_HEAD, s);
-    HIP_TRY(launch_head(lay, packed, a, x, s));
-    profile_end(BESO_SITE_HEAD, s);
+    if (!(fused_edges & 2)) {
+        profile_begin(BESO_SITE_HEAD, s);
+        HIP_TRY(launch_head(lay, packed, a, x, s));
+        profile_end(BESO_SITE_HEAD, s);
+    }
     return BESO_OK;
 }
 

@@ -47,6 +47,9 @@ struct FusedDims {
     // per-layer image: [w1 | b1 | w2 | b2 | wqkv | bqkv | wproj | bproj]
     size_t w1_bytes, b1_bytes, w2_bytes, b2_bytes, wqkv_bytes, bqkv_bytes, wproj_bytes, bproj_bytes, layer_bytes;
     size_t o_b1, o_w2, o_b2, o_wqkv, o_bqkv, o_wproj, o_bproj;
+    // per-model image behind the L per-layer images (fp32): embeddings transposed to [in][Dp], head with ln_f folded
+    int Dp, obs, act, seq, G, L, head_fused;
+    size_t g_tokT, g_tokb, g_actT, g_actb, g_sigw, g_sigb, g_pos, g_headw, g_headb, global_bytes;
 };
 
 bool fused_dims(const Layout& lay, FusedDims* d) {
@@ -81,6 +84,17 @@ bool fused_dims(const Layout& lay, FusedDims* d) {
     d->o_wproj = d->o_bqkv + d->bqkv_bytes;
     d->o_bproj = d->o_wproj + d->wproj_bytes;
     d->layer_bytes = d->o_bproj + d->bproj_bytes;
+    d->Dp = d->RPW * kWaves * 16;
+    d->obs = lay.obs; d->act = lay.act; d->seq = lay.seq_size; d->G = lay.G; d->L = lay.L;
+    d->head_fused = lay.linear_output && lay.act <= 16;
+    size_t cur = 0;
+    auto carve = [&](size_t n_floats) { size_t o = cur; cur = round_up_sz(cur + n_floats * sizeof(float), 256); return o; };
+    d->g_tokT = carve((size_t)lay.obs * d->Dp); d->g_tokb = carve(d->Dp);
+    d->g_actT = carve((size_t)lay.act * d->Dp); d->g_actb = carve(d->Dp);
+    d->g_sigw = carve(d->Dp); d->g_sigb = carve(d->Dp);
+    d->g_pos = carve((size_t)lay.seq_size * d->Dp);
+    d->g_headw = carve((size_t)16 * d->Dp); d->g_headb = carve(16);
+    d->global_bytes = cur;
     return true;
 }
 
@@ -173,6 +187,33 @@ __global__ void pack_proj_kernel(const float* __restrict__ wp, uint16_t* __restr
         float v = 0.f;
         if (o < D && d < hd) v = wp[(size_t)o * D + h * hd + d];
         dst[i] = f2bf(v);
+    }
+}
+
+// dst[c][f] = src[f][c] * (scale ? scale[f] : 1) for f < rows, c < cols; zero padded to [cols][rows_p]
+__global__ void transpose_pad_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst, int rows_p) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cols * rows_p) return;
+    int c = i / rows_p, f = i % rows_p;
+    dst[i] = f < rows ? src[(size_t)f * cols + c] : 0.f;
+}
+
+// head with ln_f folded:  Wh[a][f] = W[a][f] * gamma[f] (padded to [16][Dp]),  bh[a] = b[a] + sum_f W[a][f] * beta[f]
+__global__ void pack_head_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* __restrict__ Wh, float* __restrict__ bh, int act,
+                                 int D, int Dp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 16 * Dp) {
+        int a = i / Dp, f = i % Dp;
+        Wh[i] = (a < act && f < D) ? W[(size_t)a * D + f] * gamma[f] : 0.f;
+    }
+    if (i < 16) {
+        float acc = 0.f;
+        if (i < act) {
+            acc = b[i];
+            for (int f = 0; f < D; ++f) acc = fmaf(W[(size_t)i * D + f], beta[f], acc);
+        }
+        bh[i] = acc;
     }
 }
 
@@ -449,14 +490,12 @@ __device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restri
 // feature slices of all 8 waves, then (x - mean) * rstd as bf16 B fragments into xnT.  Ends with a
 // barrier; `bias` (the residual-add bias of the block's last Linear) is added to the residual after
 // the normalised copy has been taken.
-template <int RPW, int KS>
-__device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float* red, int D, int w, int lane,
-                                                 const float* __restrict__ bias, Stamps& st) {
-    // `lane` is made opaque at the top of every phase: otherwise the per-lane address arithmetic of ALL
-    // phases is hoisted out of the layer loop and kept live across it (46 spilled VGPRs).
-    asm volatile("" : "+v"(lane));
+// Two-pass fp32 LayerNorm statistics of every token of the tile over the feature slices of all 8
+// waves (partial sums exchanged through LDS; two barriers).
+template <int RPW>
+__device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, int w, int lane, float (&mean)[kNTT],
+                                         float (&rstd)[kNTT], Stamps& st) {
     const int n = lane & 15, g = lane >> 4;
-    float mean[kNTT], rstd[kNTT];
     const float invD = 1.0f / (float)D;
 #pragma unroll
     for (int t = 0; t < kNTT; ++t) {
@@ -501,6 +540,17 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         for (int ww = 0; ww < kWaves; ++ww) q += red[(1 * kWaves + ww) * kMT + t * 16 + n];
         rstd[t] = 1.0f / sqrtf(q * invD + 1e-5f);
     }
+}
+
+template <int RPW, int KS>
+__device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float* red, int D, int w, int lane,
+                                                 const float* __restrict__ bias, Stamps& st) {
+    // `lane` is made opaque at the top of every phase: otherwise the per-lane address arithmetic of ALL
+    // phases is hoisted out of the layer loop and kept live across it (46 spilled VGPRs).
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4;
+    float mean[kNTT], rstd[kNTT];
+    ln_stats<RPW>(T, red, D, w, lane, mean, rstd, st);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int Rf = w * RPW + i;
@@ -523,6 +573,181 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
     }
     stamp(st, 34);
     __syncthreads();
+}
+
+// Inputs / outputs of the network edges when they are fused into layers_kernel.
+struct EdgeArgs {
+    const float* state;    // [B][t][obs]
+    const float* action;   // [B][t][act]
+    const float* goal;     // [B][G][obs]
+    const float* sigma;    // [B]
+    float* out;            // [B][t][act]
+    int B, t, precondition, uncond_all, two;   // two: classifier-free pair (cond, uncond) = virtual samples (2b, 2b+1)
+    float cond_lambda, sigma_data;
+    int fuse_embed, fuse_head;
+};
+
+// Which real sample and which conditioning a virtual sample stands for.
+__device__ __forceinline__ void sample_of(const EdgeArgs& e, int vb, int& b, bool& uncond) {
+    if (e.two) { b = vb >> 1; uncond = vb & 1; }
+    else { b = vb; uncond = e.uncond_all != 0; }
+}
+
+// K1 fused: the residual tile is built in registers from (state, action, goal, sigma):
+//   token 0: sigma_emb(log(sigma)/4); 1..G: tok_emb(goal)+pos; then tok_emb(state_i)+pos, action_emb(action_i*c_in)+pos
+// (score_gpts.py:284-337, score_wrappers.py:96).  Weights come transposed ([in][Dp] fp32) so that a lane's
+// four features are one 16-byte load.
+template <int RPW>
+__device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw, int s0,
+                                           int n_samples, int Tn, int w, int lane) {
+    asm volatile("" : "+v"(lane));
+    const int n = lane & 15, g = lane >> 4;
+    const int G = d.G, Dp = d.Dp;
+    const float* tokT = (const float*)(gw + d.g_tokT);
+    const float* actT = (const float*)(gw + d.g_actT);
+    const float* src[kNTT];
+    float scale[kNTT], lsig[kNTT];
+    int kind[kNTT], prow[kNTT];       // kind: 0 none, 1 tok_emb input (state / goal), 2 action, 3 sigma
+#pragma unroll
+    for (int t = 0; t < kNTT; ++t) {
+        const int tokl = t * 16 + n;
+        const int sl = tokl / Tn, p = tokl - sl * Tn;
+        int b; bool un;
+        sample_of(e, s0 + sl, b, un);
+        kind[t] = 0; prow[t] = 0; src[t] = e.sigma; scale[t] = 1.f; lsig[t] = 0.f;
+        if (sl < n_samples) {
+            const float sg = e.sigma[b];
+            if (p == 0) { kind[t] = 3; lsig[t] = logf(sg) / 4.0f; }
+            else if (p <= G) { kind[t] = un ? 0 : 1; prow[t] = p - 1; src[t] = e.goal + ((size_t)b * G + (p - 1)) * d.obs;
+                               if (un) kind[t] = 4; }
+            else {
+                const int idx = p - G - 1, i = idx >> 1;
+                prow[t] = G + i;
+                if ((idx & 1) == 0) { kind[t] = 1; src[t] = e.state + ((size_t)b * e.t + i) * d.obs; }
+                else {
+                    kind[t] = 2; src[t] = e.action + ((size_t)b * e.t + i) * d.act;
+                    if (e.precondition) scale[t] = 1.0f / sqrtf(sg * sg + e.sigma_data * e.sigma_data);   // c_in
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        T.fvalid[i] = 16 * (w * RPW + i) + 4 * g < d.D;
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // tok_emb over states and goals
+    for (int c = 0; c < d.obs; ++c) {
+        f32x4 wv[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) wv[i] = *(const f32x4*)(tokT + (size_t)c * Dp + 16 * (w * RPW + i) + 4 * g);
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) {
+            const float v = kind[t] == 1 ? src[t][c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) T.acc[i][t] += v * wv[i];
+        }
+    }
+    // action_emb over the (pre-conditioned) noisy actions
+    for (int c = 0; c < d.act; ++c) {
+        f32x4 wv[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) wv[i] = *(const f32x4*)(actT + (size_t)c * Dp + 16 * (w * RPW + i) + 4 * g);
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) {
+            const float v = kind[t] == 2 ? src[t][c] * scale[t] : 0.f;
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) T.acc[i][t] += v * wv[i];
+        }
+    }
+    // biases, positions, sigma token
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int f0 = 16 * (w * RPW + i) + 4 * g;
+        const f32x4 bt = *(const f32x4*)((const float*)(gw + d.g_tokb) + f0);
+        const f32x4 ba = *(const f32x4*)((const float*)(gw + d.g_actb) + f0);
+        const f32x4 sw = *(const f32x4*)((const float*)(gw + d.g_sigw) + f0);
+        const f32x4 sb = *(const f32x4*)((const float*)(gw + d.g_sigb) + f0);
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) {
+            const int k = kind[t];
+            if (k == 0) continue;
+            f32x4 add;
+            if (k == 3) add = sw * lsig[t] + sb;
+            else add = (k == 2 ? ba : bt) + *(const f32x4*)((const float*)(gw + d.g_pos) + (size_t)prow[t] * Dp + f0);
+            T.acc[i][t] += add;
+        }
+    }
+}
+
+// K7 fused: ln_f on the action tokens, action_pred (ln_f folded into it), c_out / c_skip and the
+// classifier-free combination (score_gpts.py:341-354, score_wrappers.py:96, classifier_free_sampler.py:49).
+// Every wave reduces its 48 features of every action token to `act` partial sums; LDS sums the waves.
+template <int RPW>
+__device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw,
+                                          float* red, float* part, int s0, int n_samples, int Tn, int w, int lane,
+                                          Stamps& st) {
+    asm volatile("" : "+v"(lane));
+    const int n = lane & 15, g = lane >> 4;
+    const int act = d.act, Dp = d.Dp;
+    float mean[kNTT], rstd[kNTT];
+    ln_stats<RPW>(T, red, d.D, w, lane, mean, rstd, st);
+    const float* Wh = (const float*)(gw + d.g_headw);
+    // part[(w*kMT + tokl)*16 + a]
+    for (int a = 0; a < act; ++a) {
+        f32x4 wv[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) wv[i] = *(const f32x4*)(Wh + (size_t)a * Dp + 16 * (w * RPW + i) + 4 * g);
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                if (T.fvalid[i]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s = fmaf((T.acc[i][t][r] - mean[t]) * rstd[t], wv[i][r], s);
+                }
+            }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (g == 0) part[((size_t)w * kMT + t * 16 + n) * 16 + a] = s;
+        }
+    }
+    __syncthreads();
+    // one thread per (real sample slot, step i, action dim)
+    const int G = d.G, per = e.two ? 2 : 1;
+    const int n_real = n_samples / per;
+    const float* bh = (const float*)(gw + d.g_headb);
+    for (int it = threadIdx.x; it < n_real * e.t * act; it += blockDim.x) {
+        const int a = it % act, i = (it / act) % e.t, sr = it / (act * e.t);
+        const int sl = sr * per;
+        int b; bool un;
+        sample_of(e, s0 + sl, b, un);
+        const int tok_c = sl * Tn + G + 2 + 2 * i;          // action token of step i (conditional / only sample)
+        float fc = bh[a], fu = bh[a];
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ++ww) fc += part[((size_t)ww * kMT + tok_c) * 16 + a];
+        if (e.two) {
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ++ww) fu += part[((size_t)ww * kMT + tok_c + Tn) * 16 + a];
+        }
+        const float sg = e.sigma[b];
+        const float av = e.action[((size_t)b * e.t + i) * act + a];
+        float c_skip = 0.f, c_out = 1.f;
+        if (e.precondition) {
+            const float sd2 = e.sigma_data * e.sigma_data;
+            c_skip = sd2 / (sg * sg + sd2);
+            c_out = sg * e.sigma_data / sqrtf(sg * sg + sd2);
+        }
+        const float oc = fc * c_out + av * c_skip;
+        float r = oc;
+        if (e.two) {
+            const float ou = fu * c_out + av * c_skip;
+            r = ou + e.cond_lambda * (oc - ou);
+        }
+        e.out[((size_t)b * e.t + i) * act + a] = r;
+    }
 }
 
 // GELU of one chunk's FC1 accumulators -> packed bf16 B fragments (one FC2 k-step per wave), as a
@@ -564,7 +789,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     // w1p: [chunk][kk][16 row tiles]; w2p: [kk2][8*RPW row tiles]
     auto fc1_a = [&](int c) { return ABL_PTR(w1p + (size_t)(2 * w) * 64 + lane, (size_t)c * KS * kChunkTiles * 64); };
     auto fc2_a = [&](int c) { return ABL_PTR(w2p + (size_t)(w * RPW) * 64 + lane, (size_t)(c * kWaves) * (kWaves * RPW) * 64); };
-    constexpr int PF1 = 4;
+    constexpr int PF1 = 2;
     auto fc1 = [&](int c, f32x4 (&h)[2][kNTT], u32x4 (&ar)[PF1][2]) {
         const int R0 = c * kChunkTiles + 2 * w;
         const f32x4 bias0 = *(const f32x4*)(b1f + 16 * R0 + 4 * g);
@@ -687,16 +912,16 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         // ---- q, k, v of head h for all tokens of the tile
         {
             f32x4 qa[3][3];
-            u32x4 ar[4][3];
+            u32x4 ar[2][3];
             const u32x4* a = ABL_PTR(wqkv + (size_t)(3 * wa) * 64 + lane, (size_t)h * KS * 12 * 64);   // [head][kk][12 row tiles]
-            prefetch_ring<3, 4>(ar, a, 12 * 64);
+            prefetch_ring<3, 2>(ar, a, 12 * 64);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const f32x4 bv = *(const f32x4*)(bqkv + (h * 12 + 3 * wa + i) * 16 + 4 * g);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) qa[i][t] = bv;
             }
-            gemm_phase_ring<3, 3, 4>(qa, ar, a, 12 * 64, xnT + (size_t)(3 * wb) * KS * 64 + lane, KS * 64, 64, KS);
+            gemm_phase_ring<3, 3, 2>(qa, ar, a, 12 * 64, xnT + (size_t)(3 * wb) * KS * 64 + lane, KS * 64, 64, KS);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int rt = 3 * wa + i, part = rt >> 2, d0 = (rt & 3) * 16 + 4 * g;
@@ -806,7 +1031,7 @@ __global__ __launch_bounds__(512, 2) void mlp_block_kernel(float* __restrict__ x
 template <int RPW, int KS>
 __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, const char* __restrict__ lw0,
                                                         FusedDims d, int l0, int l1, int n_samples_total, int Tn,
-                                                        unsigned long long* stamps, int cap) {
+                                                        EdgeArgs e, unsigned long long* stamps, int cap) {
     Stamps st{stamps, cap, 0};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr LdsMap L = lds_map(KS);
@@ -825,7 +1050,9 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     }
     Tile<RPW> T;
     stamp(st, 1);
-    load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
+    const char* gw = lw0 + (size_t)d.L * d.layer_bytes;          // per-model image (embeddings, head)
+    if (e.fuse_embed) embed_tile<RPW>(T, e, d, gw, s0, n_samples, Tn, w, lane);
+    else load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     for (int l = l0; l < l1; ++l) {
         const char* lw = lw0 + (size_t)l * d.layer_bytes;
         stamp(st, 2);
@@ -843,7 +1070,8 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
                            (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, st);
     }
     stamp(st, 4);
-    store_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
+    if (e.fuse_head) head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, st);
+    else store_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 5);
 }
 
@@ -871,14 +1099,14 @@ hipError_t launch_mlp_block(float* x, const char* lw, const FusedDims& d, int M,
 
 template <int RPW, int KS>
 hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
-                         hipStream_t s) {
+                         const EdgeArgs& edge, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS);
     static bool attr = false;
     hipError_t e = ensure_lds(layers_kernel<RPW, KS>, L.total, &attr);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
     hipLaunchKernelGGL((layers_kernel<RPW, KS>), dim3((n_samples + kSPW - 1) / kSPW), dim3(512), L.total, s, x, lw0, d,
-                       l0, l1, n_samples, Tn, g_stamps, g_stamps_cap);
+                       l0, l1, n_samples, Tn, edge, g_stamps, g_stamps_cap);
     return hipGetLastError();
 }
 
@@ -888,7 +1116,7 @@ hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, 
 size_t fused_packed_bytes(const Layout& lay, int precision) {
     FusedDims d;
     if (precision != BESO_PREC_BF16 || !fused_dims(lay, &d) || !shape_has_kernel(d)) return 0;
-    return d.layer_bytes * lay.L;
+    return d.layer_bytes * lay.L + d.global_bytes;
 }
 
 size_t fused_workspace_bytes(const Layout&, int, int, int) { return 0; }
@@ -929,6 +1157,31 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
             FTRY(launch_pack_matrix(pb, 1, D, base + d.o_bproj, 1, rt2 * 16, -1, s));
         }
     }
+    if (d.attn) {
+        // per-model image: parameter order pos_emb, tok_emb.{w,b}, blocks..., ln_f.{w,b}, sigma_emb.{w,b},
+        // action_emb.{w,b}, action_pred.{w,b}
+        char* gw = packed + lay.fused + (size_t)lay.L * d.layer_bytes;
+        const float* const* tail = p + 3 + 16 * lay.L;
+        const float *pos = p[0], *tokw = p[1], *tokb = p[2];
+        const float *lnfw = tail[0], *lnfb = tail[1], *sigw = tail[2], *sigb = tail[3], *actw = tail[4], *actb = tail[5];
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(transpose_pad_kernel, dim3((lay.obs * d.Dp + 255) / 256), dim3(256), 0, s, tokw, D, lay.obs,
+                           (float*)(gw + d.g_tokT), d.Dp);
+        hipLaunchKernelGGL(transpose_pad_kernel, dim3((lay.act * d.Dp + 255) / 256), dim3(256), 0, s, actw, D, lay.act,
+                           (float*)(gw + d.g_actT), d.Dp);
+        FTRY(hipGetLastError());
+        FTRY(launch_pack_matrix(tokb, 1, D, gw + d.g_tokb, 1, d.Dp, -1, s));
+        FTRY(launch_pack_matrix(actb, 1, D, gw + d.g_actb, 1, d.Dp, -1, s));
+        FTRY(launch_pack_matrix(sigw, 1, D, gw + d.g_sigw, 1, d.Dp, -1, s));
+        FTRY(launch_pack_matrix(sigb, 1, D, gw + d.g_sigb, 1, d.Dp, -1, s));
+        FTRY(launch_pack_matrix(pos, lay.seq_size, D, gw + d.g_pos, lay.seq_size, d.Dp, -1, s));
+        if (d.head_fused) {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(pack_head_kernel, dim3((16 * d.Dp + 255) / 256), dim3(256), 0, s, tail[6], tail[7], lnfw,
+                               lnfb, (float*)(gw + d.g_headw), (float*)(gw + d.g_headb), lay.act, D, d.Dp);
+            FTRY(hipGetLastError());
+        }
+    }
     return BESO_OK;
 }
 
@@ -936,7 +1189,7 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
 int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     FusedDims d;
     if (precision != BESO_PREC_BF16 || lay.fused == lay.total || !fused_dims(lay, &d) || !shape_has_kernel(d)) return 0;
-    if (d.attn && d.RPW == 3 && d.KS == 12 && kSPW * a.T <= kMT) return 2;
+    if (d.attn && d.RPW == 3 && d.KS == 12 && kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused)) return 2;
     return 1;
 }
 
@@ -953,15 +1206,28 @@ int fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, 
     return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
-int fused_layers(const Layout& lay, const char* packed, int l0, int l1, float* x, int n_samples, int Tn,
-                 hipStream_t s) {
+// Whole network (embed -> all layers -> head) or layers only.  Returns in *fused_edges whether the token
+// embedding / action head ran inside the kernel (bit 0 / bit 1).
+int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, hipStream_t s) {
     FusedDims d;
     if (!fused_dims(lay, &d) || !d.attn) return BESO_ERR_UNSUPPORTED;
     const char* base = packed + lay.fused;
-    hipError_t e;
-    if (d.RPW == 3 && d.KS == 12) e = launch_layers<3, 12>(x, base, d, l0, l1, n_samples, Tn, s);
+    EdgeArgs e;
+    e.state = a.state; e.action = a.action; e.goal = a.goal; e.sigma = a.sigma; e.out = a.out;
+    e.B = a.batch; e.t = a.t; e.precondition = a.precondition;
+    e.two = a.vbatch > a.batch ? 1 : 0;
+    e.uncond_all = (!e.two && a.uncond_from == 0) ? 1 : 0;
+    e.cond_lambda = a.cond_lambda; e.sigma_data = a.sigma_data;
+    e.fuse_embed = 1;
+    e.fuse_head = d.head_fused;
+    // with a classifier-free pair the virtual samples are interleaved (2b, 2b+1) so that both halves of a
+    // pair live in one workgroup; that ordering only exists inside the kernel, so the head must be fused too
+    if (e.two && !e.fuse_head) return BESO_ERR_UNSUPPORTED;
+    if (fused_edges) *fused_edges = (e.fuse_embed ? 1 : 0) | (e.fuse_head ? 2 : 0);
+    hipError_t err;
+    if (d.RPW == 3 && d.KS == 12) err = launch_layers<3, 12>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);
     else return BESO_ERR_UNSUPPORTED;
-    return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+    return err == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
 void fused_set_stamps(void* buf, int cap) {
