@@ -21,6 +21,7 @@
 //                      attention per head: QKV_h GEMM -> q,k,v (bf16) in LDS -> scores with
 //                      v_dot2_f32_bf16, causal softmax, P.V on the VALU -> y_h^T B fragments -> the
 //                      head's slice of the out-projection accumulated into the residual.
+#include <stdlib.h>
 #include "fused.h"
 
 namespace beso {
@@ -1185,9 +1186,23 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
     return BESO_OK;
 }
 
+// Batches below BESO_FUSED_MIN_BATCH (virtual samples) take the per-op path.  Default 0: measured on MI355X
+// (tools/latency.py) the one-launch kernel wins at every batch size -- 0.53 ms flat from B = 1 to 2048 (one
+// workgroup per 8 samples, one round) against 0.60 ms (B = 1) .. 1.6 ms (B = 1024) for ~45 launches.
+static int fused_min_batch() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("BESO_FUSED_MIN_BATCH");
+        v = e ? atoi(e) : 0;
+        if (v < 0) v = 0;
+    }
+    return v;
+}
+
 // 0: no fused kernel, 1: MLP block only, 2: whole layers
 int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     FusedDims d;
+    if (a.vbatch < fused_min_batch()) return 0;
     if (precision != BESO_PREC_BF16 || lay.fused == lay.total || !fused_dims(lay, &d) || !shape_has_kernel(d)) return 0;
     if (d.attn && d.RPW == 3 && d.KS == 12 && kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused)) return 2;
     return 1;
