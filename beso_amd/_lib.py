@@ -7,7 +7,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbeso_hip.so")
+# BESO_HIP_LIB points the binding at another build of the same library (kernel experiments: tools/variants.py)
+LIB_PATH = os.environ.get("BESO_HIP_LIB") or os.path.join(_HERE, "lib", "libbeso_hip.so")
 
 PREC_BF16, PREC_FP32, PREC_BF16X3 = 0, 1, 2
 PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_BF16X3}

@@ -234,6 +234,10 @@ __global__ void fold_bias_kernel(const float* __restrict__ W, const float* __res
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
+#ifndef BESO_ABL_MASK
+#define BESO_ABL_MASK 0              // timing experiments only (results are wrong): 1 GELU = identity, 2 no MLP-loop
+#endif                               // barriers, 4 no embedding, 8 LayerNorm statistics skipped, 16 no attention core,
+                                     // 32 no LDS refills of the activation fragments
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     f32x2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
@@ -249,19 +253,23 @@ __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
 // GELU(v) = v * Phi(v) with the exact-erf Phi of nn.GELU() (score_gpts.py:107), evaluated without
 // transcendentals:  Phi(v) - 1/2 = vc * P(vc^2),  vc = clamp(v, +-4),  P a degree-6 minimax polynomial
 // fitted to erf (tools/fit_gelu.py): max |error| of GELU over all v is 1.9e-4, an order of magnitude
-// below the bf16 rounding (2^-9 relative) that the result receives next.  11 plain VALU ops; the
-// rcp/exp2 formulation cost 13 ops of which 2 quarter-rate, and VALU issue is what bounds the MLP phase.
-__device__ __forceinline__ float gelu_fast(float v) {
-    const float vc = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);
-    const float s = vc * vc;
-    float p = fmaf(s, 2.277972093e-08f, -1.598515742e-06f);
-    p = fmaf(p, s, 4.795382804e-05f);
-    p = fmaf(p, s, -0.0008139993719f);
-    p = fmaf(p, s, 0.00877231165f);
-    p = fmaf(p, s, -0.06457294506f);
-    p = fmaf(p, s, 0.3978832308f);
-    const float u = vc * p;
-    return fmaf(v, u, 0.5f * v);
+// below the bf16 rounding (2^-9 relative) that the result receives next.  Two values per call on the
+// packed-fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32, constants broadcast from SGPRs): 11 VALU ops per PAIR
+// -- VALU issue is what bounds the MLP phase next to the MFMAs.
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 v) {
+    if (BESO_ABL_MASK & 1) return v;
+    f32x2 vc;
+    vc.x = __builtin_amdgcn_fmed3f(v.x, -4.0f, 4.0f);
+    vc.y = __builtin_amdgcn_fmed3f(v.y, -4.0f, 4.0f);
+    const f32x2 s = vc * vc;
+    f32x2 p = __builtin_elementwise_fma(s, (f32x2)(2.277972093e-08f), (f32x2)(-1.598515742e-06f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(4.795382804e-05f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-0.0008139993719f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(0.00877231165f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-0.06457294506f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(0.3978832308f));
+    const f32x2 u = __builtin_elementwise_fma(vc, p, (f32x2)(0.5f));      // Phi(v)
+    return v * u;
 }
 
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
@@ -327,7 +335,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
             for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aE[r], bf[t], acc[r][t]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < H1; ++t) bf[t] = b[t * b_ts + (kk + 1) * b_ks];
+        for (int t = 0; t < H1; ++t) if (!(BESO_ABL_MASK & 32)) bf[t] = b[t * b_ts + (kk + 1) * b_ks];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = H1; t < NT; ++t)
@@ -335,7 +343,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
             for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aE[r], bf[t], acc[r][t]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = H1; t < NT; ++t) bf[t] = b[t * b_ts + (kk + 1) * b_ks];
+        for (int t = H1; t < NT; ++t) if (!(BESO_ABL_MASK & 32)) bf[t] = b[t * b_ts + (kk + 1) * b_ks];
         if (kk + 2 < ksteps) {
 #pragma unroll
             for (int r = 0; r < R; ++r) aE[r] = wload(a + r * 64 + ABL_KS((kk + 2) * a_ks));
@@ -347,7 +355,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aO[r], bf[t], acc[r][t]);
         __builtin_amdgcn_sched_barrier(0);
-        if (kk + 2 < ksteps) {
+        if (kk + 2 < ksteps && !(BESO_ABL_MASK & 32)) {
 #pragma unroll
             for (int t = 0; t < H1; ++t) bf[t] = b[t * b_ts + (kk + 2) * b_ks];
         }
@@ -357,7 +365,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aO[r], bf[t], acc[r][t]);
         __builtin_amdgcn_sched_barrier(0);
-        if (kk + 2 < ksteps) {
+        if (kk + 2 < ksteps && !(BESO_ABL_MASK & 32)) {
 #pragma unroll
             for (int t = H1; t < NT; ++t) bf[t] = b[t * b_ts + (kk + 2) * b_ks];
         }
@@ -400,7 +408,7 @@ __device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)
 #pragma unroll
                 for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(ar[p][r], bb[p & 1][t], acc[r][t]);
             __builtin_amdgcn_sched_barrier(0);
-            if (BESO_FUSED_ABLATE != 2 && kk + 2 < ksteps) {
+            if (BESO_FUSED_ABLATE != 2 && !(BESO_ABL_MASK & 32) && kk + 2 < ksteps) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) bb[p & 1][t] = b[t * b_ts + (kk + 2) * b_ks];
             }
@@ -444,7 +452,9 @@ __device__ __forceinline__ void stamp(Stamps& st, int id) {
     if (BESO_FUSED_STAMPS && st.buf && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && st.n + 2 <= st.cap / 8) {
         unsigned long long* b = st.buf + (size_t)(threadIdx.x >> 6) * (st.cap / 8);
         b[st.n] = (unsigned long long)id;
-        b[st.n + 1] = __builtin_amdgcn_s_memtime();
+        // ids >= 100 record the constant-rate (100 MHz) counter instead of the shader clock: the pair gives the
+        // core frequency the kernel actually ran at
+        b[st.n + 1] = id >= 100 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
         st.n += 2;
     }
 }
@@ -487,12 +497,10 @@ __device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restri
     }
 }
 
-// LayerNorm without affine (gamma/beta are folded into the consumer): two-pass fp32 statistics over the
-// feature slices of all 8 waves, then (x - mean) * rstd as bf16 B fragments into xnT.  Ends with a
-// barrier; `bias` (the residual-add bias of the block's last Linear) is added to the residual after
-// the normalised copy has been taken.
-// Two-pass fp32 LayerNorm statistics of every token of the tile over the feature slices of all 8
-// waves (partial sums exchanged through LDS; two barriers).
+// LayerNorm statistics of every token of the tile over the feature slices of all 8 waves: per-wave
+// partial (sum, sum of squares) in fp32, exchanged through LDS behind ONE barrier; var = E[x^2] - mean^2
+// (the residual stream is O(1..10) with |mean| << std, and the result is rounded to bf16 next: the
+// cancellation is far below that rounding).  Invalid (padding) features hold exact zeros.
 template <int RPW>
 __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, int w, int lane, float (&mean)[kNTT],
                                          float (&rstd)[kNTT], Stamps& st) {
@@ -500,49 +508,43 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
     const float invD = 1.0f / (float)D;
 #pragma unroll
     for (int t = 0; t < kNTT; ++t) {
-        float s = 0.f;
+        float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) s += (T.acc[i][t][0] + T.acc[i][t][1]) + (T.acc[i][t][2] + T.acc[i][t][3]);
+        for (int i = 0; i < RPW; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float v = T.acc[i][t][r]; s += v; q = fmaf(v, v, q); }
+        }
         s += __shfl_xor(s, 16, 64);
+        q += __shfl_xor(q, 16, 64);
         s += __shfl_xor(s, 32, 64);
-        if (g == 0) red[(0 * kWaves + w) * kMT + t * 16 + n] = s;
+        q += __shfl_xor(q, 32, 64);
+        if (g == 0) {
+            red[(0 * kWaves + w) * kMT + t * 16 + n] = s;
+            red[(1 * kWaves + w) * kMT + t * 16 + n] = q;
+        }
     }
     stamp(st, 30);
     __syncthreads();
     stamp(st, 31);
 #pragma unroll
     for (int t = 0; t < kNTT; ++t) {
-        float s = 0.f;
+        float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < kWaves; ++ww) s += red[(0 * kWaves + ww) * kMT + t * 16 + n];
-        mean[t] = s * invD;
-    }
-#pragma unroll
-    for (int t = 0; t < kNTT; ++t) {
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            if (T.fvalid[i]) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = T.acc[i][t][r] - mean[t]; q = fmaf(d, d, q); }
-            }
+        for (int ww = 0; ww < kWaves; ++ww) {
+            s += red[(0 * kWaves + ww) * kMT + t * 16 + n];
+            q += red[(1 * kWaves + ww) * kMT + t * 16 + n];
         }
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
-        if (g == 0) red[(1 * kWaves + w) * kMT + t * 16 + n] = q;
-    }
-    stamp(st, 32);
-    __syncthreads();
-    stamp(st, 33);
-#pragma unroll
-    for (int t = 0; t < kNTT; ++t) {
-        float q = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < kWaves; ++ww) q += red[(1 * kWaves + ww) * kMT + t * 16 + n];
-        rstd[t] = 1.0f / sqrtf(q * invD + 1e-5f);
+        mean[t] = s * invD;
+        rstd[t] = 1.0f / sqrtf(fmaxf(q * invD - mean[t] * mean[t], 0.f) + 1e-5f);
     }
 }
 
+// LayerNorm without affine (gamma/beta are folded into the consumer): (x - mean) * rstd as bf16 B
+// fragments into xnT.  Ends with a barrier; `bias` (the residual-add bias of the block's last Linear) is
+// added to the residual after the normalised copy has been taken.  A wave's row tiles (Rf, Rf+1) with Rf
+// even are the two halves of one k-step fragment and go out as one 16-byte LDS write per lane.
+// NOTE: the red[] buffer is re-used by the next LayerNorm; the barrier at the end of this function (and
+// the phases in between) orders the reads above against those writes.
 template <int RPW, int KS>
 __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float* red, int D, int w, int lane,
                                                  const float* __restrict__ bias, Stamps& st) {
@@ -551,24 +553,47 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
     asm volatile("" : "+v"(lane));
     const int g = lane >> 4;
     float mean[kNTT], rstd[kNTT];
-    ln_stats<RPW>(T, red, D, w, lane, mean, rstd, st);
+    if (BESO_ABL_MASK & 8) {
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
+        for (int t = 0; t < kNTT; ++t) { mean[t] = 0.01f * lane; rstd[t] = 0.5f; }
+    } else ln_stats<RPW>(T, red, D, w, lane, mean, rstd, st);
+    auto half = [&](int i, int t) {
+        uint2 pk = make_uint2(0u, 0u);
+        if (T.fvalid[i]) {
+            const float a = rstd[t], b = -mean[t] * rstd[t];
+            pk.x = pack_bf16x2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
+            pk.y = pack_bf16x2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
+        }
+        return pk;
+    };
+    auto write_pair = [&](int i) {          // row tiles i, i+1 of this wave: Rf = w*RPW + i is even
+        const int ks = (w * RPW + i) >> 1;
+        if (ks < KS) {
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) {
+                const uint2 lo = half(i, t), hi = half(i + 1, t);
+                xnT[((size_t)t * KS + ks) * 64 + lane] = u32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+        }
+    };
+    auto write_single = [&](int i) {
         const int Rf = w * RPW + i;
         if ((Rf >> 1) < KS) {
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) {
-                uint2 pk = make_uint2(0u, 0u);
-                if (T.fvalid[i]) {
-                    const float a = rstd[t], b = -mean[t] * rstd[t];
-                    pk.x = pack_bf16x2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
-                    pk.y = pack_bf16x2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
-                }
-                uint2* dst = (uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane) + (Rf & 1);
-                *dst = pk;
-            }
+            for (int t = 0; t < kNTT; ++t)
+                *((uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane) + (Rf & 1)) = half(i, t);
         }
-        const f32x4 bv = *(const f32x4*)(bias + 16 * Rf + 4 * g);
+    };
+    if constexpr (RPW == 2) {
+        write_pair(0);
+    } else {
+        static_assert(RPW == 3, "row tiles per wave");
+        if (w & 1) { write_single(0); write_pair(1); }
+        else { write_pair(0); write_single(2); }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const f32x4 bv = *(const f32x4*)(bias + 16 * (w * RPW + i) + 4 * g);
 #pragma unroll
         for (int t = 0; t < kNTT; ++t) T.acc[i][t] += bv;
     }
@@ -638,30 +663,38 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
 #pragma unroll
         for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // tok_emb over states and goals
-    for (int c = 0; c < d.obs; ++c) {
-        f32x4 wv[RPW];
+    // tok_emb over states / goals and action_emb over the (pre-conditioned) noisy actions, exact fp32 on the
+    // matrix pipe: X^T[f][tok] += W^T[f][c] * in[tok][c], four input features per v_mfma_f32_16x16x4_f32
+    // (A: lane (f = lane&15, c = 4kk + g) from the transposed weights; B: lane (tok = lane&15, c = 4kk + g)
+    // gathered from the inputs, zero for tokens of another kind).  Operands of k-step kk+1 are requested
+    // before the MFMAs of k-step kk.
+    auto emb = [&](const float* wT, int n_in, int want) {
+        const int ksteps = (n_in + 3) >> 2;
+        float av[RPW], bv[kNTT], an[RPW], bn[kNTT];
+        auto load = [&](int kk, float (&a_)[RPW], float (&b_)[kNTT]) {
+            const int c = 4 * kk + g;
+            const bool cv = c < n_in;
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) wv[i] = *(const f32x4*)(tokT + (size_t)c * Dp + 16 * (w * RPW + i) + 4 * g);
+            for (int i = 0; i < RPW; ++i) a_[i] = cv ? wT[(size_t)c * Dp + 16 * (w * RPW + i) + n] : 0.f;
 #pragma unroll
-        for (int t = 0; t < kNTT; ++t) {
-            const float v = kind[t] == 1 ? src[t][c] : 0.f;
+            for (int t = 0; t < kNTT; ++t) b_[t] = (cv && kind[t] == want) ? src[t][c] * scale[t] : 0.f;
+        };
+        load(0, av, bv);
+        for (int kk = 0; kk < ksteps; ++kk) {
+            if (kk + 1 < ksteps) load(kk + 1, an, bn);
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) T.acc[i][t] += v * wv[i];
+            for (int t = 0; t < kNTT; ++t)
+#pragma unroll
+                for (int i = 0; i < RPW; ++i)
+                    T.acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], T.acc[i][t], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) av[i] = an[i];
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) bv[t] = bn[t];
         }
-    }
-    // action_emb over the (pre-conditioned) noisy actions
-    for (int c = 0; c < d.act; ++c) {
-        f32x4 wv[RPW];
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) wv[i] = *(const f32x4*)(actT + (size_t)c * Dp + 16 * (w * RPW + i) + 4 * g);
-#pragma unroll
-        for (int t = 0; t < kNTT; ++t) {
-            const float v = kind[t] == 2 ? src[t][c] * scale[t] : 0.f;
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) T.acc[i][t] += v * wv[i];
-        }
-    }
+    };
+    emb(tokT, d.obs, 1);
+    emb(actT, d.act, 2);
     // biases, positions, sigma token
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
@@ -752,21 +785,19 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
 }
 
 // GELU of one chunk's FC1 accumulators -> packed bf16 B fragments (one FC2 k-step per wave), as a
-// sequence of 6*kNTT... = 48 scalar evaluations that can be issued in slices between MFMAs.
-template <int LO, int HI>
-__device__ __forceinline__ void gelu_slice(const f32x4 (&h)[2][kNTT], float (&gq)[8], u32x4 (&hb)[kNTT]) {
-    // evaluation idx -> token tile idx/8, element idx%8 (0..3: row tile 0 regs, 4..7: row tile 1 regs)
-#pragma unroll
-    for (int idx = LO; idx < HI; ++idx) {
-        const int t = idx >> 3, j = idx & 7;
-        gq[j] = gelu_fast(h[j >> 2][t][j & 3]);
-        asm volatile("" : "+v"(gq[j]));      // keep the evaluation HERE (between the MFMAs), not sunk to its use
-        if (j == 7) {
-            hb[t][0] = pack_bf16x2(gq[0], gq[1]);
-            hb[t][1] = pack_bf16x2(gq[2], gq[3]);
-            hb[t][2] = pack_bf16x2(gq[4], gq[5]);
-            hb[t][3] = pack_bf16x2(gq[6], gq[7]);
-        }
+// sequence of 4*kNTT pair evaluations that can be issued one at a time between MFMAs.
+// pair index pi (0..4*kNTT-1) -> token tile pi/4, elements 2*(pi%4), 2*(pi%4)+1 (0..3: row tile 0 regs, 4..7: row tile 1)
+__device__ __forceinline__ void gelu_pair(const f32x4 (&h)[2][kNTT], float (&gq)[8], u32x4 (&hb)[kNTT], int pi) {
+    const int t = pi >> 2, j = (pi & 3) * 2;
+    const f32x2 r = gelu_fast2(f32x2{h[j >> 2][t][j & 3], h[j >> 2][t][(j & 3) + 1]});
+    gq[j] = r.x;
+    gq[j + 1] = r.y;
+    asm volatile("" : "+v"(gq[j]), "+v"(gq[j + 1]));      // keep the evaluation HERE (between the MFMAs), not sunk to its use
+    if ((pi & 3) == 3) {
+        hb[t][0] = pack_bf16x2(gq[0], gq[1]);
+        hb[t][1] = pack_bf16x2(gq[2], gq[3]);
+        hb[t][2] = pack_bf16x2(gq[4], gq[5]);
+        hb[t][3] = pack_bf16x2(gq[6], gq[7]);
     }
 }
 
@@ -778,21 +809,30 @@ __device__ __forceinline__ void gelu_slice(const f32x4 (&h)[2][kNTT], float (&gq
 //     FC1(0)
 //     for c:  [FC2(c-1) || GELU(c)]  barrier  hT <- GELU(c)  FC1(c+1)  barrier
 //     FC2(n-1)
+constexpr int kFc1PF = 2;                // k-steps of FC1 weight fragments in flight per wave
+// First k-steps of chunk 0's FC1 weights of a layer (issued before the LayerNorm that precedes the phase).
+template <int KS>
+__device__ __forceinline__ void mlp_prefetch(u32x4 (&a1r)[kFc1PF][2], const u32x4* __restrict__ w1p, int w, int lane, int rot) {
+    prefetch_ring<2, kFc1PF>(a1r, w1p + (size_t)(2 * w) * 64 + lane + (size_t)rot * KS * kChunkTiles * 64, kChunkTiles * 64);
+}
+
 template <int RPW, int KS>
 __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
                                           const float* __restrict__ b1f, const u32x4* __restrict__ w2p, int HT,
-                                          int KS2p, int w, int lane, Stamps& st) {
+                                          int KS2p, int w, int lane, int rot, u32x4 (&a1r)[kFc1PF][2], Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int g = lane >> 4;
     const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
     constexpr int A2KS = kWaves * RPW * 64;                  // u32x4 stride between FC2 k-steps
     constexpr int H1 = kNTT / 2;
     // w1p: [chunk][kk][16 row tiles]; w2p: [kk2][8*RPW row tiles]
-    auto fc1_a = [&](int c) { return ABL_PTR(w1p + (size_t)(2 * w) * 64 + lane, (size_t)c * KS * kChunkTiles * 64); };
-    auto fc2_a = [&](int c) { return ABL_PTR(w2p + (size_t)(w * RPW) * 64 + lane, (size_t)(c * kWaves) * (kWaves * RPW) * 64); };
-    constexpr int PF1 = 2;
+    // hidden chunks are independent, so every workgroup walks them in its own rotation (see layers_kernel)
+    auto pc = [&](int c) { const int q = c + rot; return q >= n_chunks ? q - n_chunks : q; };
+    auto fc1_a = [&](int c) { return ABL_PTR(w1p + (size_t)(2 * w) * 64 + lane, (size_t)pc(c) * KS * kChunkTiles * 64); };
+    auto fc2_a = [&](int c) { return ABL_PTR(w2p + (size_t)(w * RPW) * 64 + lane, (size_t)(pc(c) * kWaves) * (kWaves * RPW) * 64); };
+    constexpr int PF1 = kFc1PF;
     auto fc1 = [&](int c, f32x4 (&h)[2][kNTT], u32x4 (&ar)[PF1][2]) {
-        const int R0 = c * kChunkTiles + 2 * w;
+        const int R0 = pc(c) * kChunkTiles + 2 * w;
         const f32x4 bias0 = *(const f32x4*)(b1f + 16 * R0 + 4 * g);
         const f32x4 bias1 = *(const f32x4*)(b1f + 16 * (R0 + 1) + 4 * g);
 #pragma unroll
@@ -801,15 +841,22 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     };
 
     f32x4 h[2][kNTT];
-    u32x4 a1r[PF1][2];
     u32x4 hb[kNTT];
+    u32x4 af2[2][RPW];                   // FC2 weight fragments of two k-steps, [k-step parity][row tile]
     float gq[8];
-    // ---- prologue: FC1(0), GELU(0) (nothing to hide it under yet), hT(0), FC1(1)
+    auto fc2_prefetch = [&](int c) {
+        const u32x4* a2 = fc2_a(c);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) { af2[0][r] = wload(a2 + r * 64); af2[1][r] = wload(a2 + r * 64 + ABL_KS(A2KS)); }
+    };
+    // ---- prologue: FC1(0) (its first weight fragments arrive preloaded in a1r), GELU(0) (nothing to hide
+    // it under yet), hT(0), FC1(1).  Every later weight request is issued one phase ahead of its use.
     static_assert(KS % PF1 == 0, "FC1 weight ring");
-    prefetch_ring<2, PF1>(a1r, fc1_a(0), kChunkTiles * 64);
     fc1(0, h, a1r);                 // rows beyond HT are zero weights + zero bias: harmless for every wave
     if (n_chunks > 1) prefetch_ring<2, PF1>(a1r, fc1_a(1), kChunkTiles * 64);
-    gelu_slice<0, 8 * kNTT>(h, gq, hb);
+    fc2_prefetch(0);
+#pragma unroll
+    for (int pi = 0; pi < 4 * kNTT; ++pi) gelu_pair(h, gq, hb, pi);
 #pragma unroll
     for (int t = 0; t < kNTT; ++t) hT[((size_t)t * kWaves + w) * 64 + lane] = hb[t];
     if (n_chunks > 1) fc1(1, h, a1r);
@@ -817,7 +864,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     __syncthreads();                     // hT(0) complete
 #pragma unroll 1
     for (int c = 1; c < n_chunks; ++c) {
-        const int tiles_here = min(kChunkTiles, HT - c * kChunkTiles);
+        const int tiles_here = min(kChunkTiles, HT - pc(c) * kChunkTiles);
         const bool fc1_active = 2 * w < tiles_here;
         const int cn = min(c + 1, n_chunks - 1);
         prefetch_ring<2, PF1>(a1r, fc1_a(cn), kChunkTiles * 64);
@@ -825,39 +872,28 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
             // ---- FC2(c-1) (always a full chunk: 8 k-steps) with GELU(c) woven in, fully unrolled
             const u32x4* a2 = fc2_a(c - 1);
             const u32x4* b = hT + lane;
-            u32x4 af2[2][RPW], bf[kNTT];               // [k-step parity][row tile]
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) { af2[0][r] = wload(a2 + r * 64); af2[1][r] = wload(a2 + r * 64 + ABL_KS(A2KS)); }
+            u32x4 bf[kNTT];
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) bf[t] = b[t * kWaves * 64];
 #pragma unroll
             for (int kk = 0; kk < kWaves; ++kk) {
 #pragma unroll
                 for (int t = 0; t < kNTT; ++t) {
-                    // unit of the weave: RPW MFMAs (48 cycles of matrix pipe) + one GELU evaluation (~14 VALU)
+                    // unit of the weave: RPW MFMAs (48 cycles of matrix pipe); every other unit + one GELU pair (11 VALU)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) T.acc[r][t] = mfma_bf16(af2[kk & 1][r], bf[t], T.acc[r][t]);
                     {
-                        constexpr int dummy = 0; (void)dummy;
-                        const int idx = kk * kNTT + t;             // 8 * 6 = 48 evaluations
-                        const int tt = idx >> 3, j = idx & 7;
-                        gq[j] = gelu_fast(h[j >> 2][tt][j & 3]);
-                        asm volatile("" : "+v"(gq[j]));
-                        if (j == 7) {
-                            hb[tt][0] = pack_bf16x2(gq[0], gq[1]);
-                            hb[tt][1] = pack_bf16x2(gq[2], gq[3]);
-                            hb[tt][2] = pack_bf16x2(gq[4], gq[5]);
-                            hb[tt][3] = pack_bf16x2(gq[6], gq[7]);
-                        }
+                        const int idx = kk * kNTT + t;             // 48 units, 24 pair evaluations: every other unit
+                        if ((idx & 1) == 0) gelu_pair(h, gq, hb, idx >> 1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (t == H1 - 1 && kk + 1 < kWaves) {
+                    if (t == H1 - 1 && kk + 1 < kWaves && !(BESO_ABL_MASK & 32)) {
 #pragma unroll
                         for (int t2 = 0; t2 < H1; ++t2) bf[t2] = b[t2 * kWaves * 64 + (kk + 1) * 64];
                     }
                     if (t == kNTT - 1) {
-                        if (kk + 1 < kWaves) {
+                        if (kk + 1 < kWaves && !(BESO_ABL_MASK & 32)) {
 #pragma unroll
                             for (int t2 = H1; t2 < kNTT; ++t2) bf[t2] = b[t2 * kWaves * 64 + (kk + 1) * 64];
                         }
@@ -869,8 +905,9 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
                 }
             }
         }
+        fc2_prefetch(c);                 // first two k-steps of FC2(c): in flight across the barriers and FC1(c+1)
         stamp(st, 21);
-        __syncthreads();                 // every wave is done reading hT(c-1)
+        if (!(BESO_ABL_MASK & 2)) __syncthreads();                 // every wave is done reading hT(c-1)
         stamp(st, 22);
         if (fc1_active) {
 #pragma unroll
@@ -878,17 +915,15 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
         }
         if (c + 1 < n_chunks) fc1(c + 1, h, a1r);
         stamp(st, 23);
-        __syncthreads();                 // hT(c) complete
+        if (!(BESO_ABL_MASK & 2)) __syncthreads();                 // hT(c) complete
         stamp(st, 24);
     }
     {
         // ---- FC2 of the last chunk; k-steps are consumed in pairs: an odd tail reads a stale (finite) hT
         // slot against zero weights
         const int c = n_chunks - 1;
-        const int tiles_here = min(kChunkTiles, HT - c * kChunkTiles);
-        u32x4 a2E[RPW], a2O[RPW];
-        prefetch_a<RPW>(a2E, a2O, fc2_a(c), A2KS);
-        gemm_phase<RPW, kNTT>(T.acc, a2E, a2O, fc2_a(c), A2KS, hT + lane, kWaves * 64, 64, ((tiles_here >> 1) + 1) & ~1);
+        const int tiles_here = min(kChunkTiles, HT - pc(c) * kChunkTiles);
+        gemm_phase<RPW, kNTT>(T.acc, af2[0], af2[1], fc2_a(c), A2KS, hT + lane, kWaves * 64, 64, ((tiles_here >> 1) + 1) & ~1);
     }
     stamp(st, 25);
     __syncthreads();
@@ -896,11 +931,21 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 
 // Attention phase (xnT holds LN1(x) fragments on entry).  Tokens of the tile are in natural order:
 // slot = sample*Tn + position, n_samples*Tn valid slots.
+#ifndef BESO_QKV_PF
+#define BESO_QKV_PF 2
+#endif
+constexpr int kQkvPF = BESO_QKV_PF;      // k-steps of QKV weight fragments in flight per wave
+// First k-steps of head 0's QKV weights of a layer (issued before the LayerNorm that precedes the phase).
+template <int KS>
+__device__ __forceinline__ void attn_prefetch(u32x4 (&ar)[kQkvPF][3], const u32x4* __restrict__ wqkv, int w, int lane, int rot) {
+    prefetch_ring<3, kQkvPF>(ar, wqkv + (size_t)(3 * (w & 3)) * 64 + lane + (size_t)rot * KS * 12 * 64, 12 * 64);
+}
+
 template <int RPW, int KS>
 __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsigned char* u,
                                            const u32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
                                            const u32x4* __restrict__ wproj, int H, int hd, int Tn, int n_samples,
-                                           int w, int lane, Stamps& st) {
+                                           int w, int lane, int rot, u32x4 (&ar)[kQkvPF][3], Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int n = lane & 15, g = lane >> 4;
     uint16_t* qkv = (uint16_t*)u;                         // [3][kQKVRows][kQKVRow] bf16
@@ -908,21 +953,29 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     const int wa = w & 3, wb = w >> 2;                    // QKV split: row tiles 3wa..3wa+2 x token tiles 3wb..3wb+2
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
 
-    for (int h = 0; h < H; ++h) {
+    // Weight fragments are requested one phase ahead of their use, so that the L2 round trip is hidden
+    // behind the barrier / attention core / projection in between: `ar` (first k-steps of the head's QKV
+    // weights) arrives preloaded and is refilled for head h+1 before the core of head h; the head's
+    // projection weights (all of them: two k-steps) are requested before the QKV epilogue.
+    auto qkv_a = [&](int h) { return ABL_PTR(wqkv + (size_t)(3 * wa) * 64 + lane, (size_t)h * KS * 12 * 64); };   // [head][kk][12 row tiles]
+    // heads are independent (the projection accumulates), so every workgroup walks them in its own rotation
+    for (int hi = 0; hi < H; ++hi) {
+        const int h = hi + rot >= H ? hi + rot - H : hi + rot;
+        const int hn = h + 1 >= H ? 0 : h + 1;
         stamp(st, 10);
+        u32x4 aE[RPW], aO[RPW];
+        const u32x4* ap = ABL_PTR(wproj + (size_t)(w * RPW) * 64 + lane, (size_t)(2 * h) * (kWaves * RPW) * 64);   // [2h+kk][row tiles]
         // ---- q, k, v of head h for all tokens of the tile
         {
             f32x4 qa[3][3];
-            u32x4 ar[2][3];
-            const u32x4* a = ABL_PTR(wqkv + (size_t)(3 * wa) * 64 + lane, (size_t)h * KS * 12 * 64);   // [head][kk][12 row tiles]
-            prefetch_ring<3, 2>(ar, a, 12 * 64);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const f32x4 bv = *(const f32x4*)(bqkv + (h * 12 + 3 * wa + i) * 16 + 4 * g);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) qa[i][t] = bv;
             }
-            gemm_phase_ring<3, 3, 2>(qa, ar, a, 12 * 64, xnT + (size_t)(3 * wb) * KS * 64 + lane, KS * 64, 64, KS);
+            gemm_phase_ring<3, 3, kQkvPF>(qa, ar, qkv_a(h), 12 * 64, xnT + (size_t)(3 * wb) * KS * 64 + lane, KS * 64, 64, KS);
+            prefetch_a<RPW>(aE, aO, ap, kWaves * RPW * 64);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int rt = 3 * wa + i, part = rt >> 2, d0 = (rt & 3) * 16 + 4 * g;
@@ -936,6 +989,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                 }
             }
         }
+        if (hi + 1 < H) prefetch_ring<3, kQkvPF>(ar, qkv_a(hn), 12 * 64);
         stamp(st, 11);
         __syncthreads();
         stamp(st, 12);
@@ -946,7 +1000,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         //   operand (k = 4g..4g+3) of v_mfma_f32_16x16x16_bf16 for
         //   Y^T[d][i] = sum_j V[j][d] P[i][j]          4 x (A = V^T gathered with 16-bit LDS reads)
         //   whose D layout is the B fragment of the out-projection (same k permutation as the weights).
-        if (w < n_samples) {
+        if (w < n_samples && !(BESO_ABL_MASK & 16)) {
             const uint16_t* qb = qkv + ((size_t)0 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
             const uint16_t* kb = qkv + ((size_t)1 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
             f32x4 sT = {0.f, 0.f, 0.f, 0.f};
@@ -996,12 +1050,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         __syncthreads();
         stamp(st, 17);
         // ---- the head's slice of the out-projection, accumulated into the residual
-        {
-            u32x4 aE[RPW], aO[RPW];
-            const u32x4* a = ABL_PTR(wproj + (size_t)(w * RPW) * 64 + lane, (size_t)(2 * h) * (kWaves * RPW) * 64);   // [2h+kk][row tiles]
-            prefetch_a<RPW>(aE, aO, a, kWaves * RPW * 64);
-            gemm_phase<RPW, kNTT>(T.acc, aE, aO, a, kWaves * RPW * 64, yT + lane, 2 * 64, 64, 2);
-        }
+        gemm_phase<RPW, kNTT>(T.acc, aE, aO, ap, kWaves * RPW * 64, yT + lane, 2 * 64, 64, 2);
         // no barrier needed here: the next writes to qkv/yT happen behind the next head's barriers
     }
     __syncthreads();
@@ -1022,9 +1071,11 @@ __global__ __launch_bounds__(512, 2) void mlp_block_kernel(float* __restrict__ x
     const int m0 = blockIdx.x * kMT;
     Tile<RPW> T;
     load_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
+    u32x4 a1r[kFc1PF][2];
+    mlp_prefetch<KS>(a1r, (const u32x4*)lw, w, lane, 0);
     layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane, (const float*)(lw + d.o_b2), st);
     mlp_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
-                       (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, st);
+                       (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, 0, a1r, st);
     store_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
 }
 
@@ -1049,31 +1100,56 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         const int part = i / (8 * kQKVRow / 2), rem = i % (8 * kQKVRow / 2);
         ((uint32_t*)(lds + L.u))[((size_t)part * kQKVRows + kMT) * kQKVRow / 2 + rem] = 0u;
     }
+    // Workgroups of one XCD (blockIdx % 8) stream the same weights at about the same time; walking the
+    // heads / hidden chunks in a per-workgroup rotation spreads those reads over the L2 channels.
+#ifndef BESO_ROT
+#define BESO_ROT 0            // measured: 1.16 ms with the rotation vs 1.13 ms without (lockstep sharing wins)
+#endif
+    const int n_chunks_k = (d.HT + kChunkTiles - 1) / kChunkTiles;
+    const int rot_h = BESO_ROT ? (int)((blockIdx.x >> 3) % (unsigned)d.H) : 0;
+    const int rot_c = BESO_ROT ? (int)((blockIdx.x >> 3) % (unsigned)n_chunks_k) : 0;
     Tile<RPW> T;
+    stamp(st, 100);
     stamp(st, 1);
     const char* gw = lw0 + (size_t)d.L * d.layer_bytes;          // per-model image (embeddings, head)
-    if (e.fuse_embed) embed_tile<RPW>(T, e, d, gw, s0, n_samples, Tn, w, lane);
+    if ((BESO_ABL_MASK & 4) && e.fuse_embed) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            T.fvalid[i] = 16 * (w * RPW + i) + 4 * g < d.D;
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.1f * n, 0.2f, 0.3f * g, 0.4f};
+        }
+    } else if (e.fuse_embed) embed_tile<RPW>(T, e, d, gw, s0, n_samples, Tn, w, lane);
     else load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     for (int l = l0; l < l1; ++l) {
+#if BESO_FUSED_ABLATE == 4
+        const char* lw = lw0;                                    // timing experiment: the weights of ONE layer fit in L2
+#else
         const char* lw = lw0 + (size_t)l * d.layer_bytes;
+#endif
         stamp(st, 2);
+        u32x4 ar[kQkvPF][3];
+        attn_prefetch<KS>(ar, (const u32x4*)(lw + d.o_wqkv), w, lane, rot_h);
         layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                   (const float*)(lw + d.o_bproj), st);
         stamp(st, 7);
         attn_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
                             (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.H, d.hd, Tn, n_samples, w,
-                            lane, st);
+                            lane, rot_h, ar, st);
         stamp(st, 3);
+        u32x4 a1r[kFc1PF][2];
+        mlp_prefetch<KS>(a1r, (const u32x4*)lw, w, lane, rot_c);
         layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                   (const float*)(lw + d.o_b2), st);
         stamp(st, 6);
         mlp_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
-                           (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, st);
+                           (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, rot_c, a1r, st);
     }
     stamp(st, 4);
     if (e.fuse_head) head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, st);
     else store_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 5);
+    stamp(st, 101);
 }
 
 unsigned long long* g_stamps = nullptr;

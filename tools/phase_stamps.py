@@ -46,6 +46,13 @@ def main():
         ids, ts = ids[:n], ts[:n]
         if n == 0:
             continue
+        real = {int(i): int(t) for i, t in zip(ids, ts) if i >= 100}
+        keep = ids < 100
+        ids, ts = ids[keep], ts[keep]
+        n = len(ids)
+        if wave == 0 and 100 in real and 101 in real:
+            dt_us = (real[101] - real[100]) / 100.0
+            print(f"workgroup 0 lifetime {dt_us:.1f} us; shader clock {(ts[-1] - ts[0]) / dt_us:.0f} MHz")
         total = ts[-1] - ts[0]
         acc = collections.OrderedDict()
         for k in range(1, n):

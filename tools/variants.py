@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Development aid: build and time compile-time variants of the fused kernel in one GPU call.
+
+    python tools/variants.py build  name1=-DFLAG=1,-DX=2  name2=...     (CPU box: hipcc cross-compile)
+    python tools/variants.py time   [--batch 4096] [--stamps]           (GPU box: times every built variant)
+
+Variants are libbeso_hip_<name>.so under beso_amd/lib/variants/ (only fused.hip is recompiled; the other
+objects come from the regular build).  `time` runs each variant in its own process (BESO_HIP_LIB).
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VDIR = os.path.join(ROOT, "beso_amd", "lib", "variants")
+
+
+def build(specs):
+    from beso_amd import build as B
+    B.build()
+    os.makedirs(VDIR, exist_ok=True)
+    for f in os.listdir(VDIR):
+        os.remove(os.path.join(VDIR, f))
+    procs = []
+    for spec in specs:
+        name, _, flags = spec.partition("=")
+        flags = [f for f in flags.split(",") if f]
+        obj = os.path.join(B.OBJDIR, f"fused_{name}.o")
+        cmd = [B._hipcc(), *B.FLAGS, *flags, "-c", os.path.join(B.CSRC, "fused.hip"), "-o", obj]
+        procs.append((name, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+    for name, obj, p in procs:
+        _, err = p.communicate()
+        if p.returncode:
+            raise SystemExit(f"variant {name}: hipcc failed\n{err}")
+        objs = [os.path.join(B.OBJDIR, u + ".o") for u in B.UNITS if u != "fused"] + [obj]
+        lib = os.path.join(VDIR, f"libbeso_hip_{name}.so")
+        subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", lib, *objs])
+        print("built", lib)
+
+
+def time_one(batch, steps=30):
+    import torch
+    from bench import build_model
+    from oracle import beso_oracle as O
+    dev = "cuda:0"
+    cfg = O.KITCHEN
+    model = build_model(cfg, O.make_weights(cfg, seed=0, std=0.02), "bf16", dev)
+    s, g, a = (torch.from_numpy(v).to(dev) for v in O.make_inputs(cfg, batch, seed=1))
+    sig = torch.full((batch,), 0.3, device=dev)
+    inner = model.inner_model
+    rt, packed = inner.runtime(cfg.sigma_data), inner.packed_weights()
+    with torch.no_grad():
+        for _ in range(5):
+            rt.denoise(packed, s, a, g, sig, precondition=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            rt.denoise(packed, s, a, g, sig, precondition=True)
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def main():
+    if sys.argv[1] == "build":
+        return build(sys.argv[2:])
+    if sys.argv[1] == "one":
+        print(json.dumps({"ms": time_one(int(sys.argv[2]))}))
+        return
+    batch = 4096
+    if "--batch" in sys.argv:
+        batch = int(sys.argv[sys.argv.index("--batch") + 1])
+    libs = sorted(f for f in os.listdir(VDIR) if f.endswith(".so"))
+    for rep in range(2):
+        for f in libs:
+            env = dict(os.environ, BESO_HIP_LIB=os.path.join(VDIR, f))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "one", str(batch)], env=env,
+                               capture_output=True, text=True)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            ms = json.loads(line[-1])["ms"] if line else None
+            print(f"{f[len('libbeso_hip_'):-3]:24s} {ms if ms is None else round(ms, 4)} ms" + ("" if line else "  " + r.stderr[-300:]))
+            sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()
