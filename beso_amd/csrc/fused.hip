@@ -27,6 +27,7 @@
 namespace beso {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -504,36 +505,42 @@ __device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restri
 template <int RPW>
 __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, int w, int lane, float (&mean)[kNTT],
                                          float (&rstd)[kNTT], Stamps& st) {
-    const int n = lane & 15, g = lane >> 4;
+    static_assert(kNTT % 2 == 0, "token tiles are reduced in pairs");
+    const int n = lane & 15, row = lane >> 4;
     const float invD = 1.0f / (float)D;
+    // Cross-lane part of the reduction (over the four 16-lane rows g) on gfx950's lane-swap instructions:
+    //   v_permlane32_swap(s, q) + add : rows {0,1} = s(g) + s(g+2), rows {2,3} = q(g) + q(g+2)
+    //   v_permlane16_swap(r_t, r_t+1) + add : row 0 = S_t, row 1 = S_t+1, row 2 = Q_t, row 3 = Q_t+1
+    // so every lane ends up with one finished (token, statistic) and writes it: red[token][wave][stat].
 #pragma unroll
-    for (int t = 0; t < kNTT; ++t) {
-        float s = 0.f, q = 0.f;
+    for (int tp = 0; tp < kNTT / 2; ++tp) {
+        float r[2];
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
+        for (int h = 0; h < 2; ++h) {
+            const int t = 2 * tp + h;
+            float s = 0.f, q = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float v = T.acc[i][t][r]; s += v; q = fmaf(v, v, q); }
+            for (int i = 0; i < RPW; ++i) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float v = T.acc[i][t][k]; s += v; q = fmaf(v, v, q); }
+            }
+            const u32x2 x = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(q), false, false);
+            r[h] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
         }
-        s += __shfl_xor(s, 16, 64);
-        q += __shfl_xor(q, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        q += __shfl_xor(q, 32, 64);
-        if (g == 0) {
-            red[(0 * kWaves + w) * kMT + t * 16 + n] = s;
-            red[(1 * kWaves + w) * kMT + t * 16 + n] = q;
-        }
+        const u32x2 y = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[0]), __float_as_uint(r[1]), false, false);
+        const float v = __uint_as_float(y[0]) + __uint_as_float(y[1]);
+        const int tok = (2 * tp + (row & 1)) * 16 + n;
+        red[(tok * kWaves + w) * 2 + (row >> 1)] = v;
     }
     stamp(st, 30);
     __syncthreads();
     stamp(st, 31);
 #pragma unroll
     for (int t = 0; t < kNTT; ++t) {
+        const f32x4* pr = (const f32x4*)(red + (size_t)(t * 16 + n) * kWaves * 2);
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < kWaves; ++ww) {
-            s += red[(0 * kWaves + ww) * kMT + t * 16 + n];
-            q += red[(1 * kWaves + ww) * kMT + t * 16 + n];
-        }
+        for (int k = 0; k < kWaves / 2; ++k) { const f32x4 v = pr[k]; s += v[0] + v[2]; q += v[1] + v[3]; }
         mean[t] = s * invD;
         rstd[t] = 1.0f / sqrtf(fmaxf(q * invD - mean[t] * mean[t], 0.f) + 1e-5f);
     }
@@ -613,6 +620,8 @@ struct EdgeArgs {
     int fuse_embed, fuse_head;
 };
 
+constexpr int kEmbObsK = 8, kEmbActK = 3;     // k-steps (4 inputs each) of the fused embedding GEMMs: obs <= 32, act <= 12
+
 // Which real sample and which conditioning a virtual sample stands for.
 __device__ __forceinline__ void sample_of(const EdgeArgs& e, int vb, int& b, bool& uncond) {
     if (e.two) { b = vb >> 1; uncond = vb & 1; }
@@ -621,84 +630,75 @@ __device__ __forceinline__ void sample_of(const EdgeArgs& e, int vb, int& b, boo
 
 // K1 fused: the residual tile is built in registers from (state, action, goal, sigma):
 //   token 0: sigma_emb(log(sigma)/4); 1..G: tok_emb(goal)+pos; then tok_emb(state_i)+pos, action_emb(action_i*c_in)+pos
-// (score_gpts.py:284-337, score_wrappers.py:96).  Weights come transposed ([in][Dp] fp32) so that a lane's
-// four features are one 16-byte load.
+// (score_gpts.py:284-337, score_wrappers.py:96).  Weights come transposed ([in][Dp] fp32).
+// Written WITHOUT divergent control flow around loads: every load is unconditional from a clamped
+// (always valid) address and its value is selected afterwards -- a load inside a per-lane `if` is waited
+// for at the end of its block, which serialised ~120 cache-cold round trips (70 kcycles per workgroup).
 template <int RPW>
 __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw, int s0,
-                                           int n_samples, int Tn, int w, int lane) {
+                                           int n_samples, int Tn, int w, int lane, Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int n = lane & 15, g = lane >> 4;
     const int G = d.G, Dp = d.Dp;
     const float* tokT = (const float*)(gw + d.g_tokT);
     const float* actT = (const float*)(gw + d.g_actT);
     const float* src[kNTT];
-    float scale[kNTT], lsig[kNTT];
-    int kind[kNTT], prow[kNTT];       // kind: 0 none, 1 tok_emb input (state / goal), 2 action, 3 sigma
+    float scale[kNTT], sg[kNTT];
+    int kind[kNTT], prow[kNTT];       // kind: 0 none, 1 tok_emb input (state / goal), 2 action, 3 sigma, 4 zeroed goal
+    const int last = s0 + n_samples - 1;
 #pragma unroll
     for (int t = 0; t < kNTT; ++t) {
         const int tokl = t * 16 + n;
         const int sl = tokl / Tn, p = tokl - sl * Tn;
+        const bool live = sl < n_samples;
         int b; bool un;
-        sample_of(e, s0 + sl, b, un);
-        kind[t] = 0; prow[t] = 0; src[t] = e.sigma; scale[t] = 1.f; lsig[t] = 0.f;
-        if (sl < n_samples) {
-            const float sg = e.sigma[b];
-            if (p == 0) { kind[t] = 3; lsig[t] = logf(sg) / 4.0f; }
-            else if (p <= G) { kind[t] = un ? 0 : 1; prow[t] = p - 1; src[t] = e.goal + ((size_t)b * G + (p - 1)) * d.obs;
-                               if (un) kind[t] = 4; }
-            else {
-                const int idx = p - G - 1, i = idx >> 1;
-                prow[t] = G + i;
-                if ((idx & 1) == 0) { kind[t] = 1; src[t] = e.state + ((size_t)b * e.t + i) * d.obs; }
-                else {
-                    kind[t] = 2; src[t] = e.action + ((size_t)b * e.t + i) * d.act;
-                    if (e.precondition) scale[t] = 1.0f / sqrtf(sg * sg + e.sigma_data * e.sigma_data);   // c_in
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        T.fvalid[i] = 16 * (w * RPW + i) + 4 * g < d.D;
-#pragma unroll
-        for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sample_of(e, min(s0 + sl, last), b, un);
+        sg[t] = e.sigma[b];
+        const int idx = p - G - 1, i = max(idx, 0) >> 1;
+        const bool is_sig = p == 0, is_goal = p >= 1 && p <= G, is_act = idx >= 0 && (idx & 1);
+        kind[t] = !live ? 0 : is_sig ? 3 : is_goal ? (un ? 4 : 1) : is_act ? 2 : 1;
+        prow[t] = is_sig ? 0 : is_goal ? p - 1 : G + i;
+        const float* ps = e.state + ((size_t)b * e.t + i) * d.obs;
+        const float* pg = e.goal + ((size_t)b * G + max(p - 1, 0)) * d.obs;
+        const float* pa = e.action + ((size_t)b * e.t + i) * d.act;
+        src[t] = kind[t] == 1 ? (is_goal ? pg : ps) : kind[t] == 2 ? pa : tokT;      // tokT: any readable address
+        scale[t] = 1.f;
+        if (kind[t] == 2 && e.precondition) scale[t] = 1.0f / sqrtf(sg[t] * sg[t] + e.sigma_data * e.sigma_data);   // c_in
     }
     // tok_emb over states / goals and action_emb over the (pre-conditioned) noisy actions, exact fp32 on the
     // matrix pipe: X^T[f][tok] += W^T[f][c] * in[tok][c], four input features per v_mfma_f32_16x16x4_f32
     // (A: lane (f = lane&15, c = 4kk + g) from the transposed weights; B: lane (tok = lane&15, c = 4kk + g)
-    // gathered from the inputs, zero for tokens of another kind).  Operands of k-step kk+1 are requested
-    // before the MFMAs of k-step kk.
-    auto emb = [&](const float* wT, int n_in, int want) {
-        const int ksteps = (n_in + 3) >> 2;
-        float av[RPW], bv[kNTT], an[RPW], bn[kNTT];
-        auto load = [&](int kk, float (&a_)[RPW], float (&b_)[kNTT]) {
-            const int c = 4 * kk + g;
-            const bool cv = c < n_in;
+    // gathered from the inputs, zero for tokens of another kind).  Every operand of both GEMMs is requested
+    // up front; kEmbObsK / kEmbActK bound obs / act (fused_level).
+    stamp(st, 40);
+    float aT[kEmbObsK][RPW], bT[kEmbObsK][kNTT], aA[kEmbActK][RPW], bA[kEmbActK][kNTT];
+    auto load = [&](const float* wT, int n_in, int kk, float (&a_)[RPW], float (&b_)[kNTT]) {
+        const int cl = min(4 * kk + g, n_in - 1);
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) a_[i] = cv ? wT[(size_t)c * Dp + 16 * (w * RPW + i) + n] : 0.f;
+        for (int i = 0; i < RPW; ++i) a_[i] = wT[(size_t)cl * Dp + 16 * (w * RPW + i) + n];
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) b_[t] = (cv && kind[t] == want) ? src[t][c] * scale[t] : 0.f;
-        };
-        load(0, av, bv);
-        for (int kk = 0; kk < ksteps; ++kk) {
-            if (kk + 1 < ksteps) load(kk + 1, an, bn);
-#pragma unroll
-            for (int t = 0; t < kNTT; ++t)
-#pragma unroll
-                for (int i = 0; i < RPW; ++i)
-                    T.acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], T.acc[i][t], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) av[i] = an[i];
-#pragma unroll
-            for (int t = 0; t < kNTT; ++t) bv[t] = bn[t];
-        }
+        for (int t = 0; t < kNTT; ++t) b_[t] = src[t][cl];
     };
-    emb(tokT, d.obs, 1);
-    emb(actT, d.act, 2);
-    // biases, positions, sigma token
+    auto mask = [&](int n_in, int want, int kk, float (&a_)[RPW], float (&b_)[kNTT]) {
+        const bool cv = 4 * kk + g < n_in;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) a_[i] = cv ? a_[i] : 0.f;
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) b_[t] = (cv && kind[t] == want) ? b_[t] * scale[t] : 0.f;
+    };
+#pragma unroll
+    for (int kk = 0; kk < kEmbObsK; ++kk) load(tokT, d.obs, kk, aT[kk], bT[kk]);
+#pragma unroll
+    for (int kk = 0; kk < kEmbActK; ++kk) load(actT, d.act, kk, aA[kk], bA[kk]);
+    stamp(st, 41);
+    // biases, positions, sigma token: the accumulators start from them
+    float lsig[kNTT];
+#pragma unroll
+    for (int t = 0; t < kNTT; ++t) lsig[t] = logf(sg[t]) / 4.0f;
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int f0 = 16 * (w * RPW + i) + 4 * g;
+        T.fvalid[i] = f0 < d.D;
         const f32x4 bt = *(const f32x4*)((const float*)(gw + d.g_tokb) + f0);
         const f32x4 ba = *(const f32x4*)((const float*)(gw + d.g_actb) + f0);
         const f32x4 sw = *(const f32x4*)((const float*)(gw + d.g_sigw) + f0);
@@ -706,12 +706,31 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
 #pragma unroll
         for (int t = 0; t < kNTT; ++t) {
             const int k = kind[t];
-            if (k == 0) continue;
-            f32x4 add;
-            if (k == 3) add = sw * lsig[t] + sb;
-            else add = (k == 2 ? ba : bt) + *(const f32x4*)((const float*)(gw + d.g_pos) + (size_t)prow[t] * Dp + f0);
-            T.acc[i][t] += add;
+            const f32x4 pos = *(const f32x4*)((const float*)(gw + d.g_pos) + (size_t)prow[t] * Dp + f0);
+            const f32x4 sig = sw * lsig[t] + sb;
+            const f32x4 lin = (k == 2 ? ba : bt) + pos;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            T.acc[i][t] = k == 0 ? zero : k == 3 ? sig : lin;
         }
+    }
+    stamp(st, 42);
+#pragma unroll
+    for (int kk = 0; kk < kEmbObsK; ++kk) {
+        mask(d.obs, 1, kk, aT[kk], bT[kk]);
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+                T.acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[kk][i], bT[kk][t], T.acc[i][t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < kEmbActK; ++kk) {
+        mask(d.act, 2, kk, aA[kk], bA[kk]);
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+                T.acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[kk][i], bA[kk][t], T.acc[i][t], 0, 0, 0);
     }
 }
 
@@ -1119,8 +1138,9 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.1f * n, 0.2f, 0.3f * g, 0.4f};
         }
-    } else if (e.fuse_embed) embed_tile<RPW>(T, e, d, gw, s0, n_samples, Tn, w, lane);
+    } else if (e.fuse_embed) embed_tile<RPW>(T, e, d, gw, s0, n_samples, Tn, w, lane, st);
     else load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
+    stamp(st, 43);
     for (int l = l0; l < l1; ++l) {
 #if BESO_FUSED_ABLATE == 4
         const char* lw = lw0;                                    // timing experiment: the weights of ONE layer fit in L2
@@ -1280,7 +1300,8 @@ int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     FusedDims d;
     if (a.vbatch < fused_min_batch()) return 0;
     if (precision != BESO_PREC_BF16 || lay.fused == lay.total || !fused_dims(lay, &d) || !shape_has_kernel(d)) return 0;
-    if (d.attn && d.RPW == 3 && d.KS == 12 && kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused)) return 2;
+    if (d.attn && d.RPW == 3 && d.KS == 12 && kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused) &&
+        d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK) return 2;
     return 1;
 }
 
