@@ -68,7 +68,7 @@ bool fused_dims(const Layout& lay, FusedDims* d) {
     d->NCH = (d->HT + kChunkTiles - 1) / kChunkTiles;
     d->KS2p = d->NCH * kWaves;
     const int T = 1 + lay.G + 2 * lay.W;
-    d->attn = lay.hd <= kHDP && lay.hd % 4 == 0 && kSPW * T <= kMT;
+    d->attn = lay.hd <= kHDP && lay.hd % 4 == 0 && kSPW * T <= kMT && lay.H % 2 == 0;
     const size_t rt2 = (size_t)d->RPW * kWaves;
     d->w1_bytes = (size_t)d->NCH * kChunkTiles * d->KS * 1024;
     d->b1_bytes = round_up_sz((size_t)d->NCH * kChunkTiles * 16 * sizeof(float), 256);
@@ -132,7 +132,8 @@ __global__ void pack_mfma_a_kernel(const float* __restrict__ src, int rows, int 
     }
 }
 
-// q/k/v weights of all heads: tile index = (h*3 + part)*4 + R4, rows of head h padded hd -> 64;
+// q/k/v weights of all heads, two heads per k-step group: tile index = ((h/2)*kt + kk)*24 + (h%2)*12 + part*4 + R4,
+// rows of head h padded hd -> 64;
 // LayerNorm-1 gamma folded in.  part 0 = query, 1 = key, 2 = value.
 __global__ void pack_qkv_kernel(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
                                 const float* __restrict__ gamma, uint16_t* __restrict__ dst, int D, int H, int hd,
@@ -140,10 +141,10 @@ __global__ void pack_qkv_kernel(const float* __restrict__ wq, const float* __res
     size_t total = (size_t)H * 12 * kt * 512;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        size_t tile = i >> 9;                    // (h*kt + kk)*12 + rt12
+        size_t tile = i >> 9;                    // (pair*kt + kk)*24 + (h&1)*12 + rt12
         int rt12 = (int)(tile % 12);
-        int kk = (int)((tile / 12) % kt);
-        int h = (int)(tile / ((size_t)12 * kt));
+        int kk = (int)((tile / 24) % kt);
+        int h = 2 * (int)(tile / ((size_t)24 * kt)) + (int)((tile / 12) & 1);
         int R4 = rt12 & 3, part = rt12 >> 2;
         int d = 16 * R4 + (lane & 15);
         int c = 32 * kk + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
@@ -502,7 +503,7 @@ __device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restri
 // partial (sum, sum of squares) in fp32, exchanged through LDS behind ONE barrier; var = E[x^2] - mean^2
 // (the residual stream is O(1..10) with |mean| << std, and the result is rounded to bf16 next: the
 // cancellation is far below that rounding).  Invalid (padding) features hold exact zeros.
-template <int RPW>
+template <int RPW, int NW>
 __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, int w, int lane, float (&mean)[kNTT],
                                          float (&rstd)[kNTT], Stamps& st) {
     static_assert(kNTT % 2 == 0, "token tiles are reduced in pairs");
@@ -530,17 +531,17 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
         const u32x2 y = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[0]), __float_as_uint(r[1]), false, false);
         const float v = __uint_as_float(y[0]) + __uint_as_float(y[1]);
         const int tok = (2 * tp + (row & 1)) * 16 + n;
-        red[(tok * kWaves + w) * 2 + (row >> 1)] = v;
+        red[(tok * NW + w) * 2 + (row >> 1)] = v;
     }
     stamp(st, 30);
     __syncthreads();
     stamp(st, 31);
 #pragma unroll
     for (int t = 0; t < kNTT; ++t) {
-        const f32x4* pr = (const f32x4*)(red + (size_t)(t * 16 + n) * kWaves * 2);
+        const f32x4* pr = (const f32x4*)(red + (size_t)(t * 16 + n) * NW * 2);
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int k = 0; k < kWaves / 2; ++k) { const f32x4 v = pr[k]; s += v[0] + v[2]; q += v[1] + v[3]; }
+        for (int k = 0; k < NW / 2; ++k) { const f32x4 v = pr[k]; s += v[0] + v[2]; q += v[1] + v[3]; }
         mean[t] = s * invD;
         rstd[t] = 1.0f / sqrtf(fmaxf(q * invD - mean[t] * mean[t], 0.f) + 1e-5f);
     }
@@ -552,7 +553,7 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
 // even are the two halves of one k-step fragment and go out as one 16-byte LDS write per lane.
 // NOTE: the red[] buffer is re-used by the next LayerNorm; the barrier at the end of this function (and
 // the phases in between) orders the reads above against those writes.
-template <int RPW, int KS>
+template <int RPW, int KS, int NW>
 __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float* red, int D, int w, int lane,
                                                  const float* __restrict__ bias, Stamps& st) {
     // `lane` is made opaque at the top of every phase: otherwise the per-lane address arithmetic of ALL
@@ -563,7 +564,7 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
     if (BESO_ABL_MASK & 8) {
 #pragma unroll
         for (int t = 0; t < kNTT; ++t) { mean[t] = 0.01f * lane; rstd[t] = 0.5f; }
-    } else ln_stats<RPW>(T, red, D, w, lane, mean, rstd, st);
+    } else ln_stats<RPW, NW>(T, red, D, w, lane, mean, rstd, st);
     auto half = [&](int i, int t) {
         uint2 pk = make_uint2(0u, 0u);
         if (T.fvalid[i]) {
@@ -591,8 +592,9 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
                 *((uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane) + (Rf & 1)) = half(i, t);
         }
     };
-    if constexpr (RPW == 2) {
-        write_pair(0);
+    if constexpr (RPW % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < RPW; i += 2) write_pair(i);
     } else {
         static_assert(RPW == 3, "row tiles per wave");
         if (w & 1) { write_single(0); write_pair(1); }
@@ -745,7 +747,7 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
     const int n = lane & 15, g = lane >> 4;
     const int act = d.act, Dp = d.Dp;
     float mean[kNTT], rstd[kNTT];
-    ln_stats<RPW>(T, red, d.D, w, lane, mean, rstd, st);
+    ln_stats<RPW, kWaves>(T, red, d.D, w, lane, mean, rstd, st);
     const float* Wh = (const float*)(gw + d.g_headw);
     // part[(w*kMT + tokl)*16 + a]
     for (int a = 0; a < act; ++a) {
@@ -803,64 +805,83 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
     }
 }
 
-// GELU of one chunk's FC1 accumulators -> packed bf16 B fragments (one FC2 k-step per wave), as a
-// sequence of 4*kNTT pair evaluations that can be issued one at a time between MFMAs.
-// pair index pi (0..4*kNTT-1) -> token tile pi/4, elements 2*(pi%4), 2*(pi%4)+1 (0..3: row tile 0 regs, 4..7: row tile 1)
-__device__ __forceinline__ void gelu_pair(const f32x4 (&h)[2][kNTT], float (&gq)[8], u32x4 (&hb)[kNTT], int pi) {
-    const int t = pi >> 2, j = (pi & 3) * 2;
-    const f32x2 r = gelu_fast2(f32x2{h[j >> 2][t][j & 3], h[j >> 2][t][(j & 3) + 1]});
+// GELU of one chunk's FC1 accumulators (RC row tiles x kNTT token tiles per wave) -> packed bf16 B
+// fragments (RC/2 FC2 k-steps per wave), as a sequence of (RC/2)*kNTT*4 pair evaluations that can be issued
+// one at a time between MFMAs.  Pair pi -> k-step pi/(4*kNTT), token tile (pi/4)%kNTT, elements 2*(pi%4),
+// 2*(pi%4)+1 of the fragment's eight (0..3: even row tile's registers, 4..7: odd row tile's).
+template <int RC>
+__device__ __forceinline__ void gelu_pair(const f32x4 (&h)[RC][kNTT], float (&gq)[8], u32x4 (&hb)[RC / 2][kNTT], int pi) {
+    const int j2 = pi / (4 * kNTT), t = (pi >> 2) % kNTT, j = (pi & 3) * 2;
+    const f32x4& hv = h[2 * j2 + (j >> 2)][t];
+    const f32x2 r = gelu_fast2(f32x2{hv[j & 3], hv[(j & 3) + 1]});
     gq[j] = r.x;
     gq[j + 1] = r.y;
     asm volatile("" : "+v"(gq[j]), "+v"(gq[j + 1]));      // keep the evaluation HERE (between the MFMAs), not sunk to its use
     if ((pi & 3) == 3) {
-        hb[t][0] = pack_bf16x2(gq[0], gq[1]);
-        hb[t][1] = pack_bf16x2(gq[2], gq[3]);
-        hb[t][2] = pack_bf16x2(gq[4], gq[5]);
-        hb[t][3] = pack_bf16x2(gq[6], gq[7]);
+        hb[j2][t][0] = pack_bf16x2(gq[0], gq[1]);
+        hb[j2][t][1] = pack_bf16x2(gq[2], gq[3]);
+        hb[j2][t][2] = pack_bf16x2(gq[4], gq[5]);
+        hb[j2][t][3] = pack_bf16x2(gq[6], gq[7]);
     }
 }
 
-// MLP phase (xnT holds LN2(x) fragments on entry): hidden chunks of 16 row tiles; per chunk FC1 (+bias)
-// -> GELU -> hT (one FC2 k-step per wave) -> FC2 accumulated into the residual.  Software pipelined
-// so that the VALU work hides under the matrix pipe: the GELU of chunk c is issued in slices of 3
-// evaluations between the MFMAs of FC2(c-1), whose operands (hT(c-1)) are still in LDS; the packed
-// result waits in registers until every wave has finished reading hT(c-1).
+// MLP phase (xnT holds LN2(x) fragments on entry): hidden chunks of 16 row tiles (= 8 FC2 k-steps); per
+// chunk FC1 (+bias) -> GELU -> hT -> FC2 accumulated into the residual.  NW waves: each owns RC = 16/NW
+// row tiles of the chunk (RC/2 k-steps of hT) and RPW row tiles of the residual.  Software pipelined so
+// that the VALU work hides under the matrix pipe: the GELU of chunk c is issued pair by pair between the
+// MFMAs of FC2(c-1), whose operands (hT(c-1)) are still in LDS; the packed result waits in registers
+// until every wave has finished reading hT(c-1).
 //     FC1(0)
 //     for c:  [FC2(c-1) || GELU(c)]  barrier  hT <- GELU(c)  FC1(c+1)  barrier
 //     FC2(n-1)
 constexpr int kFc1PF = 2;                // k-steps of FC1 weight fragments in flight per wave
+constexpr int kKC = kChunkTiles / 2;     // FC2 k-steps per hidden chunk
 // First k-steps of chunk 0's FC1 weights of a layer (issued before the LayerNorm that precedes the phase).
-template <int KS>
-__device__ __forceinline__ void mlp_prefetch(u32x4 (&a1r)[kFc1PF][2], const u32x4* __restrict__ w1p, int w, int lane, int rot) {
-    prefetch_ring<2, kFc1PF>(a1r, w1p + (size_t)(2 * w) * 64 + lane + (size_t)rot * KS * kChunkTiles * 64, kChunkTiles * 64);
+template <int KS, int NW>
+__device__ __forceinline__ void mlp_prefetch(u32x4 (&a1r)[kFc1PF][kChunkTiles / NW], const u32x4* __restrict__ w1p, int w,
+                                             int lane, int rot) {
+    constexpr int RC = kChunkTiles / NW;
+    prefetch_ring<RC, kFc1PF>(a1r, w1p + (size_t)(RC * w) * 64 + lane + (size_t)rot * KS * kChunkTiles * 64, kChunkTiles * 64);
 }
 
-template <int RPW, int KS>
+template <int RPW, int KS, int NW>
 __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
                                           const float* __restrict__ b1f, const u32x4* __restrict__ w2p, int HT,
-                                          int KS2p, int w, int lane, int rot, u32x4 (&a1r)[kFc1PF][2], Stamps& st) {
+                                          int KS2p, int w, int lane, int rot, u32x4 (&a1r)[kFc1PF][kChunkTiles / NW],
+                                          Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int g = lane >> 4;
     const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
-    constexpr int A2KS = kWaves * RPW * 64;                  // u32x4 stride between FC2 k-steps
+    constexpr int RC = kChunkTiles / NW, KW = RC / 2;       // row tiles / FC2 k-steps of a chunk per wave
+    constexpr int A2KS = NW * RPW * 64;                      // u32x4 stride between FC2 k-steps
     constexpr int H1 = kNTT / 2;
-    // w1p: [chunk][kk][16 row tiles]; w2p: [kk2][8*RPW row tiles]
+    constexpr int PAIRS = KW * kNTT * 4, UNITS = kKC * kNTT; // GELU pair evaluations / weave units per chunk
+    static_assert(RC % 2 == 0 && PAIRS <= UNITS, "one GELU pair per weave unit at most");
+    // w1p: [chunk][kk][16 row tiles]; w2p: [kk2][NW*RPW row tiles]
     // hidden chunks are independent, so every workgroup walks them in its own rotation (see layers_kernel)
     auto pc = [&](int c) { const int q = c + rot; return q >= n_chunks ? q - n_chunks : q; };
-    auto fc1_a = [&](int c) { return ABL_PTR(w1p + (size_t)(2 * w) * 64 + lane, (size_t)pc(c) * KS * kChunkTiles * 64); };
-    auto fc2_a = [&](int c) { return ABL_PTR(w2p + (size_t)(w * RPW) * 64 + lane, (size_t)(pc(c) * kWaves) * (kWaves * RPW) * 64); };
+    auto fc1_a = [&](int c) { return ABL_PTR(w1p + (size_t)(RC * w) * 64 + lane, (size_t)pc(c) * KS * kChunkTiles * 64); };
+    auto fc2_a = [&](int c) { return ABL_PTR(w2p + (size_t)(w * RPW) * 64 + lane, (size_t)(pc(c) * kKC) * (NW * RPW) * 64); };
     constexpr int PF1 = kFc1PF;
-    auto fc1 = [&](int c, f32x4 (&h)[2][kNTT], u32x4 (&ar)[PF1][2]) {
-        const int R0 = pc(c) * kChunkTiles + 2 * w;
-        const f32x4 bias0 = *(const f32x4*)(b1f + 16 * R0 + 4 * g);
-        const f32x4 bias1 = *(const f32x4*)(b1f + 16 * (R0 + 1) + 4 * g);
+    auto fc1 = [&](int c, f32x4 (&h)[RC][kNTT], u32x4 (&ar)[PF1][RC]) {
+        const int R0 = pc(c) * kChunkTiles + RC * w;
 #pragma unroll
-        for (int t = 0; t < kNTT; ++t) { h[0][t] = bias0; h[1][t] = bias1; }
-        gemm_phase_ring<2, kNTT, PF1>(h, ar, fc1_a(c), kChunkTiles * 64, xnT + lane, KS * 64, 64, KS);
+        for (int r = 0; r < RC; ++r) {
+            const f32x4 bias = *(const f32x4*)(b1f + 16 * (R0 + r) + 4 * g);
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) h[r][t] = bias;
+        }
+        gemm_phase_ring<RC, kNTT, PF1>(h, ar, fc1_a(c), kChunkTiles * 64, xnT + lane, KS * 64, 64, KS);
+    };
+    auto write_hT = [&](u32x4 (&hb)[KW][kNTT]) {
+#pragma unroll
+        for (int j2 = 0; j2 < KW; ++j2)
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) hT[((size_t)t * kKC + KW * w + j2) * 64 + lane] = hb[j2][t];
     };
 
-    f32x4 h[2][kNTT];
-    u32x4 hb[kNTT];
+    f32x4 h[RC][kNTT];
+    u32x4 hb[KW][kNTT];
     u32x4 af2[2][RPW];                   // FC2 weight fragments of two k-steps, [k-step parity][row tile]
     float gq[8];
     auto fc2_prefetch = [&](int c) {
@@ -872,51 +893,51 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     // it under yet), hT(0), FC1(1).  Every later weight request is issued one phase ahead of its use.
     static_assert(KS % PF1 == 0, "FC1 weight ring");
     fc1(0, h, a1r);                 // rows beyond HT are zero weights + zero bias: harmless for every wave
-    if (n_chunks > 1) prefetch_ring<2, PF1>(a1r, fc1_a(1), kChunkTiles * 64);
+    if (n_chunks > 1) prefetch_ring<RC, PF1>(a1r, fc1_a(1), kChunkTiles * 64);
     fc2_prefetch(0);
 #pragma unroll
-    for (int pi = 0; pi < 4 * kNTT; ++pi) gelu_pair(h, gq, hb, pi);
-#pragma unroll
-    for (int t = 0; t < kNTT; ++t) hT[((size_t)t * kWaves + w) * 64 + lane] = hb[t];
+    for (int pi = 0; pi < PAIRS; ++pi) gelu_pair<RC>(h, gq, hb, pi);
+    write_hT(hb);
     if (n_chunks > 1) fc1(1, h, a1r);
     stamp(st, 20);
     __syncthreads();                     // hT(0) complete
 #pragma unroll 1
     for (int c = 1; c < n_chunks; ++c) {
         const int tiles_here = min(kChunkTiles, HT - pc(c) * kChunkTiles);
-        const bool fc1_active = 2 * w < tiles_here;
+        const bool fc1_active = RC * w < tiles_here;
         const int cn = min(c + 1, n_chunks - 1);
-        prefetch_ring<2, PF1>(a1r, fc1_a(cn), kChunkTiles * 64);
+        prefetch_ring<RC, PF1>(a1r, fc1_a(cn), kChunkTiles * 64);
         {
             // ---- FC2(c-1) (always a full chunk: 8 k-steps) with GELU(c) woven in, fully unrolled
             const u32x4* a2 = fc2_a(c - 1);
             const u32x4* b = hT + lane;
             u32x4 bf[kNTT];
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) bf[t] = b[t * kWaves * 64];
+            for (int t = 0; t < kNTT; ++t) bf[t] = b[t * kKC * 64];
 #pragma unroll
-            for (int kk = 0; kk < kWaves; ++kk) {
+            for (int kk = 0; kk < kKC; ++kk) {
 #pragma unroll
                 for (int t = 0; t < kNTT; ++t) {
-                    // unit of the weave: RPW MFMAs (48 cycles of matrix pipe); every other unit + one GELU pair (11 VALU)
+                    // unit of the weave: RPW MFMAs (16 cycles of matrix pipe each) + PAIRS/UNITS GELU pairs (11 VALU each)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) T.acc[r][t] = mfma_bf16(af2[kk & 1][r], bf[t], T.acc[r][t]);
                     {
-                        const int idx = kk * kNTT + t;             // 48 units, 24 pair evaluations: every other unit
-                        if ((idx & 1) == 0) gelu_pair(h, gq, hb, idx >> 1);
+                        const int idx = kk * kNTT + t;
+#pragma unroll
+                        for (int pi = idx * PAIRS / UNITS; pi < (idx + 1) * PAIRS / UNITS; ++pi) gelu_pair<RC>(h, gq, hb, pi);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (t == H1 - 1 && kk + 1 < kWaves && !(BESO_ABL_MASK & 32)) {
+                    if (t == H1 - 1 && kk + 1 < kKC && !(BESO_ABL_MASK & 32)) {
 #pragma unroll
-                        for (int t2 = 0; t2 < H1; ++t2) bf[t2] = b[t2 * kWaves * 64 + (kk + 1) * 64];
+                        for (int t2 = 0; t2 < H1; ++t2) bf[t2] = b[t2 * kKC * 64 + (kk + 1) * 64];
                     }
                     if (t == kNTT - 1) {
-                        if (kk + 1 < kWaves && !(BESO_ABL_MASK & 32)) {
+                        if (kk + 1 < kKC && !(BESO_ABL_MASK & 32)) {
 #pragma unroll
-                            for (int t2 = H1; t2 < kNTT; ++t2) bf[t2] = b[t2 * kWaves * 64 + (kk + 1) * 64];
+                            for (int t2 = H1; t2 < kNTT; ++t2) bf[t2] = b[t2 * kKC * 64 + (kk + 1) * 64];
                         }
-                        if (kk + 2 < kWaves) {
+                        if (kk + 2 < kKC) {
 #pragma unroll
                             for (int r = 0; r < RPW; ++r) af2[kk & 1][r] = wload(a2 + r * 64 + ABL_KS((kk + 2) * A2KS));
                         }
@@ -928,10 +949,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
         stamp(st, 21);
         if (!(BESO_ABL_MASK & 2)) __syncthreads();                 // every wave is done reading hT(c-1)
         stamp(st, 22);
-        if (fc1_active) {
-#pragma unroll
-            for (int t = 0; t < kNTT; ++t) hT[((size_t)t * kWaves + w) * 64 + lane] = hb[t];
-        }
+        if (fc1_active) write_hT(hb);
         if (c + 1 < n_chunks) fc1(c + 1, h, a1r);
         stamp(st, 23);
         if (!(BESO_ABL_MASK & 2)) __syncthreads();                 // hT(c) complete
@@ -942,135 +960,157 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
         // slot against zero weights
         const int c = n_chunks - 1;
         const int tiles_here = min(kChunkTiles, HT - pc(c) * kChunkTiles);
-        gemm_phase<RPW, kNTT>(T.acc, af2[0], af2[1], fc2_a(c), A2KS, hT + lane, kWaves * 64, 64, ((tiles_here >> 1) + 1) & ~1);
+        gemm_phase<RPW, kNTT>(T.acc, af2[0], af2[1], fc2_a(c), A2KS, hT + lane, kKC * 64, 64, ((tiles_here >> 1) + 1) & ~1);
     }
     stamp(st, 25);
     __syncthreads();
 }
 
-// Attention phase (xnT holds LN1(x) fragments on entry).  Tokens of the tile are in natural order:
-// slot = sample*Tn + position, n_samples*Tn valid slots.
-#ifndef BESO_QKV_PF
-#define BESO_QKV_PF 2
-#endif
-constexpr int kQkvPF = BESO_QKV_PF;      // k-steps of QKV weight fragments in flight per wave
-// First k-steps of head 0's QKV weights of a layer (issued before the LayerNorm that precedes the phase).
+// First two k-steps of the first head pair's QKV weights of a layer (issued before the LayerNorm that precedes
+// the phase): even / odd fragments of gemm_phase.
 template <int KS>
-__device__ __forceinline__ void attn_prefetch(u32x4 (&ar)[kQkvPF][3], const u32x4* __restrict__ wqkv, int w, int lane, int rot) {
-    prefetch_ring<3, kQkvPF>(ar, wqkv + (size_t)(3 * (w & 3)) * 64 + lane + (size_t)rot * KS * 12 * 64, 12 * 64);
+__device__ __forceinline__ void attn_prefetch(u32x4 (&qE)[3], u32x4 (&qO)[3], const u32x4* __restrict__ wqkv, int w, int lane) {
+    prefetch_a<3>(qE, qO, wqkv + (size_t)(3 * w) * 64 + lane, 24 * 64);
 }
 
+// Attention phase (xnT holds LN1(x) fragments on entry).  Tokens of the tile are in natural order:
+// slot = sample*Tn + position, n_samples*Tn valid slots.
+//
+// Heads are processed in PAIRS: the q/k/v rows of two heads are 24 row tiles = 3 per wave over all 6 token
+// tiles, so every QKV weight fragment is loaded by exactly one wave (one head at a time is 12 row tiles =
+// 1.5 per wave: the 4x2 wave split it forces loads every fragment twice, +25 % of the layer's weight bytes).
+// LDS holds q/k/v of ONE head: waves 0-3 (head A's rows) write theirs at once, waves 4-7 keep head B's
+// accumulators in registers until head A's attention core is done.
+//   QKV(A,B)  write(A) | bar | core(A) | bar | proj(A), write(B) | bar | core(B) | bar | proj(B)
+// Weight fragments are requested one phase ahead of their use (the L2 round trip hides behind the barriers
+// and the core): qE/qO (first two k-steps of the pair's QKV weights) arrive preloaded and are refilled for
+// the next pair before core(B); each head's projection weights (two k-steps: all of them) are requested
+// before the barrier that precedes its core.
 template <int RPW, int KS>
 __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsigned char* u,
                                            const u32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
                                            const u32x4* __restrict__ wproj, int H, int hd, int Tn, int n_samples,
-                                           int w, int lane, int rot, u32x4 (&ar)[kQkvPF][3], Stamps& st) {
+                                           int w, int lane, u32x4 (&qE)[3], u32x4 (&qO)[3], Stamps& st) {
     asm volatile("" : "+v"(lane));
-    const int n = lane & 15, g = lane >> 4;
     uint16_t* qkv = (uint16_t*)u;                         // [3][kQKVRows][kQKVRow] bf16
     u32x4* yT = (u32x4*)(u + kQKVBytes);                  // [(t*2 + kk)*64 + lane]
-    const int wa = w & 3, wb = w >> 2;                    // QKV split: row tiles 3wa..3wa+2 x token tiles 3wb..3wb+2
+    const int wa = w & 3, hsel = w >> 2;                  // this wave's rows: tiles 3wa..3wa+2 of head 2*pair + hsel
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
-
-    // Weight fragments are requested one phase ahead of their use, so that the L2 round trip is hidden
-    // behind the barrier / attention core / projection in between: `ar` (first k-steps of the head's QKV
-    // weights) arrives preloaded and is refilled for head h+1 before the core of head h; the head's
-    // projection weights (all of them: two k-steps) are requested before the QKV epilogue.
-    auto qkv_a = [&](int h) { return ABL_PTR(wqkv + (size_t)(3 * wa) * 64 + lane, (size_t)h * KS * 12 * 64); };   // [head][kk][12 row tiles]
-    // heads are independent (the projection accumulates), so every workgroup walks them in its own rotation
-    for (int hi = 0; hi < H; ++hi) {
-        const int h = hi + rot >= H ? hi + rot - H : hi + rot;
-        const int hn = h + 1 >= H ? 0 : h + 1;
-        stamp(st, 10);
-        u32x4 aE[RPW], aO[RPW];
-        const u32x4* ap = ABL_PTR(wproj + (size_t)(w * RPW) * 64 + lane, (size_t)(2 * h) * (kWaves * RPW) * 64);   // [2h+kk][row tiles]
-        // ---- q, k, v of head h for all tokens of the tile
-        {
-            f32x4 qa[3][3];
+    auto qkv_a = [&](int pair) { return ABL_PTR(wqkv + (size_t)(3 * w) * 64 + lane, (size_t)pair * KS * 24 * 64); };   // [pair][kk][24 row tiles]
+    auto proj_a = [&](int h) { return ABL_PTR(wproj + (size_t)(w * RPW) * 64 + lane, (size_t)(2 * h) * (kWaves * RPW) * 64); };   // [2h+kk][row tiles]
+    // `ln` (= lane) is re-made opaque in every pair iteration: the LDS addresses below are loop invariant
+    // and would otherwise be hoisted out of the pair loop and spilled (24 VGPRs).
+    int ln = lane;
+    auto write_qkv = [&](const f32x4 (&qa)[3][kNTT]) {
+        const int n = ln & 15, g = ln >> 4;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const f32x4 bv = *(const f32x4*)(bqkv + (h * 12 + 3 * wa + i) * 16 + 4 * g);
+        for (int i = 0; i < 3; ++i) {
+            const int rt = 3 * wa + i, part = rt >> 2, d0 = (rt & 3) * 16 + 4 * g;
+            uint16_t* dst = qkv + ((size_t)part * kQKVRows + n) * kQKVRow + d0;       // + t*16 rows: immediate offsets
 #pragma unroll
-                for (int t = 0; t < 3; ++t) qa[i][t] = bv;
-            }
-            gemm_phase_ring<3, 3, kQkvPF>(qa, ar, qkv_a(h), 12 * 64, xnT + (size_t)(3 * wb) * KS * 64 + lane, KS * 64, 64, KS);
-            prefetch_a<RPW>(aE, aO, ap, kWaves * RPW * 64);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int rt = 3 * wa + i, part = rt >> 2, d0 = (rt & 3) * 16 + 4 * g;
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int tok = (3 * wb + t) * 16 + n;
-                    uint2 pk;
-                    pk.x = pack_bf16x2(qa[i][t][0], qa[i][t][1]);
-                    pk.y = pack_bf16x2(qa[i][t][2], qa[i][t][3]);
-                    *(uint2*)(qkv + ((size_t)part * kQKVRows + tok) * kQKVRow + d0) = pk;
-                }
+            for (int t = 0; t < kNTT; ++t) {
+                uint2 pk;
+                pk.x = pack_bf16x2(qa[i][t][0], qa[i][t][1]);
+                pk.y = pack_bf16x2(qa[i][t][2], qa[i][t][3]);
+                *(uint2*)(dst + (size_t)t * 16 * kQKVRow) = pk;
             }
         }
-        if (hi + 1 < H) prefetch_ring<3, kQkvPF>(ar, qkv_a(hn), 12 * 64);
+    };
+    // ---- attention core on the matrix pipe, one sample per wave (score_gpts.py:69-73):
+    //   S^T[j][i] = sum_d K[j][d] Q[i][d]        2 x v_mfma_f32_16x16x32_bf16 (A = K rows, B = Q rows)
+    //   D layout: lane (i = lane&15, g) holds keys j = 4g + r  ->  causal mask, softmax over j =
+    //   in-lane over r + two xor-shuffles over g; the unnormalised probabilities are already the B
+    //   operand (k = 4g..4g+3) of v_mfma_f32_16x16x16_bf16 for
+    //   Y^T[d][i] = sum_j V[j][d] P[i][j]          4 x (A = V^T gathered with 16-bit LDS reads)
+    //   whose D layout is the B fragment of the out-projection (same k permutation as the weights).
+    auto core = [&]() {
+    const int n = ln & 15, g = ln >> 4;
+    if (w < n_samples && !(BESO_ABL_MASK & 16)) {
+        const uint16_t* qb = qkv + ((size_t)0 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
+        const uint16_t* kb = qkv + ((size_t)1 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
+        f32x4 sT = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            sT = mfma_bf16(*(const u32x4*)(kb + 32 * kk), *(const u32x4*)(qb + 32 * kk), sT);
+        float e[4], m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            e[r] = (4 * g + r <= n) ? sT[r] * scale_log2e : -INFINITY;     // (q k^T)/sqrt(hd), in log2 units
+            m = fmaxf(m, e[r]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - m); sum += e[r]; }   // exp2(-inf) = 0
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        uint2 pb = make_uint2(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]));
+        const uint16_t* vb = qkv + ((size_t)2 * kQKVRows + w * Tn + 4 * g) * kQKVRow + n;
+        f32x4 y[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 va;
+            va.x = (uint32_t)vb[16 * dt] | ((uint32_t)vb[kQKVRow + 16 * dt] << 16);
+            va.y = (uint32_t)vb[2 * kQKVRow + 16 * dt] | ((uint32_t)vb[3 * kQKVRow + 16 * dt] << 16);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            y[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, va),
+                                                              __builtin_bit_cast(s16x4, pb), z, 0, 0, 0);
+        }
+        if (n < Tn) {
+            const int tok = w * Tn + n;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 yb;
+                yb[0] = pack_bf16x2(y[2 * kk][0] * inv, y[2 * kk][1] * inv);
+                yb[1] = pack_bf16x2(y[2 * kk][2] * inv, y[2 * kk][3] * inv);
+                yb[2] = pack_bf16x2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
+                yb[3] = pack_bf16x2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
+                yT[((size_t)(tok >> 4) * 2 + kk) * 64 + (g << 4) + (tok & 15)] = yb;
+            }
+        }
+    }
+    };
+
+    for (int pair = 0; pair < H / 2; ++pair) {
+        const int hA = 2 * pair, hB = hA + 1;
+        asm volatile("" : "+v"(ln));
+        const int g = ln >> 4;
+        stamp(st, 10);
+        u32x4 aE[RPW], aO[RPW];
+        f32x4 qa[3][kNTT];
+        // ---- q, k, v of both heads for all tokens of the tile
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x4 bv = *(const f32x4*)(bqkv + ((hA + hsel) * 12 + 3 * wa + i) * 16 + 4 * g);
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) qa[i][t] = bv;
+        }
+        gemm_phase<3, kNTT>(qa, qE, qO, qkv_a(pair), 24 * 64, xnT + lane, KS * 64, 64, KS);
+        prefetch_a<RPW>(aE, aO, proj_a(hA), kWaves * RPW * 64);
+        if (hsel == 0) write_qkv(qa);
         stamp(st, 11);
         __syncthreads();
         stamp(st, 12);
-        // ---- attention core on the matrix pipe, one sample per wave (score_gpts.py:69-73):
-        //   S^T[j][i] = sum_d K[j][d] Q[i][d]        2 x v_mfma_f32_16x16x32_bf16 (A = K rows, B = Q rows)
-        //   D layout: lane (i = lane&15, g) holds keys j = 4g + r  ->  causal mask, softmax over j =
-        //   in-lane over r + two xor-shuffles over g; the unnormalised probabilities are already the B
-        //   operand (k = 4g..4g+3) of v_mfma_f32_16x16x16_bf16 for
-        //   Y^T[d][i] = sum_j V[j][d] P[i][j]          4 x (A = V^T gathered with 16-bit LDS reads)
-        //   whose D layout is the B fragment of the out-projection (same k permutation as the weights).
-        if (w < n_samples && !(BESO_ABL_MASK & 16)) {
-            const uint16_t* qb = qkv + ((size_t)0 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
-            const uint16_t* kb = qkv + ((size_t)1 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
-            f32x4 sT = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                sT = mfma_bf16(*(const u32x4*)(kb + 32 * kk), *(const u32x4*)(qb + 32 * kk), sT);
-            float e[4], m = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                e[r] = (4 * g + r <= n) ? sT[r] * scale_log2e : -INFINITY;     // (q k^T)/sqrt(hd), in log2 units
-                m = fmaxf(m, e[r]);
-            }
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float sum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - m); sum += e[r]; }   // exp2(-inf) = 0
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.0f / sum;
-            uint2 pb = make_uint2(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]));
-            const uint16_t* vb = qkv + ((size_t)2 * kQKVRows + w * Tn + 4 * g) * kQKVRow + n;
-            f32x4 y[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                uint2 va;
-                va.x = (uint32_t)vb[16 * dt] | ((uint32_t)vb[kQKVRow + 16 * dt] << 16);
-                va.y = (uint32_t)vb[2 * kQKVRow + 16 * dt] | ((uint32_t)vb[3 * kQKVRow + 16 * dt] << 16);
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                y[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, va),
-                                                                  __builtin_bit_cast(s16x4, pb), z, 0, 0, 0);
-            }
-            if (n < Tn) {
-                const int tok = w * Tn + n;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    u32x4 yb;
-                    yb[0] = pack_bf16x2(y[2 * kk][0] * inv, y[2 * kk][1] * inv);
-                    yb[1] = pack_bf16x2(y[2 * kk][2] * inv, y[2 * kk][3] * inv);
-                    yb[2] = pack_bf16x2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
-                    yb[3] = pack_bf16x2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
-                    yT[((size_t)(tok >> 4) * 2 + kk) * 64 + (g << 4) + (tok & 15)] = yb;
-                }
-            }
-        }
+        core();
         stamp(st, 16);
         __syncthreads();
         stamp(st, 17);
-        // ---- the head's slice of the out-projection, accumulated into the residual
-        gemm_phase<RPW, kNTT>(T.acc, aE, aO, ap, kWaves * RPW * 64, yT + lane, 2 * 64, 64, 2);
-        // no barrier needed here: the next writes to qkv/yT happen behind the next head's barriers
+        // ---- head A's slice of the out-projection, accumulated into the residual; head B's q/k/v to LDS
+        gemm_phase<RPW, kNTT>(T.acc, aE, aO, proj_a(hA), kWaves * RPW * 64, yT + lane, 2 * 64, 64, 2);
+        prefetch_a<RPW>(aE, aO, proj_a(hB), kWaves * RPW * 64);
+        if (hsel == 1) write_qkv(qa);
+        if (pair + 1 < H / 2) prefetch_a<3>(qE, qO, qkv_a(pair + 1), 24 * 64);   // qa's registers are free from here
+        stamp(st, 13);
+        __syncthreads();
+        stamp(st, 14);
+        core();
+        stamp(st, 15);
+        __syncthreads();
+        stamp(st, 18);
+        gemm_phase<RPW, kNTT>(T.acc, aE, aO, proj_a(hB), kWaves * RPW * 64, yT + lane, 2 * 64, 64, 2);
+        // no barrier needed here: the next writes to qkv/yT happen behind the next pair's barriers
     }
     __syncthreads();
 }
@@ -1078,8 +1118,8 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <int RPW, int KS>
-__global__ __launch_bounds__(512, 2) void mlp_block_kernel(float* __restrict__ x, const char* __restrict__ lw,
+template <int RPW, int KS, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_block_kernel(float* __restrict__ x, const char* __restrict__ lw,
                                                            FusedDims d, int M, unsigned long long* stamps, int cap) {
     Stamps st{stamps, cap, 0};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1090,10 +1130,10 @@ __global__ __launch_bounds__(512, 2) void mlp_block_kernel(float* __restrict__ x
     const int m0 = blockIdx.x * kMT;
     Tile<RPW> T;
     load_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
-    u32x4 a1r[kFc1PF][2];
-    mlp_prefetch<KS>(a1r, (const u32x4*)lw, w, lane, 0);
-    layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane, (const float*)(lw + d.o_b2), st);
-    mlp_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
+    u32x4 a1r[kFc1PF][kChunkTiles / NW];
+    mlp_prefetch<KS, NW>(a1r, (const u32x4*)lw, w, lane, 0);
+    layernorm_to_lds<RPW, KS, NW>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane, (const float*)(lw + d.o_b2), st);
+    mlp_phase<RPW, KS, NW>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
                        (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, 0, a1r, st);
     store_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
 }
@@ -1125,7 +1165,6 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
 #define BESO_ROT 0            // measured: 1.16 ms with the rotation vs 1.13 ms without (lockstep sharing wins)
 #endif
     const int n_chunks_k = (d.HT + kChunkTiles - 1) / kChunkTiles;
-    const int rot_h = BESO_ROT ? (int)((blockIdx.x >> 3) % (unsigned)d.H) : 0;
     const int rot_c = BESO_ROT ? (int)((blockIdx.x >> 3) % (unsigned)n_chunks_k) : 0;
     Tile<RPW> T;
     stamp(st, 100);
@@ -1148,21 +1187,21 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         const char* lw = lw0 + (size_t)l * d.layer_bytes;
 #endif
         stamp(st, 2);
-        u32x4 ar[kQkvPF][3];
-        attn_prefetch<KS>(ar, (const u32x4*)(lw + d.o_wqkv), w, lane, rot_h);
-        layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
-                                  (const float*)(lw + d.o_bproj), st);
+        u32x4 qE[3], qO[3];
+        attn_prefetch<KS>(qE, qO, (const u32x4*)(lw + d.o_wqkv), w, lane);
+        layernorm_to_lds<RPW, KS, kWaves>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+                                          (const float*)(lw + d.o_bproj), st);
         stamp(st, 7);
         attn_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
                             (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.H, d.hd, Tn, n_samples, w,
-                            lane, rot_h, ar, st);
+                            lane, qE, qO, st);
         stamp(st, 3);
-        u32x4 a1r[kFc1PF][2];
-        mlp_prefetch<KS>(a1r, (const u32x4*)lw, w, lane, rot_c);
-        layernorm_to_lds<RPW, KS>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
-                                  (const float*)(lw + d.o_b2), st);
+        u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
+        mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)lw, w, lane, rot_c);
+        layernorm_to_lds<RPW, KS, kWaves>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+                                          (const float*)(lw + d.o_b2), st);
         stamp(st, 6);
-        mlp_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
+        mlp_phase<RPW, KS, kWaves>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
                            (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, rot_c, a1r, st);
     }
     stamp(st, 4);
@@ -1183,14 +1222,14 @@ hipError_t ensure_lds(K kernel, size_t bytes, bool* done) {
     return e;
 }
 
-template <int RPW, int KS>
+template <int RPW, int KS, int NW>
 hipError_t launch_mlp_block(float* x, const char* lw, const FusedDims& d, int M, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS);
     static bool attr = false;
-    hipError_t e = ensure_lds(mlp_block_kernel<RPW, KS>, L.total, &attr);
+    hipError_t e = ensure_lds(mlp_block_kernel<RPW, KS, NW>, L.total, &attr);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((mlp_block_kernel<RPW, KS>), dim3((M + kMT - 1) / kMT), dim3(512), L.total, s, x, lw, d, M, g_stamps, g_stamps_cap);
+    hipLaunchKernelGGL((mlp_block_kernel<RPW, KS, NW>), dim3((M + kMT - 1) / kMT), dim3(64 * NW), L.total, s, x, lw, d, M, g_stamps, g_stamps_cap);
     return hipGetLastError();
 }
 
@@ -1300,6 +1339,8 @@ int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     FusedDims d;
     if (a.vbatch < fused_min_batch()) return 0;
     if (precision != BESO_PREC_BF16 || lay.fused == lay.total || !fused_dims(lay, &d) || !shape_has_kernel(d)) return 0;
+    static const int level_max = getenv("BESO_FUSED_LEVEL_MAX") ? atoi(getenv("BESO_FUSED_LEVEL_MAX")) : 2;   // kernel experiments
+    if (level_max < 2) return level_max;
     if (d.attn && d.RPW == 3 && d.KS == 12 && kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused) &&
         d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK) return 2;
     return 1;
@@ -1312,8 +1353,9 @@ int fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, 
     if (!fused_dims(lay, &d)) return BESO_ERR_UNSUPPORTED;
     const char* base = packed + lay.fused + (size_t)layer * d.layer_bytes;
     hipError_t e;
-    if (d.RPW == 3 && d.KS == 12) e = launch_mlp_block<3, 12>(x, base, d, M, s);
-    else if (d.RPW == 2 && d.KS == 8) e = launch_mlp_block<2, 8>(x, base, d, M, s);
+    static const int nw4 = getenv("BESO_FUSED_NW4") ? atoi(getenv("BESO_FUSED_NW4")) : 0;   // kernel experiments
+    if (d.RPW == 3 && d.KS == 12) e = nw4 ? launch_mlp_block<6, 12, 4>(x, base, d, M, s) : launch_mlp_block<3, 12, 8>(x, base, d, M, s);
+    else if (d.RPW == 2 && d.KS == 8) e = launch_mlp_block<2, 8, 8>(x, base, d, M, s);
     else return BESO_ERR_UNSUPPORTED;
     return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }

@@ -14,8 +14,8 @@ from bench import build_model          # noqa: E402
 from beso_amd import _lib              # noqa: E402
 from oracle import beso_oracle as O    # noqa: E402
 
-NAMES = {40: "emb_prologue", 41: "emb_loads_issued", 42: "emb_bias", 43: "emb_mfma", 1: "start", 2: "layer_start", 7: "ln1_done", 10: "head_start", 11: "qkv_gemm+write", 12: "bar_qkv",
-         13: "scores", 14: "softmax(+bar)", 15: "bar_softmax", 16: "pv", 17: "bar_pv", 3: "attn_done(proj..)",
+NAMES = {40: "emb_prologue", 41: "emb_loads_issued", 42: "emb_bias", 43: "emb_mfma", 1: "start", 2: "layer_start", 7: "ln1_done", 10: "pair_start(proj B)", 11: "qkv_gemm(pair)+write(A)", 12: "bar_qkv",
+         13: "proj(A)+write(B)", 14: "bar_B", 15: "core(B)", 18: "bar_coreB", 16: "core(A)", 17: "bar_coreA", 3: "attn_done(proj B)",
          6: "ln2_done", 20: "fc1(0)", 21: "fc2(c-1)||gelu(c)", 22: "bar_a", 23: "hT_write+fc1(c+1)", 24: "bar_b", 25: "fc2(last)", 4: "layers_done",
          5: "stored", 30: "ln_pass1", 31: "ln_bar1", 32: "ln_pass2", 33: "ln_bar2", 34: "ln_write"}
 
