@@ -28,6 +28,15 @@ namespace beso {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -543,7 +552,7 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
 #pragma unroll
         for (int k = 0; k < NW / 2; ++k) { const f32x4 v = pr[k]; s += v[0] + v[2]; q += v[1] + v[3]; }
         mean[t] = s * invD;
-        rstd[t] = 1.0f / sqrtf(fmaxf(q * invD - mean[t] * mean[t], 0.f) + 1e-5f);
+        rstd[t] = __builtin_amdgcn_rsqf(fmaxf(q * invD - mean[t] * mean[t], 0.f) + 1e-5f);     // v_rsq_f32 (1 ulp); 1/sqrtf is ~35 VALU ops
     }
 }
 
@@ -565,13 +574,13 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
 #pragma unroll
         for (int t = 0; t < kNTT; ++t) { mean[t] = 0.01f * lane; rstd[t] = 0.5f; }
     } else ln_stats<RPW, NW>(T, red, D, w, lane, mean, rstd, st);
+    // Padding features (>= D) are NOT masked here: their xnT entries only ever meet the zero-padded
+    // contraction columns of the packed QKV / FC1 weights, and (0 - mean) * rstd is finite.
     auto half = [&](int i, int t) {
-        uint2 pk = make_uint2(0u, 0u);
-        if (T.fvalid[i]) {
-            const float a = rstd[t], b = -mean[t] * rstd[t];
-            pk.x = pack_bf16x2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
-            pk.y = pack_bf16x2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
-        }
+        const float a = rstd[t], b = -mean[t] * rstd[t];
+        uint2 pk;
+        pk.x = pack_bf16x2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
+        pk.y = pack_bf16x2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
         return pk;
     };
     auto write_pair = [&](int i) {          // row tiles i, i+1 of this wave: Rf = w*RPW + i is even
@@ -665,7 +674,7 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
         const float* pa = e.action + ((size_t)b * e.t + i) * d.act;
         src[t] = kind[t] == 1 ? (is_goal ? pg : ps) : kind[t] == 2 ? pa : tokT;      // tokT: any readable address
         scale[t] = 1.f;
-        if (kind[t] == 2 && e.precondition) scale[t] = 1.0f / sqrtf(sg[t] * sg[t] + e.sigma_data * e.sigma_data);   // c_in
+        if (kind[t] == 2 && e.precondition) scale[t] = __builtin_amdgcn_rsqf(sg[t] * sg[t] + e.sigma_data * e.sigma_data);   // c_in
     }
     // tok_emb over states / goals and action_emb over the (pre-conditioned) noisy actions, exact fp32 on the
     // matrix pipe: X^T[f][tok] += W^T[f][c] * in[tok][c], four input features per v_mfma_f32_16x16x4_f32
@@ -825,6 +834,48 @@ __device__ __forceinline__ void gelu_pair(const f32x4 (&h)[RC][kNTT], float (&gq
     }
 }
 
+// The same evaluation cut into 12 single-instruction slots, for two pairs (2q, 2q+1) at once: slot sigma of
+// group q is step sigma/2 of pair 2q + sigma%2.  The MLP weave issues a few slots behind every MFMA: a wave's
+// VALU instruction directly behind its own MFMA issues in that MFMA's shadow, a run of them does not
+// (measured, tools/microbench/issue_rate.hip), and alternating two independent chains keeps the packed-fp32
+// pipe (8 cycles dependent, 5.5 independent) from waiting on itself.
+struct GeluChain { f32x2 v, vc, s, p; };
+template <int RC, int SIGMA>
+__device__ __forceinline__ void gelu_slot(const f32x4 (&h)[RC][kNTT], GeluChain& c0, GeluChain& c1, float (&gq)[8],
+                                          u32x4 (&hb)[RC / 2][kNTT]) {
+    constexpr int q = SIGMA / 24, step = (SIGMA % 24) >> 1, ch = SIGMA & 1, pi = 2 * q + ch;
+    constexpr int j2 = pi / (4 * kNTT), t = (pi >> 2) % kNTT, j = (pi & 3) * 2;
+    GeluChain& g = ch ? c1 : c0;
+    if constexpr ((BESO_ABL_MASK & 1) != 0) {
+        if constexpr (step == 0) { gq[j] = h[2 * j2 + (j >> 2)][t][j & 3]; gq[j + 1] = h[2 * j2 + (j >> 2)][t][(j & 3) + 1]; }
+    } else {
+        if constexpr (step == 0) {
+            g.v = f32x2{h[2 * j2 + (j >> 2)][t][j & 3], h[2 * j2 + (j >> 2)][t][(j & 3) + 1]};
+            g.vc.x = __builtin_amdgcn_fmed3f(g.v.x, -4.0f, 4.0f);
+        } else if constexpr (step == 1) g.vc.y = __builtin_amdgcn_fmed3f(g.v.y, -4.0f, 4.0f);
+        else if constexpr (step == 2) g.s = g.vc * g.vc;
+        else if constexpr (step == 3) g.p = __builtin_elementwise_fma(g.s, (f32x2)(2.277972093e-08f), (f32x2)(-1.598515742e-06f));
+        else if constexpr (step == 4) g.p = __builtin_elementwise_fma(g.p, g.s, (f32x2)(4.795382804e-05f));
+        else if constexpr (step == 5) g.p = __builtin_elementwise_fma(g.p, g.s, (f32x2)(-0.0008139993719f));
+        else if constexpr (step == 6) g.p = __builtin_elementwise_fma(g.p, g.s, (f32x2)(0.00877231165f));
+        else if constexpr (step == 7) g.p = __builtin_elementwise_fma(g.p, g.s, (f32x2)(-0.06457294506f));
+        else if constexpr (step == 8) g.p = __builtin_elementwise_fma(g.p, g.s, (f32x2)(0.3978832308f));
+        else if constexpr (step == 9) g.p = __builtin_elementwise_fma(g.vc, g.p, (f32x2)(0.5f));
+        else if constexpr (step == 10) { const f32x2 r = g.v * g.p; gq[j] = r.x; gq[j + 1] = r.y; }
+        // every slot is pinned where it is issued (otherwise the whole chain sinks to its use)
+        if constexpr (step <= 1) asm volatile("" : "+v"(g.vc));
+        else if constexpr (step == 2) asm volatile("" : "+v"(g.s));
+        else if constexpr (step <= 9) asm volatile("" : "+v"(g.p));
+        else if constexpr (step == 10) asm volatile("" : "+v"(gq[j]), "+v"(gq[j + 1]));
+    }
+    if constexpr (step == 11 && (pi & 3) == 3) {
+        hb[j2][t][0] = pack_bf16x2(gq[0], gq[1]);
+        hb[j2][t][1] = pack_bf16x2(gq[2], gq[3]);
+        hb[j2][t][2] = pack_bf16x2(gq[4], gq[5]);
+        hb[j2][t][3] = pack_bf16x2(gq[6], gq[7]);
+    }
+}
+
 // MLP phase (xnT holds LN2(x) fragments on entry): hidden chunks of 16 row tiles (= 8 FC2 k-steps); per
 // chunk FC1 (+bias) -> GELU -> hT -> FC2 accumulated into the residual.  NW waves: each owns RC = 16/NW
 // row tiles of the chunk (RC/2 k-steps of hT) and RPW row tiles of the residual.  Software pipelined so
@@ -855,8 +906,9 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     constexpr int RC = kChunkTiles / NW, KW = RC / 2;       // row tiles / FC2 k-steps of a chunk per wave
     constexpr int A2KS = NW * RPW * 64;                      // u32x4 stride between FC2 k-steps
     constexpr int H1 = kNTT / 2;
-    constexpr int PAIRS = KW * kNTT * 4, UNITS = kKC * kNTT; // GELU pair evaluations / weave units per chunk
-    static_assert(RC % 2 == 0 && PAIRS <= UNITS, "one GELU pair per weave unit at most");
+    constexpr int PAIRS = KW * kNTT * 4;                     // GELU pair evaluations per chunk and wave
+    constexpr int SLOTS = PAIRS * 12, MFMAS = kKC * kNTT * RPW;   // their instruction slots / the MFMAs they hide behind
+    static_assert(RC % 2 == 0 && PAIRS % 2 == 0, "pairs are evaluated two at a time");
     // w1p: [chunk][kk][16 row tiles]; w2p: [kk2][NW*RPW row tiles]
     // hidden chunks are independent, so every workgroup walks them in its own rotation (see layers_kernel)
     auto pc = [&](int c) { const int q = c + rot; return q >= n_chunks ? q - n_chunks : q; };
@@ -884,6 +936,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     u32x4 hb[KW][kNTT];
     u32x4 af2[2][RPW];                   // FC2 weight fragments of two k-steps, [k-step parity][row tile]
     float gq[8];
+    GeluChain gc0, gc1;
     auto fc2_prefetch = [&](int c) {
         const u32x4* a2 = fc2_a(c);
 #pragma unroll
@@ -914,19 +967,20 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
             u32x4 bf[kNTT];
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) bf[t] = b[t * kKC * 64];
-#pragma unroll
-            for (int kk = 0; kk < kKC; ++kk) {
-#pragma unroll
-                for (int t = 0; t < kNTT; ++t) {
-                    // unit of the weave: RPW MFMAs (16 cycles of matrix pipe each) + PAIRS/UNITS GELU pairs (11 VALU each)
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int r = 0; r < RPW; ++r) T.acc[r][t] = mfma_bf16(af2[kk & 1][r], bf[t], T.acc[r][t]);
-                    {
-                        const int idx = kk * kNTT + t;
-#pragma unroll
-                        for (int pi = idx * PAIRS / UNITS; pi < (idx + 1) * PAIRS / UNITS; ++pi) gelu_pair<RC>(h, gq, hb, pi);
-                    }
+            static_for<0, kKC>([&](auto KK) {
+                constexpr int kk = decltype(KK)::value;
+                static_for<0, kNTT>([&](auto TT) {
+                    constexpr int t = decltype(TT)::value;
+                    // unit of the weave: ONE MFMA + its share of the chunk's GELU slots (2 for RPW = 3)
+                    static_for<0, RPW>([&](auto RR) {
+                        constexpr int r = decltype(RR)::value;
+                        constexpr int unit = (kk * kNTT + t) * RPW + r;
+                        __builtin_amdgcn_sched_barrier(0);
+                        T.acc[r][t] = mfma_bf16(af2[kk & 1][r], bf[t], T.acc[r][t]);
+                        static_for<unit * SLOTS / MFMAS, (unit + 1) * SLOTS / MFMAS>([&](auto SG) {
+                            gelu_slot<RC, decltype(SG)::value>(h, gc0, gc1, gq, hb);
+                        });
+                    });
                     __builtin_amdgcn_sched_barrier(0);
                     if (t == H1 - 1 && kk + 1 < kKC && !(BESO_ABL_MASK & 32)) {
 #pragma unroll
@@ -942,8 +996,8 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
                             for (int r = 0; r < RPW; ++r) af2[kk & 1][r] = wload(a2 + r * 64 + ABL_KS((kk + 2) * A2KS));
                         }
                     }
-                }
-            }
+                });
+            });
         }
         fc2_prefetch(c);                 // first two k-steps of FC2(c): in flight across the barriers and FC1(c+1)
         stamp(st, 21);
@@ -995,7 +1049,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     uint16_t* qkv = (uint16_t*)u;                         // [3][kQKVRows][kQKVRow] bf16
     u32x4* yT = (u32x4*)(u + kQKVBytes);                  // [(t*2 + kk)*64 + lane]
     const int wa = w & 3, hsel = w >> 2;                  // this wave's rows: tiles 3wa..3wa+2 of head 2*pair + hsel
-    const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
+    const float scale_log2e = 1.4426950408889634f * __builtin_amdgcn_rsqf((float)hd);
     auto qkv_a = [&](int pair) { return ABL_PTR(wqkv + (size_t)(3 * w) * 64 + lane, (size_t)pair * KS * 24 * 64); };   // [pair][kk][24 row tiles]
     auto proj_a = [&](int h) { return ABL_PTR(wproj + (size_t)(w * RPW) * 64 + lane, (size_t)(2 * h) * (kWaves * RPW) * 64); };   // [2h+kk][row tiles]
     // `ln` (= lane) is re-made opaque in every pair iteration: the LDS addresses below are loop invariant
@@ -1045,7 +1099,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - m); sum += e[r]; }   // exp2(-inf) = 0
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
         uint2 pb = make_uint2(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]));
         const uint16_t* vb = qkv + ((size_t)2 * kQKVRows + w * Tn + 4 * g) * kQKVRow + n;
         f32x4 y[4];
