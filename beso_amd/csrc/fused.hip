@@ -890,15 +890,15 @@ constexpr int kKC = kChunkTiles / 2;     // FC2 k-steps per hidden chunk
 // First k-steps of chunk 0's FC1 weights of a layer (issued before the LayerNorm that precedes the phase).
 template <int KS, int NW>
 __device__ __forceinline__ void mlp_prefetch(u32x4 (&a1r)[kFc1PF][kChunkTiles / NW], const u32x4* __restrict__ w1p, int w,
-                                             int lane, int rot) {
+                                             int lane) {
     constexpr int RC = kChunkTiles / NW;
-    prefetch_ring<RC, kFc1PF>(a1r, w1p + (size_t)(RC * w) * 64 + lane + (size_t)rot * KS * kChunkTiles * 64, kChunkTiles * 64);
+    prefetch_ring<RC, kFc1PF>(a1r, w1p + (size_t)(RC * w) * 64 + lane, kChunkTiles * 64);
 }
 
 template <int RPW, int KS, int NW>
 __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
                                           const float* __restrict__ b1f, const u32x4* __restrict__ w2p, int HT,
-                                          int KS2p, int w, int lane, int rot, u32x4 (&a1r)[kFc1PF][kChunkTiles / NW],
+                                          int KS2p, int w, int lane, u32x4 (&a1r)[kFc1PF][kChunkTiles / NW],
                                           Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int g = lane >> 4;
@@ -910,8 +910,9 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     constexpr int SLOTS = PAIRS * 12, MFMAS = kKC * kNTT * RPW;   // their instruction slots / the MFMAs they hide behind
     static_assert(RC % 2 == 0 && PAIRS % 2 == 0, "pairs are evaluated two at a time");
     // w1p: [chunk][kk][16 row tiles]; w2p: [kk2][NW*RPW row tiles]
-    // hidden chunks are independent, so every workgroup walks them in its own rotation (see layers_kernel)
-    auto pc = [&](int c) { const int q = c + rot; return q >= n_chunks ? q - n_chunks : q; };
+    // (walking the chunks in a per-workgroup rotation to spread L2 channel load was measured SLOWER: 1.16 vs 1.13 ms;
+    // workgroups of an XCD streaming the same weights in lockstep is what keeps them L2-resident)
+    auto pc = [&](int c) { return c; };
     auto fc1_a = [&](int c) { return ABL_PTR(w1p + (size_t)(RC * w) * 64 + lane, (size_t)pc(c) * KS * kChunkTiles * 64); };
     auto fc2_a = [&](int c) { return ABL_PTR(w2p + (size_t)(w * RPW) * 64 + lane, (size_t)(pc(c) * kKC) * (NW * RPW) * 64); };
     constexpr int PF1 = kFc1PF;
@@ -1185,10 +1186,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_block_kernel(flo
     Tile<RPW> T;
     load_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
     u32x4 a1r[kFc1PF][kChunkTiles / NW];
-    mlp_prefetch<KS, NW>(a1r, (const u32x4*)lw, w, lane, 0);
+    mlp_prefetch<KS, NW>(a1r, (const u32x4*)lw, w, lane);
     layernorm_to_lds<RPW, KS, NW>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane, (const float*)(lw + d.o_b2), st);
     mlp_phase<RPW, KS, NW>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
-                       (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, 0, a1r, st);
+                       (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
     store_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
 }
 
@@ -1213,13 +1214,6 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         const int part = i / (8 * kQKVRow / 2), rem = i % (8 * kQKVRow / 2);
         ((uint32_t*)(lds + L.u))[((size_t)part * kQKVRows + kMT) * kQKVRow / 2 + rem] = 0u;
     }
-    // Workgroups of one XCD (blockIdx % 8) stream the same weights at about the same time; walking the
-    // heads / hidden chunks in a per-workgroup rotation spreads those reads over the L2 channels.
-#ifndef BESO_ROT
-#define BESO_ROT 0            // measured: 1.16 ms with the rotation vs 1.13 ms without (lockstep sharing wins)
-#endif
-    const int n_chunks_k = (d.HT + kChunkTiles - 1) / kChunkTiles;
-    const int rot_c = BESO_ROT ? (int)((blockIdx.x >> 3) % (unsigned)n_chunks_k) : 0;
     Tile<RPW> T;
     stamp(st, 100);
     stamp(st, 1);
@@ -1251,12 +1245,12 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
                             lane, qE, qO, st);
         stamp(st, 3);
         u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
-        mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)lw, w, lane, rot_c);
+        mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)lw, w, lane);
         layernorm_to_lds<RPW, KS, kWaves>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                           (const float*)(lw + d.o_b2), st);
         stamp(st, 6);
         mlp_phase<RPW, KS, kWaves>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
-                           (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, rot_c, a1r, st);
+                           (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
     }
     stamp(st, 4);
     if (e.fuse_head) head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, st);
@@ -1407,8 +1401,8 @@ int fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, 
     if (!fused_dims(lay, &d)) return BESO_ERR_UNSUPPORTED;
     const char* base = packed + lay.fused + (size_t)layer * d.layer_bytes;
     hipError_t e;
-    static const int nw4 = getenv("BESO_FUSED_NW4") ? atoi(getenv("BESO_FUSED_NW4")) : 0;   // kernel experiments
-    if (d.RPW == 3 && d.KS == 12) e = nw4 ? launch_mlp_block<6, 12, 4>(x, base, d, M, s) : launch_mlp_block<3, 12, 8>(x, base, d, M, s);
+    // (a 4-wave, 512-VGPR instance <6, 12, 4> of the same phase code was measured no faster than <3, 12, 8>)
+    if (d.RPW == 3 && d.KS == 12) e = launch_mlp_block<3, 12, 8>(x, base, d, M, s);
     else if (d.RPW == 2 && d.KS == 8) e = launch_mlp_block<2, 8, 8>(x, base, d, M, s);
     else return BESO_ERR_UNSUPPORTED;
     return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
