@@ -917,7 +917,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     auto fc2_a = [&](int c) { return ABL_PTR(w2p + (size_t)(w * RPW) * 64 + lane, (size_t)(pc(c) * kKC) * (NW * RPW) * 64); };
     constexpr int PF1 = kFc1PF;
     auto fc1 = [&](int c, f32x4 (&h)[RC][kNTT], u32x4 (&ar)[PF1][RC]) {
-        const int R0 = pc(c) * kChunkTiles + RC * w;
+        const int R0 = pc(c) * kChunkTiles + RC * w, g = lane >> 4;
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
             const f32x4 bias = *(const f32x4*)(b1f + 16 * (R0 + r) + 4 * g);
@@ -957,10 +957,17 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     __syncthreads();                     // hT(0) complete
 #pragma unroll 1
     for (int c = 1; c < n_chunks; ++c) {
+        // lane-derived addresses are recomputed per chunk: hoisted out of this loop they stay live across the
+        // weave (the register-pressure peak), get spilled, and every scratch reload is a vmcnt(0) stall
+        asm volatile("" : "+v"(lane));
         const int tiles_here = min(kChunkTiles, HT - pc(c) * kChunkTiles);
         const bool fc1_active = RC * w < tiles_here;
+        // waves whose rows of the NEXT chunk are all padding (hidden 1440 -> 1536: the last chunk has 10 of 16
+        // row tiles) skip its FC1 (their GELU slots run on the bias-only accumulators: branching
+        // around the weave costs 190 spilled VGPRs) and the hT write
         const int cn = min(c + 1, n_chunks - 1);
-        prefetch_ring<RC, PF1>(a1r, fc1_a(cn), kChunkTiles * 64);
+        const bool next_active = RC * w < min(kChunkTiles, HT - pc(cn) * kChunkTiles);
+        if (next_active) prefetch_ring<RC, PF1>(a1r, fc1_a(cn), kChunkTiles * 64);
         {
             // ---- FC2(c-1) (always a full chunk: 8 k-steps) with GELU(c) woven in, fully unrolled
             const u32x4* a2 = fc2_a(c - 1);
@@ -1005,7 +1012,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
         if (!(BESO_ABL_MASK & 2)) __syncthreads();                 // every wave is done reading hT(c-1)
         stamp(st, 22);
         if (fc1_active) write_hT(hb);
-        if (c + 1 < n_chunks) fc1(c + 1, h, a1r);
+        if (c + 1 < n_chunks && next_active) fc1(c + 1, h, a1r);
         stamp(st, 23);
         if (!(BESO_ABL_MASK & 2)) __syncthreads();                 // hT(c) complete
         stamp(st, 24);
