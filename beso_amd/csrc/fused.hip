@@ -290,7 +290,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
 
 // ---------------------------------------------------------------------------------------------
 // One GEMM phase of the transposed formulation:  acc[r][t] += sum_kk A(r,kk) * B(t,kk)
-//   A(r,kk) = a[r*64 + kk*a_ks]    weights, L2 -> registers (pointer already offset by the lane)
+//   A(r,kk) = fragment r + kk*a_ks of `a`   weights, L2 -> registers (WPtr: uniform base + lane offset)
 //   B(t,kk) = b[t*b_ts + kk*b_ks]  activations, LDS -> registers (pointer already offset by the lane)
 // Two k-steps per iteration with named even/odd weight-fragment registers; the loads that refill a
 // register set are issued right behind the MFMAs that consumed it, so weight fragments are ~1.5
@@ -307,7 +307,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
 #define ABL_PTR(base, off) (base)
 #else
 #define ABL_KS(x) (x)
-#define ABL_PTR(base, off) ((base) + (off))
+#define ABL_PTR(base, off) ((base).adv(off))
 #endif
 
 #ifndef BESO_FUSED_WLOAD
@@ -321,15 +321,34 @@ __device__ __forceinline__ u32x4 wload(const u32x4* p) {
 #endif
 }
 
+// Address of a wave's weight fragments: a buffer resource over a wave-uniform base (SGPRs: kernel
+// arguments, wave index), a uniform byte offset (SGPR: k-step / chunk / head stepping is scalar arithmetic)
+// and the lane's byte offset inside a 1 KiB fragment (one VGPR).  `buffer_load_dwordx4 v, v_lo, s[rsrc], s_off
+// offen` needs no per-load VALU address arithmetic; with per-lane 64-bit pointers (`global_load ... v[a:a+1]`)
+// every step was 2-3 VALU instructions plus two VGPRs, which then got spilled.
+struct WPtr {
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t so;         // uniform byte offset
+    uint32_t lo;         // lane * 16
+    __device__ __forceinline__ u32x4 at(int frag) const {
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, lo, so + (uint32_t)frag * 1024u, 0);
+    }
+    __device__ __forceinline__ WPtr adv(size_t frags) const { return WPtr{rs, so + (uint32_t)frags * 1024u, lo}; }
+};
+// 0x00020000: raw buffer, 32-bit data format field as CK / rocPRIM set it for gfx9; range checking is unused
+__device__ __forceinline__ WPtr wptr(const u32x4* uniform_base, int lane) {
+    return WPtr{__builtin_amdgcn_make_buffer_rsrc((void*)uniform_base, 0, 0x7fffffff, 0x00020000), 0u, (uint32_t)lane * 16u};
+}
+
 template <int R>
-__device__ __forceinline__ void prefetch_a(u32x4 (&aE)[R], u32x4 (&aO)[R], const u32x4* __restrict__ a, int a_ks) {
+__device__ __forceinline__ void prefetch_a(u32x4 (&aE)[R], u32x4 (&aO)[R], WPtr a, int a_ks) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) { aE[r] = wload(a + r * 64); aO[r] = wload(a + r * 64 + ABL_KS(a_ks)); }
+    for (int r = 0; r < R; ++r) { aE[r] = a.at(r); aO[r] = a.at(r + ABL_KS(a_ks)); }
 }
 
 template <int R, int NT>
 __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], u32x4 (&aO)[R],
-                                           const u32x4* __restrict__ a, int a_ks, const u32x4* b, int b_ts,
+                                           WPtr a, int a_ks, const u32x4* b, int b_ts,
                                            int b_ks, int ksteps) {
     // ONE set of B fragments: each half of it is refilled for the next k-step as soon as the MFMAs that
     // read it have been issued (prefetch distance = half a k-step of MFMAs, enough for LDS latency).
@@ -357,7 +376,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
         for (int t = H1; t < NT; ++t) if (!(BESO_ABL_MASK & 32)) bf[t] = b[t * b_ts + (kk + 1) * b_ks];
         if (kk + 2 < ksteps) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) aE[r] = wload(a + r * 64 + ABL_KS((kk + 2) * a_ks));
+            for (int r = 0; r < R; ++r) aE[r] = a.at(r + ABL_KS((kk + 2) * a_ks));
         }
         // ---- k-step kk+1 (odd fragments)
         __builtin_amdgcn_sched_barrier(0);
@@ -382,7 +401,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
         }
         if (kk + 3 < ksteps) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) aO[r] = wload(a + r * 64 + ABL_KS((kk + 3) * a_ks));
+            for (int r = 0; r < R; ++r) aO[r] = a.at(r + ABL_KS((kk + 3) * a_ks));
         }
     }
 }
@@ -392,16 +411,16 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
 // k-step of MFMAs) and two sets of B fragments (a whole k-step of LDS prefetch distance).
 // ksteps must be a multiple of PFA, PFA even.
 template <int R, int PFA>
-__device__ __forceinline__ void prefetch_ring(u32x4 (&ar)[PFA][R], const u32x4* __restrict__ a, int a_ks) {
+__device__ __forceinline__ void prefetch_ring(u32x4 (&ar)[PFA][R], WPtr a, int a_ks) {
 #pragma unroll
     for (int p = 0; p < PFA; ++p)
 #pragma unroll
-        for (int r = 0; r < R; ++r) ar[p][r] = wload(a + r * 64 + ABL_KS(p * a_ks));
+        for (int r = 0; r < R; ++r) ar[p][r] = a.at(r + ABL_KS(p * a_ks));
 }
 
 template <int R, int NT, int PFA>
 __device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)[PFA][R],
-                                                const u32x4* __restrict__ a, int a_ks, const u32x4* b, int b_ts,
+                                                WPtr a, int a_ks, const u32x4* b, int b_ts,
                                                 int b_ks, int ksteps) {
     static_assert(PFA % 2 == 0, "B fragments alternate between two sets");
     u32x4 bb[2][NT];
@@ -425,7 +444,7 @@ __device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)
             }
             if (BESO_FUSED_ABLATE != 3 && kk + PFA < ksteps) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) ar[p][r] = wload(a + r * 64 + ABL_KS((kk + PFA) * a_ks));
+                for (int r = 0; r < R; ++r) ar[p][r] = a.at(r + ABL_KS((kk + PFA) * a_ks));
             }
         }
     }
@@ -892,7 +911,7 @@ template <int KS, int NW>
 __device__ __forceinline__ void mlp_prefetch(u32x4 (&a1r)[kFc1PF][kChunkTiles / NW], const u32x4* __restrict__ w1p, int w,
                                              int lane) {
     constexpr int RC = kChunkTiles / NW;
-    prefetch_ring<RC, kFc1PF>(a1r, w1p + (size_t)(RC * w) * 64 + lane, kChunkTiles * 64);
+    prefetch_ring<RC, kFc1PF>(a1r, wptr(w1p + (size_t)(RC * w) * 64, lane), kChunkTiles);
 }
 
 template <int RPW, int KS, int NW>
@@ -901,10 +920,9 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
                                           int KS2p, int w, int lane, u32x4 (&a1r)[kFc1PF][kChunkTiles / NW],
                                           Stamps& st) {
     asm volatile("" : "+v"(lane));
-    const int g = lane >> 4;
     const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
     constexpr int RC = kChunkTiles / NW, KW = RC / 2;       // row tiles / FC2 k-steps of a chunk per wave
-    constexpr int A2KS = NW * RPW * 64;                      // u32x4 stride between FC2 k-steps
+    constexpr int A2KS = NW * RPW;                           // fragments between FC2 k-steps
     constexpr int H1 = kNTT / 2;
     constexpr int PAIRS = KW * kNTT * 4;                     // GELU pair evaluations per chunk and wave
     constexpr int SLOTS = PAIRS * 12, MFMAS = kKC * kNTT * RPW;   // their instruction slots / the MFMAs they hide behind
@@ -913,8 +931,8 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     // (walking the chunks in a per-workgroup rotation to spread L2 channel load was measured SLOWER: 1.16 vs 1.13 ms;
     // workgroups of an XCD streaming the same weights in lockstep is what keeps them L2-resident)
     auto pc = [&](int c) { return c; };
-    auto fc1_a = [&](int c) { return ABL_PTR(w1p + (size_t)(RC * w) * 64 + lane, (size_t)pc(c) * KS * kChunkTiles * 64); };
-    auto fc2_a = [&](int c) { return ABL_PTR(w2p + (size_t)(w * RPW) * 64 + lane, (size_t)(pc(c) * kKC) * (NW * RPW) * 64); };
+    auto fc1_a = [&](int c) { return ABL_PTR(wptr(w1p + (size_t)(RC * w) * 64, lane), (size_t)pc(c) * KS * kChunkTiles); };
+    auto fc2_a = [&](int c) { return ABL_PTR(wptr(w2p + (size_t)(w * RPW) * 64, lane), (size_t)(pc(c) * kKC) * (NW * RPW)); };
     constexpr int PF1 = kFc1PF;
     auto fc1 = [&](int c, f32x4 (&h)[RC][kNTT], u32x4 (&ar)[PF1][RC]) {
         const int R0 = pc(c) * kChunkTiles + RC * w, g = lane >> 4;
@@ -924,7 +942,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) h[r][t] = bias;
         }
-        gemm_phase_ring<RC, kNTT, PF1>(h, ar, fc1_a(c), kChunkTiles * 64, xnT + lane, KS * 64, 64, KS);
+        gemm_phase_ring<RC, kNTT, PF1>(h, ar, fc1_a(c), kChunkTiles, xnT + lane, KS * 64, 64, KS);
     };
     auto write_hT = [&](u32x4 (&hb)[KW][kNTT]) {
 #pragma unroll
@@ -939,15 +957,15 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     float gq[8];
     GeluChain gc0, gc1;
     auto fc2_prefetch = [&](int c) {
-        const u32x4* a2 = fc2_a(c);
+        const WPtr a2 = fc2_a(c);
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) { af2[0][r] = wload(a2 + r * 64); af2[1][r] = wload(a2 + r * 64 + ABL_KS(A2KS)); }
+        for (int r = 0; r < RPW; ++r) { af2[0][r] = a2.at(r); af2[1][r] = a2.at(r + ABL_KS(A2KS)); }
     };
     // ---- prologue: FC1(0) (its first weight fragments arrive preloaded in a1r), GELU(0) (nothing to hide
     // it under yet), hT(0), FC1(1).  Every later weight request is issued one phase ahead of its use.
     static_assert(KS % PF1 == 0, "FC1 weight ring");
     fc1(0, h, a1r);                 // rows beyond HT are zero weights + zero bias: harmless for every wave
-    if (n_chunks > 1) prefetch_ring<RC, PF1>(a1r, fc1_a(1), kChunkTiles * 64);
+    if (n_chunks > 1) prefetch_ring<RC, PF1>(a1r, fc1_a(1), kChunkTiles);
     fc2_prefetch(0);
 #pragma unroll
     for (int pi = 0; pi < PAIRS; ++pi) gelu_pair<RC>(h, gq, hb, pi);
@@ -967,10 +985,10 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
         // around the weave costs 190 spilled VGPRs) and the hT write
         const int cn = min(c + 1, n_chunks - 1);
         const bool next_active = RC * w < min(kChunkTiles, HT - pc(cn) * kChunkTiles);
-        if (next_active) prefetch_ring<RC, PF1>(a1r, fc1_a(cn), kChunkTiles * 64);
+        if (next_active) prefetch_ring<RC, PF1>(a1r, fc1_a(cn), kChunkTiles);
         {
             // ---- FC2(c-1) (always a full chunk: 8 k-steps) with GELU(c) woven in, fully unrolled
-            const u32x4* a2 = fc2_a(c - 1);
+            const WPtr a2 = fc2_a(c - 1);
             const u32x4* b = hT + lane;
             u32x4 bf[kNTT];
 #pragma unroll
@@ -1001,7 +1019,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
                         }
                         if (kk + 2 < kKC) {
 #pragma unroll
-                            for (int r = 0; r < RPW; ++r) af2[kk & 1][r] = wload(a2 + r * 64 + ABL_KS((kk + 2) * A2KS));
+                            for (int r = 0; r < RPW; ++r) af2[kk & 1][r] = a2.at(r + ABL_KS((kk + 2) * A2KS));
                         }
                     }
                 });
@@ -1032,7 +1050,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 // the phase): even / odd fragments of gemm_phase.
 template <int KS>
 __device__ __forceinline__ void attn_prefetch(u32x4 (&qE)[3], u32x4 (&qO)[3], const u32x4* __restrict__ wqkv, int w, int lane) {
-    prefetch_a<3>(qE, qO, wqkv + (size_t)(3 * w) * 64 + lane, 24 * 64);
+    prefetch_a<3>(qE, qO, wptr(wqkv + (size_t)(3 * w) * 64, lane), 24);
 }
 
 // Attention phase (xnT holds LN1(x) fragments on entry).  Tokens of the tile are in natural order:
@@ -1058,8 +1076,8 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     u32x4* yT = (u32x4*)(u + kQKVBytes);                  // [(t*2 + kk)*64 + lane]
     const int wa = w & 3, hsel = w >> 2;                  // this wave's rows: tiles 3wa..3wa+2 of head 2*pair + hsel
     const float scale_log2e = 1.4426950408889634f * __builtin_amdgcn_rsqf((float)hd);
-    auto qkv_a = [&](int pair) { return ABL_PTR(wqkv + (size_t)(3 * w) * 64 + lane, (size_t)pair * KS * 24 * 64); };   // [pair][kk][24 row tiles]
-    auto proj_a = [&](int h) { return ABL_PTR(wproj + (size_t)(w * RPW) * 64 + lane, (size_t)(2 * h) * (kWaves * RPW) * 64); };   // [2h+kk][row tiles]
+    auto qkv_a = [&](int pair) { return ABL_PTR(wptr(wqkv + (size_t)(3 * w) * 64, lane), (size_t)pair * KS * 24); };   // [pair][kk][24 row tiles]
+    auto proj_a = [&](int h) { return ABL_PTR(wptr(wproj + (size_t)(w * RPW) * 64, lane), (size_t)(2 * h) * (kWaves * RPW)); };   // [2h+kk][row tiles]
     // `ln` (= lane) is re-made opaque in every pair iteration: the LDS addresses below are loop invariant
     // and would otherwise be hoisted out of the pair loop and spilled (24 VGPRs).
     int ln = lane;
@@ -1149,8 +1167,8 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) qa[i][t] = bv;
         }
-        gemm_phase<3, kNTT>(qa, qE, qO, qkv_a(pair), 24 * 64, xnT + lane, KS * 64, 64, KS);
-        prefetch_a<RPW>(aE, aO, proj_a(hA), kWaves * RPW * 64);
+        gemm_phase<3, kNTT>(qa, qE, qO, qkv_a(pair), 24, xnT + lane, KS * 64, 64, KS);
+        prefetch_a<RPW>(aE, aO, proj_a(hA), kWaves * RPW);
         if (hsel == 0) write_qkv(qa);
         stamp(st, 11);
         __syncthreads();
@@ -1160,10 +1178,10 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         __syncthreads();
         stamp(st, 17);
         // ---- head A's slice of the out-projection, accumulated into the residual; head B's q/k/v to LDS
-        gemm_phase<RPW, kNTT>(T.acc, aE, aO, proj_a(hA), kWaves * RPW * 64, yT + lane, 2 * 64, 64, 2);
-        prefetch_a<RPW>(aE, aO, proj_a(hB), kWaves * RPW * 64);
+        gemm_phase<RPW, kNTT>(T.acc, aE, aO, proj_a(hA), kWaves * RPW, yT + lane, 2 * 64, 64, 2);
+        prefetch_a<RPW>(aE, aO, proj_a(hB), kWaves * RPW);
         if (hsel == 1) write_qkv(qa);
-        if (pair + 1 < H / 2) prefetch_a<3>(qE, qO, qkv_a(pair + 1), 24 * 64);   // qa's registers are free from here
+        if (pair + 1 < H / 2) prefetch_a<3>(qE, qO, qkv_a(pair + 1), 24);   // qa's registers are free from here
         stamp(st, 13);
         __syncthreads();
         stamp(st, 14);
@@ -1171,7 +1189,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         stamp(st, 15);
         __syncthreads();
         stamp(st, 18);
-        gemm_phase<RPW, kNTT>(T.acc, aE, aO, proj_a(hB), kWaves * RPW * 64, yT + lane, 2 * 64, 64, 2);
+        gemm_phase<RPW, kNTT>(T.acc, aE, aO, proj_a(hB), kWaves * RPW, yT + lane, 2 * 64, 64, 2);
         // no barrier needed here: the next writes to qkv/yT happen behind the next pair's barriers
     }
     __syncthreads();
