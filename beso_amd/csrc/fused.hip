@@ -54,7 +54,8 @@ constexpr int kQKVBytes = 3 * kQKVRows * kQKVRow * 2;   // 44928
 
 struct FusedDims {
     int D, FT, RPW, KS, HT, NCH, KS2p, H, hd;
-    bool attn;                            // attention phase available (hd <= 64 and 8*block_size <= 96)
+    int HG, Hv, hdv;                      // HG real heads form one 'virtual head' of hdv = HG*hd <= 64 dims; Hv = H / HG
+    bool attn;                            // attention phase available (hd <= 64, 8*block_size <= 96, even Hv)
     // per-layer image: [w1 | b1 | w2 | b2 | wqkv | bqkv | wproj | bproj]
     size_t w1_bytes, b1_bytes, w2_bytes, b2_bytes, wqkv_bytes, bqkv_bytes, wproj_bytes, bproj_bytes, layer_bytes;
     size_t o_b1, o_w2, o_b2, o_wqkv, o_bqkv, o_wproj, o_bproj;
@@ -77,15 +78,24 @@ bool fused_dims(const Layout& lay, FusedDims* d) {
     d->NCH = (d->HT + kChunkTiles - 1) / kChunkTiles;
     d->KS2p = d->NCH * kWaves;
     const int T = 1 + lay.G + 2 * lay.W;
-    d->attn = lay.hd <= kHDP && lay.hd % 4 == 0 && kSPW * T <= kMT && lay.H % 2 == 0;
+    // The attention phase works on 64-wide 'virtual heads' in pairs.  Small heads are grouped: HG consecutive
+    // heads are HG*hd consecutive rows of the q/k/v weights, i.e. exactly one wider head as far as the GEMMs
+    // and the LDS layout go; only the attention core tells them apart (masked operands).  Block-push:
+    // 12 heads of 20 -> 4 virtual heads of 60, the kitchen geometry.
+    d->HG = 1;
+    for (int g = 3; g >= 2; --g)
+        if (lay.hd * g <= kHDP && lay.H % (2 * g) == 0) { d->HG = g; break; }
+    d->Hv = lay.H / d->HG;
+    d->hdv = lay.hd * d->HG;
+    d->attn = d->hdv <= kHDP && lay.hd % 4 == 0 && kSPW * T <= kMT && d->Hv % 2 == 0;
     const size_t rt2 = (size_t)d->RPW * kWaves;
     d->w1_bytes = (size_t)d->NCH * kChunkTiles * d->KS * 1024;
     d->b1_bytes = round_up_sz((size_t)d->NCH * kChunkTiles * 16 * sizeof(float), 256);
     d->w2_bytes = rt2 * d->KS2p * 1024;
     d->b2_bytes = round_up_sz(rt2 * 16 * sizeof(float), 256);
-    d->wqkv_bytes = d->attn ? (size_t)lay.H * 12 * d->KS * 1024 : 0;
-    d->bqkv_bytes = d->attn ? round_up_sz((size_t)lay.H * 3 * kHDP * sizeof(float), 256) : 0;
-    d->wproj_bytes = d->attn ? rt2 * (2 * lay.H) * 1024 : 0;
+    d->wqkv_bytes = d->attn ? (size_t)d->Hv * 12 * d->KS * 1024 : 0;
+    d->bqkv_bytes = d->attn ? round_up_sz((size_t)d->Hv * 3 * kHDP * sizeof(float), 256) : 0;
+    d->wproj_bytes = d->attn ? rt2 * (2 * d->Hv) * 1024 : 0;
     d->bproj_bytes = d->attn ? round_up_sz(rt2 * 16 * sizeof(float), 256) : 0;
     d->o_b1 = d->w1_bytes;
     d->o_w2 = d->o_b1 + d->b1_bytes;
@@ -1066,7 +1076,8 @@ __device__ __forceinline__ void attn_prefetch(u32x4 (&qE)[3], u32x4 (&qO)[3], co
 // and the core): qE/qO (first two k-steps of the pair's QKV weights) arrive preloaded and are refilled for
 // the next pair before core(B); each head's projection weights (two k-steps: all of them) are requested
 // before the barrier that precedes its core.
-template <int RPW, int KS>
+// HG > 1: a virtual head is HG real heads of `hd` dims side by side (FusedDims); H counts virtual heads.
+template <int RPW, int KS, int HG>
 __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsigned char* u,
                                            const u32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
                                            const u32x4* __restrict__ wproj, int H, int hd, int Tn, int n_samples,
@@ -1105,6 +1116,82 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     //   whose D layout is the B fragment of the out-projection (same k permutation as the weights).
     auto core = [&]() {
     const int n = ln & 15, g = ln >> 4;
+    if constexpr (HG > 1) {
+        // Grouped heads: the same fragments, but head h only sees its own dims.  S_h: the Q fragment with the
+        // other heads' dims zeroed (dword granular: hd is a multiple of 4); Y rows are taken from the head they
+        // belong to (lane-group granular for the same reason), already normalised by that head's 1/sum.
+        if (w < n_samples && !(BESO_ABL_MASK & 16)) {
+            const uint16_t* qb = qkv + ((size_t)0 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
+            const uint16_t* kb = qkv + ((size_t)1 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
+            const uint16_t* vb = qkv + ((size_t)2 * kQKVRows + w * Tn + 4 * g) * kQKVRow + n;
+            u32x4 qf[2], kf[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) { qf[kk] = *(const u32x4*)(qb + 32 * kk); kf[kk] = *(const u32x4*)(kb + 32 * kk); }
+            uint2 va[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                va[dt].x = (uint32_t)vb[16 * dt] | ((uint32_t)vb[kQKVRow + 16 * dt] << 16);
+                va[dt].y = (uint32_t)vb[2 * kQKVRow + 16 * dt] | ((uint32_t)vb[3 * kQKVRow + 16 * dt] << 16);
+            }
+            f32x4 y[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) y[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < HG; ++h) {
+                const int lo_d = h * hd, hi_d = lo_d + hd;
+                f32x4 sT = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    u32x4 qm;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int d0 = 32 * kk + 8 * g + 2 * m;
+                        qm[m] = (d0 >= lo_d && d0 < hi_d) ? qf[kk][m] : 0u;
+                    }
+                    sT = mfma_bf16(kf[kk], qm, sT);
+                }
+                float e[4], mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = (4 * g + r <= n) ? sT[r] * scale_log2e : -INFINITY;
+                    mx = fmaxf(mx, e[r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - mx); sum += e[r]; }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = __builtin_amdgcn_rcpf(sum);
+                const uint2 pb = make_uint2(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]));
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    if (16 * dt < hi_d && 16 * dt + 16 > lo_d) {             // wave-uniform: tile dt holds rows of head h
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        const f32x4 yh = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, va[dt]),
+                                                                                __builtin_bit_cast(s16x4, pb), z, 0, 0, 0);
+                        const int d0 = 16 * dt + 4 * g;                        // this lane's rows d0 .. d0+3
+                        const bool mine = d0 >= lo_d && d0 < hi_d;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[dt][r] = mine ? yh[r] * inv : y[dt][r];
+                    }
+                }
+            }
+            if (n < Tn) {
+                const int tok = w * Tn + n;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    u32x4 yb;
+                    yb[0] = pack_bf16x2(y[2 * kk][0], y[2 * kk][1]);
+                    yb[1] = pack_bf16x2(y[2 * kk][2], y[2 * kk][3]);
+                    yb[2] = pack_bf16x2(y[2 * kk + 1][0], y[2 * kk + 1][1]);
+                    yb[3] = pack_bf16x2(y[2 * kk + 1][2], y[2 * kk + 1][3]);
+                    yT[((size_t)(tok >> 4) * 2 + kk) * 64 + (g << 4) + (tok & 15)] = yb;
+                }
+            }
+        }
+    } else {
     if (w < n_samples && !(BESO_ABL_MASK & 16)) {
         const uint16_t* qb = qkv + ((size_t)0 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
         const uint16_t* kb = qkv + ((size_t)1 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
@@ -1150,6 +1237,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                 yT[((size_t)(tok >> 4) * 2 + kk) * 64 + (g << 4) + (tok & 15)] = yb;
             }
         }
+    }
     }
     };
 
@@ -1219,7 +1307,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_block_kernel(flo
 }
 
 // Whole transformer layers [l0, l1) over the tile's 8 samples; x stays in registers in between.
-template <int RPW, int KS>
+template <int RPW, int KS, int HG>
 __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, const char* __restrict__ lw0,
                                                         FusedDims d, int l0, int l1, int n_samples_total, int Tn,
                                                         EdgeArgs e, unsigned long long* stamps, int cap) {
@@ -1265,8 +1353,8 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         layernorm_to_lds<RPW, KS, kWaves>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                           (const float*)(lw + d.o_bproj), st);
         stamp(st, 7);
-        attn_phase<RPW, KS>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
-                            (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.H, d.hd, Tn, n_samples, w,
+        attn_phase<RPW, KS, HG>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
+                            (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
                             lane, qE, qO, st);
         stamp(st, 3);
         u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
@@ -1306,15 +1394,15 @@ hipError_t launch_mlp_block(float* x, const char* lw, const FusedDims& d, int M,
     return hipGetLastError();
 }
 
-template <int RPW, int KS>
+template <int RPW, int KS, int HG>
 hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
                          const EdgeArgs& edge, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS);
     static bool attr = false;
-    hipError_t e = ensure_lds(layers_kernel<RPW, KS>, L.total, &attr);
+    hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG>, L.total, &attr);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((layers_kernel<RPW, KS>), dim3((n_samples + kSPW - 1) / kSPW), dim3(512), L.total, s, x, lw0, d,
+    hipLaunchKernelGGL((layers_kernel<RPW, KS, HG>), dim3((n_samples + kSPW - 1) / kSPW), dim3(512), L.total, s, x, lw0, d,
                        l0, l1, n_samples, Tn, edge, g_stamps, g_stamps_cap);
     return hipGetLastError();
 }
@@ -1357,11 +1445,11 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
         if (d.attn) {
             (void)hipGetLastError();
             hipLaunchKernelGGL(pack_qkv_kernel, dim3(1024), dim3(256), 0, s, qw, kw, vw, ln1w,
-                               (uint16_t*)(base + d.o_wqkv), D, lay.H, lay.hd, d.KS);
-            hipLaunchKernelGGL(fold_qkv_bias_kernel, dim3((lay.H * 3 * kHDP + 255) / 256), dim3(256), 0, s, qw, kw, vw,
-                               qb, kb, vb, ln1b, (float*)(base + d.o_bqkv), D, lay.H, lay.hd);
-            hipLaunchKernelGGL(pack_proj_kernel, dim3(512), dim3(256), 0, s, pw, (uint16_t*)(base + d.o_wproj), D, lay.H,
-                               lay.hd, rt2);
+                               (uint16_t*)(base + d.o_wqkv), D, d.Hv, d.hdv, d.KS);
+            hipLaunchKernelGGL(fold_qkv_bias_kernel, dim3((d.Hv * 3 * kHDP + 255) / 256), dim3(256), 0, s, qw, kw, vw,
+                               qb, kb, vb, ln1b, (float*)(base + d.o_bqkv), D, d.Hv, d.hdv);
+            hipLaunchKernelGGL(pack_proj_kernel, dim3(512), dim3(256), 0, s, pw, (uint16_t*)(base + d.o_wproj), D, d.Hv,
+                               d.hdv, rt2);
             FTRY(hipGetLastError());
             FTRY(launch_pack_matrix(pb, 1, D, base + d.o_bproj, 1, rt2 * 16, -1, s));
         }
@@ -1414,7 +1502,8 @@ int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     if (precision != BESO_PREC_BF16 || lay.fused == lay.total || !fused_dims(lay, &d) || !shape_has_kernel(d)) return 0;
     static const int level_max = getenv("BESO_FUSED_LEVEL_MAX") ? atoi(getenv("BESO_FUSED_LEVEL_MAX")) : 2;   // kernel experiments
     if (level_max < 2) return level_max;
-    if (d.attn && d.RPW == 3 && d.KS == 12 && kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused) &&
+    if (d.attn && ((d.RPW == 3 && d.KS == 12 && d.HG == 1) || (d.RPW == 2 && d.KS == 8 && d.HG == 3)) &&
+        kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused) &&
         d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK) return 2;
     return 1;
 }
@@ -1452,7 +1541,8 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     if (e.two && !e.fuse_head) return BESO_ERR_UNSUPPORTED;
     if (fused_edges) *fused_edges = (e.fuse_embed ? 1 : 0) | (e.fuse_head ? 2 : 0);
     hipError_t err;
-    if (d.RPW == 3 && d.KS == 12) err = launch_layers<3, 12>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);
+    if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);
+    else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);
     else return BESO_ERR_UNSUPPORTED;
     return err == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
