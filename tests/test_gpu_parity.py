@@ -251,3 +251,28 @@ def test_ragged_and_edge_shapes():
         assert rel_err(out.cpu().numpy(), ref) < TOL["fp32"]
         with pytest.raises(ValueError):
             m(G(np.zeros((2, 5, 30), np.float32)), G(np.zeros((2, 5, 9), np.float32)), G(g_np[:2]), G(np.ones(2, np.float32)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,H,hd", [(17, 4, 64), (33, 2, 32), (67, 8, 64), (96, 4, 48), (128, 2, 64)])
+def test_generic_mfma_attention_matches_fp32_attention(T, H, hd):
+    """The bf16 MFMA attention kernel of the generic path (16 < T <= 128 tokens, hd <= 64; score_gpts.py:69-76):
+    one-layer networks of shapes that no fused kernel takes, so the whole forward runs on the generic
+    kernels, against the oracle.  Window chosen so that 1 + G + 2W = T (ragged last tile, full tiles,
+    the 128-token maximum)."""
+    G_len = 2 if (T - 3) % 2 == 0 else 1
+    W = (T - 1 - G_len) // 2
+    if 1 + G_len + 2 * W != T:
+        pytest.skip("T not representable as 1 + G + 2W")
+    cfg = O.ScoreGPTConfig(obs_dim=6, act_dim=3, embed_dim=H * hd, n_layers=1, n_heads=H, goal_seq_len=G_len,
+                           obs_seq_len=W, sigma_data=0.5)
+    w = O.make_weights(cfg, seed=5, std=0.05)
+    s, g, a = O.make_inputs(cfg, 5, seed=3)
+    sg = np.linspace(0.1, 0.9, 5).astype(np.float32)
+    ref = O.denoise(w, cfg, s, a, g, sg)
+    m = make_module(cfg, w, "bf16")
+    with torch.no_grad():
+        out = m(G(s), G(a), G(g), G(sg)).cpu().numpy()
+    err = rel_err(out, ref)
+    print(f"[parity] generic MFMA attention T={T} H={H} hd={hd}: {err:.3e}")
+    assert err < TOL["bf16"]

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""BASELINE config 3 on one GPU's share: kitchen train_step (score-matching loss, backward, AdamW, EMA) at
+1024 samples per step, through BesoAgent.train_step.  The forward/backward are torch autograd ops on the
+GPU in this round; this records where that stands.   python tools/bench_train.py"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from bench import build_model  # noqa: E402
+from oracle import beso_oracle as O  # noqa: E402
+from test_host_logic import build_agent  # noqa: E402
+from beso_amd.networks.scaler.scaler_class import Scaler  # noqa: E402
+
+
+def main():
+    dev = "cuda:0"
+    cfg = O.KITCHEN
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    w = O.make_weights(cfg, seed=0, std=0.02)
+    agent = build_agent(cfg, lambda: build_model(cfg, w, "bf16", dev), device=dev)
+    rng = np.random.default_rng(0)
+    agent.get_scaler(Scaler(rng.standard_normal((256, cfg.obs_dim)).astype(np.float32),
+                            rng.standard_normal((256, cfg.act_dim)).astype(np.float32), True, dev))
+    agent.set_bounds(agent.scaler)
+    batch = {"observation": torch.randn(B, cfg.obs_seq_len, cfg.obs_dim), "action": torch.randn(B, cfg.obs_seq_len, cfg.act_dim),
+             "goal_observation": torch.randn(B, cfg.goal_seq_len, cfg.obs_dim)}
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    for _ in range(3):
+        loss = agent.train_step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        loss = agent.train_step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    flops = 3.0 * cfg.flops_per_sample() * B
+    print(json.dumps({"config": "3: kitchen train_step, one GPU's share", "batch": B, "seconds_per_step": dt,
+                      "samples_per_s": B / dt, "tflops_fwd_bwd": flops / dt / 1e12, "loss": loss,
+                      "path": "torch autograd fp32 forward/backward + torch AdamW + flat EMA"}))
+
+
+if __name__ == "__main__":
+    main()
