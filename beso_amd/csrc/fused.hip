@@ -57,11 +57,12 @@ struct FusedDims {
     int HG, Hv, hdv;                      // HG real heads form one 'virtual head' of hdv = HG*hd <= 64 dims; Hv = H / HG
     bool attn;                            // attention phase available (hd <= 64, 8*block_size <= 96, even Hv)
     // per-layer image: [w1 | b1 | w2 | b2 | wqkv | bqkv | wproj | bproj]
-    size_t w1_bytes, b1_bytes, w2_bytes, b2_bytes, wqkv_bytes, bqkv_bytes, wproj_bytes, bproj_bytes, layer_bytes;
-    size_t o_b1, o_w2, o_b2, o_wqkv, o_bqkv, o_wproj, o_bproj;
+    // (32-bit: the struct is a kernel argument and every field the kernel touches costs SGPRs)
+    uint32_t w1_bytes, b1_bytes, w2_bytes, b2_bytes, wqkv_bytes, bqkv_bytes, wproj_bytes, bproj_bytes, layer_bytes;
+    uint32_t o_b1, o_w2, o_b2, o_wqkv, o_bqkv, o_wproj, o_bproj;
     // per-model image behind the L per-layer images (fp32): embeddings transposed to [in][Dp], head with ln_f folded
     int Dp, obs, act, seq, G, L, head_fused;
-    size_t g_tokT, g_tokb, g_actT, g_actb, g_sigw, g_sigb, g_pos, g_headw, g_headb, global_bytes;
+    uint32_t g_tokT, g_tokb, g_actT, g_actb, g_sigw, g_sigb, g_pos, g_headw, g_headb, global_bytes;
 };
 
 bool fused_dims(const Layout& lay, FusedDims* d) {

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Development aid: build and time compile-time variants of the fused kernel in one GPU call.
 
-    python tools/variants.py build  name1=-DFLAG=1,-DX=2  name2=...     (CPU box: hipcc cross-compile)
+    python tools/variants.py build  name1=-DFLAG=1,-DX=2  name2=@<git-rev>,...   (CPU box: hipcc cross-compile;
+                                                                       "@rev" = fused.hip as of that commit)
     python tools/variants.py time   [--batch 4096] [--stamps]           (GPU box: times every built variant)
 
 Variants are libbeso_hip_<name>.so under beso_amd/lib/variants/ (only fused.hip is recompiled; the other
@@ -27,8 +28,15 @@ def build(specs):
     for spec in specs:
         name, _, flags = spec.partition("=")
         flags = [f for f in flags.split(",") if f]
+        src = os.path.join(B.CSRC, "fused.hip")
+        rev = [f for f in flags if f.startswith("@")]
+        if rev:                                   # "@<git revision>": fused.hip as of that commit (A/B on one GPU box)
+            flags = [f for f in flags if not f.startswith("@")]
+            src = os.path.join(B.CSRC, f"_fused_{name}.hip")
+            text = subprocess.check_output(["git", "-C", ROOT, "show", f"{rev[0][1:]}:beso_amd/csrc/fused.hip"], text=True)
+            open(src, "w").write(text)
         obj = os.path.join(B.OBJDIR, f"fused_{name}.o")
-        cmd = [B._hipcc(), *B.FLAGS, *flags, "-c", os.path.join(B.CSRC, "fused.hip"), "-o", obj]
+        cmd = [B._hipcc(), *B.FLAGS, *flags, "-c", src, "-o", obj]
         procs.append((name, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
     for name, obj, p in procs:
         _, err = p.communicate()
@@ -38,6 +46,9 @@ def build(specs):
         lib = os.path.join(VDIR, f"libbeso_hip_{name}.so")
         subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", lib, *objs])
         print("built", lib)
+    for f in os.listdir(B.CSRC):
+        if f.startswith("_fused_"):
+            os.remove(os.path.join(B.CSRC, f))
 
 
 def time_one(batch, steps=30):
