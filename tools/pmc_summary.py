@@ -62,10 +62,10 @@ def main():
             pmc[f"_launches_{leg}"] = n
     if pmc:
         json.dump(pmc, open(os.path.join(a.out, f"{tag}_layers_kernel_pmc.json"), "w"), indent=1)
-    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and bench:
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         hbm = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         cfgname = "kitchen"
-        tj = {"kernel": a.site, "batch": bench["config"]["batch_per_gpu"], "config": cfgname,
+        tj = {"kernel": a.site, "batch": bench["config"]["batch_per_gpu"] if bench else 4096, "config": cfgname,
               "hbm_bytes_per_launch": hbm,
               "FETCH_SIZE_KiB_avg": pmc["FETCH_SIZE"], "WRITE_SIZE_KiB_avg": pmc["WRITE_SIZE"],
               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, averaged over the launches of "
