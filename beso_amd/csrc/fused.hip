@@ -17,10 +17,16 @@
 //
 // Kernels:
 //   mlp_block_kernel   x <- x + W2 GELU(W1 LN2(x) + b1) + b2                       (score_gpts.py:105-114)
-//   layers_kernel      for l in [l0, l1): x <- x + proj(attn(LN1 x)); x <- x + mlp(LN2 x)   (:50-115)
-//                      attention per head: QKV_h GEMM -> q,k,v (bf16) in LDS -> scores with
-//                      v_dot2_f32_bf16, causal softmax, P.V on the VALU -> y_h^T B fragments -> the
-//                      head's slice of the out-projection accumulated into the residual.
+//   layers_kernel      [token embedding ->] for l in [l0, l1): x <- x + proj(attn(LN1 x)); x <- x + mlp(LN2 x)
+//                      [-> ln_f, action head, preconditioning, CFG]        (:50-115, :272-358; score_wrappers.py:81-96)
+//                      attention per PAIR of (virtual) heads: one QKV GEMM -> q,k,v (bf16) of one head in LDS,
+//                      the other head's accumulators parked in registers -> scores, causal softmax and P.V
+//                      on the matrix pipe, one sample per wave -> y_h^T B fragments -> the head's slice of
+//                      the out-projection accumulated into the residual.
+//
+// What bounds these kernels: they run at the board's power cap, VALU instructions do
+// not hide under MFMAs beyond about one per MFMA, and every workgroup streams all weights out of L2 --
+// so the code below counts VALU instructions, LDS/L2 bytes and padding MFMAs, not stalls.
 #include <stdlib.h>
 #include "fused.h"
 
@@ -263,13 +269,6 @@ __global__ void fold_bias_kernel(const float* __restrict__ W, const float* __res
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     f32x2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
-}
-
-__device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
-
-__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
 }
 
 // GELU(v) = v * Phi(v) with the exact-erf Phi of nn.GELU() (score_gpts.py:107), evaluated without
