@@ -204,7 +204,7 @@ def main():
                          "flops_per_launch": site_flops.get(dominant, 0.0),
                          "site_ms_one_forward": {k: v[0] for k, v in site_ms.items()}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only (the other ranks would idle at the barrier)
             result["cpu_baseline"] = cpu_baseline(cfg, w, B)
         print(json.dumps(result))
     if world > 1:
