@@ -21,7 +21,7 @@ SITES = {"off": 0, "gemm_qkv": 1, "gemm_proj": 2, "gemm_fc1": 3, "gemm_fc2": 4, 
 # every symbol include/beso_hip.h declares (tests check that the library exports all of them)
 EXPORTS = ["beso_version", "beso_status_string", "beso_last_error", "beso_num_params", "beso_packed_bytes", "beso_pack_weights",
            "beso_workspace_bytes", "beso_score_fwd", "beso_denoise_fwd", "beso_sampler_step", "beso_sample",
-           "beso_profile_enable", "beso_profile_read", "beso_debug_set_stamps"]
+           "beso_profile_enable", "beso_profile_read", "beso_debug_set_stamps", "beso_adam_step"]
 
 
 class BesoConfig(C.Structure):
@@ -86,6 +86,8 @@ def load() -> C.CDLL:
         lib.beso_profile_enable.argtypes = [i32]
         lib.beso_debug_set_stamps.restype = None
         lib.beso_debug_set_stamps.argtypes = [vp, i32]
+        lib.beso_adam_step.restype = i32
+        lib.beso_adam_step.argtypes = [vp, i32, vp, vp, vp, f32, f32, f32, f32, f32, i32, i32, f32, vp]
         lib.beso_profile_read.restype = i32
         lib.beso_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
         _lib = lib

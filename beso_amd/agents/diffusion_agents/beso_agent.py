@@ -24,6 +24,7 @@ import torch.nn as nn
 from ... import distributed as bdist
 from ..._instantiate import instantiate
 from ...networks.ema_helper.ema import ExponentialMovingAverage
+from ...optim import FusedAdam, maybe_fuse
 from ..base_agent import BaseAgent
 from .k_diffusion import gc_sampling as ks
 from .k_diffusion import utils
@@ -57,6 +58,10 @@ class BesoAgent(BaseAgent):
                          device, max_train_steps, eval_every_n_steps, max_epochs)
         self.ema_helper = ExponentialMovingAverage(self.model.get_params(), decay, self.device)
         self.use_ema = use_ema
+        # torch Adam / AdamW on a HIP device -> the one-launch fused step (same hyper-parameters, same
+        # param_groups surface for the LR scheduler); BESO_AMD_FUSED_OPTIM=0 keeps the eager optimizer
+        if os.environ.get("BESO_AMD_FUSED_OPTIM", "1") != "0":
+            self.optimizer = maybe_fuse(self.optimizer)
         self.lr_scheduler = instantiate(lr_scheduler, optimizer=self.optimizer)
         self.gc = goal_conditioned
         self.train_method = train_method
@@ -210,11 +215,17 @@ class BesoAgent(BaseAgent):
             if self._grad_bucket is None:
                 self._grad_bucket = bdist.GradientBucket(self.model.get_params())
             self._grad_bucket.sync()
-        self.optimizer.step()
-        self.lr_scheduler.step()
         self.steps += 1
-        if self.steps % self.update_ema_every_n_steps == 0:
-            self.ema_helper.update(self.model.parameters())
+        do_ema = self.steps % self.update_ema_every_n_steps == 0
+        if isinstance(self.optimizer, FusedAdam):
+            # Adam(W) over all tensors and the EMA of the updated parameters in ONE HIP launch
+            self.optimizer.step(ema=self.ema_helper if do_ema else None)
+            self.lr_scheduler.step()
+        else:
+            self.optimizer.step()
+            self.lr_scheduler.step()
+            if do_ema:
+                self.ema_helper.update(self.model.parameters())
         return loss.item()
 
     @torch.no_grad()

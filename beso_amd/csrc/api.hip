@@ -421,6 +421,19 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
 
 void beso_debug_set_stamps(void* device_buf, int capacity_u64) { fused_set_stamps(device_buf, capacity_u64); }
 
+int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg, float* exp_avg_sq, float* ema,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,
+                   float ema_decay, void* stream) {
+    if (!chunks || !exp_avg || !exp_avg_sq || n_chunks < 0 || step < 1) return BESO_ERR_BAD_ARG;
+    if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f && lr >= 0.f)) return BESO_ERR_BAD_ARG;
+    if (ema && !(ema_decay >= 0.f && ema_decay <= 1.f)) return BESO_ERR_BAD_ARG;
+    if (n_chunks == 0) return BESO_OK;
+    hipError_t e = launch_adam_ema(chunks, n_chunks, exp_avg, exp_avg_sq, ema, lr, beta1, beta2, eps, weight_decay,
+                                   decoupled_wd ? 1 : 0, step, ema_decay, (hipStream_t)stream);
+    if (e != hipSuccess) return record_hip_error(e, "adam_ema_kernel", __LINE__);
+    return BESO_OK;
+}
+
 void beso_profile_enable(int site) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_site = site;

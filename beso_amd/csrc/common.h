@@ -124,4 +124,7 @@ hipError_t launch_sampler_step(int mode, float* out, float* aux, const float* x,
 void profile_begin(int site, hipStream_t s);
 void profile_end(int site, hipStream_t s);
 
+hipError_t launch_adam_ema(const void* chunks, int n_chunks, float* m, float* v, float* ema, float lr, float beta1,
+                           float beta2, float eps, float wd, int decoupled, int step, float ema_decay, hipStream_t s);
+
 }  // namespace beso

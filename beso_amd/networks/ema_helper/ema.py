@@ -30,12 +30,17 @@ class ExponentialMovingAverage:
             off += n
         return out
 
-    def update(self, parameters):
-        """shadow -= (1 - decay) * (shadow - param)   (ema.py:36-53)."""
+    def next_decay(self) -> float:
+        """Counts one update and returns the decay it uses: min(decay, (1+n)/(10+n))   (ema.py:45-48)."""
         decay = self.decay
         if self.num_updates is not None:
             self.num_updates += 1
             decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+        return decay
+
+    def update(self, parameters):
+        """shadow -= (1 - decay) * (shadow - param)   (ema.py:36-53)."""
+        decay = self.next_decay()
         with torch.no_grad():
             params = [p for p in parameters if p.requires_grad]
             if params:

@@ -136,6 +136,26 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
                 const float* sigmas, int n_sigmas, float cond_lambda,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* One Adam / AdamW step over ALL parameter tensors in one launch, optionally followed by the EMA update
+ * of the shadow copy on the updated parameters.  Replaces `self.optimizer.step()` + `self.ema_helper.update`
+ * of the training step (reference beso_agent.py:236-244; torch.optim.AdamW for kitchen, torch.optim.Adam
+ * for block-push: configs/agents/beso_kitchen.yaml:9-12, beso_block_push.yaml:9-11; ema.py:45-53); the
+ * arithmetic is torch's single-tensor Adam(W) with amsgrad = False, maximize = False, in fp32.
+ *   chunks      DEVICE array: each entry is at most 4096 consecutive elements of one parameter tensor
+ *   exp_avg, exp_avg_sq, ema   flat fp32 state buffers indexed by chunk.off + i (ema may be NULL)
+ *   decoupled_wd 1 = AdamW (p *= 1 - lr*wd), 0 = Adam (g += wd*p);  step = 1-based step count
+ *   ema_decay   the decay actually applied this step, min(decay, (1+n)/(10+n)) (ema.py:45-48)       */
+typedef struct beso_optim_chunk {
+    float* p;
+    const float* g;
+    unsigned long long off;
+    unsigned int n;
+    unsigned int pad;
+} beso_optim_chunk;
+int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg, float* exp_avg_sq, float* ema,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,
+                   float ema_decay, void* stream);
+
 /* Timing hooks for bench.py: HIP events are recorded on the launch stream around every launch of
  * the selected launch site while enabled (site 0 = off).  beso_profile_read synchronises the
  * recorded events, returns their summed elapsed time and count, and clears them.               */

@@ -276,3 +276,72 @@ def test_generic_mfma_attention_matches_fp32_attention(T, H, hd):
     err = rel_err(out, ref)
     print(f"[parity] generic MFMA attention T={T} H={H} hd={hd}: {err:.3e}")
     assert err < TOL["bf16"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["adamw", "adam_l2"])
+def test_fused_adam_matches_torch(kind):
+    """beso_adam_step (all tensors + EMA in one launch) against torch.optim.AdamW / Adam and the eager EMA
+    (beso_agent.py:236-244, ema.py:45-53) over several steps with a StepLR schedule."""
+    from beso_amd.optim import FusedAdam, maybe_fuse
+    from beso_amd.networks.ema_helper.ema import ExponentialMovingAverage
+    torch.manual_seed(0)
+    shapes = [(360, 30), (360,), (1440, 360), (5000,), (9, 360), (1,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, device=DEV) * 0.1) for s in shapes]
+    fus_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    if kind == "adamw":
+        ref = torch.optim.AdamW(ref_p, lr=1e-3, betas=(0.9, 0.999))
+        fus = maybe_fuse(torch.optim.AdamW(fus_p, lr=1e-3, betas=(0.9, 0.999)))
+    else:
+        ref = torch.optim.Adam(ref_p, lr=2e-3, weight_decay=0.05)
+        fus = maybe_fuse(torch.optim.Adam(fus_p, lr=2e-3, weight_decay=0.05))
+    assert isinstance(fus, FusedAdam)
+    s_ref = torch.optim.lr_scheduler.StepLR(ref, 2, 0.5)
+    s_fus = torch.optim.lr_scheduler.StepLR(fus, 2, 0.5)
+    e_ref = ExponentialMovingAverage(ref_p, 0.999, DEV)
+    e_fus = ExponentialMovingAverage(fus_p, 0.999, DEV)
+    for it in range(6):
+        grads = [torch.randn_like(p) for p in ref_p]
+        ref.zero_grad(); fus.zero_grad()
+        for p, q, g in zip(ref_p, fus_p, grads):
+            p.grad = g.clone()
+            q.grad = g.clone()
+        ref.step(); s_ref.step(); e_ref.update(ref_p)
+        fus.step(ema=e_fus); s_fus.step()
+    for p, q in zip(ref_p, fus_p):
+        assert rel_err(q.detach().cpu().numpy(), p.detach().cpu().numpy()) < 2e-6
+    for a, b in zip(e_ref.shadow_params, e_fus.shadow_params):
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 2e-6
+    assert e_ref.num_updates == e_fus.num_updates == 6 and e_fus.version == 6
+
+
+@pytest.mark.gpu
+def test_train_step_with_fused_optimizer_matches_eager(monkeypatch):
+    """BesoAgent.train_step: fused Adam(W)+EMA launch == eager torch optimizer + EMA helper on the same batches."""
+    from test_host_logic import build_agent
+    from beso_amd.optim import FusedAdam
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=2, std=0.05)
+    losses, finals, shadows = {}, {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BESO_AMD_FUSED_OPTIM", mode)
+        agent = build_agent(cfg, lambda: make_module(cfg, w, "fp32"), device=DEV)
+        assert isinstance(agent.optimizer, FusedAdam) == (mode == "1")
+        agent.get_scaler(Scaler(np.random.default_rng(0).standard_normal((64, cfg.obs_dim)).astype(np.float32),
+                                np.random.default_rng(1).standard_normal((64, cfg.act_dim)).astype(np.float32), True, DEV))
+        agent.set_bounds(agent.scaler)
+        torch.manual_seed(7)
+        batch = {"observation": torch.randn(16, cfg.obs_seq_len, cfg.obs_dim, device=DEV),
+                 "action": torch.randn(16, cfg.obs_seq_len, cfg.act_dim, device=DEV),
+                 "goal_observation": torch.randn(16, cfg.goal_seq_len, cfg.obs_dim, device=DEV)}
+        losses[mode] = [agent.train_step(batch) for _ in range(4)]
+        finals[mode] = [p.detach().cpu().numpy().copy() for p in agent.model.parameters()]
+        shadows[mode] = [s.cpu().numpy().copy() for s in agent.ema_helper.shadow_params]
+    assert np.allclose(losses["1"], losses["0"], rtol=1e-5, atol=1e-6), (losses["1"], losses["0"])
+    # Adam's update is lr * m / (sqrt(v) + eps): for elements whose gradient is ~0 a last-bit difference moves
+    # the parameter by O(lr) (= 1e-4 here); the bar is a few lr relative to the tensor's largest entry
+    for a, b in zip(finals["1"], finals["0"]):
+        assert rel_err(a, b) < 5e-3
+    for a, b in zip(shadows["1"], shadows["0"]):
+        assert rel_err(a, b) < 5e-3

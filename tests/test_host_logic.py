@@ -291,3 +291,20 @@ def test_train_step_and_checkpoint_roundtrip(tmp_path):
     agent2.load_pretrained_model(str(tmp_path))
     assert torch.equal(agent2.model.state_dict()[k], ema_sd[k])
     assert torch.equal(agent2.ema_helper.shadow_params[1], ema_sd[k])
+
+
+def test_fused_optimizer_is_not_used_on_cpu():
+    """maybe_fuse only replaces torch Adam / AdamW over HIP fp32 parameters; on CPU (no kernel: there is no
+    CPU implementation) and for any other optimizer the object comes back unchanged."""
+    from beso_amd.optim import FusedAdam, maybe_fuse
+    p = [torch.nn.Parameter(torch.randn(4, 3))]
+    for opt in (torch.optim.AdamW(p, lr=1e-3), torch.optim.Adam(p, lr=1e-3), torch.optim.SGD(p, lr=1e-3)):
+        assert maybe_fuse(opt) is opt
+    f = FusedAdam(p, lr=1e-3, decoupled_weight_decay=True)
+    assert f.param_groups[0]["lr"] == 1e-3 and f.param_groups[0]["betas"] == (0.9, 0.999)
+    torch.optim.lr_scheduler.StepLR(f, 100, 0.99)           # LR schedulers attach to it
+    p[0].grad = torch.ones_like(p[0])
+    with pytest.raises(ValueError):
+        f.step()                                              # CPU parameters: refused, no fallback
+    with pytest.raises(ValueError):
+        FusedAdam(p, lr=-1.0)

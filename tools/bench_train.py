@@ -45,7 +45,7 @@ def main():
     flops = 3.0 * cfg.flops_per_sample() * B
     print(json.dumps({"config": "3: kitchen train_step, one GPU's share", "batch": B, "seconds_per_step": dt,
                       "samples_per_s": B / dt, "tflops_fwd_bwd": flops / dt / 1e12, "loss": loss,
-                      "path": "torch autograd fp32 forward/backward + torch AdamW + flat EMA"}))
+                      "path": "torch autograd fp32 forward/backward + " + type(agent.optimizer).__name__ + " (+EMA)"}))
 
 
 if __name__ == "__main__":
