@@ -22,11 +22,16 @@ def rand_log_normal(shape, loc=0., scale=1., device='cpu', dtype=torch.float32):
 
 def rand_log_logistic(shape, loc=0., scale=1., min_value=0., max_value=float('inf'), device='cpu',
                       dtype=torch.float32):
-    """Truncated log-logistic, drawn in float64 like the reference (utils.py:178-185)."""
-    f64 = dict(device=device, dtype=torch.float64)
-    lo = torch.as_tensor(min_value, **f64).log().sub(loc).div(scale).sigmoid()
-    hi = torch.as_tensor(max_value, **f64).log().sub(loc).div(scale).sigmoid()
-    u = torch.rand(shape, **f64) * (hi - lo) + lo
+    """Truncated log-logistic, drawn in float64 like the reference (utils.py:178-185).  The two CDF bounds
+    are host doubles (the reference builds them as 0-d device tensors from the same Python floats): no
+    host-to-device copy, so the draw can be captured into a HIP graph."""
+    def cdf(v):
+        if v <= 0.0:
+            return 0.0
+        z = (math.log(v) - loc) / scale if v != float('inf') else float('inf')
+        return 1.0 / (1.0 + math.exp(-z)) if z > -700.0 else 0.0
+    lo, hi = cdf(float(min_value)), cdf(float(max_value))
+    u = torch.rand(shape, device=device, dtype=torch.float64) * (hi - lo) + lo
     return u.logit().mul(scale).add(loc).exp().to(dtype)
 
 

@@ -345,3 +345,36 @@ def test_train_step_with_fused_optimizer_matches_eager(monkeypatch):
         assert rel_err(a, b) < 5e-3
     for a, b in zip(shadows["1"], shadows["0"]):
         assert rel_err(a, b) < 5e-3
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_matches_eager(monkeypatch):
+    """train_step with forward + backward replayed as one HIP graph == the eager step, with the random draws
+    (noise, sigma) pinned to fixed tensors so that both see the same numbers."""
+    from test_host_logic import build_agent
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=2, std=0.05)
+    torch.manual_seed(11)
+    B = 16
+    noise = torch.randn(B, cfg.obs_seq_len, cfg.act_dim, device=DEV)
+    sigma = torch.rand(B, device=DEV) * 0.9 + 0.05
+    batches = [{"observation": torch.randn(B, cfg.obs_seq_len, cfg.obs_dim, device=DEV),
+                "action": torch.randn(B, cfg.obs_seq_len, cfg.act_dim, device=DEV),
+                "goal_observation": torch.randn(B, cfg.goal_seq_len, cfg.obs_dim, device=DEV)} for _ in range(4)]
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BESO_AMD_TRAIN_GRAPH", mode)
+        agent = build_agent(cfg, lambda: make_module(cfg, w, "fp32"), device=DEV)
+        agent.get_scaler(Scaler(np.random.default_rng(0).standard_normal((64, cfg.obs_dim)).astype(np.float32),
+                                np.random.default_rng(1).standard_normal((64, cfg.act_dim)).astype(np.float32), True, DEV))
+        agent.set_bounds(agent.scaler)
+        monkeypatch.setattr(agent, "make_sample_density", lambda: (lambda shape, device: sigma.clone()))
+        monkeypatch.setattr(torch, "randn_like", lambda t, *a, **k: noise.clone())
+        losses = [agent.train_step(b) for b in batches]
+        monkeypatch.undo()
+        assert (len(agent._train_graphs) == 1) == (mode == "1")
+        results[mode] = (losses, [p.detach().cpu().numpy().copy() for p in agent.model.parameters()])
+    assert np.allclose(results["1"][0], results["0"][0], rtol=1e-5, atol=1e-6), (results["1"][0], results["0"][0])
+    for a, b in zip(results["1"][1], results["0"][1]):
+        assert rel_err(a, b) < 5e-3            # Adam amplifies last-bit differences to O(lr), see above
