@@ -126,8 +126,13 @@ bool fused_dims(const Layout& lay, FusedDims* d) {
     return true;
 }
 
+// The kernels run the last k-step of the K = D contractions as a HALF k-step (mfma_bf16_half): the shapes
+// they are used for must have at most 16 real indices there.
+constexpr bool KT16 = true;
+
 bool shape_has_kernel(const FusedDims& d) {
     // instantiated (RPW, KS): kitchen D=360 -> (3, 12); block-push D=240 -> (2, 8)
+    if (KT16 && d.D > 32 * (d.KS - 1) + 16) return false;
     return (d.RPW == 3 && d.KS == 12) || (d.RPW == 2 && d.KS == 8);
 }
 
@@ -298,6 +303,15 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
                                                    0, 0, 0);
 }
 
+// Half k-step: contraction over the FIRST 16 indices of a k-step only.  The low 8 bytes of a lane's
+// A / B fragment (slots j = 0..3) are exactly the operands of v_mfma_f32_16x16x16_bf16 for those indices
+// (index 32kk + 4g + j), so a k-step whose upper 16 indices are all padding (D = 360: indices 352..359 of
+// 352..383 are real) costs half an MFMA instead of a whole one.
+__device__ __forceinline__ f32x4 mfma_bf16_half(const u32x4& a, const u32x4& b, const f32x4& c) {
+    const uint2 a2 = make_uint2(a[0], a[1]), b2 = make_uint2(b[0], b[1]);
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a2), __builtin_bit_cast(s16x4, b2), c, 0, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // One GEMM phase of the transposed formulation:  acc[r][t] += sum_kk A(r,kk) * B(t,kk)
 //   A(r,kk) = fragment r + kk*a_ks of `a`   weights, L2 -> registers (WPtr: uniform base + lane offset)
@@ -356,7 +370,7 @@ __device__ __forceinline__ void prefetch_a(u32x4 (&aE)[R], u32x4 (&aO)[R], WPtr 
     for (int r = 0; r < R; ++r) { aE[r] = a.at(r); aO[r] = a.at(r + ABL_KS(a_ks)); }
 }
 
-template <int R, int NT>
+template <int R, int NT, bool TAIL16 = false>
 __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], u32x4 (&aO)[R],
                                            WPtr a, int a_ks, const u32x4* b, int b_ts,
                                            int b_ks, int ksteps) {
@@ -388,8 +402,16 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], 
 #pragma unroll
             for (int r = 0; r < R; ++r) aE[r] = a.at(r + ABL_KS((kk + 2) * a_ks));
         }
-        // ---- k-step kk+1 (odd fragments)
+        // ---- k-step kk+1 (odd fragments); TAIL16: the last k-step of the phase is a half k-step
+        const bool tail = TAIL16 && kk + 2 >= ksteps;
         __builtin_amdgcn_sched_barrier(0);
+        if (tail) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(aO[r], bf[t], acc[r][t]);
+            break;
+        }
 #pragma unroll
         for (int t = 0; t < H1; ++t)
 #pragma unroll
@@ -428,7 +450,7 @@ __device__ __forceinline__ void prefetch_ring(u32x4 (&ar)[PFA][R], WPtr a, int a
         for (int r = 0; r < R; ++r) ar[p][r] = a.at(r + ABL_KS(p * a_ks));
 }
 
-template <int R, int NT, int PFA>
+template <int R, int NT, int PFA, bool TAIL16 = false>
 __device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)[PFA][R],
                                                 WPtr a, int a_ks, const u32x4* b, int b_ts,
                                                 int b_ks, int ksteps) {
@@ -443,10 +465,17 @@ __device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)
         for (int p = 0; p < PFA; ++p) {
             const int kk = k0 + p;
             __builtin_amdgcn_sched_barrier(0);
+            if (TAIL16 && kk + 1 >= ksteps) {                // the last k-step of the phase is a half k-step
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(ar[p][r], bb[p & 1][t], acc[r][t]);
+                    for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(ar[p][r], bb[p & 1][t], acc[r][t]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(ar[p][r], bb[p & 1][t], acc[r][t]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (BESO_FUSED_ABLATE != 2 && !(BESO_ABL_MASK & 32) && kk + 2 < ksteps) {
 #pragma unroll
@@ -952,7 +981,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) h[r][t] = bias;
         }
-        gemm_phase_ring<RC, kNTT, PF1>(h, ar, fc1_a(c), kChunkTiles, xnT + lane, KS * 64, 64, KS);
+        gemm_phase_ring<RC, kNTT, PF1, KT16>(h, ar, fc1_a(c), kChunkTiles, xnT + lane, KS * 64, 64, KS);
     };
     auto write_hT = [&](u32x4 (&hb)[KW][kNTT]) {
 #pragma unroll
@@ -1255,7 +1284,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) qa[i][t] = bv;
         }
-        gemm_phase<3, kNTT>(qa, qE, qO, qkv_a(pair), 24, xnT + lane, KS * 64, 64, KS);
+        gemm_phase<3, kNTT, KT16>(qa, qE, qO, qkv_a(pair), 24, xnT + lane, KS * 64, 64, KS);
         prefetch_a<RPW>(aE, aO, proj_a(hA), kWaves * RPW);
         if (hsel == 0) write_qkv(qa);
         stamp(st, 11);
