@@ -378,3 +378,31 @@ def test_graphed_train_step_matches_eager(monkeypatch):
     assert np.allclose(results["1"][0], results["0"][0], rtol=1e-5, atol=1e-6), (results["1"][0], results["0"][0])
     for a, b in zip(results["1"][1], results["0"][1]):
         assert rel_err(a, b) < 5e-3            # Adam amplifies last-bit differences to O(lr), see above
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", ["kitchen", "block_push"])
+def test_fused_path_ragged_shapes_and_cfg(cfg_name):
+    """The fused layers kernel (bf16) on what rollouts feed it: B = 1, batches that do not fill a workgroup's
+    8-sample tile (or leave its last tile ragged), every warm-up window t = 1 .. W, unconditional calls, and
+    classifier-free pairs with an odd batch -- each against the oracle."""
+    from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
+    cfg = O.CONFIGS[cfg_name]
+    w = O.make_weights(cfg, seed=21, std=0.03)
+    m = make_module(cfg, w, "bf16")
+    worst = 0.0
+    with torch.no_grad():
+        for B, t in [(1, 1), (1, cfg.obs_seq_len), (3, 2), (9, cfg.obs_seq_len - 1), (37, 3), (129, cfg.obs_seq_len)]:
+            s_np, g_np, a_np = O.make_inputs(cfg, B, seed=100 * B + t, t=t)
+            sg_np = np.linspace(0.06, 1.0, B).astype(np.float32)
+            s, a, g, sg = G(s_np), G(a_np), G(g_np), G(sg_np)
+            out = m(s, a, g, sg)
+            assert out.shape == (B, t, cfg.act_dim)
+            worst = max(worst, rel_err(out.cpu().numpy(), O.denoise(w, cfg, s_np, a_np, g_np, sg_np)))
+            out_u = m(s, a, g, sg, uncond=True)
+            worst = max(worst, rel_err(out_u.cpu().numpy(), O.denoise(w, cfg, s_np, a_np, g_np, sg_np, uncond=True)))
+            out_cfg = ClassifierFreeSampleModel(m, 2.0)(s, a, g, sg)
+            ref_cfg = O.denoise_cfg(w, cfg, s_np, a_np, g_np, sg_np, 2.0)
+            worst = max(worst, rel_err(out_cfg.cpu().numpy(), ref_cfg))
+    print(f"[parity] fused ragged/CFG {cfg_name} bf16: {worst:.3e}")
+    assert worst < TOL["bf16"]
