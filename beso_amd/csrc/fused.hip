@@ -128,12 +128,13 @@ bool fused_dims(const Layout& lay, FusedDims* d) {
 
 // The kernels run the last k-step of the K = D contractions as a HALF k-step (mfma_bf16_half): the shapes
 // they are used for must have at most 16 real indices there.
-constexpr bool KT16 = true;
+// (KS = 12: D = 360 and KS = 8: D = 240 qualify; the KS = 16 instance serves D = 512, a full tail.)
+constexpr bool kt16(int KS) { return KS == 12 || KS == 8; }
 
 bool shape_has_kernel(const FusedDims& d) {
-    // instantiated (RPW, KS): kitchen D=360 -> (3, 12); block-push D=240 -> (2, 8)
-    if (KT16 && d.D > 32 * (d.KS - 1) + 16) return false;
-    return (d.RPW == 3 && d.KS == 12) || (d.RPW == 2 && d.KS == 8);
+    // instantiated (RPW, KS): kitchen D=360 -> (3, 12); block-push D=240 -> (2, 8); long-horizon D=512 -> (4, 16), MLP block only
+    if (kt16(d.KS) && d.D > 32 * (d.KS - 1) + 16) return false;
+    return (d.RPW == 3 && d.KS == 12) || (d.RPW == 2 && d.KS == 8) || (d.RPW == 4 && d.KS == 16);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -492,15 +493,17 @@ __device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)
 // ---------------------------------------------------------------------------------------------
 // shared pieces of the kernels
 // ---------------------------------------------------------------------------------------------
+constexpr int kKCc = kChunkTiles / 2;      // FC2 k-steps per hidden chunk (= kKC below)
 struct LdsMap {            // byte offsets inside the dynamic LDS block
     int xnT, u, red, tab, total;
 };
-__host__ __device__ constexpr LdsMap lds_map(int KS) {
-    // u is the phase-local region: attention (q/k/v 3*104*72*2 = 44928 | yT 12288) or MLP (hT 6*8 KiB = 49152)
+__host__ __device__ constexpr LdsMap lds_map(int KS, bool mlp_only = false) {
+    // u is the phase-local region: attention (q/k/v 3*104*72*2 = 44928 | yT 12288) or MLP (hT 6*8 KiB = 49152);
+    // the MLP-block kernel needs only the latter (which lets D = 512, KS = 16: 96 KiB of xnT, fit in 160 KiB)
     LdsMap m{};
     m.xnT = 0;
     m.u = kNTT * KS * 1024;
-    m.red = m.u + 59648;
+    m.red = m.u + (mlp_only ? kNTT * kKCc * 1024 : 59648);
     m.tab = m.red + 2 * kWaves * kMT * 4;
     m.total = m.tab + 512;
     return m;
@@ -981,7 +984,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) h[r][t] = bias;
         }
-        gemm_phase_ring<RC, kNTT, PF1, KT16>(h, ar, fc1_a(c), kChunkTiles, xnT + lane, KS * 64, 64, KS);
+        gemm_phase_ring<RC, kNTT, PF1, kt16(KS)>(h, ar, fc1_a(c), kChunkTiles, xnT + lane, KS * 64, 64, KS);
     };
     auto write_hT = [&](u32x4 (&hb)[KW][kNTT]) {
 #pragma unroll
@@ -1284,7 +1287,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) qa[i][t] = bv;
         }
-        gemm_phase<3, kNTT, KT16>(qa, qE, qO, qkv_a(pair), 24, xnT + lane, KS * 64, 64, KS);
+        gemm_phase<3, kNTT, kt16(KS)>(qa, qE, qO, qkv_a(pair), 24, xnT + lane, KS * 64, 64, KS);
         prefetch_a<RPW>(aE, aO, proj_a(hA), kWaves * RPW);
         if (hsel == 0) write_qkv(qa);
         stamp(st, 11);
@@ -1320,7 +1323,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_block_kernel(flo
                                                            FusedDims d, int M, unsigned long long* stamps, int cap) {
     Stamps st{stamps, cap, 0};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr LdsMap L = lds_map(KS);
+    constexpr LdsMap L = lds_map(KS, true);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
@@ -1414,7 +1417,7 @@ hipError_t ensure_lds(K kernel, size_t bytes, bool* done) {
 
 template <int RPW, int KS, int NW>
 hipError_t launch_mlp_block(float* x, const char* lw, const FusedDims& d, int M, hipStream_t s) {
-    constexpr LdsMap L = lds_map(KS);
+    constexpr LdsMap L = lds_map(KS, true);
     static bool attr = false;
     hipError_t e = ensure_lds(mlp_block_kernel<RPW, KS, NW>, L.total, &attr);
     if (e != hipSuccess) return e;
@@ -1547,6 +1550,7 @@ int fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, 
     // (a 4-wave, 512-VGPR instance <6, 12, 4> of the same phase code was measured no faster than <3, 12, 8>)
     if (d.RPW == 3 && d.KS == 12) e = launch_mlp_block<3, 12, 8>(x, base, d, M, s);
     else if (d.RPW == 2 && d.KS == 8) e = launch_mlp_block<2, 8, 8>(x, base, d, M, s);
+    else if (d.RPW == 4 && d.KS == 16) e = launch_mlp_block<4, 16, 8>(x, base, d, M, s);
     else return BESO_ERR_UNSUPPORTED;
     return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
