@@ -25,6 +25,7 @@ from ... import distributed as bdist
 from ..._instantiate import instantiate
 from ...networks.ema_helper.ema import ExponentialMovingAverage
 from ...optim import FusedAdam, maybe_fuse
+from ...data.prefetch import DevicePrefetcher
 from ..base_agent import BaseAgent
 from .k_diffusion import gc_sampling as ks
 from .k_diffusion import utils
@@ -178,6 +179,8 @@ class BesoAgent(BaseAgent):
         """max_train_steps optimizer steps; every eval_every_n_steps: test MSE of the sampler and a
         checkpoint on improvement (beso_agent.py:177-213)."""
         best_test_mse, avg_test_mse = 1e10, 1e10
+        # next batch is copied host -> device on a side stream while the current step runs
+        train_loader = DevicePrefetcher(train_loader, self.device)
         stream = iter(train_loader)
         for step in range(self.max_train_steps):
             if not self.steps % self.eval_every_n_steps:

@@ -406,3 +406,16 @@ def test_fused_path_ragged_shapes_and_cfg(cfg_name):
             worst = max(worst, rel_err(out_cfg.cpu().numpy(), ref_cfg))
     print(f"[parity] fused ragged/CFG {cfg_name} bf16: {worst:.3e}")
     assert worst < TOL["bf16"]
+
+
+@pytest.mark.gpu
+def test_device_prefetcher_on_gpu():
+    """Batches arrive on the device, complete and in order, while their staging buffers are being reused."""
+    from beso_amd.data import DevicePrefetcher
+    batches = [{"observation": torch.full((64, 4, 30), float(i)), "action": torch.full((64, 4, 9), float(-i)), "i": i}
+               for i in range(9)]
+    seen = []
+    for b in DevicePrefetcher(batches, DEV, depth=2):
+        assert b["observation"].is_cuda and b["action"].is_cuda
+        seen.append((b["i"], float(b["observation"].sum().item()), float(b["action"].sum().item())))
+    assert seen == [(i, 64 * 4 * 30 * float(i), 64 * 4 * 9 * float(-i)) for i in range(9)]

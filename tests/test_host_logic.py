@@ -308,3 +308,16 @@ def test_fused_optimizer_is_not_used_on_cpu():
         f.step()                                              # CPU parameters: refused, no fallback
     with pytest.raises(ValueError):
         FusedAdam(p, lr=-1.0)
+
+
+def test_device_prefetcher_passthrough_and_order():
+    """DevicePrefetcher yields every batch once, in order, with non-tensor entries untouched; on a CPU device it
+    hands the loader's own objects through."""
+    from beso_amd.data import DevicePrefetcher
+    batches = [{"observation": torch.full((2, 3), float(i)), "action": torch.full((2, 1), float(-i)), "tag": f"b{i}"}
+               for i in range(5)]
+    got = list(DevicePrefetcher(batches, "cpu", depth=2))
+    assert [b["tag"] for b in got] == [f"b{i}" for i in range(5)]
+    assert all(g is b for g, b in zip(got, batches))
+    assert len(DevicePrefetcher(batches, "cpu")) == 5
+    assert list(DevicePrefetcher([], "cpu")) == []
