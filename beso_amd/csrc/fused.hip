@@ -744,12 +744,14 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
     // up front; kEmbObsK / kEmbActK bound obs / act (fused_level).
     stamp(st, 40);
     float aT[kEmbObsK][RPW], bT[kEmbObsK][kNTT], aA[kEmbActK][RPW], bA[kEmbActK][kNTT];
-    auto load = [&](const float* wT, int n_in, int kk, float (&a_)[RPW], float (&b_)[kNTT]) {
+    // A token's source row has obs (state / goal) or act (action) elements: a row is only ever read by the
+    // pass it belongs to -- every other token reads the (always long enough) weight table instead.
+    auto load = [&](const float* wT, int n_in, int want, int kk, float (&a_)[RPW], float (&b_)[kNTT]) {
         const int cl = min(4 * kk + g, n_in - 1);
 #pragma unroll
         for (int i = 0; i < RPW; ++i) a_[i] = wT[(size_t)cl * Dp + 16 * (w * RPW + i) + n];
 #pragma unroll
-        for (int t = 0; t < kNTT; ++t) b_[t] = src[t][cl];
+        for (int t = 0; t < kNTT; ++t) b_[t] = (kind[t] == want ? src[t] : wT)[cl];
     };
     auto mask = [&](int n_in, int want, int kk, float (&a_)[RPW], float (&b_)[kNTT]) {
         const bool cv = 4 * kk + g < n_in;
@@ -759,9 +761,9 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
         for (int t = 0; t < kNTT; ++t) b_[t] = (cv && kind[t] == want) ? b_[t] * scale[t] : 0.f;
     };
 #pragma unroll
-    for (int kk = 0; kk < kEmbObsK; ++kk) load(tokT, d.obs, kk, aT[kk], bT[kk]);
+    for (int kk = 0; kk < kEmbObsK; ++kk) load(tokT, d.obs, 1, kk, aT[kk], bT[kk]);
 #pragma unroll
-    for (int kk = 0; kk < kEmbActK; ++kk) load(actT, d.act, kk, aA[kk], bA[kk]);
+    for (int kk = 0; kk < kEmbActK; ++kk) load(actT, d.act, 2, kk, aA[kk], bA[kk]);
     stamp(st, 41);
     // biases, positions, sigma token: the accumulators start from them
     float lsig[kNTT];
