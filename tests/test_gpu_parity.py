@@ -7,6 +7,7 @@ Tolerances (relative to max |reference| over the output tensor):
               measured values are printed and recorded in DESIGN.md (typically 2e-3 .. 8e-3).
 """
 import functools
+import os
 
 import numpy as np
 import pytest
@@ -419,3 +420,17 @@ def test_device_prefetcher_on_gpu():
         assert b["observation"].is_cuda and b["action"].is_cuda
         seen.append((b["i"], float(b["observation"].sum().item()), float(b["action"].sum().item())))
     assert seen == [(i, 64 * 4 * 30 * float(i), 64 * 4 * 9 * float(-i)) for i in range(9)]
+
+
+@pytest.mark.gpu
+def test_no_reads_past_the_end_of_the_inputs():
+    """tools/guard_check.py in a subprocess with the caching allocator off: inputs sit at the end of their own
+    allocations, so an out-of-bounds read by any kernel on the path is a GPU memory fault (process abort)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTORCH_NO_CUDA_MEMORY_CACHING="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "guard_check.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "no fault" in r.stdout
