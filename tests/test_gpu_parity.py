@@ -434,3 +434,47 @@ def test_no_reads_past_the_end_of_the_inputs():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "no fault" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name,precision", [("kitchen", "bf16"), ("kitchen", "fp32"), ("block_push", "bf16"),
+                                                ("long_horizon", "bf16")])
+def test_no_writes_outside_output_and_workspace(cfg_name, precision):
+    """beso_denoise_fwd / beso_sample through the C ABI with the output, the in/out sample and the workspace
+    embedded in larger buffers full of sentinel bytes: nothing outside [ptr, ptr + size) may change."""
+    import ctypes as C
+    from beso_amd import _lib
+    cfg = O.CONFIGS[cfg_name]
+    m = make_module(cfg, O.make_weights(cfg, seed=4, std=0.03), precision)
+    inner = m.inner_model
+    rt, packed = inner.runtime(cfg.sigma_data), inner.packed_weights()
+    lib = rt.lib
+    PAD = 4096
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    shapes = [(1, 1), (5, cfg.obs_seq_len), (67, cfg.obs_seq_len)] if cfg_name != "long_horizon" else [(2, cfg.obs_seq_len)]
+    for B, t in shapes:
+        s_np, g_np, a_np = O.make_inputs(cfg, B, seed=B + 3 * t, t=t)
+        s, g, a = G(s_np), G(g_np), G(a_np)
+        sg = G(np.linspace(0.1, 0.9, B).astype(np.float32))
+        for lam in (1.0, 2.0):
+            two = 1 if lam != 1.0 else 0
+            ws_bytes = lib.beso_workspace_bytes(C.byref(rt.cfg), B, t, packed.precision, two)
+            wsbig = torch.full((ws_bytes + 2 * PAD,), 0xAB, dtype=torch.uint8, device=DEV)
+            n_out = B * t * cfg.act_dim
+            outbig = torch.full((n_out + 2048,), -777.0, device=DEV)
+            xbig = torch.full((n_out + 2048,), -777.0, device=DEV)
+            xbig[1024:1024 + n_out] = a.reshape(-1)
+            st = lib.beso_denoise_fwd(C.byref(rt.cfg), packed.buf.data_ptr(), packed.precision, s.data_ptr(), a.data_ptr(),
+                                      g.data_ptr(), sg.data_ptr(), outbig.data_ptr() + 4096, B, t, 0, lam,
+                                      wsbig.data_ptr() + PAD, ws_bytes, stream)
+            _lib.check(st, "denoise_fwd")
+            sig = (C.c_float * 4)(1.0, 0.3, 0.05, 0.0)
+            st = lib.beso_sample(C.byref(rt.cfg), packed.buf.data_ptr(), packed.precision, _lib.SAMPLER_IDS["heun"],
+                                 s.data_ptr(), g.data_ptr(), xbig.data_ptr() + 4096, B, t, sig, 4, lam,
+                                 wsbig.data_ptr() + PAD, ws_bytes, stream)
+            _lib.check(st, "sample")
+            torch.cuda.synchronize()
+            assert bool((wsbig[:PAD] == 0xAB).all()) and bool((wsbig[PAD + ws_bytes:] == 0xAB).all()), (B, t, lam, "workspace")
+            for big in (outbig, xbig):
+                assert bool((big[:1024] == -777.0).all()) and bool((big[1024 + n_out:] == -777.0).all()), (B, t, lam)
+                assert torch.isfinite(big[1024:1024 + n_out]).all()
