@@ -17,6 +17,7 @@ from bench import build_model  # noqa: E402
 from oracle import beso_oracle as O  # noqa: E402
 from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks  # noqa: E402
 from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel  # noqa: E402
+from beso_amd.runtime import PackedWeights  # noqa: E402
 
 PAGE = 2 << 20            # allocation granule assumed for the tail placement (2 MiB fragments)
 
@@ -40,6 +41,17 @@ def main():
         w = O.make_weights(cfg, seed=1, std=0.03)
         for precision in precisions:
             model = build_model(cfg, w, precision, dev)
+            # the packed weight image too: re-packed into a buffer that ends where its allocation ends
+            inner = model.inner_model
+            rt = inner.runtime(cfg.sigma_data)
+            nbytes = inner.packed_weights().buf.numel()
+            total = ((nbytes + PAGE - 1) // PAGE) * PAGE
+            big = torch.empty(total, dtype=torch.uint8, device=dev)
+            tail = PackedWeights(big[total - nbytes:], inner.packed_weights().precision, None)
+            assert tail.buf.data_ptr() % 256 == 0
+            rt.pack([p for p in inner.parameters()], into=tail)
+            scope = inner.use_weights(tail)
+            scope.__enter__()
             cfgm = ClassifierFreeSampleModel(model, 2.0)
             shapes = [(1, 1), (1, cfg.obs_seq_len), (3, max(1, cfg.obs_seq_len - 1)), (8, cfg.obs_seq_len), (9, 2),
                       (65, cfg.obs_seq_len)]
@@ -49,6 +61,13 @@ def main():
                 s_np, g_np, a_np = O.make_inputs(cfg, B, seed=B * 7 + t, t=t)
                 s, g, a = at_tail(s_np, dev), at_tail(g_np, dev), at_tail(a_np, dev)
                 sg = at_tail(np.linspace(0.1, 0.9, B).astype(np.float32), dev)
+                # ... and the workspace: exactly the size the library asks for, ending where its allocation ends
+                import ctypes as C
+                need = rt.lib.beso_workspace_bytes(C.byref(rt.cfg), B, t, rt.precision, 1)
+                wtotal = ((need + PAGE - 1) // PAGE) * PAGE
+                wbig = torch.empty(wtotal, dtype=torch.uint8, device=dev)
+                rt._ws = wbig[wtotal - need:]
+                assert rt._ws.data_ptr() % 256 == 0
                 with torch.no_grad():
                     out = model(s, a, g, sg)
                     out_u = model(s, a, g, sg, uncond=True)
@@ -57,7 +76,8 @@ def main():
                     torch.cuda.synchronize()
                 assert all(torch.isfinite(x).all() for x in (out, out_u, out_c, smp))
                 n_calls += 4
-    print(f"guard_check: {n_calls} calls with inputs at the end of their allocations, no fault")
+            scope.__exit__(None, None, None)
+    print(f"guard_check: {n_calls} calls with inputs, packed weights and workspace at the end of their allocations, no fault")
 
 
 if __name__ == "__main__":
