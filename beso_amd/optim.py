@@ -5,7 +5,9 @@
 configs/agents/beso_kitchen.yaml:9-12, beso_block_push.yaml:9-11), so LR schedulers attach to it
 unchanged.  ``step()`` updates ALL parameters -- and, when an EMA helper is handed over, its shadow copy
 (ema.py:45-53) -- in one HIP launch (``beso_adam_step``) instead of several hundred eager launches.
-There is no CPU implementation: ``maybe_fuse`` leaves a CPU optimizer untouched."""
+There is no CPU implementation: ``maybe_fuse`` leaves a CPU optimizer untouched.  The moments live in flat
+buffers owned by the optimizer object (not in ``Optimizer.state``): like the reference's training loop
+(``beso_agent.py:466-476`` stores model weights only) optimizer state is not checkpointed."""
 from __future__ import annotations
 
 import ctypes as C
