@@ -156,22 +156,38 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
         HIP_TRY(launch_embed(lay, packed, a, x, s));
         profile_end(BESO_SITE_EMBED, s);
     }
+    const bool lin_blocks = fused == 1 && fused_has_lin_blocks(lay, precision);
     for (int l = 0; l < (fused == 2 ? 0 : lay.L); ++l) {
         const LayerOff& o = lay.layer[l];
-        profile_begin(BESO_SITE_LAYERNORM, s);
-        HIP_TRY(launch_layernorm(x, F(o.ln1_w), F(o.ln1_b), xn, M, lay.D, lay.Kd, precision, s));
-        profile_end(BESO_SITE_LAYERNORM, s);
-        profile_begin(BESO_SITE_GEMM_QKV, s);
-        HIP_TRY(launch_gemm(precision, EPI_BIAS_STORE, xn, lay.Kd, packed + o.w_qkv, lay.Kd, F(o.b_qkv), qkv,
-                            3 * lay.D, 3 * lay.D, M, lay.Nqkv, lay.Kd, s));
-        profile_end(BESO_SITE_GEMM_QKV, s);
-        profile_begin(BESO_SITE_ATTENTION, s);
-        HIP_TRY(launch_attention(qkv, y, a.vbatch, a.T, lay.D, lay.H, lay.Kd, precision, s));
-        profile_end(BESO_SITE_ATTENTION, s);
-        profile_begin(BESO_SITE_GEMM_PROJ, s);
-        HIP_TRY(launch_gemm(precision, EPI_BIAS_RESID, y, lay.Kd, packed + o.w_proj, lay.Kd, F(o.b_proj), x, lay.D,
-                            lay.D, M, lay.Nd, lay.Kd, s));
-        profile_end(BESO_SITE_GEMM_PROJ, s);
+        if (lin_blocks) {
+            // LN1 + q/k/v and proj + residual as MLP-block style kernels (long sequences: no fused attention phase)
+            profile_begin(BESO_SITE_GEMM_QKV, s);
+            int st = fused_lin_block(lay, packed, l, 0, x, qkv, 3 * lay.D, M, s);
+            profile_end(BESO_SITE_GEMM_QKV, s);
+            if (st != BESO_OK) return st;
+            profile_begin(BESO_SITE_ATTENTION, s);
+            HIP_TRY(launch_attention(qkv, y, a.vbatch, a.T, lay.D, lay.H, lay.Kd, precision, s));
+            profile_end(BESO_SITE_ATTENTION, s);
+            profile_begin(BESO_SITE_GEMM_PROJ, s);
+            st = fused_lin_block(lay, packed, l, 1, x, y, lay.Kd, M, s);
+            profile_end(BESO_SITE_GEMM_PROJ, s);
+            if (st != BESO_OK) return st;
+        } else {
+            profile_begin(BESO_SITE_LAYERNORM, s);
+            HIP_TRY(launch_layernorm(x, F(o.ln1_w), F(o.ln1_b), xn, M, lay.D, lay.Kd, precision, s));
+            profile_end(BESO_SITE_LAYERNORM, s);
+            profile_begin(BESO_SITE_GEMM_QKV, s);
+            HIP_TRY(launch_gemm(precision, EPI_BIAS_STORE, xn, lay.Kd, packed + o.w_qkv, lay.Kd, F(o.b_qkv), qkv,
+                                3 * lay.D, 3 * lay.D, M, lay.Nqkv, lay.Kd, s));
+            profile_end(BESO_SITE_GEMM_QKV, s);
+            profile_begin(BESO_SITE_ATTENTION, s);
+            HIP_TRY(launch_attention(qkv, y, a.vbatch, a.T, lay.D, lay.H, lay.Kd, precision, s));
+            profile_end(BESO_SITE_ATTENTION, s);
+            profile_begin(BESO_SITE_GEMM_PROJ, s);
+            HIP_TRY(launch_gemm(precision, EPI_BIAS_RESID, y, lay.Kd, packed + o.w_proj, lay.Kd, F(o.b_proj), x, lay.D,
+                                lay.D, M, lay.Nd, lay.Kd, s));
+            profile_end(BESO_SITE_GEMM_PROJ, s);
+        }
         if (fused == 1) {
             // LN2 + FC1 + GELU + FC2 + residual as one kernel, hidden activations never leave the CU
             profile_begin(BESO_SITE_FUSED_LAYER, s);

@@ -11,6 +11,9 @@ bool   fused_supported(const Layout& lay, const FwdArgs& a, int precision);
 int    fused_level(const Layout& lay, const FwdArgs& a, int precision);   // 0 none, 1 MLP block, 2 whole layers
 int    fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, hipStream_t s);
 int    fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, int M, hipStream_t s);
+bool   fused_has_lin_blocks(const Layout& lay, int precision);
+int    fused_lin_block(const Layout& lay, const char* packed, int layer, int which, float* x, void* buf, int ld, int M,
+                       hipStream_t s);
 void   fused_set_stamps(void* buf, int cap);
 int    forward_fused(const Layout& lay, const Workspace& ws, const char* packed, int precision, const FwdArgs& a,
                      char* wsp, hipStream_t s);

@@ -66,6 +66,10 @@ struct FusedDims {
     // (32-bit: the struct is a kernel argument and every field the kernel touches costs SGPRs)
     uint32_t w1_bytes, b1_bytes, w2_bytes, b2_bytes, wqkv_bytes, bqkv_bytes, wproj_bytes, bproj_bytes, layer_bytes;
     uint32_t o_b1, o_w2, o_b2, o_wqkv, o_bqkv, o_wproj, o_bproj;
+    // shapes without the attention phase (long sequences): q/k/v and proj as MLP-block style kernels, natural
+    // [q | k | v] row order, one part = 8*RPW row tiles
+    int lin;
+    uint32_t o_wqkv_lin, o_bqkv_lin, o_wproj_lin, o_bproj_lin, part_bytes;
     // per-model image behind the L per-layer images (fp32): embeddings transposed to [in][Dp], head with ln_f folded
     int Dp, obs, act, seq, G, L, head_fused;
     uint32_t g_tokT, g_tokb, g_actT, g_actb, g_sigw, g_sigb, g_pos, g_headw, g_headb, global_bytes;
@@ -112,6 +116,17 @@ bool fused_dims(const Layout& lay, FusedDims* d) {
     d->o_wproj = d->o_bqkv + d->bqkv_bytes;
     d->o_bproj = d->o_wproj + d->wproj_bytes;
     d->layer_bytes = d->o_bproj + d->bproj_bytes;
+    d->lin = d->attn ? 0 : 1;
+    d->part_bytes = (uint32_t)(rt2 * d->KS * 1024);
+    if (d->lin) {
+        d->o_wqkv_lin = d->layer_bytes;
+        d->o_bqkv_lin = d->o_wqkv_lin + 3 * d->part_bytes;
+        d->o_wproj_lin = d->o_bqkv_lin + (uint32_t)round_up_sz(3 * rt2 * 16 * sizeof(float), 256);
+        d->o_bproj_lin = d->o_wproj_lin + d->part_bytes;
+        d->layer_bytes = d->o_bproj_lin + (uint32_t)round_up_sz(rt2 * 16 * sizeof(float), 256);
+    } else {
+        d->o_wqkv_lin = d->o_bqkv_lin = d->o_wproj_lin = d->o_bproj_lin = 0;
+    }
     d->Dp = d->RPW * kWaves * 16;
     d->obs = lay.obs; d->act = lay.act; d->seq = lay.seq_size; d->G = lay.G; d->L = lay.L;
     d->head_fused = lay.linear_output && lay.act <= 16;
@@ -623,7 +638,7 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
 // even are the two halves of one k-step fragment and go out as one 16-byte LDS write per lane.
 // NOTE: the red[] buffer is re-used by the next LayerNorm; the barrier at the end of this function (and
 // the phases in between) orders the reads above against those writes.
-template <int RPW, int KS, int NW>
+template <int RPW, int KS, int NW, bool ADD_BIAS = true>
 __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float* red, int D, int w, int lane,
                                                  const float* __restrict__ bias, Stamps& st) {
     // `lane` is made opaque at the top of every phase: otherwise the per-lane address arithmetic of ALL
@@ -670,11 +685,13 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         if (w & 1) { write_single(0); write_pair(1); }
         else { write_pair(0); write_single(2); }
     }
+    if constexpr (ADD_BIAS) {
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const f32x4 bv = *(const f32x4*)(bias + 16 * (w * RPW + i) + 4 * g);
+        for (int i = 0; i < RPW; ++i) {
+            const f32x4 bv = *(const f32x4*)(bias + 16 * (w * RPW + i) + 4 * g);
 #pragma unroll
-        for (int t = 0; t < kNTT; ++t) T.acc[i][t] += bv;
+            for (int t = 0; t < kNTT; ++t) T.acc[i][t] += bv;
+        }
     }
     stamp(st, 34);
     __syncthreads();
@@ -1340,6 +1357,102 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_block_kernel(flo
     store_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
 }
 
+// LN1 + q/k/v projection of a 96-token tile for shapes whose sequences are too long for the fused attention
+// phase (score_gpts.py:58-66 after :113's ln1): qkv[M][3D] bf16, rows [q | k | v], for the attention kernel.
+template <int RPW, int KS>
+__global__ __launch_bounds__(512, 2) void qkv_block_kernel(const float* __restrict__ x, const char* __restrict__ lw,
+                                                           FusedDims d, int M, uint16_t* __restrict__ qkv,
+                                                           unsigned long long* stamps, int cap) {
+    Stamps st{stamps, cap, 0};
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr LdsMap L = lds_map(KS, true);
+    int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * kMT;
+    const u32x4* xnT = (const u32x4*)(lds + L.xnT);
+    {
+        Tile<RPW> T;
+        load_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
+        layernorm_to_lds<RPW, KS, kWaves, false>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane, nullptr, st);
+    }
+    const size_t ldq = (size_t)3 * d.D;
+#pragma unroll 1
+    for (int part = 0; part < 3; ++part) {
+        asm volatile("" : "+v"(lane));
+        const int gg = lane >> 4, nn = lane & 15;
+        f32x4 qa[RPW][kNTT];
+        const float* bq = (const float*)(lw + d.o_bqkv_lin) + (size_t)part * (kWaves * RPW * 16);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const f32x4 bv = *(const f32x4*)(bq + 16 * (w * RPW + i) + 4 * gg);
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) qa[i][t] = bv;
+        }
+        u32x4 aE[RPW], aO[RPW];
+        const WPtr a = wptr((const u32x4*)(lw + d.o_wqkv_lin + (size_t)part * d.part_bytes) + (size_t)(w * RPW) * 64, lane);
+        prefetch_a<RPW>(aE, aO, a, kWaves * RPW);
+        gemm_phase<RPW, kNTT, kt16(KS)>(qa, aE, aO, a, kWaves * RPW, xnT + lane, KS * 64, 64, KS);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int f0 = 16 * (w * RPW + i) + 4 * gg;
+            if (f0 < d.D) {
+#pragma unroll
+                for (int t = 0; t < kNTT; ++t) {
+                    const int tok = m0 + 16 * t + nn;
+                    if (tok < M) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(qa[i][t][0], qa[i][t][1]);
+                        pk.y = pack_bf16x2(qa[i][t][2], qa[i][t][3]);
+                        *(uint2*)(qkv + (size_t)tok * ldq + (size_t)part * d.D + f0) = pk;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Out-projection of the attention output + residual add on a 96-token tile (score_gpts.py:79, :113): the
+// y rows (bf16, row-major) are re-read as B fragments (two 8-byte pieces per lane and fragment).
+template <int RPW, int KS>
+__global__ __launch_bounds__(512, 2) void proj_block_kernel(float* __restrict__ x, const char* __restrict__ lw, FusedDims d,
+                                                            int M, const uint16_t* __restrict__ y, int ld_y,
+                                                            unsigned long long* stamps, int cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr LdsMap L = lds_map(KS, true);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * kMT;
+    u32x4* yT = (u32x4*)(lds + L.xnT);
+    for (int f = w; f < kNTT * KS; f += kWaves) {
+        const int t = f / KS, kk = f - t * KS;
+        const int tok = m0 + 16 * t + n;
+        uint2 lo = make_uint2(0u, 0u), hi = lo;
+        if (tok < M) {
+            const uint16_t* row = y + (size_t)tok * ld_y + 32 * kk + 4 * g;
+            lo = *(const uint2*)row;
+            hi = *(const uint2*)(row + 16);
+        }
+        yT[(size_t)f * 64 + lane] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+    Tile<RPW> T;
+    load_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
+    u32x4 aE[RPW], aO[RPW];
+    const WPtr a = wptr((const u32x4*)(lw + d.o_wproj_lin) + (size_t)(w * RPW) * 64, lane);
+    prefetch_a<RPW>(aE, aO, a, kWaves * RPW);
+    __syncthreads();
+    gemm_phase<RPW, kNTT, kt16(KS)>(T.acc, aE, aO, a, kWaves * RPW, (const u32x4*)yT + lane, KS * 64, 64, KS);
+    const float* bp = (const float*)(lw + d.o_bproj_lin);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const f32x4 bv = *(const f32x4*)(bp + 16 * (w * RPW + i) + 4 * g);
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) T.acc[i][t] += bv;
+    }
+    store_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
+}
+
 // Whole transformer layers [l0, l1) over the tile's 8 samples; x stays in registers in between.
 template <int RPW, int KS, int HG>
 __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, const char* __restrict__ lw0,
@@ -1428,6 +1541,24 @@ hipError_t launch_mlp_block(float* x, const char* lw, const FusedDims& d, int M,
     return hipGetLastError();
 }
 
+template <int RPW, int KS>
+hipError_t launch_lin_blocks(int which, float* x, const char* lw, const FusedDims& d, int M, void* buf, int ld, hipStream_t s) {
+    constexpr LdsMap L = lds_map(KS, true);
+    static bool attr_q = false, attr_p = false;
+    hipError_t e = which == 0 ? ensure_lds(qkv_block_kernel<RPW, KS>, L.total, &attr_q)
+                              : ensure_lds(proj_block_kernel<RPW, KS>, L.total, &attr_p);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    const dim3 grid((M + kMT - 1) / kMT), block(512);
+    if (which == 0)
+        hipLaunchKernelGGL((qkv_block_kernel<RPW, KS>), grid, block, L.total, s, (const float*)x, lw, d, M, (uint16_t*)buf,
+                           g_stamps, g_stamps_cap);
+    else
+        hipLaunchKernelGGL((proj_block_kernel<RPW, KS>), grid, block, L.total, s, x, lw, d, M, (const uint16_t*)buf, ld,
+                           g_stamps, g_stamps_cap);
+    return hipGetLastError();
+}
+
 template <int RPW, int KS, int HG>
 hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
                          const EdgeArgs& edge, hipStream_t s) {
@@ -1486,6 +1617,21 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
                                d.hdv, rt2);
             FTRY(hipGetLastError());
             FTRY(launch_pack_matrix(pb, 1, D, base + d.o_bproj, 1, rt2 * 16, -1, s));
+        }
+        if (d.lin) {
+            const float* ws3[3] = {qw, kw, vw};
+            const float* bs3[3] = {qb, kb, vb};
+            (void)hipGetLastError();
+            for (int part = 0; part < 3; ++part) {
+                hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, ws3[part], D, D, ln1w,
+                                   (uint16_t*)(base + d.o_wqkv_lin + (size_t)part * d.part_bytes), rt2, d.KS, rt2);
+                hipLaunchKernelGGL(fold_bias_kernel, dim3((rt2 * 16 + 255) / 256), dim3(256), 0, s, ws3[part], bs3[part], ln1b,
+                                   (float*)(base + d.o_bqkv_lin) + (size_t)part * rt2 * 16, D, D, rt2 * 16);
+            }
+            hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, pw, D, D, (const float*)nullptr,
+                               (uint16_t*)(base + d.o_wproj_lin), rt2, d.KS, rt2);
+            FTRY(hipGetLastError());
+            FTRY(launch_pack_matrix(pb, 1, D, base + d.o_bproj_lin, 1, rt2 * 16, -1, s));
         }
     }
     if (d.attn) {
@@ -1553,6 +1699,25 @@ int fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, 
     if (d.RPW == 3 && d.KS == 12) e = launch_mlp_block<3, 12, 8>(x, base, d, M, s);
     else if (d.RPW == 2 && d.KS == 8) e = launch_mlp_block<2, 8, 8>(x, base, d, M, s);
     else if (d.RPW == 4 && d.KS == 16) e = launch_mlp_block<4, 16, 8>(x, base, d, M, s);
+    else return BESO_ERR_UNSUPPORTED;
+    return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+// LN1 + q/k/v (which = 0: buf = qkv[M][3D] bf16 out) / proj + residual (which = 1: buf = y[M][ld] bf16 in) blocks
+// for shapes without the fused attention phase; false if this shape has no such kernels.
+bool fused_has_lin_blocks(const Layout& lay, int precision) {
+    FusedDims d;
+    if (precision != BESO_PREC_BF16 || lay.fused == lay.total || !fused_dims(lay, &d) || !shape_has_kernel(d)) return false;
+    return d.lin && d.RPW == 4 && d.KS == 16 && d.D == 16 * kWaves * d.RPW;
+}
+
+int fused_lin_block(const Layout& lay, const char* packed, int layer, int which, float* x, void* buf, int ld, int M,
+                    hipStream_t s) {
+    FusedDims d;
+    if (!fused_dims(lay, &d) || !d.lin) return BESO_ERR_UNSUPPORTED;
+    const char* base = packed + lay.fused + (size_t)layer * d.layer_bytes;
+    hipError_t e;
+    if (d.RPW == 4 && d.KS == 16) e = launch_lin_blocks<4, 16>(which, x, base, d, M, buf, ld, s);
     else return BESO_ERR_UNSUPPORTED;
     return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
