@@ -86,8 +86,9 @@ def load() -> C.CDLL:
         lib.beso_profile_enable.argtypes = [i32]
         lib.beso_debug_set_stamps.restype = None
         lib.beso_debug_set_stamps.argtypes = [vp, i32]
-        lib.beso_adam_step.restype = i32
-        lib.beso_adam_step.argtypes = [vp, i32, vp, vp, vp, f32, f32, f32, f32, f32, i32, i32, f32, vp]
+        if hasattr(lib, "beso_adam_step") or not os.environ.get("BESO_HIP_LIB"):   # (A/B builds of older revisions)
+            lib.beso_adam_step.restype = i32
+            lib.beso_adam_step.argtypes = [vp, i32, vp, vp, vp, f32, f32, f32, f32, f32, i32, i32, f32, vp]
         lib.beso_profile_read.restype = i32
         lib.beso_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
         _lib = lib

@@ -2,7 +2,7 @@
 """Development aid: build and time compile-time variants of the fused kernel in one GPU call.
 
     python tools/variants.py build  name1=-DFLAG=1,-DX=2  name2=@<git-rev>,...   (CPU box: hipcc cross-compile;
-                                                                       "@rev" = fused.hip as of that commit)
+                                                                       "@rev" = all of csrc/ as of that commit)
     python tools/variants.py time   [--batch 4096] [--stamps]           (GPU box: times every built variant)
 
 Variants are libbeso_hip_<name>.so under beso_amd/lib/variants/ (only fused.hip is recompiled; the other
@@ -24,31 +24,42 @@ def build(specs):
     os.makedirs(VDIR, exist_ok=True)
     for f in os.listdir(VDIR):
         os.remove(os.path.join(VDIR, f))
-    procs = []
+    jobs = []
     for spec in specs:
         name, _, flags = spec.partition("=")
         flags = [f for f in flags.split(",") if f]
-        src = os.path.join(B.CSRC, "fused.hip")
         rev = [f for f in flags if f.startswith("@")]
-        if rev:                                   # "@<git revision>": fused.hip as of that commit (A/B on one GPU box)
-            flags = [f for f in flags if not f.startswith("@")]
-            src = os.path.join(B.CSRC, f"_fused_{name}.hip")
-            text = subprocess.check_output(["git", "-C", ROOT, "show", f"{rev[0][1:]}:beso_amd/csrc/fused.hip"], text=True)
-            open(src, "w").write(text)
-        obj = os.path.join(B.OBJDIR, f"fused_{name}.o")
-        cmd = [B._hipcc(), *B.FLAGS, *flags, "-c", src, "-o", obj]
-        procs.append((name, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
-    for name, obj, p in procs:
-        _, err = p.communicate()
-        if p.returncode:
-            raise SystemExit(f"variant {name}: hipcc failed\n{err}")
-        objs = [os.path.join(B.OBJDIR, u + ".o") for u in B.UNITS if u != "fused"] + [obj]
+        flags = [f for f in flags if not f.startswith("@")]
+        if rev:
+            # "@<git revision>": the whole csrc/ + include/ tree as of that commit (A/B against history on one GPU
+            # box even when the internal interfaces between the units changed since)
+            tree = os.path.join(B.OBJDIR, f"src_{name}")
+            subprocess.check_call(["rm", "-rf", tree])
+            os.makedirs(tree)
+            subprocess.check_call(f"git -C {ROOT} archive {rev[0][1:]} beso_amd/csrc include | tar -x -C {tree}", shell=True)
+            csrc = os.path.join(tree, "beso_amd", "csrc")
+            units = sorted(f[:-4] for f in os.listdir(csrc) if f.endswith(".hip"))
+        else:
+            csrc, units = B.CSRC, ["fused"]
+        procs = []
+        for u in units:
+            obj = os.path.join(B.OBJDIR, f"{u}_{name}.o")
+            extra = flags if u == "fused" else []
+            cmd = [B._hipcc(), *B.FLAGS, *extra, "-c", os.path.join(csrc, u + ".hip"), "-o", obj]
+            procs.append((u, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+        jobs.append((name, bool(rev), procs))
+    for name, is_rev, procs in jobs:
+        objs = []
+        for u, obj, p in procs:
+            _, err = p.communicate()
+            if p.returncode:
+                raise SystemExit(f"variant {name}/{u}: hipcc failed\n{err}")
+            objs.append(obj)
+        if not is_rev:
+            objs += [os.path.join(B.OBJDIR, u + ".o") for u in B.UNITS if u != "fused"]
         lib = os.path.join(VDIR, f"libbeso_hip_{name}.so")
         subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", lib, *objs])
         print("built", lib)
-    for f in os.listdir(B.CSRC):
-        if f.startswith("_fused_"):
-            os.remove(os.path.join(B.CSRC, f))
 
 
 def time_one(batch, steps=30):
