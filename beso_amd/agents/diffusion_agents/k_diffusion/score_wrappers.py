@@ -5,7 +5,6 @@ With a ``beso_amd`` DiffusionGPT inside, ``forward`` is ONE call into the HIP li
 (``beso_denoise_fwd``): c_in is folded into the token-embedding kernel, c_out / c_skip into the
 action-head kernel.  Any other inner model is evaluated by the textbook formula on top of it.
 """
-import torch
 from torch import nn
 
 from ...._instantiate import instantiate

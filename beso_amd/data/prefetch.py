@@ -10,7 +10,7 @@ step k runs; the consumer stream waits on an event, never on the host.  On a CPU
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, Iterator, Optional
+from typing import Dict, Iterable, Iterator
 
 import torch
 

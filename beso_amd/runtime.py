@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import Iterable, List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 

@@ -1,7 +1,6 @@
 """N > 1 path on CPU: two processes, gloo backend.  Covers the gradient all-reduce of the training
 step (C1), the weight broadcast (C2), batch sharding of the inference path, and that a 2-rank
 train_step equals a single-process step on the concatenated batch."""
-import functools
 import os
 import socket
 import sys

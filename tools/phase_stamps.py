@@ -2,7 +2,6 @@
 """Development aid: per-phase cycle breakdown of the fused layers kernel (workgroup 0, wave 0), from
 the in-kernel s_memtime stamps (beso_debug_set_stamps).  Run on the GPU box."""
 import collections
-import ctypes as C
 import os
 import sys
 
