@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Randomised soak of the HIP path: random batch sizes / window lengths / conditioning / samplers on the
+shipped shapes, inputs at the end of their allocations (run with PYTORCH_NO_CUDA_MEMORY_CACHING=1), small
+cases checked against the oracle.   python tools/fuzz_shapes.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from bench import build_model  # noqa: E402
+from guard_check import at_tail  # noqa: E402
+from oracle import beso_oracle as O  # noqa: E402
+from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks  # noqa: E402
+from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    dev = "cuda:0"
+    models = {}
+    for name in ("kitchen", "block_push"):
+        cfg = O.CONFIGS[name]
+        w = O.make_weights(cfg, seed=3, std=0.03)
+        models[name] = (cfg, w, build_model(cfg, w, "bf16", dev))
+    t0, n, worst = time.time(), 0, 0.0
+    while time.time() - t0 < budget:
+        name = ("kitchen", "block_push")[int(rng.integers(2))]
+        cfg, w, m = models[name]
+        B = int(rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 33, 64, 100, 255, 257, int(rng.integers(1, 600))]))
+        t = int(rng.integers(1, cfg.obs_seq_len + 1))
+        s_np, g_np, a_np = O.make_inputs(cfg, B, seed=int(rng.integers(1 << 30)), t=t)
+        sg_np = np.exp(rng.uniform(np.log(0.005), 0.0, B)).astype(np.float32)
+        s, g, a, sg = at_tail(s_np, dev), at_tail(g_np, dev), at_tail(a_np, dev), at_tail(sg_np, dev)
+        mode = int(rng.integers(4))
+        with torch.no_grad():
+            if mode == 0:
+                out, ref = m(s, a, g, sg), (O.denoise(w, cfg, s_np, a_np, g_np, sg_np) if B <= 16 else None)
+            elif mode == 1:
+                out = m(s, a, g, sg, uncond=True)
+                ref = O.denoise(w, cfg, s_np, a_np, g_np, sg_np, uncond=True) if B <= 16 else None
+            elif mode == 2:
+                lam = float(rng.choice([0.0, 1.0, 1.5, 2.0]))
+                out = ClassifierFreeSampleModel(m, lam)(s, a, g, sg)
+                ref = O.denoise_cfg(w, cfg, s_np, a_np, g_np, sg_np, lam) if B <= 16 else None
+            else:
+                fn = (ks.sample_ddim, ks.sample_euler, ks.sample_heun)[int(rng.integers(3))]
+                out = fn(ClassifierFreeSampleModel(m, 2.0) if rng.integers(2) else m, s, a, g,
+                         ks.get_sigmas_exponential(int(rng.integers(1, 6)), 0.05, 1.0), disable=True)
+                ref = None
+            torch.cuda.synchronize()
+        assert torch.isfinite(out).all(), (name, B, t, mode)
+        if ref is not None:
+            err = float(np.abs(out.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12))
+            worst = max(worst, err)
+            assert err < 3e-2, (name, B, t, mode, err)
+        n += 1
+    print(f"fuzz_shapes: {n} random calls in {time.time() - t0:.0f} s, worst rel err vs oracle {worst:.2e}, no fault")
+
+
+if __name__ == "__main__":
+    main()
