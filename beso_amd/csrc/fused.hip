@@ -697,6 +697,44 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
     __syncthreads();
 }
 
+// Token slots of a workgroup tile.  The GEMMs, LayerNorm and GELU do not care which token sits in which of
+// the 96 slots; attention and the edges do.  layers_kernel puts the ACTION tokens of all samples first
+// (slots [0, n_samples*t)) and the sigma / goal / state tokens behind them, so that the last layer -- whose
+// MLP, out-projection and LayerNorm-2 only matter for the action tokens (the head reads nothing else,
+// score_gpts.py:344-354) -- can run them on the first two token tiles only.  q/k/v rows in LDS stay in natural
+// order (sample-major, position order) for the attention core; the tables translate.
+struct SlotTabs {
+    unsigned char sp_of_slot[kMT];    // (sample << 4) | position of the token in a slot; 0xFF = empty slot
+    unsigned char row_of_slot[kMT];   // natural row (sample*Tn + position) of a slot; empty slots map to themselves
+    unsigned char slot_of_row[kMT];   // inverse
+};
+__device__ __forceinline__ void build_slot_tabs(SlotTabs* tb, int n_samples, int Tn, int t_win, int G, bool actions_first) {
+    const int slot = threadIdx.x;
+    if (slot < kMT) {
+        const int nv = n_samples * Tn;
+        unsigned char sp = 0xFF;
+        int row = slot;
+        if (slot < nv) {
+            int sl, p;
+            if (actions_first) {
+                const int na = n_samples * t_win, no = Tn - t_win;
+                if (slot < na) { sl = slot / t_win; p = G + 2 + 2 * (slot - sl * t_win); }
+                else {
+                    const int q = slot - na;
+                    sl = q / no;
+                    const int r = q - sl * no;
+                    p = r <= G ? r : G + 1 + 2 * (r - G - 1);
+                }
+            } else { sl = slot / Tn; p = slot - sl * Tn; }
+            sp = (unsigned char)((sl << 4) | p);
+            row = sl * Tn + p;
+        }
+        tb->sp_of_slot[slot] = sp;
+        tb->row_of_slot[slot] = (unsigned char)row;
+        tb->slot_of_row[row] = (unsigned char)slot;
+    }
+}
+
 // Inputs / outputs of the network edges when they are fused into layers_kernel.
 struct EdgeArgs {
     const float* state;    // [B][t][obs]
@@ -725,7 +763,7 @@ __device__ __forceinline__ void sample_of(const EdgeArgs& e, int vb, int& b, boo
 // for at the end of its block, which serialised ~120 cache-cold round trips (70 kcycles per workgroup).
 template <int RPW>
 __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw, int s0,
-                                           int n_samples, int Tn, int w, int lane, Stamps& st) {
+                                           int n_samples, int Tn, int w, int lane, const SlotTabs* tb, Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int n = lane & 15, g = lane >> 4;
     const int G = d.G, Dp = d.Dp;
@@ -737,9 +775,9 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
     const int last = s0 + n_samples - 1;
 #pragma unroll
     for (int t = 0; t < kNTT; ++t) {
-        const int tokl = t * 16 + n;
-        const int sl = tokl / Tn, p = tokl - sl * Tn;
-        const bool live = sl < n_samples;
+        const int sp = tb->sp_of_slot[t * 16 + n];
+        const bool live = sp != 0xFF;
+        const int sl = live ? sp >> 4 : 0, p = live ? sp & 15 : 0;
         int b; bool un;
         sample_of(e, min(s0 + sl, last), b, un);
         sg[t] = e.sigma[b];
@@ -831,7 +869,7 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
 template <int RPW>
 __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw,
                                           float* red, float* part, int s0, int n_samples, int Tn, int w, int lane,
-                                          Stamps& st) {
+                                          const SlotTabs* tb, Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int n = lane & 15, g = lane >> 4;
     const int act = d.act, Dp = d.Dp;
@@ -868,13 +906,15 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
         const int sl = sr * per;
         int b; bool un;
         sample_of(e, s0 + sl, b, un);
-        const int tok_c = sl * Tn + G + 2 + 2 * i;          // action token of step i (conditional / only sample)
+        // slot of the action token of step i (conditional / only sample); the unconditional copy is sample sl+1
+        const int tok_c = tb->slot_of_row[sl * Tn + G + 2 + 2 * i];
         float fc = bh[a], fu = bh[a];
 #pragma unroll
         for (int ww = 0; ww < kWaves; ++ww) fc += part[((size_t)ww * kMT + tok_c) * 16 + a];
         if (e.two) {
+            const int tok_u = tb->slot_of_row[(sl + 1) * Tn + G + 2 + 2 * i];
 #pragma unroll
-            for (int ww = 0; ww < kWaves; ++ww) fu += part[((size_t)ww * kMT + tok_c + Tn) * 16 + a];
+            for (int ww = 0; ww < kWaves; ++ww) fu += part[((size_t)ww * kMT + tok_u) * 16 + a];
         }
         const float sg = e.sigma[b];
         const float av = e.action[((size_t)b * e.t + i) * act + a];
@@ -1132,7 +1172,7 @@ template <int RPW, int KS, int HG>
 __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsigned char* u,
                                            const u32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
                                            const u32x4* __restrict__ wproj, int H, int hd, int Tn, int n_samples,
-                                           int w, int lane, u32x4 (&qE)[3], u32x4 (&qO)[3], Stamps& st) {
+                                           int w, int lane, const SlotTabs* tb, u32x4 (&qE)[3], u32x4 (&qO)[3], Stamps& st) {
     asm volatile("" : "+v"(lane));
     uint16_t* qkv = (uint16_t*)u;                         // [3][kQKVRows][kQKVRow] bf16
     u32x4* yT = (u32x4*)(u + kQKVBytes);                  // [(t*2 + kk)*64 + lane]
@@ -1145,16 +1185,19 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     int ln = lane;
     auto write_qkv = [&](const f32x4 (&qa)[3][kNTT]) {
         const int n = ln & 15, g = ln >> 4;
+        int row[kNTT];                                    // natural q/k/v row of this lane's token in each token tile
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) row[t] = tb->row_of_slot[t * 16 + n];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int rt = 3 * wa + i, part = rt >> 2, d0 = (rt & 3) * 16 + 4 * g;
-            uint16_t* dst = qkv + ((size_t)part * kQKVRows + n) * kQKVRow + d0;       // + t*16 rows: immediate offsets
+            uint16_t* dst = qkv + (size_t)part * kQKVRows * kQKVRow + d0;
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) {
                 uint2 pk;
                 pk.x = pack_bf16x2(qa[i][t][0], qa[i][t][1]);
                 pk.y = pack_bf16x2(qa[i][t][2], qa[i][t][3]);
-                *(uint2*)(dst + (size_t)t * 16 * kQKVRow) = pk;
+                *(uint2*)(dst + (size_t)row[t] * kQKVRow) = pk;
             }
         }
     };
@@ -1230,7 +1273,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                 }
             }
             if (n < Tn) {
-                const int tok = w * Tn + n;
+                const int tok = tb->slot_of_row[w * Tn + n];          // token slot of (sample w, position n)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     u32x4 yb;
@@ -1277,7 +1320,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                                                               __builtin_bit_cast(s16x4, pb), z, 0, 0, 0);
         }
         if (n < Tn) {
-            const int tok = w * Tn + n;
+            const int tok = tb->slot_of_row[w * Tn + n];          // token slot of (sample w, position n)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 u32x4 yb;
@@ -1474,6 +1517,10 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         const int part = i / (8 * kQKVRow / 2), rem = i % (8 * kQKVRow / 2);
         ((uint32_t*)(lds + L.u))[((size_t)part * kQKVRows + kMT) * kQKVRow / 2 + rem] = 0u;
     }
+    // action tokens first whenever both network edges are inside the kernel (otherwise x travels in natural order)
+    SlotTabs* tb = (SlotTabs*)(lds + L.tab);
+    build_slot_tabs(tb, n_samples, Tn, e.t, d.G, e.fuse_embed && e.fuse_head);
+    __syncthreads();
     Tile<RPW> T;
     stamp(st, 100);
     stamp(st, 1);
@@ -1485,7 +1532,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.1f * n, 0.2f, 0.3f * g, 0.4f};
         }
-    } else if (e.fuse_embed) embed_tile<RPW>(T, e, d, gw, s0, n_samples, Tn, w, lane, st);
+    } else if (e.fuse_embed) embed_tile<RPW>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, st);
     else load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 43);
     for (int l = l0; l < l1; ++l) {
@@ -1502,7 +1549,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         stamp(st, 7);
         attn_phase<RPW, KS, HG>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
                             (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
-                            lane, qE, qO, st);
+                            lane, tb, qE, qO, st);
         stamp(st, 3);
         u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
         mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)lw, w, lane);
@@ -1513,7 +1560,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
                            (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
     }
     stamp(st, 4);
-    if (e.fuse_head) head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, st);
+    if (e.fuse_head) head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
     else store_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 5);
     stamp(st, 101);
