@@ -386,8 +386,8 @@ __device__ __forceinline__ void prefetch_a(u32x4 (&aE)[R], u32x4 (&aO)[R], WPtr 
     for (int r = 0; r < R; ++r) { aE[r] = a.at(r); aO[r] = a.at(r + ABL_KS(a_ks)); }
 }
 
-template <int R, int NT, bool TAIL16 = false>
-__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NT], u32x4 (&aE)[R], u32x4 (&aO)[R],
+template <int R, int NT, bool TAIL16 = false, int NTA = NT>      // NTA: token tiles the accumulator array holds (>= NT used)
+__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NTA], u32x4 (&aE)[R], u32x4 (&aO)[R],
                                            WPtr a, int a_ks, const u32x4* b, int b_ts,
                                            int b_ks, int ksteps) {
     // ONE set of B fragments: each half of it is refilled for the next k-step as soon as the MFMAs that
@@ -588,10 +588,10 @@ __device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restri
 // partial (sum, sum of squares) in fp32, exchanged through LDS behind ONE barrier; var = E[x^2] - mean^2
 // (the residual stream is O(1..10) with |mean| << std, and the result is rounded to bf16 next: the
 // cancellation is far below that rounding).  Invalid (padding) features hold exact zeros.
-template <int RPW, int NW>
-__device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, int w, int lane, float (&mean)[kNTT],
-                                         float (&rstd)[kNTT], Stamps& st) {
-    static_assert(kNTT % 2 == 0, "token tiles are reduced in pairs");
+template <int RPW, int NW, int NT = kNTT>         // NT: the first NT token tiles only
+__device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, int w, int lane, float (&mean)[NT],
+                                         float (&rstd)[NT], Stamps& st) {
+    static_assert(NT % 2 == 0, "token tiles are reduced in pairs");
     const int n = lane & 15, row = lane >> 4;
     const float invD = 1.0f / (float)D;
     // Cross-lane part of the reduction (over the four 16-lane rows g) on gfx950's lane-swap instructions:
@@ -599,7 +599,7 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
     //   v_permlane16_swap(r_t, r_t+1) + add : row 0 = S_t, row 1 = S_t+1, row 2 = Q_t, row 3 = Q_t+1
     // so every lane ends up with one finished (token, statistic) and writes it: red[token][wave][stat].
 #pragma unroll
-    for (int tp = 0; tp < kNTT / 2; ++tp) {
+    for (int tp = 0; tp < NT / 2; ++tp) {
         float r[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -622,7 +622,7 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
     __syncthreads();
     stamp(st, 31);
 #pragma unroll
-    for (int t = 0; t < kNTT; ++t) {
+    for (int t = 0; t < NT; ++t) {
         const f32x4* pr = (const f32x4*)(red + (size_t)(t * 16 + n) * NW * 2);
         float s = 0.f, q = 0.f;
 #pragma unroll
@@ -638,18 +638,18 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
 // even are the two halves of one k-step fragment and go out as one 16-byte LDS write per lane.
 // NOTE: the red[] buffer is re-used by the next LayerNorm; the barrier at the end of this function (and
 // the phases in between) orders the reads above against those writes.
-template <int RPW, int KS, int NW, bool ADD_BIAS = true>
+template <int RPW, int KS, int NW, bool ADD_BIAS = true, int NT = kNTT>
 __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float* red, int D, int w, int lane,
                                                  const float* __restrict__ bias, Stamps& st) {
     // `lane` is made opaque at the top of every phase: otherwise the per-lane address arithmetic of ALL
     // phases is hoisted out of the layer loop and kept live across it (46 spilled VGPRs).
     asm volatile("" : "+v"(lane));
     const int g = lane >> 4;
-    float mean[kNTT], rstd[kNTT];
+    float mean[NT], rstd[NT];
     if (BESO_ABL_MASK & 8) {
 #pragma unroll
-        for (int t = 0; t < kNTT; ++t) { mean[t] = 0.01f * lane; rstd[t] = 0.5f; }
-    } else ln_stats<RPW, NW>(T, red, D, w, lane, mean, rstd, st);
+        for (int t = 0; t < NT; ++t) { mean[t] = 0.01f * lane; rstd[t] = 0.5f; }
+    } else ln_stats<RPW, NW, NT>(T, red, D, w, lane, mean, rstd, st);
     // Padding features (>= D) are NOT masked here: their xnT entries only ever meet the zero-padded
     // contraction columns of the packed QKV / FC1 weights, and (0 - mean) * rstd is finite.
     auto half = [&](int i, int t) {
@@ -663,7 +663,7 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         const int ks = (w * RPW + i) >> 1;
         if (ks < KS) {
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 const uint2 lo = half(i, t), hi = half(i + 1, t);
                 xnT[((size_t)t * KS + ks) * 64 + lane] = u32x4{lo.x, lo.y, hi.x, hi.y};
             }
@@ -673,7 +673,7 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         const int Rf = w * RPW + i;
         if ((Rf >> 1) < KS) {
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t)
+            for (int t = 0; t < NT; ++t)
                 *((uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane) + (Rf & 1)) = half(i, t);
         }
     };
@@ -690,7 +690,7 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         for (int i = 0; i < RPW; ++i) {
             const f32x4 bv = *(const f32x4*)(bias + 16 * (w * RPW + i) + 4 * g);
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) T.acc[i][t] += bv;
+            for (int t = 0; t < NT; ++t) T.acc[i][t] += bv;
         }
     }
     stamp(st, 34);
@@ -938,9 +938,9 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
 // fragments (RC/2 FC2 k-steps per wave), as a sequence of (RC/2)*kNTT*4 pair evaluations that can be issued
 // one at a time between MFMAs.  Pair pi -> k-step pi/(4*kNTT), token tile (pi/4)%kNTT, elements 2*(pi%4),
 // 2*(pi%4)+1 of the fragment's eight (0..3: even row tile's registers, 4..7: odd row tile's).
-template <int RC>
-__device__ __forceinline__ void gelu_pair(const f32x4 (&h)[RC][kNTT], float (&gq)[8], u32x4 (&hb)[RC / 2][kNTT], int pi) {
-    const int j2 = pi / (4 * kNTT), t = (pi >> 2) % kNTT, j = (pi & 3) * 2;
+template <int RC, int NT>
+__device__ __forceinline__ void gelu_pair(const f32x4 (&h)[RC][NT], float (&gq)[8], u32x4 (&hb)[RC / 2][NT], int pi) {
+    const int j2 = pi / (4 * NT), t = (pi >> 2) % NT, j = (pi & 3) * 2;
     const f32x4& hv = h[2 * j2 + (j >> 2)][t];
     const f32x2 r = gelu_fast2(f32x2{hv[j & 3], hv[(j & 3) + 1]});
     gq[j] = r.x;
@@ -960,11 +960,11 @@ __device__ __forceinline__ void gelu_pair(const f32x4 (&h)[RC][kNTT], float (&gq
 // (measured, tools/microbench/issue_rate.hip), and alternating two independent chains keeps the packed-fp32
 // pipe (8 cycles dependent, 5.5 independent) from waiting on itself.
 struct GeluChain { f32x2 v, vc, s, p; };
-template <int RC, int SIGMA>
-__device__ __forceinline__ void gelu_slot(const f32x4 (&h)[RC][kNTT], GeluChain& c0, GeluChain& c1, float (&gq)[8],
-                                          u32x4 (&hb)[RC / 2][kNTT]) {
+template <int RC, int NT, int SIGMA>
+__device__ __forceinline__ void gelu_slot(const f32x4 (&h)[RC][NT], GeluChain& c0, GeluChain& c1, float (&gq)[8],
+                                          u32x4 (&hb)[RC / 2][NT]) {
     constexpr int q = SIGMA / 24, step = (SIGMA % 24) >> 1, ch = SIGMA & 1, pi = 2 * q + ch;
-    constexpr int j2 = pi / (4 * kNTT), t = (pi >> 2) % kNTT, j = (pi & 3) * 2;
+    constexpr int j2 = pi / (4 * NT), t = (pi >> 2) % NT, j = (pi & 3) * 2;
     GeluChain& g = ch ? c1 : c0;
     if constexpr ((BESO_ABL_MASK & 1) != 0) {
         if constexpr (step == 0) { gq[j] = h[2 * j2 + (j >> 2)][t][j & 3]; gq[j + 1] = h[2 * j2 + (j >> 2)][t][(j & 3) + 1]; }
@@ -1015,7 +1015,7 @@ __device__ __forceinline__ void mlp_prefetch(u32x4 (&a1r)[kFc1PF][kChunkTiles / 
     prefetch_ring<RC, kFc1PF>(a1r, wptr(w1p + (size_t)(RC * w) * 64, lane), kChunkTiles);
 }
 
-template <int RPW, int KS, int NW>
+template <int RPW, int KS, int NW, int NT = kNTT>          // NT: the first NT token tiles only (last layer)
 __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
                                           const float* __restrict__ b1f, const u32x4* __restrict__ w2p, int HT,
                                           int KS2p, int w, int lane, u32x4 (&a1r)[kFc1PF][kChunkTiles / NW],
@@ -1024,9 +1024,9 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
     constexpr int RC = kChunkTiles / NW, KW = RC / 2;       // row tiles / FC2 k-steps of a chunk per wave
     constexpr int A2KS = NW * RPW;                           // fragments between FC2 k-steps
-    constexpr int H1 = kNTT / 2;
-    constexpr int PAIRS = KW * kNTT * 4;                     // GELU pair evaluations per chunk and wave
-    constexpr int SLOTS = PAIRS * 12, MFMAS = kKC * kNTT * RPW;   // their instruction slots / the MFMAs they hide behind
+    constexpr int H1 = NT / 2;
+    constexpr int PAIRS = KW * NT * 4;                     // GELU pair evaluations per chunk and wave
+    constexpr int SLOTS = PAIRS * 12, MFMAS = kKC * NT * RPW;   // their instruction slots / the MFMAs they hide behind
     static_assert(RC % 2 == 0 && PAIRS % 2 == 0, "pairs are evaluated two at a time");
     // w1p: [chunk][kk][16 row tiles]; w2p: [kk2][NW*RPW row tiles]
     // (walking the chunks in a per-workgroup rotation to spread L2 channel load was measured SLOWER: 1.16 vs 1.13 ms;
@@ -1035,25 +1035,25 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     auto fc1_a = [&](int c) { return ABL_PTR(wptr(w1p + (size_t)(RC * w) * 64, lane), (size_t)pc(c) * KS * kChunkTiles); };
     auto fc2_a = [&](int c) { return ABL_PTR(wptr(w2p + (size_t)(w * RPW) * 64, lane), (size_t)(pc(c) * kKC) * (NW * RPW)); };
     constexpr int PF1 = kFc1PF;
-    auto fc1 = [&](int c, f32x4 (&h)[RC][kNTT], u32x4 (&ar)[PF1][RC]) {
+    auto fc1 = [&](int c, f32x4 (&h)[RC][NT], u32x4 (&ar)[PF1][RC]) {
         const int R0 = pc(c) * kChunkTiles + RC * w, g = lane >> 4;
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
             const f32x4 bias = *(const f32x4*)(b1f + 16 * (R0 + r) + 4 * g);
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) h[r][t] = bias;
+            for (int t = 0; t < NT; ++t) h[r][t] = bias;
         }
-        gemm_phase_ring<RC, kNTT, PF1, kt16(KS)>(h, ar, fc1_a(c), kChunkTiles, xnT + lane, KS * 64, 64, KS);
+        gemm_phase_ring<RC, NT, PF1, kt16(KS)>(h, ar, fc1_a(c), kChunkTiles, xnT + lane, KS * 64, 64, KS);
     };
-    auto write_hT = [&](u32x4 (&hb)[KW][kNTT]) {
+    auto write_hT = [&](u32x4 (&hb)[KW][NT]) {
 #pragma unroll
         for (int j2 = 0; j2 < KW; ++j2)
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) hT[((size_t)t * kKC + KW * w + j2) * 64 + lane] = hb[j2][t];
+            for (int t = 0; t < NT; ++t) hT[((size_t)t * kKC + KW * w + j2) * 64 + lane] = hb[j2][t];
     };
 
-    f32x4 h[RC][kNTT];
-    u32x4 hb[KW][kNTT];
+    f32x4 h[RC][NT];
+    u32x4 hb[KW][NT];
     u32x4 af2[2][RPW];                   // FC2 weight fragments of two k-steps, [k-step parity][row tile]
     float gq[8];
     GeluChain gc0, gc1;
@@ -1069,7 +1069,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     if (n_chunks > 1) prefetch_ring<RC, PF1>(a1r, fc1_a(1), kChunkTiles);
     fc2_prefetch(0);
 #pragma unroll
-    for (int pi = 0; pi < PAIRS; ++pi) gelu_pair<RC>(h, gq, hb, pi);
+    for (int pi = 0; pi < PAIRS; ++pi) gelu_pair<RC, NT>(h, gq, hb, pi);
     write_hT(hb);
     if (n_chunks > 1) fc1(1, h, a1r);
     stamp(st, 20);
@@ -1091,21 +1091,21 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
             // ---- FC2(c-1) (always a full chunk: 8 k-steps) with GELU(c) woven in, fully unrolled
             const WPtr a2 = fc2_a(c - 1);
             const u32x4* b = hT + lane;
-            u32x4 bf[kNTT];
+            u32x4 bf[NT];
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) bf[t] = b[t * kKC * 64];
+            for (int t = 0; t < NT; ++t) bf[t] = b[t * kKC * 64];
             static_for<0, kKC>([&](auto KK) {
                 constexpr int kk = decltype(KK)::value;
-                static_for<0, kNTT>([&](auto TT) {
+                static_for<0, NT>([&](auto TT) {
                     constexpr int t = decltype(TT)::value;
                     // unit of the weave: ONE MFMA + its share of the chunk's GELU slots (2 for RPW = 3)
                     static_for<0, RPW>([&](auto RR) {
                         constexpr int r = decltype(RR)::value;
-                        constexpr int unit = (kk * kNTT + t) * RPW + r;
+                        constexpr int unit = (kk * NT + t) * RPW + r;
                         __builtin_amdgcn_sched_barrier(0);
                         T.acc[r][t] = mfma_bf16(af2[kk & 1][r], bf[t], T.acc[r][t]);
                         static_for<unit * SLOTS / MFMAS, (unit + 1) * SLOTS / MFMAS>([&](auto SG) {
-                            gelu_slot<RC, decltype(SG)::value>(h, gc0, gc1, gq, hb);
+                            gelu_slot<RC, NT, decltype(SG)::value>(h, gc0, gc1, gq, hb);
                         });
                     });
                     __builtin_amdgcn_sched_barrier(0);
@@ -1113,10 +1113,10 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 #pragma unroll
                         for (int t2 = 0; t2 < H1; ++t2) bf[t2] = b[t2 * kKC * 64 + (kk + 1) * 64];
                     }
-                    if (t == kNTT - 1) {
+                    if (t == NT - 1) {
                         if (kk + 1 < kKC && !(BESO_ABL_MASK & 32)) {
 #pragma unroll
-                            for (int t2 = H1; t2 < kNTT; ++t2) bf[t2] = b[t2 * kKC * 64 + (kk + 1) * 64];
+                            for (int t2 = H1; t2 < NT; ++t2) bf[t2] = b[t2 * kKC * 64 + (kk + 1) * 64];
                         }
                         if (kk + 2 < kKC) {
 #pragma unroll
@@ -1141,7 +1141,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
         // slot against zero weights
         const int c = n_chunks - 1;
         const int tiles_here = min(kChunkTiles, HT - pc(c) * kChunkTiles);
-        gemm_phase<RPW, kNTT>(T.acc, af2[0], af2[1], fc2_a(c), A2KS, hT + lane, kKC * 64, 64, ((tiles_here >> 1) + 1) & ~1);
+        gemm_phase<RPW, NT, false, kNTT>(T.acc, af2[0], af2[1], fc2_a(c), A2KS, hT + lane, kKC * 64, 64, ((tiles_here >> 1) + 1) & ~1);
     }
     stamp(st, 25);
     __syncthreads();
@@ -1168,7 +1168,7 @@ __device__ __forceinline__ void attn_prefetch(u32x4 (&qE)[3], u32x4 (&qO)[3], co
 // the next pair before core(B); each head's projection weights (two k-steps: all of them) are requested
 // before the barrier that precedes its core.
 // HG > 1: a virtual head is HG real heads of `hd` dims side by side (FusedDims); H counts virtual heads.
-template <int RPW, int KS, int HG>
+template <int RPW, int KS, int HG, int NTP = kNTT>      // NTP: token tiles that receive the out-projection (last layer: action tokens only)
 __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsigned char* u,
                                            const u32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
                                            const u32x4* __restrict__ wproj, int H, int hd, int Tn, int n_samples,
@@ -1360,7 +1360,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         __syncthreads();
         stamp(st, 17);
         // ---- head A's slice of the out-projection, accumulated into the residual; head B's q/k/v to LDS
-        gemm_phase<RPW, kNTT>(T.acc, aE, aO, proj_a(hA), kWaves * RPW, yT + lane, 2 * 64, 64, 2);
+        gemm_phase<RPW, NTP, false, kNTT>(T.acc, aE, aO, proj_a(hA), kWaves * RPW, yT + lane, 2 * 64, 64, 2);
         prefetch_a<RPW>(aE, aO, proj_a(hB), kWaves * RPW);
         if (hsel == 1) write_qkv(qa);
         if (pair + 1 < H / 2) prefetch_a<3>(qE, qO, qkv_a(pair + 1), 24);   // qa's registers are free from here
@@ -1371,7 +1371,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         stamp(st, 15);
         __syncthreads();
         stamp(st, 18);
-        gemm_phase<RPW, kNTT>(T.acc, aE, aO, proj_a(hB), kWaves * RPW, yT + lane, 2 * 64, 64, 2);
+        gemm_phase<RPW, NTP, false, kNTT>(T.acc, aE, aO, proj_a(hB), kWaves * RPW, yT + lane, 2 * 64, 64, 2);
         // no barrier needed here: the next writes to qkv/yT happen behind the next pair's barriers
     }
     __syncthreads();
@@ -1497,7 +1497,10 @@ __global__ __launch_bounds__(512, 2) void proj_block_kernel(float* __restrict__ 
 }
 
 // Whole transformer layers [l0, l1) over the tile's 8 samples; x stays in registers in between.
-template <int RPW, int KS, int HG>
+// NTL: token tiles that hold the action tokens of a full tile (8 samples x window, rounded up to an even count):
+// in the LAST layer only those go through the out-projection, LayerNorm-2 and the MLP -- nothing else reaches
+// the head (score_gpts.py:344-354; SURVEY.md section 8 parity note 7: numerically identical per row).
+template <int RPW, int KS, int HG, int NTL>
 __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, const char* __restrict__ lw0,
                                                         FusedDims d, int l0, int l1, int n_samples_total, int Tn,
                                                         EdgeArgs e, unsigned long long* stamps, int cap) {
@@ -1519,7 +1522,8 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     }
     // action tokens first whenever both network edges are inside the kernel (otherwise x travels in natural order)
     SlotTabs* tb = (SlotTabs*)(lds + L.tab);
-    build_slot_tabs(tb, n_samples, Tn, e.t, d.G, e.fuse_embed && e.fuse_head);
+    const bool actions_first = e.fuse_embed && e.fuse_head;
+    build_slot_tabs(tb, n_samples, Tn, e.t, d.G, actions_first);
     __syncthreads();
     Tile<RPW> T;
     stamp(st, 100);
@@ -1535,12 +1539,21 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     } else if (e.fuse_embed) embed_tile<RPW>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, st);
     else load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 43);
-    for (int l = l0; l < l1; ++l) {
+    // The last layer (when this launch contains it and the action tokens of the tile fit NTL token tiles) runs its
+    // out-projection, LayerNorm-2 and MLP on the action-token tiles only; it is peeled off the loop -- a branch
+    // between the two variants INSIDE the loop costs 150 spilled VGPRs.
+    const bool peel = actions_first && l1 == d.L && l1 > l0 && n_samples * e.t <= 16 * NTL;
+    const int l_loop_end = peel ? l1 - 1 : l1;
+    auto layer_weights = [&](int l) {
 #if BESO_FUSED_ABLATE == 4
-        const char* lw = lw0;                                    // timing experiment: the weights of ONE layer fit in L2
+        (void)l;
+        return lw0;                                              // timing experiment: the weights of ONE layer fit in L2
 #else
-        const char* lw = lw0 + (size_t)l * d.layer_bytes;
+        return lw0 + (size_t)l * d.layer_bytes;
 #endif
+    };
+    for (int l = l0; l < l_loop_end; ++l) {
+        const char* lw = layer_weights(l);
         stamp(st, 2);
         u32x4 qE[3], qO[3];
         attn_prefetch<KS>(qE, qO, (const u32x4*)(lw + d.o_wqkv), w, lane);
@@ -1548,8 +1561,8 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
                                           (const float*)(lw + d.o_bproj), st);
         stamp(st, 7);
         attn_phase<RPW, KS, HG>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
-                            (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
-                            lane, tb, qE, qO, st);
+                                (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
+                                lane, tb, qE, qO, st);
         stamp(st, 3);
         u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
         mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)lw, w, lane);
@@ -1557,7 +1570,27 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
                                           (const float*)(lw + d.o_b2), st);
         stamp(st, 6);
         mlp_phase<RPW, KS, kWaves>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
-                           (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
+                                   (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
+    }
+    if (peel) {
+        const char* lw = layer_weights(l1 - 1);
+        stamp(st, 2);
+        u32x4 qE[3], qO[3];
+        attn_prefetch<KS>(qE, qO, (const u32x4*)(lw + d.o_wqkv), w, lane);
+        layernorm_to_lds<RPW, KS, kWaves>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+                                          (const float*)(lw + d.o_bproj), st);
+        stamp(st, 7);
+        attn_phase<RPW, KS, HG, NTL>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
+                                     (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
+                                     lane, tb, qE, qO, st);
+        stamp(st, 3);
+        u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
+        mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)lw, w, lane);
+        layernorm_to_lds<RPW, KS, kWaves, true, NTL>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+                                                     (const float*)(lw + d.o_b2), st);
+        stamp(st, 6);
+        mlp_phase<RPW, KS, kWaves, NTL>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
+                                        (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
     }
     stamp(st, 4);
     if (e.fuse_head) head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
@@ -1606,15 +1639,15 @@ hipError_t launch_lin_blocks(int which, float* x, const char* lw, const FusedDim
     return hipGetLastError();
 }
 
-template <int RPW, int KS, int HG>
+template <int RPW, int KS, int HG, int NTL>
 hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
                          const EdgeArgs& edge, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS);
     static bool attr = false;
-    hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG>, L.total, &attr);
+    hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL>, L.total, &attr);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((layers_kernel<RPW, KS, HG>), dim3((n_samples + kSPW - 1) / kSPW), dim3(512), L.total, s, x, lw0, d,
+    hipLaunchKernelGGL((layers_kernel<RPW, KS, HG, NTL>), dim3((n_samples + kSPW - 1) / kSPW), dim3(512), L.total, s, x, lw0, d,
                        l0, l1, n_samples, Tn, edge, g_stamps, g_stamps_cap);
     return hipGetLastError();
 }
@@ -1788,8 +1821,8 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     if (e.two && !e.fuse_head) return BESO_ERR_UNSUPPORTED;
     if (fused_edges) *fused_edges = (e.fuse_embed ? 1 : 0) | (e.fuse_head ? 2 : 0);
     hipError_t err;
-    if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);
-    else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);
+    if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1, 2>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);    // kitchen: 8 x 4 action tokens
+    else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3, 4>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);   // block-push: 8 x 5
     else return BESO_ERR_UNSUPPORTED;
     return err == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
