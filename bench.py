@@ -153,7 +153,8 @@ def main():
         F = cfg.flops_per_sample()
         D, T = cfg.embed_dim, cfg.block_size
         M = B * T
-        # algorithmic FLOPs of ONE launch of each launch site
+        # algorithmic FLOPs of ONE launch of each launch site: the REFERENCE's work; the fused kernel
+        # skips the part of the last layer that cannot reach the output, which is not subtracted here
         site_flops = {"gemm_qkv": 2.0 * M * 3 * D * D, "gemm_proj": 2.0 * M * D * D, "gemm_fc1": 2.0 * M * 4 * D * D,
                       "gemm_fc2": 2.0 * M * 4 * D * D, "attention": 4.0 * B * T * T * D,
                       # the fused kernel runs ALL layers in one launch
