@@ -21,7 +21,8 @@ SITES = {"off": 0, "gemm_qkv": 1, "gemm_proj": 2, "gemm_fc1": 3, "gemm_fc2": 4, 
 # every symbol include/beso_hip.h declares (tests check that the library exports all of them)
 EXPORTS = ["beso_version", "beso_status_string", "beso_last_error", "beso_num_params", "beso_packed_bytes", "beso_pack_weights",
            "beso_workspace_bytes", "beso_score_fwd", "beso_denoise_fwd", "beso_sampler_step", "beso_sample",
-           "beso_profile_enable", "beso_profile_read", "beso_debug_set_stamps", "beso_adam_step"]
+           "beso_profile_enable", "beso_profile_read", "beso_debug_set_stamps", "beso_adam_step",
+           "beso_train_workspace_bytes", "beso_grad_floats", "beso_loss_grad", "beso_debug_gemm"]
 
 
 class BesoConfig(C.Structure):
@@ -89,6 +90,16 @@ def load() -> C.CDLL:
         if hasattr(lib, "beso_adam_step") or not os.environ.get("BESO_HIP_LIB"):   # (A/B builds of older revisions)
             lib.beso_adam_step.restype = i32
             lib.beso_adam_step.argtypes = [vp, i32, vp, vp, vp, f32, f32, f32, f32, f32, i32, i32, f32, vp]
+        if hasattr(lib, "beso_loss_grad") or not os.environ.get("BESO_HIP_LIB"):
+            lib.beso_train_workspace_bytes.restype = sz
+            lib.beso_train_workspace_bytes.argtypes = [cfgp, i32, i32, i32]
+            lib.beso_grad_floats.restype = sz
+            lib.beso_grad_floats.argtypes = [cfgp]
+            lib.beso_loss_grad.restype = i32
+            lib.beso_loss_grad.argtypes = [cfgp, C.POINTER(vp), i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32,
+                                           C.c_uint, f32, vp, sz, vp]
+            lib.beso_debug_gemm.restype = i32
+            lib.beso_debug_gemm.argtypes = [i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]
         lib.beso_profile_read.restype = i32
         lib.beso_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
         _lib = lib

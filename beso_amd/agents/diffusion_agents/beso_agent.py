@@ -209,6 +209,16 @@ class BesoAgent(BaseAgent):
         """noise ~ N(0, I), sigma ~ the configured density, score-matching loss, backward (beso_agent.py:226-235)."""
         noise = torch.randn_like(action)
         sigma = self.make_sample_density()(shape=(len(action),), device=self.device)
+        step = self.model.hip_train_step(state, action, goal, noise, sigma) if hasattr(self.model, "hip_train_step") else None
+        if step is not None:
+            # HIP forward + backward (beso_loss_grad): gradients land in views of one flat buffer, already
+            # divided by the world size for the data-parallel mean
+            inner = self.model.inner_model
+            self.optimizer.zero_grad(set_to_none=True)
+            masked = inner.mask_cond(goal) if goal is not None else goal
+            self._hip_step = step
+            return step.loss_backward(state, action, masked, noise, sigma, grad_scale=1.0 / bdist.world_size())
+        self._hip_step = None
         loss = self.model.loss(state, action, goal, noise, sigma)
         self.optimizer.zero_grad()
         loss.backward()
@@ -278,9 +288,13 @@ class BesoAgent(BaseAgent):
         else:
             loss = self._loss_backward(state, action, goal)
         if bdist.is_distributed():
-            if self._grad_bucket is None:
-                self._grad_bucket = bdist.GradientBucket(self.model.get_params())
-            self._grad_bucket.sync()
+            flat = self._hip_step.flat_grads() if getattr(self, "_hip_step", None) is not None else None
+            if flat is not None:
+                bdist.all_reduce_sum(flat)                    # C1 on the flat buffer the kernels wrote (pre-scaled)
+            else:
+                if self._grad_bucket is None:
+                    self._grad_bucket = bdist.GradientBucket(self.model.get_params())
+                self._grad_bucket.sync()
         self.steps += 1
         do_ema = self.steps % self.update_ema_every_n_steps == 0
         if isinstance(self.optimizer, FusedAdam):

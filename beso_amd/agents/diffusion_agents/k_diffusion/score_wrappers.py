@@ -5,11 +5,15 @@ With a ``beso_amd`` DiffusionGPT inside, ``forward`` is ONE call into the HIP li
 (``beso_denoise_fwd``): c_in is folded into the token-embedding kernel, c_out / c_skip into the
 action-head kernel.  Any other inner model is evaluated by the textbook formula on top of it.
 """
+import os
+
+import torch
 from torch import nn
 
 from ...._instantiate import instantiate
 from .score_gpts import DiffusionGPT
 from .utils import append_dims
+from ....training import HipTrainStep, ScoreMatchingLoss
 
 
 class GCDenoiser(nn.Module):
@@ -19,6 +23,7 @@ class GCDenoiser(nn.Module):
         super().__init__()
         self.inner_model = inner_model if isinstance(inner_model, nn.Module) else instantiate(inner_model)
         self.sigma_data = sigma_data
+        self._train_steps = {}
 
     # -- reference surface ---------------------------------------------------------------------
     def get_scalings(self, sigma):
@@ -44,6 +49,12 @@ class GCDenoiser(nn.Module):
         """Score-matching objective (score_wrappers.py:45-79).  Mutates ``noise`` in place when
         ``pred_last_action_only`` is set, like the reference (:63)."""
         last_only = bool(kwargs.pop("pred_last_action_only", False))
+        step = None if (last_only or kwargs) else self.hip_train_step(state, action, goal, noise, sigma)
+        if step is not None:
+            # forward + every parameter gradient in one enqueue of beso_loss_grad (beso_amd/training.py)
+            inner = self.inner_model
+            masked = inner.mask_cond(goal) if (inner.training and goal is not None) else goal
+            return ScoreMatchingLoss.apply(step, state, action, masked, noise, sigma, *inner.parameters())
         if last_only:
             noise[:, :-1, :] = 0
         noised = action + noise * append_dims(sigma, action.ndim)
@@ -53,6 +64,22 @@ class GCDenoiser(nn.Module):
         if last_only:
             return (out[:, -1, :] - target[:, -1, :]).pow(2).mean()
         return (out - target).pow(2).flatten(1).mean()
+
+    # -- HIP training step ---------------------------------------------------------------------
+    def hip_train_step(self, state, action, goal, noise, sigma):
+        """The ``HipTrainStep`` bound to the inner model if this call can run on it, else None."""
+        inner = self.inner_model
+        if not isinstance(inner, DiffusionGPT) or not torch.is_grad_enabled():
+            return None
+        if os.environ.get("BESO_AMD_HIP_TRAIN", "1") == "0" or not HipTrainStep.supported(inner):
+            return None
+        if not (torch.is_tensor(action) and action.is_cuda):
+            return None
+        key = float(self.sigma_data)
+        step = self._train_steps.get(key)
+        if step is None:
+            step = self._train_steps[key] = HipTrainStep(inner, key)
+        return step if step.eligible(state, action, goal, noise, sigma) else None
 
     # -- fused path ----------------------------------------------------------------------------
     @staticmethod

@@ -8,6 +8,7 @@
 #include <mutex>
 #include "common.h"
 #include "fused.h"
+#include "train.h"
 
 namespace beso {
 
@@ -448,6 +449,39 @@ int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg,
                                    decoupled_wd ? 1 : 0, step, ema_decay, (hipStream_t)stream);
     if (e != hipSuccess) return record_hip_error(e, "adam_ema_kernel", __LINE__);
     return BESO_OK;
+}
+
+size_t beso_train_workspace_bytes(const beso_config* cfg, int batch, int t, int precision) {
+    return train_workspace_bytes(cfg, batch, t, precision);
+}
+
+size_t beso_grad_floats(const beso_config* cfg) { return train_grad_floats(cfg); }
+
+int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
+                   const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
+                   float* loss_out, int batch, int t, float attn_pdrop, float resid_pdrop, unsigned int seed,
+                   float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    hipError_t e = hipSuccess;
+    int line = 0;
+    int st = train_loss_grad(cfg, params, n_params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch,
+                             t, attn_pdrop, resid_pdrop, seed, grad_scale, workspace, workspace_bytes, (hipStream_t)stream,
+                             &e, &line);
+    if (st == BESO_ERR_HIP) {
+        snprintf(g_last_error, sizeof(g_last_error), "%s (%d) at train.hip:%d", hipGetErrorName(e), (int)e, line);
+    }
+    return st;
+}
+
+int beso_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,
+                    int ldc, int M, int N, int K, int splits, void* stream) {
+    hipError_t e = hipSuccess;
+    int line = 0;
+    int st = train_debug_gemm(precision, a_kslow, b_kslow, A, lda, B, ldb, C, ldc, M, N, K, splits, (hipStream_t)stream, &e,
+                              &line);
+    if (st == BESO_ERR_HIP) {
+        snprintf(g_last_error, sizeof(g_last_error), "%s (%d) at train.hip:%d", hipGetErrorName(e), (int)e, line);
+    }
+    return st;
 }
 
 void beso_profile_enable(int site) {

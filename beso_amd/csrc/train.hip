@@ -1,0 +1,1067 @@
+// Training step of the score network in HIP (row f1): GCDenoiser.loss forward + the gradient of the loss
+// with respect to every parameter, enqueued on one stream.
+//   reference: score_wrappers.py:45-79 (loss), score_gpts.py:272-358 (network), beso_agent.py:215-248 (step)
+//
+// Structure (M = batch * T token rows; E = GEMM operand type: bf16, or fp32 in the parity mode):
+//   forward    prep (noised action, target) -> embed (x0, feature matrix Xemb) -> L x [ LN1 -> QKV GEMM ->
+//              attention (dropout on the probabilities) -> proj GEMM + residual -> LN2 -> FC1 GEMM (+GELU) ->
+//              FC2 GEMM + residual ] -> ln_f -> head GEMM -> squared error.  Every GEMM input is kept.
+//   backward   the same chain reversed.  All contractions run on ONE MFMA GEMM kernel (`tgemm_kernel`) whose
+//              operands may be stored contraction-major ("k-slow"): dgrad reads W[out][in] as it lies
+//              (contraction over `out`), wgrad reads dY[m][n] and X[m][k] as they lie (contraction over the
+//              token index m).  k-slow bf16 tiles are fetched from LDS with ds_read_b64_tr_b16 (the gfx950
+//              transpose read), k-slow fp32 tiles with plain ds_read_b32 (v_mfma_f32_16x16x4_f32 takes one
+//              element per lane), so nothing is ever transposed through HBM.  Weight gradients are split over
+//              the token dimension and accumulated with fp32 atomics into the caller's (zeroed) flat buffer.
+//   LayerNorm backward also carries the residual gradient and emits its operand-typed copy (with the
+//   dropout mask of the consuming linear layer), GELU' is the epilogue of the FC2 dgrad GEMM.
+// Dropout masks come from a counter-based hash of (seed, site, element index): the backward recomputes them.
+#include <string.h>
+#include "common.h"
+#include "train.h"
+
+namespace beso {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// ---------------------------------------------------------------------------------------------
+// dropout: keep-scale of one element.  p = 0 never reaches this function.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t site, size_t idx, float p, float inv_keep) {
+    uint32_t h = (uint32_t)idx * 0x9E3779B1u + (uint32_t)(idx >> 32) * 0x7FEB352Du + site * 0x85EBCA77u + seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return ((float)(h >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.f;
+}
+
+__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float v) {
+    return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * expf(-0.5f * v * v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tgemm:  C[m][n] = sum_k Aop(m,k) * Bop(n,k)
+//   AKS = false: A is [M][lda], k contiguous ("k-contig")      AKS = true: A is [K][lda], m contiguous ("k-slow")
+//   BKS likewise for B ([N][ldb] / [K][ldb]).
+// 128x128 block tile, 4 waves as 2x2 of 64x64, 16x16 MFMA tiles; one stage = 128 bytes of k per row
+// (64 bf16 / 32 fp32); register-staged double buffering; all loads predicated (zero fill), so M, N, K are
+// arbitrary up to: K % (16/sizeof(E)) == 0 for a k-contig operand, rows % (16/sizeof(E)) == 0 for a k-slow one.
+// blockIdx.y splits K (k_per_split, a multiple of the stage); the epilogue functor decides what a partial
+// sum means (EpiAtomic accumulates).
+// ---------------------------------------------------------------------------------------------
+constexpr int kOpBytes = 16896;        // LDS bytes of one operand stage (k-slow images carry padding)
+constexpr int kSubBytes = 2112;        // bf16 k-slow image: one 16-column subtile = 64 k-rows x 32 B + 64 B pad
+constexpr int kRowBytes32 = 528;       // fp32 k-slow image: one k-row = 128 columns x 4 B + 16 B pad
+
+template <typename E, bool KS>
+__device__ __forceinline__ void op_gload(const E* __restrict__ P, int ld, int r0, int R, int k0, int k_end, int tid,
+                                         u32x4 (&r)[4]) {
+    constexpr int EPC = 16 / (int)sizeof(E);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        bool ok;
+        size_t off;
+        if (!KS) {
+            const int row = c >> 3, kc = c & 7;
+            const int gr = r0 + row, gk = k0 + kc * EPC;
+            ok = gr < R && gk < k_end;
+            off = (size_t)gr * ld + gk;
+        } else {
+            constexpr int CPR = 128 / EPC;               // 16-byte chunks per k-row
+            const int krow = c / CPR, cc = c % CPR;
+            const int gk = k0 + krow, gc = r0 + cc * EPC;
+            ok = gk < k_end && gc < R;
+            off = (size_t)gk * ld + gc;
+        }
+        r[i] = ok ? *(const u32x4*)(P + off) : u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+template <typename E, bool KS>
+__device__ __forceinline__ void op_lstore(unsigned char* base, int tid, const u32x4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        int off;
+        if (!KS) {
+            const int row = c >> 3, kc = c & 7;
+            off = row * 128 + ((kc ^ (row & 7)) << 4);
+        } else if (sizeof(E) == 2) {
+            const int krow = c >> 4, cc = c & 15;        // 8 columns per chunk: subtile cc/2, half cc%2
+            off = (cc >> 1) * kSubBytes + krow * 32 + (cc & 1) * 16;
+        } else {
+            const int krow = c >> 5, cc = c & 31;
+            off = krow * kRowBytes32 + cc * 16;
+        }
+        *(u32x4*)(base + off) = r[i];
+    }
+}
+
+// MFMA operand fragment of 16-row tile `tile` (0..7 of the block tile), half-stage s (0/1).
+// k mapping (both layouts, both operands): bf16 slot j of lane group g is k = 32 s + 8 g + j; fp32 element j of
+// lane group g is k = 16 s + 4 g + j.
+template <typename E, bool KS>
+__device__ __forceinline__ u32x4 op_frag(const unsigned char* base, int tile, int s, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    if (!KS) {
+        const int row = tile * 16 + i, kc = s * 4 + g;
+        return *(const u32x4*)(base + row * 128 + ((kc ^ (row & 7)) << 4));
+    } else if (sizeof(E) == 2) {
+        // ds_read_b64_tr_b16: the 16 lanes of a group cover a [4 k][16 col] block (lane i: k-row i/4, columns
+        // 4(i%4)..+3) and receive column i of it, k-rows 0..3.  Two reads = 8 consecutive k of column i.
+        const unsigned char* p = base + tile * kSubBytes + (s * 32 + 8 * g + (i >> 2)) * 32 + (i & 3) * 8;
+        typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * 32));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        return u32x4{l2.x, l2.y, h2.x, h2.y};
+    } else {
+        u32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[j] = *(const uint32_t*)(base + (s * 16 + 4 * g + j) * kRowBytes32 + (tile * 16 + i) * 4);
+        return v;
+    }
+}
+
+template <typename E> __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma16<uint16_t>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& a, const u32x4& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
+}
+
+template <typename E, bool AKS, bool BKS, typename Epi>
+__global__ __launch_bounds__(256, 2) void tgemm_kernel(const E* __restrict__ A, int lda, const E* __restrict__ B,
+                                                       int ldb, int M, int N, int K, int k_per_split, int nt_n,
+                                                       Epi epi) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][kOpBytes];
+    constexpr int KSTAGE = 128 / (int)sizeof(E);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tile_n = blockIdx.x % nt_n, tile_m = blockIdx.x / nt_n;
+    const int m0 = tile_m * kTileMN, n0 = tile_n * kTileMN;
+    const int k_begin = blockIdx.y * k_per_split;
+    const int k_end = min(K, k_begin + k_per_split);
+    const int nk = (k_end - k_begin + KSTAGE - 1) / KSTAGE;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+        u32x4 ra[4], rb[4];
+        op_gload<E, AKS>(A, lda, m0, M, k_begin, k_end, tid, ra);
+        op_gload<E, BKS>(B, ldb, n0, N, k_begin, k_end, tid, rb);
+        op_lstore<E, AKS>(lds[0][0], tid, ra);
+        op_lstore<E, BKS>(lds[0][1], tid, rb);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {
+                op_gload<E, AKS>(A, lda, m0, M, k_begin + (kt + 1) * KSTAGE, k_end, tid, ra);
+                op_gload<E, BKS>(B, ldb, n0, N, k_begin + (kt + 1) * KSTAGE, k_end, tid, rb);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                u32x4 af[4], bf[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) af[mi] = op_frag<E, AKS>(lds[cur][0], wm * 4 + mi, s, lane);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) bf[ni] = op_frag<E, BKS>(lds[cur][1], wn * 4 + ni, s, lane);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) mma16<E>(acc[mi][ni], bf[ni], af[mi]);   // D[n][m]: 4 consecutive n per lane
+            }
+            if (kt + 1 < nk) {
+                op_lstore<E, AKS>(lds[cur ^ 1][0], tid, ra);
+                op_lstore<E, BKS>(lds[cur ^ 1][1], tid, rb);
+            }
+            __syncthreads();
+        }
+    }
+    // The MFMA ran as D = Bfrag x Afrag^T: the lane holds C[m][n..n+3] with m = lane & 15, n = 4*(lane >> 4) + reg,
+    // so every epilogue access is a 4-element vector (N % 4 == 0).
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + (lane & 15);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+            if (m < M && n < N) epi(m, n, acc[mi][ni]);
+        }
+    }
+}
+
+// ---- epilogues: (m, n, v) = C[m][n..n+3] ------------------------------------------------------
+template <typename E> struct Vec4;
+template <> struct Vec4<float> {
+    __device__ static __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
+    __device__ static __forceinline__ void store(float* p, const f32x4& v) { *(f32x4*)p = v; }
+};
+template <> struct Vec4<uint16_t> {
+    __device__ static __forceinline__ f32x4 load(const uint16_t* p) {
+        const uint2 u = *(const uint2*)p;
+        return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u)};
+    }
+    __device__ static __forceinline__ void store(uint16_t* p, const f32x4& v) {
+        uint2 u;
+        u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *(uint2*)p = u;
+    }
+};
+
+template <typename E> struct EpiStore {          // out = acc + bias  (fp32 and / or operand-typed copy)
+    float* o32; E* oe; const float* bias; int ld;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        if (bias) v += *(const f32x4*)(bias + n);
+        const size_t i = (size_t)m * ld + n;
+        if (o32) *(f32x4*)(o32 + i) = v;
+        if (oe) Vec4<E>::store(oe + i, v);
+    }
+};
+template <typename E> struct EpiFc1 {            // h = acc + bias (kept for GELU'), g = GELU(h)   (score_gpts.py:105-108)
+    E* h; E* g; const float* bias; int ld;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        v += *(const f32x4*)(bias + n);
+        const size_t i = (size_t)m * ld + n;
+        Vec4<E>::store(h + i, v);
+        Vec4<E>::store(g + i, f32x4{gelu_exact(v[0]), gelu_exact(v[1]), gelu_exact(v[2]), gelu_exact(v[3])});
+    }
+};
+struct EpiResid {                                // x_out = x_in + dropout(acc + bias)              (:79,:109,:113-114)
+    const float* xin; float* xout; const float* bias; int ld; float p, inv_keep; uint32_t seed, site;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        v += *(const f32x4*)(bias + n);
+        const size_t i = (size_t)m * ld + n;
+        if (p > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= drop_scale(seed, site, i + j, p, inv_keep);
+        }
+        *(f32x4*)(xout + i) = *(const f32x4*)(xin + i) + v;
+    }
+};
+template <typename E> struct EpiGeluBwd {        // dh = dg * GELU'(h)
+    const E* h; E* dh; int ld;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        const size_t i = (size_t)m * ld + n;
+        const f32x4 hv = Vec4<E>::load(h + i);
+        Vec4<E>::store(dh + i, f32x4{v[0] * gelu_grad(hv[0]), v[1] * gelu_grad(hv[1]), v[2] * gelu_grad(hv[2]),
+                                     v[3] * gelu_grad(hv[3])});
+    }
+};
+struct EpiAtomic {                               // split-K partial sums accumulated with atomics (debug entry point)
+    float* out; int ld;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        float* o = out + (size_t)m * ld + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(o + r, v[r]);
+    }
+};
+inline EpiAtomic epi_atomic(float* out, int ld) { return EpiAtomic{out, ld}; }
+// Split-K partial sums of a weight gradient: split z writes its [M][N] partial into slab z with plain 16-byte
+// stores; reduce_slabs_kernel sums the slabs into the gradient tensors.  (fp32 atomics run at ~35 G/s on this
+// part: with them every weight-gradient GEMM took the same 100 us whatever its size.)
+struct EpiSlab {
+    float* slab; size_t stride; int ld;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        *(f32x4*)(slab + (size_t)blockIdx.y * stride + (size_t)m * ld + n) = v;
+    }
+};
+
+template <typename E, bool AKS, bool BKS, typename Epi>
+hipError_t tgemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int splits, Epi epi, hipStream_t s) {
+    (void)hipGetLastError();
+    constexpr int EPC = 16 / (int)sizeof(E), KSTAGE = 128 / (int)sizeof(E);
+    if (M < 1 || N < 1 || K < 1) return hipErrorInvalidValue;
+    if ((AKS ? M : K) % EPC != 0 || (BKS ? N : K) % EPC != 0 || lda % EPC != 0 || ldb % EPC != 0 || N % 4 != 0)
+        return hipErrorInvalidValue;
+    if (((uintptr_t)A | (uintptr_t)B) & 15) return hipErrorInvalidValue;
+    const int nt_n = (N + kTileMN - 1) / kTileMN, nt_m = (M + kTileMN - 1) / kTileMN;
+    if (splits < 1) splits = 1;
+    const int kps = ((K + splits - 1) / splits + KSTAGE - 1) / KSTAGE * KSTAGE;
+    splits = (K + kps - 1) / kps;                                        // == split_count(K, splits, KSTAGE)
+    hipLaunchKernelGGL((tgemm_kernel<E, AKS, BKS, Epi>), dim3(nt_n * nt_m, splits), dim3(256), 0, s, (const E*)A, lda,
+                       (const E*)B, ldb, M, N, K, kps, nt_n, epi);
+    return hipGetLastError();
+}
+
+// out_j[i] = sum_z slab[z][j*seg + i]: the gradient tensors are assigned, not accumulated (q | k | v share one pass)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slab, size_t stride, int splits, float* out0, float* out1,
+                                    float* out2, size_t seg, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 acc = *(const f32x4*)(slab + 4 * i);
+        for (int z = 1; z < splits; ++z) acc += *(const f32x4*)(slab + (size_t)z * stride + 4 * i);
+        const size_t e = 4 * i, j = e / seg;
+        float* o = j == 0 ? out0 : (j == 1 ? out1 : out2);
+        *(f32x4*)(o + (e - j * seg)) = acc;
+    }
+}
+
+// (k_per_split, splits) actually launched for a requested split count -- tgemm uses the same arithmetic
+inline int split_count(int K, int splits, int kstage) {
+    if (splits < 1) splits = 1;
+    const int kps = ((K + splits - 1) / splits + kstage - 1) / kstage * kstage;
+    return (K + kps - 1) / kps;
+}
+
+// number of K splits that gives a weight-gradient GEMM about two workgroups per CU
+int wgrad_splits(int M, int N, int K, int kstage) {
+    const int tiles = ((M + kTileMN - 1) / kTileMN) * ((N + kTileMN - 1) / kTileMN);
+    int s = (512 + tiles - 1) / tiles;
+    const int smax = K / (4 * kstage) > 1 ? K / (4 * kstage) : 1;
+    if (s > smax) s = smax;
+    return s < 1 ? 1 : s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// prep: noised = a + n*sigma; target = (a - c_skip*noised)/c_out            (score_wrappers.py:64-69)
+// ---------------------------------------------------------------------------------------------
+__global__ void prep_kernel(const float* __restrict__ action, const float* __restrict__ noise,
+                            const float* __restrict__ sigma, float* __restrict__ noised, float* __restrict__ target,
+                            int per_sample, size_t n, float sigma_data) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float sg = sigma[i / per_sample];
+        const float sd2 = sigma_data * sigma_data, den = sg * sg + sd2;
+        const float c_skip = sd2 / den, c_out = sg * sigma_data / sqrtf(den);
+        const float a = action[i], nz = a + noise[i] * sg;
+        noised[i] = nz;
+        target[i] = (a - c_skip * nz) / c_out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// embed (training): x0 row (same arithmetic as embed_kernel of elementwise.hip) + the row of the feature
+// matrix Xemb[M][Ke] whose transpose-product with dx0 yields every embedding gradient at once:
+//   columns [0,obs) state/goal features | [obs,obs+act) c_in * noised action | obs+act: log(sigma)/4 |
+//   +1,+2,+3: one-hot of the token kind (tok_emb.bias, action_emb.bias, sigma_emb.bias) |
+//   then seq_size one-hot columns of the position row used (pos_emb).
+// ---------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void train_embed_kernel(const float* __restrict__ state, const float* __restrict__ action,
+                                   const float* __restrict__ goal, const float* __restrict__ sigma,
+                                   const float* __restrict__ pos, const float* __restrict__ tok_w,
+                                   const float* __restrict__ tok_b, const float* __restrict__ sig_w,
+                                   const float* __restrict__ sig_b, const float* __restrict__ act_w,
+                                   const float* __restrict__ act_b, float* __restrict__ x, E* __restrict__ xemb,
+                                   int t, int T, int G, int D, int obs, int act, int Ke, float sigma_data) {
+    extern __shared__ float in_vec[];
+    const int row = blockIdx.x, b = row / T, j = row % T;
+    const float sg = sigma[b];
+    int kind, len = 0, posrow = -1;
+    const float* src = nullptr;
+    float scale = 1.f;
+    if (j == 0) {
+        kind = 0;
+    } else if (j <= G) {
+        kind = 1; len = obs; posrow = j - 1; src = goal + ((size_t)b * G + (j - 1)) * obs;
+    } else {
+        const int idx = j - G - 1, i = idx >> 1;
+        posrow = G + i;
+        if ((idx & 1) == 0) { kind = 1; len = obs; src = state + ((size_t)b * t + i) * obs; }
+        else {
+            kind = 2; len = act; src = action + ((size_t)b * t + i) * act;
+            scale = 1.0f / sqrtf(sg * sg + sigma_data * sigma_data);                      // c_in
+        }
+    }
+    for (int c = threadIdx.x; c < len; c += blockDim.x) in_vec[c] = src[c] * scale;
+    __syncthreads();
+    const float lsg = logf(sg) / 4.0f;
+    for (int c = threadIdx.x; c < Ke; c += blockDim.x) {
+        float v = 0.f;
+        if (c < obs) v = kind == 1 ? in_vec[c] : 0.f;
+        else if (c < obs + act) v = kind == 2 ? in_vec[c - obs] : 0.f;
+        else if (c == obs + act) v = kind == 0 ? lsg : 0.f;
+        else if (c == obs + act + 1) v = kind == 1 ? 1.f : 0.f;
+        else if (c == obs + act + 2) v = kind == 2 ? 1.f : 0.f;
+        else if (c == obs + act + 3) v = kind == 0 ? 1.f : 0.f;
+        else v = (c - (obs + act + 4)) == posrow ? 1.f : 0.f;
+        xemb[(size_t)row * Ke + c] = Act<E>::from(v);
+    }
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float v;
+        if (kind == 0) {
+            v = sig_w[d] * lsg + sig_b[d];
+        } else {
+            const float* w = (kind == 1 ? tok_w : act_w) + (size_t)d * len;
+            float acc = 0.f;
+            for (int c = 0; c < len; ++c) acc = fmaf(in_vec[c], w[c], acc);
+            v = acc + (kind == 1 ? tok_b[d] : act_b[d]) + pos[(size_t)posrow * D + d];
+        }
+        x[(size_t)row * D + d] = v;
+    }
+}
+
+// dWcat[Ke][D] -> the individual embedding gradients (accumulated: the flat buffer was zeroed)
+__global__ void scatter_emb_kernel(const float* __restrict__ dw, float* __restrict__ g_pos, float* __restrict__ g_tokw,
+                                   float* __restrict__ g_tokb, float* __restrict__ g_sigw, float* __restrict__ g_sigb,
+                                   float* __restrict__ g_actw, float* __restrict__ g_actb, int D, int obs, int act,
+                                   int seq_size) {
+    const int n = (obs + act + 4 + seq_size) * D;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = i / D, d = i % D;
+        const float v = dw[i];
+        if (c < obs) g_tokw[(size_t)d * obs + c] += v;
+        else if (c < obs + act) g_actw[(size_t)d * act + (c - obs)] += v;
+        else if (c == obs + act) g_sigw[d] += v;
+        else if (c == obs + act + 1) g_tokb[d] += v;
+        else if (c == obs + act + 2) g_actb[d] += v;
+        else if (c == obs + act + 3) g_sigb[d] += v;
+        else g_pos[(size_t)(c - (obs + act + 4)) * D + d] += v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward with saved statistics; one wave per row, the row in registers as float4 per lane
+// (D % 4 == 0, D <= 1024).
+// ---------------------------------------------------------------------------------------------
+constexpr int kLnVec = 4;              // float4 slots per lane
+
+template <typename E>
+__global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                              E* __restrict__ out, float* __restrict__ stats, int rows, int D) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    f32x4 v[kLnVec];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnVec; ++i) {
+        const int c = (lane + i * 64) * 4;
+        v[i] = c < D ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnVec; ++i) {
+        const int c = (lane + i * 64) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; sq = fmaf(d, d, sq); }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + 1e-5f);
+    if (lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+    E* o = out + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < kLnVec; ++i) {
+        const int c = (lane + i * 64) * 4;
+        if (c < D) {
+            const f32x4 wv = *(const f32x4*)(w + c), bv = *(const f32x4*)(b + c);
+            Vec4<E>::store(o + c, (v[i] - mean) * rstd * wv + bv);
+        }
+    }
+}
+
+// LayerNorm backward + residual gradient:  dres <- dres + dLN(dxn)  (dres_in == nullptr: no incoming residual
+// gradient), operand-typed copy dxb = dres * keep-scale(site) for the linear layer that consumes it, that layer's
+// bias gradient (column sums of dxb; dbias may be nullptr) and the affine gradients -- register partials per
+// wave -> LDS -> one atomic per block and feature.
+template <typename E>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ x,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     const float* dres_in, float* dres_out, E* __restrict__ dxb,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dbias, int rows, int D, int rows_per_wave, float p,
+                                                     float inv_keep, uint32_t seed, uint32_t site) {
+    __shared__ f32x4 red[3][4][64 * kLnVec];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + wid;
+    f32x4 gw[kLnVec], ag[kLnVec], ab[kLnVec], ac[kLnVec];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kLnVec; ++i) {
+        const int c = (lane + i * 64) * 4;
+        gw[i] = c < D ? *(const f32x4*)(gamma + c) : zero;
+        ag[i] = zero; ab[i] = zero; ac[i] = zero;
+    }
+    const int r_begin = wave * rows_per_wave, r_end = min(rows, r_begin + rows_per_wave);
+    for (int row = r_begin; row < r_end; ++row) {
+        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+        const float* xr = x + (size_t)row * D;
+        const float* gr = dxn + (size_t)row * D;
+        f32x4 xh[kLnVec], dy[kLnVec];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnVec; ++i) {
+            const int c = (lane + i * 64) * 4;
+            const f32x4 go = c < D ? *(const f32x4*)(gr + c) : zero;
+            xh[i] = c < D ? (*(const f32x4*)(xr + c) - mean) * rstd : zero;
+            dy[i] = go * gw[i];
+            const f32x4 t = dy[i] * xh[i];
+            s1 += (dy[i][0] + dy[i][1]) + (dy[i][2] + dy[i][3]);
+            s2 += (t[0] + t[1]) + (t[2] + t[3]);
+            ag[i] += go * xh[i];
+            ab[i] += go;
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < kLnVec; ++i) {
+            const int c = (lane + i * 64) * 4;
+            if (c < D) {
+                const size_t idx = (size_t)row * D + c;
+                f32x4 tot = (dy[i] - c1 - xh[i] * c2) * rstd;
+                if (dres_in) tot += *(const f32x4*)(dres_in + idx);
+                *(f32x4*)(dres_out + idx) = tot;
+                f32x4 op = tot;
+                if (p > 0.f) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) op[j] *= drop_scale(seed, site, idx + j, p, inv_keep);
+                }
+                Vec4<E>::store(dxb + idx, op);
+                ac[i] += op;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kLnVec; ++i) {
+        red[0][wid][lane + i * 64] = ag[i]; red[1][wid][lane + i * 64] = ab[i]; red[2][wid][lane + i * 64] = ac[i];
+    }
+    __syncthreads();
+    const float* r0 = (const float*)red[0], *r1 = (const float*)red[1], *r2 = (const float*)red[2];
+    constexpr int WS = 64 * kLnVec * 4;          // floats per wave slab
+    for (int c = threadIdx.x; c < D; c += 256) {
+        unsafeAtomicAdd(dgamma + c, r0[c] + r0[WS + c] + r0[2 * WS + c] + r0[3 * WS + c]);
+        unsafeAtomicAdd(dbeta + c, r1[c] + r1[WS + c] + r1[2 * WS + c] + r1[3 * WS + c]);
+        if (dbias) unsafeAtomicAdd(dbias + c, r2[c] + r2[WS + c] + r2[2 * WS + c] + r2[3 * WS + c]);
+    }
+}
+
+// column sums (bias gradients): out_j[n - j*seg] += sum_m a[m][n] for n in segment j (q | k | v share one pass).
+// Thread (cx, ry): 16-byte chunk cx of the row, rows ry, ry+4, ...; a wave reads 1 KB of a row at a time.
+template <typename E>
+__global__ __launch_bounds__(256) void colsum_kernel(const E* __restrict__ a, int ld, int rows, int cols, float* out0,
+                                                     float* out1, float* out2, int seg, int rows_per_block) {
+    constexpr int EPC = 16 / (int)sizeof(E);
+    __shared__ float red[4][64][EPC];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + cx) * EPC;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float acc[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) acc[j] = 0.f;
+    if (c < cols) {
+        for (int r = r0 + ry; r < r1; r += 4) {
+            const u32x4 u = *(const u32x4*)(a + (size_t)r * ld + c);
+            if (sizeof(E) == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * j] += __uint_as_float(u[j] << 16);
+                    acc[2 * j + 1] += __uint_as_float(u[j] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += __uint_as_float(u[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) red[ry][cx][j] = acc[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * EPC; i += 256) {
+        const int n = blockIdx.x * 64 * EPC + i;
+        if (n < cols) {
+            const int x = i / EPC, j = i % EPC;
+            const float v = red[0][x][j] + red[1][x][j] + red[2][x][j] + red[3][x][j];
+            const int sj = n / seg;
+            float* o = sj == 0 ? out0 : (sj == 1 ? out1 : out2);
+            unsafeAtomicAdd(o + (n - sj * seg), v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention of one (sample, head) per wave, forward (training: dropout on the probabilities, score_gpts.py:69-76)
+// and backward.  q/k/v rows of the head in LDS as fp32; T x T scores in LDS.  qkv row layout [q | k | v].
+// ---------------------------------------------------------------------------------------------
+struct AttnLds { float *q, *k, *v, *dy, *P, *dP; int ldh, ldt; };
+__device__ __forceinline__ AttnLds attn_carve(float* base, int T, int hd, bool bwd) {
+    AttnLds a;
+    a.ldh = hd + 1; a.ldt = T + 1;
+    a.q = base; a.k = a.q + T * a.ldh; a.v = a.k + T * a.ldh;
+    a.dy = a.v + T * a.ldh;
+    a.P = a.dy + (bwd ? T * a.ldh : 0);
+    a.dP = a.P + T * a.ldt;
+    return a;
+}
+size_t attn_lds_bytes(int T, int hd, bool bwd) {
+    return sizeof(float) * ((size_t)(bwd ? 4 : 3) * T * (hd + 1) + (size_t)(bwd ? 2 : 1) * T * (T + 1));
+}
+
+// P (pre-dropout probabilities) for all rows; lanes stride over rows
+template <typename E>
+__device__ __forceinline__ void attn_load_scores(const E* __restrict__ qkv, const AttnLds& a, int b, int h, int T,
+                                                 int D, int hd, float scale, int lane) {
+    const size_t ldq = (size_t)3 * D;
+    for (int u = lane; u < T * hd; u += 64) {
+        const int r = u / hd, d = u % hd;
+        const E* src = qkv + ((size_t)b * T + r) * ldq + (size_t)h * hd + d;
+        a.q[r * a.ldh + d] = Act<E>::to(src[0]);
+        a.k[r * a.ldh + d] = Act<E>::to(src[D]);
+        a.v[r * a.ldh + d] = Act<E>::to(src[2 * D]);
+    }
+    __syncthreads();
+    for (int u = lane; u < T * T; u += 64) {
+        const int i = u / T, j = u % T;
+        float s = -INFINITY;
+        if (j <= i) {
+            s = 0.f;
+            for (int d = 0; d < hd; ++d) s = fmaf(a.q[i * a.ldh + d], a.k[j * a.ldh + d], s);
+            s *= scale;
+        }
+        a.P[i * a.ldt + j] = s;
+    }
+    __syncthreads();
+    for (int i = lane; i < T; i += 64) {
+        float m = -INFINITY;
+        for (int j = 0; j <= i; ++j) m = fmaxf(m, a.P[i * a.ldt + j]);
+        float l = 0.f;
+        for (int j = 0; j <= i; ++j) { const float e = expf(a.P[i * a.ldt + j] - m); a.P[i * a.ldt + j] = e; l += e; }
+        const float inv = 1.0f / l;
+        for (int j = 0; j < T; ++j) a.P[i * a.ldt + j] = j <= i ? a.P[i * a.ldt + j] * inv : 0.f;
+    }
+    __syncthreads();
+}
+
+template <typename E>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const E* __restrict__ qkv, E* __restrict__ y, int T, int D, int H,
+                                                      int hd, float scale, float p, float inv_keep, uint32_t seed,
+                                                      uint32_t site) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int pair = blockIdx.x, b = pair / H, h = pair % H, lane = threadIdx.x;
+    const AttnLds a = attn_carve(smem_f, T, hd, false);
+    attn_load_scores<E>(qkv, a, b, h, T, D, hd, scale, lane);
+    if (p > 0.f) {
+        for (int u = lane; u < T * T; u += 64) {
+            const int i = u / T, j = u % T;
+            a.P[i * a.ldt + j] *= drop_scale(seed, site, (size_t)pair * T * T + u, p, inv_keep);
+        }
+        __syncthreads();
+    }
+    for (int u = lane; u < T * hd; u += 64) {
+        const int i = u / hd, d = u % hd;
+        float o = 0.f;
+        for (int j = 0; j <= i; ++j) o = fmaf(a.P[i * a.ldt + j], a.v[j * a.ldh + d], o);
+        y[((size_t)b * T + i) * D + (size_t)h * hd + d] = Act<E>::from(o);
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(const E* __restrict__ qkv, const E* __restrict__ dy,
+                                                      E* __restrict__ dqkv, int T, int D, int H, int hd, float scale,
+                                                      float p, float inv_keep, uint32_t seed, uint32_t site) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int pair = blockIdx.x, b = pair / H, h = pair % H, lane = threadIdx.x;
+    const AttnLds a = attn_carve(smem_f, T, hd, true);
+    attn_load_scores<E>(qkv, a, b, h, T, D, hd, scale, lane);
+    for (int u = lane; u < T * hd; u += 64) {
+        const int r = u / hd, d = u % hd;
+        a.dy[r * a.ldh + d] = Act<E>::to(dy[((size_t)b * T + r) * D + (size_t)h * hd + d]);
+    }
+    __syncthreads();
+    // dP[i][j] = keep-scale * sum_d dy[i][d] v[j][d]   (gradient w.r.t. the pre-dropout probability)
+    for (int u = lane; u < T * T; u += 64) {
+        const int i = u / T, j = u % T;
+        float g = 0.f;
+        if (j <= i) {
+            for (int d = 0; d < hd; ++d) g = fmaf(a.dy[i * a.ldh + d], a.v[j * a.ldh + d], g);
+            if (p > 0.f) g *= drop_scale(seed, site, (size_t)pair * T * T + u, p, inv_keep);
+        }
+        a.dP[i * a.ldt + j] = g;
+    }
+    __syncthreads();
+    const size_t ldq = (size_t)3 * D;
+    // dv[j][d] = sum_{i>=j} Pd[i][j] dy[i][d]  (Pd = P * keep-scale) -- before dP is turned into dS
+    for (int u = lane; u < T * hd; u += 64) {
+        const int j = u / hd, d = u % hd;
+        float g = 0.f;
+        for (int i = j; i < T; ++i) {
+            float pd = a.P[i * a.ldt + j];
+            if (p > 0.f) pd *= drop_scale(seed, site, (size_t)pair * T * T + (size_t)i * T + j, p, inv_keep);
+            g = fmaf(pd, a.dy[i * a.ldh + d], g);
+        }
+        dqkv[((size_t)b * T + j) * ldq + 2 * (size_t)D + (size_t)h * hd + d] = Act<E>::from(g);
+    }
+    __syncthreads();
+    // dS[i][j] = P[i][j] * (dP[i][j] - sum_j' dP[i][j'] P[i][j'])
+    for (int i = lane; i < T; i += 64) {
+        float dot = 0.f;
+        for (int j = 0; j <= i; ++j) dot = fmaf(a.dP[i * a.ldt + j], a.P[i * a.ldt + j], dot);
+        for (int j = 0; j < T; ++j)
+            a.dP[i * a.ldt + j] = j <= i ? a.P[i * a.ldt + j] * (a.dP[i * a.ldt + j] - dot) * scale : 0.f;
+    }
+    __syncthreads();
+    for (int u = lane; u < T * hd; u += 64) {
+        const int r = u / hd, d = u % hd;
+        float gq = 0.f, gk = 0.f;
+        for (int j = 0; j <= r; ++j) gq = fmaf(a.dP[r * a.ldt + j], a.k[j * a.ldh + d], gq);
+        for (int i = r; i < T; ++i) gk = fmaf(a.dP[i * a.ldt + r], a.q[i * a.ldh + d], gk);
+        E* dst = dqkv + ((size_t)b * T + r) * ldq + (size_t)h * hd + d;
+        dst[0] = Act<E>::from(gq);
+        dst[D] = Act<E>::from(gk);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// squared-error loss over the action-token rows (score_wrappers.py:70-79 with pred_last_action_only False:
+// per-sample mean over (t, act), then the batch mean = the mean over all B*t*act elements), its gradient
+// with respect to the prediction, operand typed, zero on every other row and on the padding columns.
+// ---------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                   E* __restrict__ dpred, float* __restrict__ loss, int M, int T, int G,
+                                                   int t, int act, int ap, float inv_count, float grad_scale) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    const size_t n = (size_t)M * ap;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / ap), a = (int)(i % ap);
+        const int b = m / T, idx = m % T - 1 - G;
+        float g = 0.f;
+        if (a < act && idx >= 0 && (idx & 1)) {
+            const float diff = pred[i] - target[((size_t)b * t + (idx >> 1)) * act + a];
+            acc = fmaf(diff, diff, acc);
+            g = 2.0f * diff * inv_count * grad_scale;
+        }
+        dpred[i] = Act<E>::from(g);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) * inv_count);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static size_t carve_t(size_t& cur, size_t bytes) {
+    const size_t off = cur;
+    cur = round_up_sz(cur + bytes, 256);
+    return off;
+}
+
+struct TrainLayerWs {
+    size_t w_qkv, b_qkv, w_proj, w_fc1, w_fc2;                    // operand-typed weight copies (b_qkv fp32 [3D])
+    size_t x_mid, x_out, st1, st2, xn1, qkv, y, xn2, h, g;        // kept activations
+};
+struct TrainWs {
+    int M, T, Ke, ap;
+    size_t noised, target, x0, xemb, stf, xf, pred, dpred, w_head, b_head, dw_cat, slab;
+    size_t dx, dxb, dxn, dy, dqkv, dh;
+    TrainLayerWs layer[kMaxLayers];
+    size_t total;
+};
+
+static bool make_train_ws(const beso_config* c, int batch, int t, int precision, TrainWs* w) {
+    memset(w, 0, sizeof(*w));
+    const size_t e = precision == BESO_PREC_FP32 ? 4 : 2, f = 4;
+    const int D = c->embed_dim, G = c->goal_seq_len;
+    const int T = 1 + G + 2 * t;
+    const size_t M = (size_t)batch * T;
+    w->M = (int)M; w->T = T;
+    w->Ke = round_up(c->obs_dim + c->act_dim + 4 + G + c->obs_seq_len + 1, 8);
+    w->ap = round_up(c->act_dim, 16);
+    size_t cur = 0;
+    const size_t na = (size_t)batch * t * c->act_dim;
+    w->noised = carve_t(cur, f * na); w->target = carve_t(cur, f * na);
+    w->x0 = carve_t(cur, f * M * D); w->xemb = carve_t(cur, e * M * w->Ke);
+    w->stf = carve_t(cur, f * M * 2); w->xf = carve_t(cur, e * M * D);
+    w->pred = carve_t(cur, f * M * w->ap); w->dpred = carve_t(cur, e * M * w->ap);
+    w->w_head = carve_t(cur, e * (size_t)w->ap * D); w->b_head = carve_t(cur, f * w->ap);
+    w->dw_cat = carve_t(cur, f * (size_t)w->Ke * D);
+    {
+        const int kstage = 128 / (int)e;
+        const int shapes[6][2] = {{D, 4 * D}, {4 * D, D}, {D, D}, {3 * D, D}, {w->ap, D}, {w->Ke, D}};
+        size_t mx = 0;
+        for (auto& sh : shapes) {
+            const size_t n = (size_t)split_count((int)M, wgrad_splits(sh[0], sh[1], (int)M, kstage), kstage) * sh[0] * sh[1];
+            mx = n > mx ? n : mx;
+        }
+        w->slab = carve_t(cur, f * mx);
+    }
+    w->dx = carve_t(cur, f * M * D); w->dxb = carve_t(cur, e * M * D); w->dxn = carve_t(cur, f * M * D);
+    w->dy = carve_t(cur, e * M * D); w->dqkv = carve_t(cur, e * M * 3 * D); w->dh = carve_t(cur, e * M * 4 * D);
+    for (int l = 0; l < c->n_layers; ++l) {
+        TrainLayerWs& y = w->layer[l];
+        y.w_qkv = carve_t(cur, e * (size_t)3 * D * D); y.b_qkv = carve_t(cur, f * (size_t)3 * D);
+        y.w_proj = carve_t(cur, e * (size_t)D * D);
+        y.w_fc1 = carve_t(cur, e * (size_t)4 * D * D); y.w_fc2 = carve_t(cur, e * (size_t)4 * D * D);
+        y.x_mid = carve_t(cur, f * M * D); y.x_out = carve_t(cur, f * M * D);
+        y.st1 = carve_t(cur, f * M * 2); y.st2 = carve_t(cur, f * M * 2);
+        y.xn1 = carve_t(cur, e * M * D); y.qkv = carve_t(cur, e * M * 3 * D); y.y = carve_t(cur, e * M * D);
+        y.xn2 = carve_t(cur, e * M * D); y.h = carve_t(cur, e * M * 4 * D); y.g = carve_t(cur, e * M * 4 * D);
+    }
+    w->total = cur;
+    return true;
+}
+
+int train_validate(const beso_config* c, int batch, int t) {
+    int st = validate_config(c);
+    if (st != BESO_OK) return st;
+    if (batch < 1 || t < 1 || t > c->obs_seq_len) return BESO_ERR_BAD_SHAPE;
+    if (!c->linear_output) return BESO_ERR_UNSUPPORTED;           // every shipped config: linear_output True
+    if (c->embed_dim % 8 != 0) return BESO_ERR_UNSUPPORTED;        // 16-byte operand chunks, float4 LayerNorm rows
+    const int T = 1 + c->goal_seq_len + 2 * t;
+    if (attn_lds_bytes(T, c->embed_dim / c->n_heads, true) > 150 * 1024) return BESO_ERR_UNSUPPORTED;
+    if ((size_t)batch * T > (size_t)1 << 24) return BESO_ERR_BAD_SHAPE;
+    return BESO_OK;
+}
+
+size_t train_workspace_bytes(const beso_config* c, int batch, int t, int precision) {
+    if (train_validate(c, batch, t) != BESO_OK) return 0;
+    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32) return 0;
+    TrainWs w;
+    make_train_ws(c, batch, t, precision, &w);
+    return w.total;
+}
+
+size_t train_grad_floats(const beso_config* c) {
+    if (validate_config(c) != BESO_OK) return 0;
+    const size_t D = c->embed_dim, seq = c->goal_seq_len + c->obs_seq_len + 1;
+    size_t n = seq * D + D * c->obs_dim + D;
+    n += (size_t)c->n_layers * (4 * D + 4 * (D * D + D) + (4 * D * D + 4 * D) + (4 * D * D + D));
+    n += 2 * D + 2 * D + D * c->act_dim + D;
+    n += c->linear_output ? (size_t)c->act_dim * D + c->act_dim
+                          : (size_t)kHeadHidden * D + kHeadHidden + (size_t)c->act_dim * kHeadHidden + c->act_dim;
+    return n;
+}
+
+#define TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { *err = _e; *err_line = __LINE__; return BESO_ERR_HIP; } } while (0)
+
+template <typename E>
+static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat, int precision, const float* state,
+                       const float* action, const float* goal, const float* noise, const float* sigma, float* loss_out,
+                       int batch, int t, float attn_p, float resid_p, uint32_t seed, float grad_scale, char* ws,
+                       const TrainWs& w, hipStream_t s, hipError_t* err, int* err_line) {
+    const int D = c->embed_dim, H = c->n_heads, hd = D / H, L = c->n_layers, G = c->goal_seq_len;
+    const int obs = c->obs_dim, act = c->act_dim, seq = G + c->obs_seq_len + 1;
+    const int M = w.M, T = w.T, Ke = w.Ke, ap = w.ap, D3 = 3 * D, D4 = 4 * D;
+    constexpr int KSTAGE = 128 / (int)sizeof(E);
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float attn_ik = attn_p > 0.f ? 1.0f / (1.0f - attn_p) : 1.f, resid_ik = resid_p > 0.f ? 1.0f / (1.0f - resid_p) : 1.f;
+    auto F = [&](size_t off) { return (float*)(ws + off); };
+    auto P = [&](size_t off) { return (E*)(ws + off); };
+
+    // parameter / gradient pointers, order of beso_pack_weights
+    const float* const* q = p;
+    float* g = gflat;
+    struct PG { const float* p; float* g; };
+    auto take = [&](size_t n) { PG r{*q, g}; ++q; g += n; return r; };
+    const PG pos = take((size_t)seq * D), tokw = take((size_t)D * obs), tokb = take(D);
+    struct LayerPG { PG ln1w, ln1b, ln2w, ln2b, kw, kb, qw, qb, vw, vb, pw, pb, f1w, f1b, f2w, f2b; };
+    LayerPG lp[kMaxLayers];
+    for (int l = 0; l < L; ++l) {
+        LayerPG& y = lp[l];
+        y.ln1w = take(D); y.ln1b = take(D); y.ln2w = take(D); y.ln2b = take(D);
+        y.kw = take((size_t)D * D); y.kb = take(D); y.qw = take((size_t)D * D); y.qb = take(D);
+        y.vw = take((size_t)D * D); y.vb = take(D); y.pw = take((size_t)D * D); y.pb = take(D);
+        y.f1w = take((size_t)D4 * D); y.f1b = take(D4); y.f2w = take((size_t)D * D4); y.f2b = take(D);
+    }
+    const PG lnfw = take(D), lnfb = take(D), sigw = take(D), sigb = take(D), actw = take((size_t)D * act), actb = take(D);
+    const PG hw = take((size_t)act * D), hb = take(act);
+    const size_t n_grad = (size_t)(g - gflat);
+
+    TRY(hipMemsetAsync(gflat, 0, sizeof(float) * n_grad, s));
+    TRY(hipMemsetAsync(loss_out, 0, sizeof(float), s));
+    TRY(hipMemsetAsync(ws + w.b_head, 0, sizeof(float) * ap, s));
+
+    // ---- operand-typed weight copies (fused q|k|v rows as in the inference image)
+    for (int l = 0; l < L; ++l) {
+        const TrainLayerWs& y = w.layer[l];
+        const size_t e = sizeof(E);
+        TRY(launch_pack_matrix(lp[l].qw.p, D, D, ws + y.w_qkv, D, D, precision, s));
+        TRY(launch_pack_matrix(lp[l].kw.p, D, D, ws + y.w_qkv + e * (size_t)D * D, D, D, precision, s));
+        TRY(launch_pack_matrix(lp[l].vw.p, D, D, ws + y.w_qkv + e * (size_t)2 * D * D, D, D, precision, s));
+        TRY(hipMemcpyAsync(ws + y.b_qkv, lp[l].qb.p, sizeof(float) * D, hipMemcpyDeviceToDevice, s));
+        TRY(hipMemcpyAsync(ws + y.b_qkv + sizeof(float) * D, lp[l].kb.p, sizeof(float) * D, hipMemcpyDeviceToDevice, s));
+        TRY(hipMemcpyAsync(ws + y.b_qkv + sizeof(float) * 2 * D, lp[l].vb.p, sizeof(float) * D, hipMemcpyDeviceToDevice, s));
+        TRY(launch_pack_matrix(lp[l].pw.p, D, D, ws + y.w_proj, D, D, precision, s));
+        TRY(launch_pack_matrix(lp[l].f1w.p, D4, D, ws + y.w_fc1, D4, D, precision, s));
+        TRY(launch_pack_matrix(lp[l].f2w.p, D, D4, ws + y.w_fc2, D, D4, precision, s));
+    }
+    TRY(launch_pack_matrix(hw.p, act, D, ws + w.w_head, ap, D, precision, s));
+    TRY(hipMemcpyAsync(ws + w.b_head, hb.p, sizeof(float) * act, hipMemcpyDeviceToDevice, s));
+
+    // ---- forward
+    {
+        const size_t n = (size_t)batch * t * act;
+        int grid = (int)((n + 255) / 256); if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(prep_kernel, dim3(grid), dim3(256), 0, s, action, noise, sigma, F(w.noised), F(w.target),
+                           t * act, n, c->sigma_data);
+        TRY(hipGetLastError());
+        const int threads = D >= 256 ? 256 : round_up(D, 64);
+        hipLaunchKernelGGL(train_embed_kernel<E>, dim3(M), dim3(threads), sizeof(float) * (size_t)(obs > act ? obs : act), s,
+                           state, (const float*)F(w.noised), goal, sigma, pos.p, tokw.p, tokb.p, sigw.p, sigb.p, actw.p,
+                           actb.p, F(w.x0), P(w.xemb), t, T, G, D, obs, act, Ke, c->sigma_data);
+        TRY(hipGetLastError());
+    }
+    const int ln_grid = (M + 3) / 4;
+    const size_t lds_f = attn_lds_bytes(T, hd, false), lds_b = attn_lds_bytes(T, hd, true);
+    if (lds_f > 64 * 1024) {
+        TRY(hipFuncSetAttribute((const void*)attn_fwd_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+    }
+    if (lds_b > 64 * 1024) {
+        TRY(hipFuncSetAttribute((const void*)attn_bwd_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    }
+    for (int l = 0; l < L; ++l) {
+        const TrainLayerWs& y = w.layer[l];
+        const float* x_in = l == 0 ? F(w.x0) : F(w.layer[l - 1].x_out);
+        hipLaunchKernelGGL(ln_fwd_kernel<E>, dim3(ln_grid), dim3(256), 0, s, x_in, lp[l].ln1w.p, lp[l].ln1b.p, P(y.xn1),
+                           F(y.st1), M, D);
+        TRY(hipGetLastError());
+        TRY((tgemm<E, false, false>(P(y.xn1), D, P(y.w_qkv), D, M, D3, D, 1,
+                                    EpiStore<E>{nullptr, P(y.qkv), F(y.b_qkv), D3}, s)));
+        hipLaunchKernelGGL(attn_fwd_kernel<E>, dim3(batch * H), dim3(64), lds_f, s, (const E*)P(y.qkv), P(y.y), T, D, H, hd,
+                           scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
+        TRY(hipGetLastError());
+        TRY((tgemm<E, false, false>(P(y.y), D, P(y.w_proj), D, M, D, D, 1,
+                                    EpiResid{x_in, F(y.x_mid), lp[l].pb.p, D, resid_p, resid_ik, seed, (uint32_t)(4 * l + 1)}, s)));
+        hipLaunchKernelGGL(ln_fwd_kernel<E>, dim3(ln_grid), dim3(256), 0, s, (const float*)F(y.x_mid), lp[l].ln2w.p,
+                           lp[l].ln2b.p, P(y.xn2), F(y.st2), M, D);
+        TRY(hipGetLastError());
+        TRY((tgemm<E, false, false>(P(y.xn2), D, P(y.w_fc1), D, M, D4, D, 1, EpiFc1<E>{P(y.h), P(y.g), lp[l].f1b.p, D4}, s)));
+        TRY((tgemm<E, false, false>(P(y.g), D4, P(y.w_fc2), D4, M, D, D4, 1,
+                                    EpiResid{(const float*)F(y.x_mid), F(y.x_out), lp[l].f2b.p, D, resid_p, resid_ik, seed,
+                                             (uint32_t)(4 * l + 2)}, s)));
+    }
+    const float* x_last = F(w.layer[L - 1].x_out);
+    hipLaunchKernelGGL(ln_fwd_kernel<E>, dim3(ln_grid), dim3(256), 0, s, x_last, lnfw.p, lnfb.p, P(w.xf), F(w.stf), M, D);
+    TRY(hipGetLastError());
+    TRY((tgemm<E, false, false>(P(w.xf), D, P(w.w_head), D, M, ap, D, 1, EpiStore<E>{F(w.pred), nullptr, F(w.b_head), ap}, s)));
+    {
+        const size_t n = (size_t)M * ap;
+        int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+        hipLaunchKernelGGL(loss_kernel<E>, dim3(grid), dim3(256), 0, s, (const float*)F(w.pred), (const float*)F(w.target),
+                           P(w.dpred), loss_out, M, T, G, t, act, ap, 1.0f / (float)((size_t)batch * t * act), grad_scale);
+        TRY(hipGetLastError());
+    }
+
+    // ---- backward
+    const int rpb = 128;                                  // rows per block of the column sums
+    constexpr int EPC = 16 / (int)sizeof(E);
+    auto colsum = [&](const E* a, int ld, int cols, float* o0, float* o1 = nullptr, float* o2 = nullptr,
+                      int seg = 1 << 30) -> hipError_t {
+        hipLaunchKernelGGL(colsum_kernel<E>, dim3((cols + 64 * EPC - 1) / (64 * EPC), (M + rpb - 1) / rpb), dim3(256), 0, s, a,
+                           ld, M, cols, o0, o1 ? o1 : o0, o2 ? o2 : o0, seg, rpb);
+        return hipGetLastError();
+    };
+    const int rpw = 4;                                    // rows per wave of the LayerNorm backward
+    const int lnb_grid = (M + 4 * rpw - 1) / (4 * rpw);
+    auto ln_bwd = [&](const float* x, size_t st, const float* gamma, bool have_res, float* dgam, float* dbet, float* dbias,
+                      float p_site, uint32_t site) -> hipError_t {
+        hipLaunchKernelGGL(ln_bwd_kernel<E>, dim3(lnb_grid), dim3(256), 0, s, (const float*)F(w.dxn), x, (const float*)F(st),
+                           gamma, have_res ? (const float*)F(w.dx) : nullptr, F(w.dx), P(w.dxb), dgam, dbet, dbias, M, D, rpw,
+                           p_site, p_site > 0.f ? 1.0f / (1.0f - p_site) : 1.f, seed, site);
+        return hipGetLastError();
+    };
+    // weight gradient C[Mo][No] = A^T B over the M token rows: split-K partials into the slab, then one reduction
+    // that assigns the gradient tensor(s); `n_out` floats are produced (the leading rows), segments of `seg` floats
+    auto wgrad = [&](const E* A, int lda, int Mo, const E* B, int ldb, int No, float* o0, float* o1, float* o2, size_t seg,
+                     size_t n_out) -> hipError_t {
+        const int req = wgrad_splits(Mo, No, M, KSTAGE), S = split_count(M, req, KSTAGE);
+        const size_t stride = (size_t)Mo * No;
+        hipError_t e = tgemm<E, true, true>(A, lda, B, ldb, Mo, No, M, req, EpiSlab{F(w.slab), stride, No}, s);
+        if (e != hipSuccess) return e;
+        const size_t n4 = n_out / 4;
+        int grid = (int)((n4 + 255) / 256); if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, s, (const float*)F(w.slab), stride, S, o0,
+                           o1 ? o1 : o0, o2 ? o2 : o0, seg, n4);
+        return hipGetLastError();
+    };
+    const size_t one_seg = (size_t)1 << 40;
+    // head: dW = dpred^T xf, db = colsum(dpred), dxf = dpred W
+    TRY(wgrad(P(w.dpred), ap, ap, P(w.xf), D, D, hw.g, nullptr, nullptr, one_seg, (size_t)act * D));
+    TRY(colsum(P(w.dpred), ap, act, hb.g));
+    TRY((tgemm<E, false, true>(P(w.dpred), ap, P(w.w_head), D, M, D, ap, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+    TRY(ln_bwd(x_last, w.stf, lnfw.p, false, lnfw.g, lnfb.g, lp[L - 1].f2b.g, resid_p, (uint32_t)(4 * (L - 1) + 2)));
+    for (int l = L - 1; l >= 0; --l) {
+        const TrainLayerWs& y = w.layer[l];
+        const float* x_in = l == 0 ? F(w.x0) : F(w.layer[l - 1].x_out);
+        // FC2: dW2 = dx^T g, db2, dh = (dx W2) * GELU'(h)
+        TRY(wgrad(P(w.dxb), D, D, P(y.g), D4, D4, lp[l].f2w.g, nullptr, nullptr, one_seg, (size_t)D * D4));
+        TRY((tgemm<E, false, true>(P(w.dxb), D, P(y.w_fc2), D4, M, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(w.dh), D4}, s)));
+        // FC1: dW1 = dh^T xn2, db1, dxn2 = dh W1
+        TRY(wgrad(P(w.dh), D4, D4, P(y.xn2), D, D, lp[l].f1w.g, nullptr, nullptr, one_seg, (size_t)D4 * D));
+        TRY(colsum(P(w.dh), D4, D4, lp[l].f1b.g));
+        TRY((tgemm<E, false, true>(P(w.dh), D4, P(y.w_fc1), D, M, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+        TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, true, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p, (uint32_t)(4 * l + 1)));
+        // proj: dWp = dx^T y, dbp, dy = dx Wp
+        TRY(wgrad(P(w.dxb), D, D, P(y.y), D, D, lp[l].pw.g, nullptr, nullptr, one_seg, (size_t)D * D));
+        TRY((tgemm<E, false, true>(P(w.dxb), D, P(y.w_proj), D, M, D, D, 1, EpiStore<E>{nullptr, P(w.dy), nullptr, D}, s)));
+        hipLaunchKernelGGL(attn_bwd_kernel<E>, dim3(batch * H), dim3(64), lds_b, s, (const E*)P(y.qkv), (const E*)P(w.dy),
+                           P(w.dqkv), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
+        TRY(hipGetLastError());
+        // q/k/v: three weight gradients from the column blocks of dqkv, bias gradients, dxn1 = dqkv Wqkv
+        TRY(wgrad(P(w.dqkv), D3, D3, P(y.xn1), D, D, lp[l].qw.g, lp[l].kw.g, lp[l].vw.g, (size_t)D * D, (size_t)D3 * D));
+        TRY(colsum(P(w.dqkv), D3, D3, lp[l].qb.g, lp[l].kb.g, lp[l].vb.g, D));
+        TRY((tgemm<E, false, true>(P(w.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+        const bool first = l == 0;
+        TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, true, lp[l].ln1w.g, lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g,
+                   first ? 0.f : resid_p, first ? 0u : (uint32_t)(4 * (l - 1) + 2)));
+    }
+    // embeddings: dWcat[Ke][D] = Xemb^T dx0, then routed to pos_emb / tok_emb / action_emb / sigma_emb
+    TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dxb), D, D, F(w.dw_cat), nullptr, nullptr, one_seg, (size_t)Ke * D));
+    hipLaunchKernelGGL(scatter_emb_kernel, dim3(64), dim3(256), 0, s, (const float*)F(w.dw_cat), pos.g, tokw.g, tokb.g, sigw.g,
+                       sigb.g, actw.g, actb.g, D, obs, act, seq);
+    TRY(hipGetLastError());
+    return BESO_OK;
+}
+
+int train_loss_grad(const beso_config* c, const float* const* params, int n_params, float* grads_flat, int precision,
+                    const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
+                    float* loss_out, int batch, int t, float attn_pdrop, float resid_pdrop, uint32_t seed, float grad_scale,
+                    void* workspace, size_t workspace_bytes, hipStream_t s, hipError_t* err, int* err_line) {
+    int st = train_validate(c, batch, t);
+    if (st != BESO_OK) return st;
+    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32) return BESO_ERR_BAD_ARG;
+    if (!params || !grads_flat || !state || !action || !noise || !sigma || !loss_out || !workspace) return BESO_ERR_BAD_ARG;
+    if (c->goal_seq_len > 0 && !goal) return BESO_ERR_BAD_ARG;
+    if (n_params != 3 + 16 * c->n_layers + 6 + 2) return BESO_ERR_BAD_ARG;
+    for (int i = 0; i < n_params; ++i) if (!params[i]) return BESO_ERR_BAD_ARG;
+    if (!(attn_pdrop >= 0.f && attn_pdrop < 1.f && resid_pdrop >= 0.f && resid_pdrop < 1.f)) return BESO_ERR_BAD_ARG;
+    TrainWs w;
+    make_train_ws(c, batch, t, precision, &w);
+    if (workspace_bytes < w.total) return BESO_ERR_WORKSPACE;
+    if (precision == BESO_PREC_FP32)
+        return loss_grad_e<float>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
+                                  attn_pdrop, resid_pdrop, seed, grad_scale, (char*)workspace, w, s, err, err_line);
+    return loss_grad_e<uint16_t>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
+                                 attn_pdrop, resid_pdrop, seed, grad_scale, (char*)workspace, w, s, err, err_line);
+}
+
+// development aid: C[M][N] = op(A) op(B)^T through tgemm (fp32 output), for the layout tests
+int train_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,
+                     int ldc, int M, int N, int K, int splits, hipStream_t s, hipError_t* err, int* err_line) {
+    if (!A || !B || !C) return BESO_ERR_BAD_ARG;
+#define DBG(E, AK, BK)                                                                                             \
+    do {                                                                                                           \
+        if (splits > 1) TRY((tgemm<E, AK, BK>(A, lda, B, ldb, M, N, K, splits, epi_atomic(C, ldc), s)));          \
+        else TRY((tgemm<E, AK, BK>(A, lda, B, ldb, M, N, K, 1, EpiStore<E>{C, nullptr, nullptr, ldc}, s)));      \
+        return BESO_OK;                                                                                            \
+    } while (0)
+    if (precision == BESO_PREC_FP32) {
+        if (!a_kslow && !b_kslow) DBG(float, false, false);
+        if (!a_kslow && b_kslow) DBG(float, false, true);
+        if (a_kslow && b_kslow) DBG(float, true, true);
+    } else if (precision == BESO_PREC_BF16) {
+        if (!a_kslow && !b_kslow) DBG(uint16_t, false, false);
+        if (!a_kslow && b_kslow) DBG(uint16_t, false, true);
+        if (a_kslow && b_kslow) DBG(uint16_t, true, true);
+    }
+#undef DBG
+    return BESO_ERR_UNSUPPORTED;
+}
+
+}  // namespace beso

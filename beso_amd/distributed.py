@@ -100,6 +100,12 @@ class GradientBucket:
             self._unpack()
 
 
+def all_reduce_sum(flat: torch.Tensor) -> None:
+    """C1 on an already averaged (pre-scaled by 1/world) flat gradient buffer: one collective, in place."""
+    if is_distributed():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+
 def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0) -> None:
     """C2: make every replica start from rank ``src``'s weights (one flat broadcast)."""
     if not is_distributed():

@@ -1,0 +1,164 @@
+"""HIP training step of the score network: ``GCDenoiser.loss`` forward and the
+gradient of the loss with respect to every parameter as ONE enqueue of ``beso_loss_grad``
+(beso_amd/csrc/train.hip), replacing ``loss = model.loss(...); loss.backward()`` of the reference's
+``train_step`` (beso_agent.py:226-235).
+
+Two ways in:
+
+* ``GCDenoiser.loss`` (training mode, HIP parameters) returns ``ScoreMatchingLoss.apply(...)``, an autograd
+  node whose backward hands the precomputed gradients to autograd -- user code that calls ``loss.backward()``
+  keeps working unchanged;
+* ``HipTrainStep.loss_backward`` is what ``BesoAgent.train_step`` uses: it writes ``p.grad`` as views of one
+  persistent flat buffer (stable addresses for the fused optimizer's chunk table, one flat tensor for the
+  data-parallel all-reduce) and returns the loss.
+
+There is no CPU implementation; shapes the kernels do not cover (``linear_output=False``, ``embed_pdrob > 0``,
+``pred_last_action_only``) stay on the torch-autograd evaluation of the same function.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+
+class HipTrainStep:
+    """Binds one ``DiffusionGPT`` to ``beso_loss_grad``: flat gradient buffer, workspace, dropout seed."""
+
+    def __init__(self, inner, sigma_data: float):
+        self.inner = inner
+        self.sigma_data = float(sigma_data)
+        self.lib = _lib.load()
+        self.cfg = inner.shape(self.sigma_data).c_struct()
+        self.n_params = self.lib.beso_num_params(C.byref(self.cfg))
+        self.n_grad = int(self.lib.beso_grad_floats(C.byref(self.cfg)))
+        self._flat: Optional[torch.Tensor] = None
+        self._views: Optional[List[torch.Tensor]] = None
+        self._ws: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ eligibility
+    @staticmethod
+    def supported(inner) -> bool:
+        embed_p, _, _ = inner._pdrops
+        return bool(inner.linear_output) and embed_p == 0.0 and inner.embed_dim % 8 == 0
+
+    def eligible(self, state, action, goal, noise, sigma) -> bool:
+        params = list(self.inner.parameters())
+        if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad for p in params):
+            return False
+        if sum(p.numel() for p in params) != self.n_grad or len(params) != self.n_params:
+            return False
+        for x in (state, action, noise, sigma) + ((goal,) if goal is not None else ()):
+            if not torch.is_tensor(x) or not x.is_cuda or x.requires_grad:
+                return False
+        if self.inner.goal_seq_len > 0 and goal is None:
+            return False
+        return self.supported(self.inner)
+
+    # ------------------------------------------------------------------ buffers
+    def _grad_buffer(self, dev, fresh: bool):
+        if fresh:
+            flat = torch.empty(self.n_grad, dtype=torch.float32, device=dev)
+        else:
+            if self._flat is None or self._flat.device != dev:
+                self._flat = torch.empty(self.n_grad, dtype=torch.float32, device=dev)
+                self._views = None
+            flat = self._flat
+        views, off = [], 0
+        if fresh or self._views is None:
+            for p in self.inner.parameters():
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            if not fresh:
+                self._views = views
+        else:
+            views = self._views
+        return flat, views
+
+    def _workspace(self, batch: int, t: int, precision: int, dev) -> torch.Tensor:
+        need = int(self.lib.beso_train_workspace_bytes(C.byref(self.cfg), batch, t, precision))
+        if need == 0:
+            raise ValueError(f"beso_hip: training step unsupported for batch={batch} t={t} with this model shape")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws
+
+    # ------------------------------------------------------------------ the call
+    def run(self, state, action, goal, noise, sigma, grad_scale: float = 1.0, seed: Optional[int] = None,
+            fresh_grads: bool = False):
+        """-> (loss 0-d tensor, flat gradient tensor, list of per-parameter views).  Inputs are NOT modified."""
+        inner = self.inner
+        dev = action.device
+        f32 = lambda x: x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        state, action, noise, sigma = f32(state), f32(action), f32(noise), f32(sigma).reshape(-1)
+        if state.dim() != 3 or action.dim() != 3:
+            raise ValueError("state must be [B,t,obs] and action [B,t,act]")
+        B, t, _ = state.shape
+        if action.shape[:2] != (B, t) or noise.shape != action.shape or sigma.numel() != B:
+            raise ValueError("action / noise must be [B,t,act] and sigma [B]")
+        G = inner.goal_seq_len
+        gptr = None
+        if G > 0:
+            goal = f32(goal)
+            if goal.dim() == 2:
+                goal = goal.unsqueeze(0)
+            goal = goal.expand(B, G, inner.obs_dim).contiguous()
+            gptr = goal.data_ptr()
+        _, attn_p, resid_p = inner._pdrops
+        if not inner.training:
+            attn_p = resid_p = 0.0
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,), device="cpu").item())
+        precision = _lib.PRECISIONS[inner.precision]
+        params = [p.detach() for p in inner.parameters()]
+        arr = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        flat, views = self._grad_buffer(dev, fresh_grads)
+        ws = self._workspace(B, t, precision, dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = self.lib.beso_loss_grad(C.byref(self.cfg), arr, len(params), flat.data_ptr(), precision,
+                                         state.data_ptr(), action.data_ptr(), gptr, noise.data_ptr(), sigma.data_ptr(),
+                                         loss.data_ptr(), B, t, float(attn_p), float(resid_p), C.c_uint(seed & 0xFFFFFFFF),
+                                         float(grad_scale), ws.data_ptr(), ws.numel(),
+                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(st, "loss_grad")
+        return loss, flat, views
+
+    def loss_backward(self, state, action, goal, noise, sigma, grad_scale: float = 1.0, seed: Optional[int] = None):
+        """The training step's ``loss = model.loss(...); loss.backward()``: returns the loss and leaves the
+        gradients in ``p.grad`` (views of the persistent flat buffer; accumulated into an existing ``.grad``)."""
+        loss, flat, views = self.run(state, action, goal, noise, sigma, grad_scale, seed, fresh_grads=False)
+        for p, v in zip(self.inner.parameters(), views):
+            if p.grad is None or p.grad.data_ptr() == v.data_ptr():
+                p.grad = v
+            else:
+                p.grad.add_(v)
+        return loss
+
+    def flat_grads(self) -> Optional[torch.Tensor]:
+        """The flat buffer if every ``p.grad`` currently is its view of it (then one all-reduce covers them)."""
+        if self._flat is None or self._views is None:
+            return None
+        for p, v in zip(self.inner.parameters(), self._views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                return None
+        return self._flat
+
+
+class ScoreMatchingLoss(torch.autograd.Function):
+    """loss = GCDenoiser.loss(...) with the parameter gradients computed alongside (HIP); backward hands them over."""
+
+    @staticmethod
+    def forward(ctx, step: HipTrainStep, state, action, goal, noise, sigma, *params):
+        loss, flat, views = step.run(state, action, goal, noise, sigma, fresh_grads=True)
+        ctx.flat, ctx.views = flat, views
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.flat.mul_(grad_out)
+        return (None,) * 6 + tuple(ctx.views)

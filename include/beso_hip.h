@@ -13,6 +13,8 @@
  *   beso_sampler_step   <- the per-step update of sample_ddim/_euler/_heun
  *                                                                      k_diffusion/gc_sampling.py:205-210,296-310,921-923
  *   beso_sample         <- sample_ddim / sample_euler / sample_heun    k_diffusion/gc_sampling.py:167-213,259-314,895-924
+ *   beso_loss_grad      <- GCDenoiser.loss + loss.backward()           k_diffusion/score_wrappers.py:45-79, beso_agent.py:228-233
+ *   beso_adam_step      <- optimizer.step() + ema_helper.update()      beso_agent.py:236-244
  *
  * Conventions
  *   - plain C, plain pointers and sizes.  No torch types.  `stream` is a hipStream_t passed as void*.
@@ -155,6 +157,32 @@ typedef struct beso_optim_chunk {
 int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg, float* exp_avg_sq, float* ema,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,
                    float ema_decay, void* stream);
+
+/* Training step, forward + backward: GCDenoiser.loss (score_wrappers.py:45-79, pred_last_action_only False) of the
+ * training-mode network (score_gpts.py:272-358 with the dropouts of :41,:79,:109) and the gradient of that loss with
+ * respect to every parameter -- what `loss = model.loss(...); loss.backward()` leaves in `.grad`
+ * (beso_agent.py:228-233).  linear_output = 1 only (all shipped configs), embed_pdrob = 0 (all shipped configs).
+ *   params      host array of n_params DEVICE pointers, order of beso_pack_weights (fp32, torch layouts)
+ *   grads_flat  device fp32 buffer of beso_grad_floats(cfg) values: the gradients of all parameters back to back in
+ *               the same order, each tensor contiguous.  OVERWRITTEN (zeroed, then accumulated with atomics).
+ *   state [batch,t,obs], action [batch,t,act] (clean), goal [batch,G,obs] (already masked by DiffusionGPT.mask_cond),
+ *   noise [batch,t,act], sigma [batch];  loss_out: one device float.
+ *   attn_pdrop / resid_pdrop: dropout probabilities of the attention weights and of the proj / MLP outputs; the
+ *   masks are a counter-based hash of (seed, site, element), recomputed in the backward.  0 disables.
+ *   grad_scale multiplies every gradient (1/world_size for data-parallel averaging); the loss is unscaled.
+ *   precision   BESO_PREC_BF16: bf16 GEMM operands (weights, kept activations, gradient operands), fp32 accumulation,
+ *               fp32 residual stream / LayerNorm / softmax / loss;  BESO_PREC_FP32: everything fp32 (parity mode).  */
+size_t beso_train_workspace_bytes(const beso_config* cfg, int batch, int t, int precision);
+size_t beso_grad_floats(const beso_config* cfg);
+int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
+                   const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
+                   float* loss_out, int batch, int t, float attn_pdrop, float resid_pdrop, unsigned int seed,
+                   float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* Development aid (tests of the operand layouts of the training GEMM): C[M][N] (fp32, ldc) = sum_k A(m,k) B(n,k);
+ * a_kslow / b_kslow = 1: the operand is stored [K][ld] (contraction index slow), 0: [rows][ld] (k contiguous).
+ * Supported pairs: (0,0), (0,1), (1,1).  splits > 1 accumulates split-K partial sums into a ZEROED C.      */
+int beso_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,
+                    int ldc, int M, int N, int K, int splits, void* stream);
 
 /* Timing hooks for bench.py: HIP events are recorded on the launch stream around every launch of
  * the selected launch site while enabled (site 0 = off).  beso_profile_read synchronises the

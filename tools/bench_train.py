@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE config 3 on one GPU's share: kitchen train_step (score-matching loss, backward, AdamW, EMA) at
-1024 samples per step, through BesoAgent.train_step.  The forward/backward are torch autograd ops on the
-GPU in this round; this records where that stands.   python tools/bench_train.py"""
+1024 samples per step, through BesoAgent.train_step: HIP forward + backward (beso_loss_grad) and the fused
+Adam(W) + EMA launch; BESO_AMD_HIP_TRAIN=0 times the torch-autograd evaluation of the same step beside it.
+    python tools/bench_train.py [batch]"""
 import json
 import os
 import sys
@@ -45,7 +46,8 @@ def main():
     flops = 3.0 * cfg.flops_per_sample() * B
     print(json.dumps({"config": "3: kitchen train_step, one GPU's share", "batch": B, "seconds_per_step": dt,
                       "samples_per_s": B / dt, "tflops_fwd_bwd": flops / dt / 1e12, "loss": loss,
-                      "path": "torch autograd fp32 forward/backward + " + type(agent.optimizer).__name__ + " (+EMA)"}))
+                      "path": ("HIP forward/backward (bf16 operands)" if getattr(agent, "_hip_step", None) is not None
+                               else "torch autograd fp32 forward/backward") + " + " + type(agent.optimizer).__name__ + " (+EMA)"}))
 
 
 if __name__ == "__main__":
