@@ -40,6 +40,35 @@ template <> struct Act<float> {
     __device__ static __forceinline__ float to(float v) { return v; }
 };
 
+// bf16 outputs: the same exact-erf GELU through the transcendental-free fit of the fused path (fused.hip
+// gelu_fast2, tools/fit_gelu.py): max |error| 1.9e-4, an order of magnitude under the bf16 rounding applied
+// next, at 11 VALU instructions instead of the ~40 of erff -- the epilogue of fc1 was costlier than its MFMAs.
+__device__ __forceinline__ float gelu_poly(float v) {
+    const float vc = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);
+    const float s = vc * vc;
+    float p = fmaf(s, 2.277972093e-08f, -1.598515742e-06f);
+    p = fmaf(p, s, 4.795382804e-05f);
+    p = fmaf(p, s, -0.0008139993719f);
+    p = fmaf(p, s, 0.00877231165f);
+    p = fmaf(p, s, -0.06457294506f);
+    p = fmaf(p, s, 0.3978832308f);
+    return v * fmaf(vc, p, 0.5f);
+}
+// Derivative of the same GELU, d/dv [v Phi(v)] = Phi(v) + v phi(v), with the fitted Phi and phi through v_exp_f32
+// (training step, bf16 mode; the fp32 mode uses erff / expf).
+__device__ __forceinline__ float gelu_grad_poly(float v) {
+    const float vc = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);
+    const float s = vc * vc;
+    float p = fmaf(s, 2.277972093e-08f, -1.598515742e-06f);
+    p = fmaf(p, s, 4.795382804e-05f);
+    p = fmaf(p, s, -0.0008139993719f);
+    p = fmaf(p, s, 0.00877231165f);
+    p = fmaf(p, s, -0.06457294506f);
+    p = fmaf(p, s, 0.3978832308f);
+    const float phi = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * v * v);
+    return fmaf(vc, p, 0.5f) + v * phi;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -31,20 +31,6 @@ template <> struct Mma<float> {
 __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU() default (score_gpts.py:107)
 }
-// bf16 outputs: the same exact-erf GELU through the transcendental-free fit of the fused path (fused.hip
-// gelu_fast2, tools/fit_gelu.py): max |error| 1.9e-4, an order of magnitude under the bf16 rounding applied
-// next, at 11 VALU instructions instead of the ~40 of erff -- the epilogue of fc1 was costlier than its MFMAs.
-__device__ __forceinline__ float gelu_poly(float v) {
-    const float vc = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);
-    const float s = vc * vc;
-    float p = fmaf(s, 2.277972093e-08f, -1.598515742e-06f);
-    p = fmaf(p, s, 4.795382804e-05f);
-    p = fmaf(p, s, -0.0008139993719f);
-    p = fmaf(p, s, 0.00877231165f);
-    p = fmaf(p, s, -0.06457294506f);
-    p = fmaf(p, s, 0.3978832308f);
-    return v * fmaf(vc, p, 0.5f);
-}
 template <typename E> __device__ __forceinline__ float gelu_for(float v);
 template <> __device__ __forceinline__ float gelu_for<float>(float v) { return gelu_erf(v); }
 template <> __device__ __forceinline__ float gelu_for<uint16_t>(float v) { return gelu_poly(v); }

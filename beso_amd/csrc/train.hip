@@ -34,17 +34,23 @@ __device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t site, size_t
     return ((float)(h >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.f;
 }
 
-__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad(float v) {
+// GELU and its derivative (nn.GELU(), score_gpts.py:107): exact erf / exp in the fp32 mode, the fitted polynomial of
+// the inference kernels (max |error| 1.9e-4, below the bf16 rounding of the stored value) in the bf16 mode
+template <typename E> __device__ __forceinline__ float gelu_t(float v);
+template <> __device__ __forceinline__ float gelu_t<float>(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+template <> __device__ __forceinline__ float gelu_t<uint16_t>(float v) { return gelu_poly(v); }
+template <typename E> __device__ __forceinline__ float gelu_grad_t(float v);
+template <> __device__ __forceinline__ float gelu_grad_t<float>(float v) {
     return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * expf(-0.5f * v * v);
 }
+template <> __device__ __forceinline__ float gelu_grad_t<uint16_t>(float v) { return gelu_grad_poly(v); }
 
 // ---------------------------------------------------------------------------------------------
 // tgemm:  C[m][n] = sum_k Aop(m,k) * Bop(n,k)
 //   AKS = false: A is [M][lda], k contiguous ("k-contig")      AKS = true: A is [K][lda], m contiguous ("k-slow")
 //   BKS likewise for B ([N][ldb] / [K][ldb]).
-// 128x128 block tile, 4 waves as 2x2 of 64x64, 16x16 MFMA tiles; one stage = 128 bytes of k per row
-// (64 bf16 / 32 fp32); register-staged double buffering; all loads predicated (zero fill), so M, N, K are
+// 128x128 block tile, 8 waves as 2x4 of 64x32, 16x16 MFMA tiles; one stage = 128 bytes of k per row
+// (64 bf16 / 32 fp32); register-staged, two stages in flight; all loads predicated (zero fill), so M, N, K are
 // arbitrary up to: K % (16/sizeof(E)) == 0 for a k-contig operand, rows % (16/sizeof(E)) == 0 for a k-slow one.
 // blockIdx.y splits K (k_per_split, a multiple of the stage); the epilogue functor decides what a partial
 // sum means (EpiAtomic accumulates).
@@ -53,36 +59,70 @@ constexpr int kOpBytes = 16896;        // LDS bytes of one operand stage (k-slow
 constexpr int kSubBytes = 2112;        // bf16 k-slow image: one 16-column subtile = 64 k-rows x 32 B + 64 B pad
 constexpr int kRowBytes32 = 528;       // fp32 k-slow image: one k-row = 128 columns x 4 B + 16 B pad
 
+// Global side of an operand: raw buffer loads with 32-bit per-lane byte offsets (computed once per tile) and the
+// k advance in the scalar offset.  Nothing relies on the descriptor's range check: rows / columns outside the
+// operand are read at offset 0 (their products land in outputs that are never stored), lanes past k_end are read
+// at a valid address and replaced by zeros.
+constexpr int kGT = 512;                   // threads of a tgemm workgroup (8 waves)
+constexpr int kGL = 1024 / kGT;            // 16-byte chunks per thread, operand and stage
+struct GOp { uint32_t voff[kGL]; };          // (the descriptor is rebuilt from the kernel argument at every use: a
+                                           //  descriptor carried in VGPRs makes every load a waterfall loop)
+
 template <typename E, bool KS>
-__device__ __forceinline__ void op_gload(const E* __restrict__ P, int ld, int r0, int R, int k0, int k_end, int tid,
-                                         u32x4 (&r)[4]) {
+__device__ __forceinline__ GOp make_gop(const E* __restrict__ P, int ld, int r0, int R, int tid) {
     constexpr int EPC = 16 / (int)sizeof(E);
+    GOp g;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
-        bool ok;
-        size_t off;
+    for (int i = 0; i < kGL; ++i) {
+        const int c = tid + kGT * i;
         if (!KS) {
-            const int row = c >> 3, kc = c & 7;
-            const int gr = r0 + row, gk = k0 + kc * EPC;
-            ok = gr < R && gk < k_end;
-            off = (size_t)gr * ld + gk;
+            const int row = c >> 3, kc = c & 7, gr = r0 + row;
+            g.voff[i] = gr < R ? (uint32_t)(((size_t)gr * ld + kc * EPC) * sizeof(E)) : 0u;
         } else {
             constexpr int CPR = 128 / EPC;               // 16-byte chunks per k-row
-            const int krow = c / CPR, cc = c % CPR;
-            const int gk = k0 + krow, gc = r0 + cc * EPC;
-            ok = gk < k_end && gc < R;
-            off = (size_t)gk * ld + gc;
+            const int krow = c / CPR, cc = c % CPR, gc = r0 + cc * EPC;
+            g.voff[i] = gc < R ? (uint32_t)(((size_t)krow * ld + gc) * sizeof(E)) : 0u;
         }
-        r[i] = ok ? *(const u32x4*)(P + off) : u32x4{0u, 0u, 0u, 0u};
+    }
+    return g;
+}
+
+template <typename E, bool KS>
+__device__ __forceinline__ void op_gload(const E* __restrict__ P, const GOp& g, int ld, int k0, int k_end, int tid,
+                                         u32x4 (&r)[kGL]) {
+    constexpr int EPC = 16 / (int)sizeof(E);
+    // P and the k offset are wave-uniform; saying so keeps the descriptor and the scalar offset in SGPRs
+    const uint64_t pv = (uint64_t)P;
+    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pv >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pv);      // (the builtin returns int)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, 0x7fffffff, 0x00020000);
+    const bool stage_ok = k0 < k_end;                        // a whole stage past the end reads stage 0 (discarded)
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    if (!KS) {
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(stage_ok ? (uint32_t)k0 * (uint32_t)sizeof(E) : 0u);
+        const bool ok = k0 + (tid & 7) * EPC < k_end;        // the chunk index along k is the same for all loads of a thread
+#pragma unroll
+        for (int i = 0; i < kGL; ++i) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? g.voff[i] : 0u, soff, 0);
+            r[i] = ok ? v : zero;
+        }
+    } else {
+        constexpr int CPR = 128 / EPC;
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(stage_ok ? (uint32_t)k0 * (uint32_t)ld * (uint32_t)sizeof(E) : 0u);
+#pragma unroll
+        for (int i = 0; i < kGL; ++i) {
+            const bool ok = k0 + (tid + kGT * i) / CPR < k_end;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? g.voff[i] : 0u, soff, 0);
+            r[i] = ok ? v : zero;
+        }
     }
 }
 
 template <typename E, bool KS>
-__device__ __forceinline__ void op_lstore(unsigned char* base, int tid, const u32x4 (&r)[4]) {
+__device__ __forceinline__ void op_lstore(unsigned char* base, int tid, const u32x4 (&r)[kGL]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
+    for (int i = 0; i < kGL; ++i) {
+        const int c = tid + kGT * i;
         int off;
         if (!KS) {
             const int row = c >> 3, kc = c & 7;
@@ -135,69 +175,115 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
 }
 
-template <typename E, bool AKS, bool BKS, typename Epi>
-__global__ __launch_bounds__(256, 2) void tgemm_kernel(const E* __restrict__ A, int lda, const E* __restrict__ B,
-                                                       int ldb, int M, int N, int K, int k_per_split, int nt_n,
-                                                       Epi epi) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][kOpBytes];
+typedef unsigned char TileLds[2][2][kOpBytes];
+
+// One 128 x 128 output tile at (m0, n0), contraction over [k_begin, k_end).
+template <typename E, bool AKS, bool BKS, typename Epi, bool DEEP = false>
+__device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A, int lda, const E* __restrict__ B, int ldb,
+                                           int M, int N, int m0, int n0, int k_begin, int k_end, const Epi& epi) {
     constexpr int KSTAGE = 128 / (int)sizeof(E);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int tile_n = blockIdx.x % nt_n, tile_m = blockIdx.x / nt_n;
-    const int m0 = tile_m * kTileMN, n0 = tile_n * kTileMN;
-    const int k_begin = blockIdx.y * k_per_split;
-    const int k_end = min(K, k_begin + k_per_split);
+    const int wm = wid >> 2, wn = wid & 3;             // 8 waves as 2 (m) x 4 (n): 64 x 32 of the tile each
     const int nk = (k_end - k_begin + KSTAGE - 1) / KSTAGE;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][2];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (nk > 0) {
-        u32x4 ra[4], rb[4];
-        op_gload<E, AKS>(A, lda, m0, M, k_begin, k_end, tid, ra);
-        op_gload<E, BKS>(B, ldb, n0, N, k_begin, k_end, tid, rb);
+    // Register-staged pipeline, two stages ahead: while stage kt is multiplied out of LDS buffer kt&1, stage kt+1
+    // sits in one register set (loaded during the previous step, written to the other LDS buffer after the MFMAs)
+    // and stage kt+2 is being fetched into the other set -- a global load has two MFMA phases to land.
+    auto compute = [&](const unsigned char* la, const unsigned char* lb) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 af[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[mi] = op_frag<E, AKS>(la, wm * 4 + mi, s, lane);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const u32x4 bf = op_frag<E, BKS>(lb, wn * 2 + ni, s, lane);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) mma16<E>(acc[mi][ni], bf, af[mi]);   // D[n][m]: 4 consecutive n per lane
+            }
+        }
+    };
+    if (DEEP && nk > 0) {
+        u32x4 ra0[kGL], rb0[kGL], ra1[kGL], rb1[kGL];
+        const GOp ga = make_gop<E, AKS>(A, lda, m0, M, tid), gb = make_gop<E, BKS>(B, ldb, n0, N, tid);
+        auto gload0 = [&](int kt) {
+            op_gload<E, AKS>(A, ga, lda, k_begin + kt * KSTAGE, k_end, tid, ra0);
+            op_gload<E, BKS>(B, gb, ldb, k_begin + kt * KSTAGE, k_end, tid, rb0);
+        };
+        auto gload1 = [&](int kt) {
+            op_gload<E, AKS>(A, ga, lda, k_begin + kt * KSTAGE, k_end, tid, ra1);
+            op_gload<E, BKS>(B, gb, ldb, k_begin + kt * KSTAGE, k_end, tid, rb1);
+        };
+        // Loads and LDS stores are UNCONDITIONAL (a stage past k_end is all out-of-range lanes: zeros, no memory
+        // traffic): a conditional load would make the compiler's vmcnt bookkeeping assume it was not issued, and the
+        // wait before the LDS store of the older register set would drain the newer one as well.
+        gload0(0);
+        gload1(1);
+        op_lstore<E, AKS>(lds[0][0], tid, ra0);
+        op_lstore<E, BKS>(lds[0][1], tid, rb0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            gload0(kt + 2);
+            compute(lds[0][0], lds[0][1]);
+            op_lstore<E, AKS>(lds[1][0], tid, ra1);
+            op_lstore<E, BKS>(lds[1][1], tid, rb1);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            gload1(kt + 3);
+            compute(lds[1][0], lds[1][1]);
+            op_lstore<E, AKS>(lds[0][0], tid, ra0);
+            op_lstore<E, BKS>(lds[0][1], tid, rb0);
+            __syncthreads();
+        }
+    }
+    if (!DEEP && nk > 0) {
+        // one register set: stage kt+1 is fetched while stage kt is multiplied (4 waves per SIMD hide the rest)
+        u32x4 ra[kGL], rb[kGL];
+        const GOp ga = make_gop<E, AKS>(A, lda, m0, M, tid), gb = make_gop<E, BKS>(B, ldb, n0, N, tid);
+        op_gload<E, AKS>(A, ga, lda, k_begin, k_end, tid, ra);
+        op_gload<E, BKS>(B, gb, ldb, k_begin, k_end, tid, rb);
         op_lstore<E, AKS>(lds[0][0], tid, ra);
         op_lstore<E, BKS>(lds[0][1], tid, rb);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk) {
-                op_gload<E, AKS>(A, lda, m0, M, k_begin + (kt + 1) * KSTAGE, k_end, tid, ra);
-                op_gload<E, BKS>(B, ldb, n0, N, k_begin + (kt + 1) * KSTAGE, k_end, tid, rb);
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                u32x4 af[4], bf[4];
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) af[mi] = op_frag<E, AKS>(lds[cur][0], wm * 4 + mi, s, lane);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) bf[ni] = op_frag<E, BKS>(lds[cur][1], wn * 4 + ni, s, lane);
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) mma16<E>(acc[mi][ni], bf[ni], af[mi]);   // D[n][m]: 4 consecutive n per lane
-            }
-            if (kt + 1 < nk) {
-                op_lstore<E, AKS>(lds[cur ^ 1][0], tid, ra);
-                op_lstore<E, BKS>(lds[cur ^ 1][1], tid, rb);
-            }
+            op_gload<E, AKS>(A, ga, lda, k_begin + (kt + 1) * KSTAGE, k_end, tid, ra);
+            op_gload<E, BKS>(B, gb, ldb, k_begin + (kt + 1) * KSTAGE, k_end, tid, rb);
+            compute(lds[cur][0], lds[cur][1]);
+            op_lstore<E, AKS>(lds[cur ^ 1][0], tid, ra);
+            op_lstore<E, BKS>(lds[cur ^ 1][1], tid, rb);
             __syncthreads();
         }
     }
-    // The MFMA ran as D = Bfrag x Afrag^T: the lane holds C[m][n..n+3] with m = lane & 15, n = 4*(lane >> 4) + reg,
-    // so every epilogue access is a 4-element vector (N % 4 == 0).
+    int te = tid;
+    asm volatile("" : "+v"(te));          // epilogue addresses are formed HERE, not hoisted above the k loop (spills)
+    const int le = te & 63, wme = te >> 8, wne = (te >> 6) & 3;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + (lane & 15);
+        const int m = m0 + wme * 64 + mi * 16 + (le & 15);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wne * 32 + ni * 16 + (le >> 4) * 4;
             if (m < M && n < N) epi(m, n, acc[mi][ni]);
         }
     }
+}
+
+template <typename E, bool AKS, bool BKS, typename Epi>
+__global__ __launch_bounds__(kGT, 4) void tgemm_kernel(const E* __restrict__ A, int lda, const E* __restrict__ B,
+                                                       int ldb, int M, int N, int K, int k_per_split, int nt_n,
+                                                       Epi epi) {
+    __shared__ __attribute__((aligned(16))) TileLds lds;
+    const int tile_n = blockIdx.x % nt_n, tile_m = blockIdx.x / nt_n;
+    const int k_begin = blockIdx.y * k_per_split;
+    tgemm_tile<E, AKS, BKS, Epi>(lds, A, lda, B, ldb, M, N, tile_m * kTileMN, tile_n * kTileMN, k_begin,
+                                 min(K, k_begin + k_per_split), epi);
 }
 
 // ---- epilogues: (m, n, v) = C[m][n..n+3] ------------------------------------------------------
@@ -235,7 +321,7 @@ template <typename E> struct EpiFc1 {            // h = acc + bias (kept for GEL
         v += *(const f32x4*)(bias + n);
         const size_t i = (size_t)m * ld + n;
         Vec4<E>::store(h + i, v);
-        Vec4<E>::store(g + i, f32x4{gelu_exact(v[0]), gelu_exact(v[1]), gelu_exact(v[2]), gelu_exact(v[3])});
+        Vec4<E>::store(g + i, f32x4{gelu_t<E>(v[0]), gelu_t<E>(v[1]), gelu_t<E>(v[2]), gelu_t<E>(v[3])});
     }
 };
 struct EpiResid {                                // x_out = x_in + dropout(acc + bias)              (:79,:109,:113-114)
@@ -255,8 +341,8 @@ template <typename E> struct EpiGeluBwd {        // dh = dg * GELU'(h)
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         const size_t i = (size_t)m * ld + n;
         const f32x4 hv = Vec4<E>::load(h + i);
-        Vec4<E>::store(dh + i, f32x4{v[0] * gelu_grad(hv[0]), v[1] * gelu_grad(hv[1]), v[2] * gelu_grad(hv[2]),
-                                     v[3] * gelu_grad(hv[3])});
+        Vec4<E>::store(dh + i, f32x4{v[0] * gelu_grad_t<E>(hv[0]), v[1] * gelu_grad_t<E>(hv[1]), v[2] * gelu_grad_t<E>(hv[2]),
+                                     v[3] * gelu_grad_t<E>(hv[3])});
     }
 };
 struct EpiAtomic {                               // split-K partial sums accumulated with atomics (debug entry point)
@@ -268,16 +354,6 @@ struct EpiAtomic {                               // split-K partial sums accumul
     }
 };
 inline EpiAtomic epi_atomic(float* out, int ld) { return EpiAtomic{out, ld}; }
-// Split-K partial sums of a weight gradient: split z writes its [M][N] partial into slab z with plain 16-byte
-// stores; reduce_slabs_kernel sums the slabs into the gradient tensors.  (fp32 atomics run at ~35 G/s on this
-// part: with them every weight-gradient GEMM took the same 100 us whatever its size.)
-struct EpiSlab {
-    float* slab; size_t stride; int ld;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-        *(f32x4*)(slab + (size_t)blockIdx.y * stride + (size_t)m * ld + n) = v;
-    }
-};
-
 template <typename E, bool AKS, bool BKS, typename Epi>
 hipError_t tgemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int splits, Epi epi, hipStream_t s) {
     (void)hipGetLastError();
@@ -286,41 +362,58 @@ hipError_t tgemm(const void* A, int lda, const void* B, int ldb, int M, int N, i
     if ((AKS ? M : K) % EPC != 0 || (BKS ? N : K) % EPC != 0 || lda % EPC != 0 || ldb % EPC != 0 || N % 4 != 0)
         return hipErrorInvalidValue;
     if (((uintptr_t)A | (uintptr_t)B) & 15) return hipErrorInvalidValue;
+    // 32-bit byte offsets inside an operand (raw buffer loads)
+    if ((size_t)(AKS ? K : M) * lda * sizeof(E) >= ((size_t)1 << 31) || (size_t)(BKS ? K : N) * ldb * sizeof(E) >= ((size_t)1 << 31))
+        return hipErrorInvalidValue;
     const int nt_n = (N + kTileMN - 1) / kTileMN, nt_m = (M + kTileMN - 1) / kTileMN;
     if (splits < 1) splits = 1;
     const int kps = ((K + splits - 1) / splits + KSTAGE - 1) / KSTAGE * KSTAGE;
-    splits = (K + kps - 1) / kps;                                        // == split_count(K, splits, KSTAGE)
-    hipLaunchKernelGGL((tgemm_kernel<E, AKS, BKS, Epi>), dim3(nt_n * nt_m, splits), dim3(256), 0, s, (const E*)A, lda,
+    splits = (K + kps - 1) / kps;
+    hipLaunchKernelGGL((tgemm_kernel<E, AKS, BKS, Epi>), dim3(nt_n * nt_m, splits), dim3(kGT), 0, s, (const E*)A, lda,
                        (const E*)B, ldb, M, N, K, kps, nt_n, epi);
     return hipGetLastError();
 }
 
-// out_j[i] = sum_z slab[z][j*seg + i]: the gradient tensors are assigned, not accumulated (q | k | v share one pass)
-__global__ void reduce_slabs_kernel(const float* __restrict__ slab, size_t stride, int splits, float* out0, float* out1,
-                                    float* out2, size_t seg, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        f32x4 acc = *(const f32x4*)(slab + 4 * i);
-        for (int z = 1; z < splits; ++z) acc += *(const f32x4*)(slab + (size_t)z * stride + 4 * i);
-        const size_t e = 4 * i, j = e / seg;
-        float* o = j == 0 ? out0 : (j == 1 ? out1 : out2);
-        *(f32x4*)(o + (e - j * seg)) = acc;
+// All weight gradients of a step in ONE launch: problem p is C_p[Mo][No] = A_p^T B_p over the M token rows (both
+// operands k-slow: the kept activation and the kept output gradient as they lie).  Every tile contracts over
+// the whole token range and stores its result -- no split-K, no atomics (fp32 atomics sustain ~35 G/s on this
+// part: a split-K version spent more time adding partial sums than multiplying), no reduction pass; a few hundred
+// tiles of equal length fill the chip by themselves.
+struct GProb { const void* A; const void* B; float* out; int lda, ldb, Mo, No, tile_begin, nt_n; };
+constexpr int kMaxGroup = 72;                          // 6 per layer + 2: up to 11 layers per launch, more launches beyond
+struct GTable { GProb p[kMaxGroup]; int n; int K; };
+struct EpiStoreF { float* out; int ld;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const { *(f32x4*)(out + (size_t)m * ld + n) = v; } };
+
+template <typename E>
+__global__ __launch_bounds__(kGT, 4) void tgemm_wgrad_group_kernel(GTable t) {
+    __shared__ __attribute__((aligned(16))) TileLds lds;
+    const int b = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < t.n && b >= t.p[pi + 1].tile_begin) ++pi;
+    const GProb g = t.p[pi];
+    const int local = b - g.tile_begin, tile_n = local % g.nt_n, tile_m = local / g.nt_n;
+    tgemm_tile<E, true, true, EpiStoreF, false>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
+                                         tile_n * kTileMN, 0, t.K, EpiStoreF{g.out, g.No});
+}
+
+// ---------------------------------------------------------------------------------------------
+// operand-typed copies of one layer's weights (and the fused q|k|v bias) in one launch
+// ---------------------------------------------------------------------------------------------
+struct PackSeg { const float* src; void* dst; uint32_t n4; uint32_t f32; };
+struct PackTable { PackSeg seg[10]; int n; };
+
+template <typename E>
+__global__ void pack_table_kernel(PackTable t, uint32_t total4) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+        uint32_t k = i;
+        int sgi = 0;
+        while (sgi + 1 < t.n && k >= t.seg[sgi].n4) { k -= t.seg[sgi].n4; ++sgi; }
+        const PackSeg& g = t.seg[sgi];
+        const f32x4 v = *(const f32x4*)(g.src + 4 * (size_t)k);
+        if (g.f32) *(f32x4*)((float*)g.dst + 4 * (size_t)k) = v;
+        else Vec4<E>::store((E*)g.dst + 4 * (size_t)k, v);
     }
-}
-
-// (k_per_split, splits) actually launched for a requested split count -- tgemm uses the same arithmetic
-inline int split_count(int K, int splits, int kstage) {
-    if (splits < 1) splits = 1;
-    const int kps = ((K + splits - 1) / splits + kstage - 1) / kstage * kstage;
-    return (K + kps - 1) / kps;
-}
-
-// number of K splits that gives a weight-gradient GEMM about two workgroups per CU
-int wgrad_splits(int M, int N, int K, int kstage) {
-    const int tiles = ((M + kTileMN - 1) / kTileMN) * ((N + kTileMN - 1) / kTileMN);
-    int s = (512 + tiles - 1) / tiles;
-    const int smax = K / (4 * kstage) > 1 ? K / (4 * kstage) : 1;
-    if (s > smax) s = smax;
-    return s < 1 ? 1 : s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -424,9 +517,9 @@ __global__ void scatter_emb_kernel(const float* __restrict__ dw, float* __restri
 // LayerNorm forward with saved statistics; one wave per row, the row in registers as float4 per lane
 // (D % 4 == 0, D <= 1024).
 // ---------------------------------------------------------------------------------------------
-constexpr int kLnVec = 4;              // float4 slots per lane
+// NV = float4 slots per lane = ceil(D / 256): 1, 2 or 4
 
-template <typename E>
+template <typename E, int kLnVec>
 __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                               E* __restrict__ out, float* __restrict__ stats, int rows, int D) {
     const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -467,7 +560,7 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 // gradient), operand-typed copy dxb = dres * keep-scale(site) for the linear layer that consumes it, that layer's
 // bias gradient (column sums of dxb; dbias may be nullptr) and the affine gradients -- register partials per
 // wave -> LDS -> one atomic per block and feature.
-template <typename E>
+template <typename E, int kLnVec>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* dres_in, float* dres_out, E* __restrict__ dxb,
@@ -713,6 +806,133 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const E* __restrict__ qkv,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Short sequences (T <= 16, hd <= 64, hd % 4 == 0: kitchen T = 11 / hd = 60, block-push T = 12 / hd = 20): the
+// same attention, forward or backward, with lane d holding column d of q / k / v (/ dy) in registers.  All global
+// loads are issued before the first use; the T x T parts run on a (4 rows x 16 columns) lane grid with float4
+// dot products from LDS (row stride 68 floats: conflict-free b128 reads), the d-parallel parts read the T x T
+// matrices as broadcasts.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTP = 16, kLdh = 68, kLdt = 20;
+
+__device__ __forceinline__ float dot_rows(const float* a, const float* b, int hd) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < hd; d += 4) acc += *(const f32x4*)(a + d) * *(const f32x4*)(b + d);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+template <typename E, bool BWD>
+__global__ __launch_bounds__(64) void attn_small_kernel(const E* __restrict__ qkv, const E* __restrict__ dy,
+                                                        E* __restrict__ out, int T, int D, int H, int hd, float scale,
+                                                        float p, float inv_keep, uint32_t seed, uint32_t site) {
+    __shared__ __attribute__((aligned(16))) float sq[kTP][kLdh], sk[kTP][kLdh], sv[BWD ? kTP : 1][kLdh],
+        sdy[BWD ? kTP : 1][kLdh];
+    __shared__ __attribute__((aligned(16))) float sP[kTP][kLdt], sdP[BWD ? kTP : 1][kLdt];
+    const int pair = blockIdx.x, b = pair / H, h = pair % H, lane = threadIdx.x;
+    const size_t ldq = (size_t)3 * D;
+    const bool act = lane < hd;
+    float qr[kTP], kr[kTP], vr[kTP], gr[kTP];
+    {
+        const E* base = qkv + (size_t)b * T * ldq + (size_t)h * hd + lane;
+        const E* gbase = BWD ? dy + (size_t)b * T * D + (size_t)h * hd + lane : nullptr;
+#pragma unroll
+        for (int r = 0; r < kTP; ++r) {
+            const bool ok = act && r < T;
+            qr[r] = ok ? Act<E>::to(base[r * ldq]) : 0.f;
+            kr[r] = ok ? Act<E>::to(base[r * ldq + D]) : 0.f;
+            vr[r] = ok ? Act<E>::to(base[r * ldq + 2 * D]) : 0.f;
+            gr[r] = (BWD && ok) ? Act<E>::to(gbase[(size_t)r * D]) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kTP; ++r) {
+        sq[r][lane] = qr[r];
+        sk[r][lane] = kr[r];
+        if (BWD) { sv[r][lane] = vr[r]; sdy[r][lane] = gr[r]; }
+    }
+    __syncthreads();
+    const int il = lane >> 4, j = lane & 15;
+    // scores (and, backward, dPd = dy v^T) on the 4 x 16 lane grid
+#pragma unroll
+    for (int ib = 0; ib < kTP / 4; ++ib) {
+        const int i = ib * 4 + il;
+        const bool in = i < T && j <= i;
+        sP[i][j] = in ? dot_rows(sq[i], sk[j], hd) * scale : -INFINITY;
+        if (BWD) sdP[i][j] = in ? dot_rows(sdy[i], sv[j], hd) : 0.f;
+    }
+    __syncthreads();
+    // row softmax (lane i), dropout scale folded: sP <- Pd = P * keep-scale; backward also dS (pre-scaled by `scale`)
+    if (lane < T) {
+        const int i = lane;
+        float m = -INFINITY, pr[kTP], l = 0.f;
+#pragma unroll
+        for (int c = 0; c < kTP; ++c) m = fmaxf(m, sP[i][c]);
+#pragma unroll
+        for (int c = 0; c < kTP; ++c) { pr[c] = c <= i ? expf(sP[i][c] - m) : 0.f; l += pr[c]; }
+        const float inv = 1.0f / l;
+        float ks[kTP], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < kTP; ++c) {
+            pr[c] *= inv;
+            ks[c] = (p > 0.f && c <= i) ? drop_scale(seed, site, (size_t)pair * T * T + (size_t)i * T + c, p, inv_keep) : 1.f;
+            if (BWD) dot = fmaf(sdP[i][c] * ks[c], pr[c], dot);
+        }
+#pragma unroll
+        for (int c = 0; c < kTP; ++c) {
+            if (BWD) sdP[i][c] = pr[c] * (sdP[i][c] * ks[c] - dot) * scale;       // dS
+            sP[i][c] = pr[c] * ks[c];                                               // Pd
+        }
+    }
+    __syncthreads();
+    if (!act) return;
+    if (!BWD) {
+        E* o = out + (size_t)b * T * D + (size_t)h * hd + lane;
+#pragma unroll
+        for (int i = 0; i < kTP; ++i) {
+            if (i < T) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < kTP; c += 4) {
+                    const f32x4 pv = *(const f32x4*)&sP[i][c];
+                    acc = fmaf(pv[0], vr[c], acc); acc = fmaf(pv[1], vr[c + 1], acc);
+                    acc = fmaf(pv[2], vr[c + 2], acc); acc = fmaf(pv[3], vr[c + 3], acc);
+                }
+                o[(size_t)i * D] = Act<E>::from(acc);
+            }
+        }
+    } else {
+        // dq[i] = sum_j dS[i][j] k[j];  dk[j] = sum_i dS[i][j] q[i];  dv[j] = sum_i Pd[i][j] dy[i]   (entries above the
+        // diagonal are zero in both matrices)
+        float dq[kTP], dk[kTP], dv[kTP];
+#pragma unroll
+        for (int r = 0; r < kTP; ++r) { dq[r] = 0.f; dk[r] = 0.f; dv[r] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < kTP; ++i) {
+            if (i < T) {
+#pragma unroll
+                for (int c = 0; c < kTP; c += 4) {
+                    const f32x4 ds = *(const f32x4*)&sdP[i][c], pd = *(const f32x4*)&sP[i][c];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dq[i] = fmaf(ds[e], kr[c + e], dq[i]);
+                        dk[c + e] = fmaf(ds[e], qr[i], dk[c + e]);
+                        dv[c + e] = fmaf(pd[e], gr[i], dv[c + e]);
+                    }
+                }
+            }
+        }
+        E* o = out + (size_t)b * T * ldq + (size_t)h * hd + lane;
+#pragma unroll
+        for (int r = 0; r < kTP; ++r) {
+            if (r < T) {
+                o[r * ldq] = Act<E>::from(dq[r]);
+                o[r * ldq + D] = Act<E>::from(dk[r]);
+                o[r * ldq + 2 * D] = Act<E>::from(dv[r]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // squared-error loss over the action-token rows (score_wrappers.py:70-79 with pred_last_action_only False:
 // per-sample mean over (t, act), then the batch mean = the mean over all B*t*act elements), its gradient
 // with respect to the prediction, operand typed, zero on every other row and on the padding columns.
@@ -755,11 +975,12 @@ static size_t carve_t(size_t& cur, size_t bytes) {
 struct TrainLayerWs {
     size_t w_qkv, b_qkv, w_proj, w_fc1, w_fc2;                    // operand-typed weight copies (b_qkv fp32 [3D])
     size_t x_mid, x_out, st1, st2, xn1, qkv, y, xn2, h, g;        // kept activations
+    size_t dyo, dym, dh, dqkv;                                    // kept output gradients (operands of the weight gradients)
 };
 struct TrainWs {
     int M, T, Ke, ap;
-    size_t noised, target, x0, xemb, stf, xf, pred, dpred, w_head, b_head, dw_cat, slab;
-    size_t dx, dxb, dxn, dy, dqkv, dh;
+    size_t noised, target, x0, xemb, stf, xf, pred, dpred, w_head, b_head, dw_cat, dw_head;
+    size_t dx, dx0b, dxn, dy;
     TrainLayerWs layer[kMaxLayers];
     size_t total;
 };
@@ -780,19 +1001,9 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
     w->stf = carve_t(cur, f * M * 2); w->xf = carve_t(cur, e * M * D);
     w->pred = carve_t(cur, f * M * w->ap); w->dpred = carve_t(cur, e * M * w->ap);
     w->w_head = carve_t(cur, e * (size_t)w->ap * D); w->b_head = carve_t(cur, f * w->ap);
-    w->dw_cat = carve_t(cur, f * (size_t)w->Ke * D);
-    {
-        const int kstage = 128 / (int)e;
-        const int shapes[6][2] = {{D, 4 * D}, {4 * D, D}, {D, D}, {3 * D, D}, {w->ap, D}, {w->Ke, D}};
-        size_t mx = 0;
-        for (auto& sh : shapes) {
-            const size_t n = (size_t)split_count((int)M, wgrad_splits(sh[0], sh[1], (int)M, kstage), kstage) * sh[0] * sh[1];
-            mx = n > mx ? n : mx;
-        }
-        w->slab = carve_t(cur, f * mx);
-    }
-    w->dx = carve_t(cur, f * M * D); w->dxb = carve_t(cur, e * M * D); w->dxn = carve_t(cur, f * M * D);
-    w->dy = carve_t(cur, e * M * D); w->dqkv = carve_t(cur, e * M * 3 * D); w->dh = carve_t(cur, e * M * 4 * D);
+    w->dw_cat = carve_t(cur, f * (size_t)w->Ke * D); w->dw_head = carve_t(cur, f * (size_t)w->ap * D);
+    w->dx = carve_t(cur, f * M * D); w->dx0b = carve_t(cur, e * M * D); w->dxn = carve_t(cur, f * M * D);
+    w->dy = carve_t(cur, e * M * D);
     for (int l = 0; l < c->n_layers; ++l) {
         TrainLayerWs& y = w->layer[l];
         y.w_qkv = carve_t(cur, e * (size_t)3 * D * D); y.b_qkv = carve_t(cur, f * (size_t)3 * D);
@@ -802,6 +1013,8 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
         y.st1 = carve_t(cur, f * M * 2); y.st2 = carve_t(cur, f * M * 2);
         y.xn1 = carve_t(cur, e * M * D); y.qkv = carve_t(cur, e * M * 3 * D); y.y = carve_t(cur, e * M * D);
         y.xn2 = carve_t(cur, e * M * D); y.h = carve_t(cur, e * M * 4 * D); y.g = carve_t(cur, e * M * 4 * D);
+        y.dyo = carve_t(cur, e * M * D); y.dym = carve_t(cur, e * M * D); y.dh = carve_t(cur, e * M * 4 * D);
+        y.dqkv = carve_t(cur, e * M * 3 * D);
     }
     w->total = cur;
     return true;
@@ -848,7 +1061,6 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     const int D = c->embed_dim, H = c->n_heads, hd = D / H, L = c->n_layers, G = c->goal_seq_len;
     const int obs = c->obs_dim, act = c->act_dim, seq = G + c->obs_seq_len + 1;
     const int M = w.M, T = w.T, Ke = w.Ke, ap = w.ap, D3 = 3 * D, D4 = 4 * D;
-    constexpr int KSTAGE = 128 / (int)sizeof(E);
     const float scale = 1.0f / sqrtf((float)hd);
     const float attn_ik = attn_p > 0.f ? 1.0f / (1.0f - attn_p) : 1.f, resid_ik = resid_p > 0.f ? 1.0f / (1.0f - resid_p) : 1.f;
     auto F = [&](size_t off) { return (float*)(ws + off); };
@@ -877,19 +1089,26 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     TRY(hipMemsetAsync(loss_out, 0, sizeof(float), s));
     TRY(hipMemsetAsync(ws + w.b_head, 0, sizeof(float) * ap, s));
 
-    // ---- operand-typed weight copies (fused q|k|v rows as in the inference image)
+    // ---- operand-typed weight copies (fused q|k|v rows as in the inference image), one launch per layer
     for (int l = 0; l < L; ++l) {
         const TrainLayerWs& y = w.layer[l];
         const size_t e = sizeof(E);
-        TRY(launch_pack_matrix(lp[l].qw.p, D, D, ws + y.w_qkv, D, D, precision, s));
-        TRY(launch_pack_matrix(lp[l].kw.p, D, D, ws + y.w_qkv + e * (size_t)D * D, D, D, precision, s));
-        TRY(launch_pack_matrix(lp[l].vw.p, D, D, ws + y.w_qkv + e * (size_t)2 * D * D, D, D, precision, s));
-        TRY(hipMemcpyAsync(ws + y.b_qkv, lp[l].qb.p, sizeof(float) * D, hipMemcpyDeviceToDevice, s));
-        TRY(hipMemcpyAsync(ws + y.b_qkv + sizeof(float) * D, lp[l].kb.p, sizeof(float) * D, hipMemcpyDeviceToDevice, s));
-        TRY(hipMemcpyAsync(ws + y.b_qkv + sizeof(float) * 2 * D, lp[l].vb.p, sizeof(float) * D, hipMemcpyDeviceToDevice, s));
-        TRY(launch_pack_matrix(lp[l].pw.p, D, D, ws + y.w_proj, D, D, precision, s));
-        TRY(launch_pack_matrix(lp[l].f1w.p, D4, D, ws + y.w_fc1, D4, D, precision, s));
-        TRY(launch_pack_matrix(lp[l].f2w.p, D, D4, ws + y.w_fc2, D, D4, precision, s));
+        const uint32_t dd4 = (uint32_t)((size_t)D * D / 4), d4 = (uint32_t)(D / 4);
+        PackTable t;
+        t.n = 9;
+        t.seg[0] = PackSeg{lp[l].qw.p, ws + y.w_qkv, dd4, 0};
+        t.seg[1] = PackSeg{lp[l].kw.p, ws + y.w_qkv + e * (size_t)D * D, dd4, 0};
+        t.seg[2] = PackSeg{lp[l].vw.p, ws + y.w_qkv + e * (size_t)2 * D * D, dd4, 0};
+        t.seg[3] = PackSeg{lp[l].pw.p, ws + y.w_proj, dd4, 0};
+        t.seg[4] = PackSeg{lp[l].f1w.p, ws + y.w_fc1, 4 * dd4, 0};
+        t.seg[5] = PackSeg{lp[l].f2w.p, ws + y.w_fc2, 4 * dd4, 0};
+        t.seg[6] = PackSeg{lp[l].qb.p, ws + y.b_qkv, d4, 1};
+        t.seg[7] = PackSeg{lp[l].kb.p, ws + y.b_qkv + sizeof(float) * D, d4, 1};
+        t.seg[8] = PackSeg{lp[l].vb.p, ws + y.b_qkv + sizeof(float) * 2 * D, d4, 1};
+        const uint32_t total4 = 12 * dd4 + 3 * d4;
+        hipLaunchKernelGGL(pack_table_kernel<E>, dim3((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256), dim3(256), 0,
+                           s, t, total4);
+        TRY(hipGetLastError());
     }
     TRY(launch_pack_matrix(hw.p, act, D, ws + w.w_head, ap, D, precision, s));
     TRY(hipMemcpyAsync(ws + w.b_head, hb.p, sizeof(float) * act, hipMemcpyDeviceToDevice, s));
@@ -908,7 +1127,15 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(hipGetLastError());
     }
     const int ln_grid = (M + 3) / 4;
+    const int nv = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
+    auto ln_fwd = [&](const float* x, const float* gw, const float* gb, E* out, float* st) -> hipError_t {
+        if (nv == 1) hipLaunchKernelGGL((ln_fwd_kernel<E, 1>), dim3(ln_grid), dim3(256), 0, s, x, gw, gb, out, st, M, D);
+        else if (nv == 2) hipLaunchKernelGGL((ln_fwd_kernel<E, 2>), dim3(ln_grid), dim3(256), 0, s, x, gw, gb, out, st, M, D);
+        else hipLaunchKernelGGL((ln_fwd_kernel<E, 4>), dim3(ln_grid), dim3(256), 0, s, x, gw, gb, out, st, M, D);
+        return hipGetLastError();
+    };
     const size_t lds_f = attn_lds_bytes(T, hd, false), lds_b = attn_lds_bytes(T, hd, true);
+    const bool attn_small = T <= kTP && hd <= 64 && hd % 4 == 0;
     if (lds_f > 64 * 1024) {
         TRY(hipFuncSetAttribute((const void*)attn_fwd_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
     }
@@ -918,27 +1145,26 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     for (int l = 0; l < L; ++l) {
         const TrainLayerWs& y = w.layer[l];
         const float* x_in = l == 0 ? F(w.x0) : F(w.layer[l - 1].x_out);
-        hipLaunchKernelGGL(ln_fwd_kernel<E>, dim3(ln_grid), dim3(256), 0, s, x_in, lp[l].ln1w.p, lp[l].ln1b.p, P(y.xn1),
-                           F(y.st1), M, D);
-        TRY(hipGetLastError());
+        TRY(ln_fwd(x_in, lp[l].ln1w.p, lp[l].ln1b.p, P(y.xn1), F(y.st1)));
         TRY((tgemm<E, false, false>(P(y.xn1), D, P(y.w_qkv), D, M, D3, D, 1,
                                     EpiStore<E>{nullptr, P(y.qkv), F(y.b_qkv), D3}, s)));
-        hipLaunchKernelGGL(attn_fwd_kernel<E>, dim3(batch * H), dim3(64), lds_f, s, (const E*)P(y.qkv), P(y.y), T, D, H, hd,
-                           scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
+        if (attn_small)
+            hipLaunchKernelGGL((attn_small_kernel<E, false>), dim3(batch * H), dim3(64), 0, s, (const E*)P(y.qkv),
+                               (const E*)nullptr, P(y.y), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
+        else
+            hipLaunchKernelGGL(attn_fwd_kernel<E>, dim3(batch * H), dim3(64), lds_f, s, (const E*)P(y.qkv), P(y.y), T, D, H,
+                               hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
         TRY(hipGetLastError());
         TRY((tgemm<E, false, false>(P(y.y), D, P(y.w_proj), D, M, D, D, 1,
                                     EpiResid{x_in, F(y.x_mid), lp[l].pb.p, D, resid_p, resid_ik, seed, (uint32_t)(4 * l + 1)}, s)));
-        hipLaunchKernelGGL(ln_fwd_kernel<E>, dim3(ln_grid), dim3(256), 0, s, (const float*)F(y.x_mid), lp[l].ln2w.p,
-                           lp[l].ln2b.p, P(y.xn2), F(y.st2), M, D);
-        TRY(hipGetLastError());
+        TRY(ln_fwd(F(y.x_mid), lp[l].ln2w.p, lp[l].ln2b.p, P(y.xn2), F(y.st2)));
         TRY((tgemm<E, false, false>(P(y.xn2), D, P(y.w_fc1), D, M, D4, D, 1, EpiFc1<E>{P(y.h), P(y.g), lp[l].f1b.p, D4}, s)));
         TRY((tgemm<E, false, false>(P(y.g), D4, P(y.w_fc2), D4, M, D, D4, 1,
                                     EpiResid{(const float*)F(y.x_mid), F(y.x_out), lp[l].f2b.p, D, resid_p, resid_ik, seed,
                                              (uint32_t)(4 * l + 2)}, s)));
     }
     const float* x_last = F(w.layer[L - 1].x_out);
-    hipLaunchKernelGGL(ln_fwd_kernel<E>, dim3(ln_grid), dim3(256), 0, s, x_last, lnfw.p, lnfb.p, P(w.xf), F(w.stf), M, D);
-    TRY(hipGetLastError());
+    TRY(ln_fwd(x_last, lnfw.p, lnfb.p, P(w.xf), F(w.stf)));
     TRY((tgemm<E, false, false>(P(w.xf), D, P(w.w_head), D, M, ap, D, 1, EpiStore<E>{F(w.pred), nullptr, F(w.b_head), ap}, s)));
     {
         const size_t n = (size_t)M * ap;
@@ -959,60 +1185,76 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     };
     const int rpw = 4;                                    // rows per wave of the LayerNorm backward
     const int lnb_grid = (M + 4 * rpw - 1) / (4 * rpw);
-    auto ln_bwd = [&](const float* x, size_t st, const float* gamma, bool have_res, float* dgam, float* dbet, float* dbias,
-                      float p_site, uint32_t site) -> hipError_t {
-        hipLaunchKernelGGL(ln_bwd_kernel<E>, dim3(lnb_grid), dim3(256), 0, s, (const float*)F(w.dxn), x, (const float*)F(st),
-                           gamma, have_res ? (const float*)F(w.dx) : nullptr, F(w.dx), P(w.dxb), dgam, dbet, dbias, M, D, rpw,
-                           p_site, p_site > 0.f ? 1.0f / (1.0f - p_site) : 1.f, seed, site);
+    auto ln_bwd = [&](const float* x, size_t st, const float* gamma, bool have_res, E* dxb, float* dgam, float* dbet,
+                      float* dbias, float p_site, uint32_t site) -> hipError_t {
+#define LNB(NV)                                                                                                     \
+        hipLaunchKernelGGL((ln_bwd_kernel<E, NV>), dim3(lnb_grid), dim3(256), 0, s, (const float*)F(w.dxn), x,                \
+                           (const float*)F(st), gamma, have_res ? (const float*)F(w.dx) : nullptr, F(w.dx), dxb, dgam,       \
+                           dbet, dbias, M, D, rpw, p_site, p_site > 0.f ? 1.0f / (1.0f - p_site) : 1.f, seed, site)
+        if (nv == 1) LNB(1); else if (nv == 2) LNB(2); else LNB(4);
+#undef LNB
         return hipGetLastError();
     };
-    // weight gradient C[Mo][No] = A^T B over the M token rows: split-K partials into the slab, then one reduction
-    // that assigns the gradient tensor(s); `n_out` floats are produced (the leading rows), segments of `seg` floats
-    auto wgrad = [&](const E* A, int lda, int Mo, const E* B, int ldb, int No, float* o0, float* o1, float* o2, size_t seg,
-                     size_t n_out) -> hipError_t {
-        const int req = wgrad_splits(Mo, No, M, KSTAGE), S = split_count(M, req, KSTAGE);
-        const size_t stride = (size_t)Mo * No;
-        hipError_t e = tgemm<E, true, true>(A, lda, B, ldb, Mo, No, M, req, EpiSlab{F(w.slab), stride, No}, s);
-        if (e != hipSuccess) return e;
-        const size_t n4 = n_out / 4;
-        int grid = (int)((n4 + 255) / 256); if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, s, (const float*)F(w.slab), stride, S, o0,
-                           o1 ? o1 : o0, o2 ? o2 : o0, seg, n4);
+    // The weight gradients are collected and run as one grouped launch after the chain of data gradients: every
+    // output gradient they need stays in its own buffer until then.
+    GTable gt;
+    gt.n = 0; gt.K = M;
+    int g_tiles = 0;
+    auto flush_group = [&]() -> hipError_t {
+        if (gt.n == 0) return hipSuccess;
+        hipLaunchKernelGGL(tgemm_wgrad_group_kernel<E>, dim3(g_tiles), dim3(kGT), 0, s, gt);
+        gt.n = 0; g_tiles = 0;
         return hipGetLastError();
     };
-    const size_t one_seg = (size_t)1 << 40;
-    // head: dW = dpred^T xf, db = colsum(dpred), dxf = dpred W
-    TRY(wgrad(P(w.dpred), ap, ap, P(w.xf), D, D, hw.g, nullptr, nullptr, one_seg, (size_t)act * D));
+    auto wgrad = [&](const E* A, int lda, int Mo, const E* B, int ldb, int No, float* out) -> hipError_t {
+        if (gt.n == kMaxGroup) { hipError_t e = flush_group(); if (e != hipSuccess) return e; }
+        const int nt_n = (No + kTileMN - 1) / kTileMN, nt_m = (Mo + kTileMN - 1) / kTileMN;
+        gt.p[gt.n++] = GProb{A, B, out, lda, ldb, Mo, No, g_tiles, nt_n};
+        g_tiles += nt_n * nt_m;
+        return hipSuccess;
+    };
+    // head: dW = dpred^T xf (padded rows, copied out below), db = colsum(dpred), dxf = dpred W
+    TRY(wgrad(P(w.dpred), ap, ap, P(w.xf), D, D, F(w.dw_head)));
     TRY(colsum(P(w.dpred), ap, act, hb.g));
     TRY((tgemm<E, false, true>(P(w.dpred), ap, P(w.w_head), D, M, D, ap, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
-    TRY(ln_bwd(x_last, w.stf, lnfw.p, false, lnfw.g, lnfb.g, lp[L - 1].f2b.g, resid_p, (uint32_t)(4 * (L - 1) + 2)));
+    TRY(ln_bwd(x_last, w.stf, lnfw.p, false, P(w.layer[L - 1].dyo), lnfw.g, lnfb.g, lp[L - 1].f2b.g, resid_p,
+               (uint32_t)(4 * (L - 1) + 2)));
     for (int l = L - 1; l >= 0; --l) {
         const TrainLayerWs& y = w.layer[l];
         const float* x_in = l == 0 ? F(w.x0) : F(w.layer[l - 1].x_out);
-        // FC2: dW2 = dx^T g, db2, dh = (dx W2) * GELU'(h)
-        TRY(wgrad(P(w.dxb), D, D, P(y.g), D4, D4, lp[l].f2w.g, nullptr, nullptr, one_seg, (size_t)D * D4));
-        TRY((tgemm<E, false, true>(P(w.dxb), D, P(y.w_fc2), D4, M, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(w.dh), D4}, s)));
+        // FC2: dW2 = dyo^T g, dh = (dyo W2) * GELU'(h)
+        TRY(wgrad(P(y.dyo), D, D, P(y.g), D4, D4, lp[l].f2w.g));
+        TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, M, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), D4}, s)));
         // FC1: dW1 = dh^T xn2, db1, dxn2 = dh W1
-        TRY(wgrad(P(w.dh), D4, D4, P(y.xn2), D, D, lp[l].f1w.g, nullptr, nullptr, one_seg, (size_t)D4 * D));
-        TRY(colsum(P(w.dh), D4, D4, lp[l].f1b.g));
-        TRY((tgemm<E, false, true>(P(w.dh), D4, P(y.w_fc1), D, M, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
-        TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, true, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p, (uint32_t)(4 * l + 1)));
-        // proj: dWp = dx^T y, dbp, dy = dx Wp
-        TRY(wgrad(P(w.dxb), D, D, P(y.y), D, D, lp[l].pw.g, nullptr, nullptr, one_seg, (size_t)D * D));
-        TRY((tgemm<E, false, true>(P(w.dxb), D, P(y.w_proj), D, M, D, D, 1, EpiStore<E>{nullptr, P(w.dy), nullptr, D}, s)));
-        hipLaunchKernelGGL(attn_bwd_kernel<E>, dim3(batch * H), dim3(64), lds_b, s, (const E*)P(y.qkv), (const E*)P(w.dy),
-                           P(w.dqkv), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
+        TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, lp[l].f1w.g));
+        TRY(colsum(P(y.dh), D4, D4, lp[l].f1b.g));
+        TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, M, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+        TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, true, P(y.dym), lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
+                   (uint32_t)(4 * l + 1)));
+        // proj: dWp = dym^T y, dy = dym Wp
+        TRY(wgrad(P(y.dym), D, D, P(y.y), D, D, lp[l].pw.g));
+        TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, M, D, D, 1, EpiStore<E>{nullptr, P(w.dy), nullptr, D}, s)));
+        if (attn_small)
+            hipLaunchKernelGGL((attn_small_kernel<E, true>), dim3(batch * H), dim3(64), 0, s, (const E*)P(y.qkv),
+                               (const E*)P(w.dy), P(y.dqkv), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
+        else
+            hipLaunchKernelGGL(attn_bwd_kernel<E>, dim3(batch * H), dim3(64), lds_b, s, (const E*)P(y.qkv), (const E*)P(w.dy),
+                               P(y.dqkv), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
         TRY(hipGetLastError());
         // q/k/v: three weight gradients from the column blocks of dqkv, bias gradients, dxn1 = dqkv Wqkv
-        TRY(wgrad(P(w.dqkv), D3, D3, P(y.xn1), D, D, lp[l].qw.g, lp[l].kw.g, lp[l].vw.g, (size_t)D * D, (size_t)D3 * D));
-        TRY(colsum(P(w.dqkv), D3, D3, lp[l].qb.g, lp[l].kb.g, lp[l].vb.g, D));
-        TRY((tgemm<E, false, true>(P(w.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+        TRY(wgrad(P(y.dqkv), D3, D, P(y.xn1), D, D, lp[l].qw.g));
+        TRY(wgrad(P(y.dqkv) + D, D3, D, P(y.xn1), D, D, lp[l].kw.g));
+        TRY(wgrad(P(y.dqkv) + 2 * D, D3, D, P(y.xn1), D, D, lp[l].vw.g));
+        TRY(colsum(P(y.dqkv), D3, D3, lp[l].qb.g, lp[l].kb.g, lp[l].vb.g, D));
+        TRY((tgemm<E, false, true>(P(y.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
         const bool first = l == 0;
-        TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, true, lp[l].ln1w.g, lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g,
-                   first ? 0.f : resid_p, first ? 0u : (uint32_t)(4 * (l - 1) + 2)));
+        TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, true, first ? P(w.dx0b) : P(w.layer[l - 1].dyo), lp[l].ln1w.g, lp[l].ln1b.g,
+                   first ? nullptr : lp[l - 1].f2b.g, first ? 0.f : resid_p, first ? 0u : (uint32_t)(4 * (l - 1) + 2)));
     }
-    // embeddings: dWcat[Ke][D] = Xemb^T dx0, then routed to pos_emb / tok_emb / action_emb / sigma_emb
-    TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dxb), D, D, F(w.dw_cat), nullptr, nullptr, one_seg, (size_t)Ke * D));
+    // embeddings: dWcat[Ke][D] = Xemb^T dx0, routed to pos_emb / tok_emb / action_emb / sigma_emb after the launch
+    TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dx0b), D, D, F(w.dw_cat)));
+    TRY(flush_group());
+    TRY(hipMemcpyAsync(hw.g, ws + w.dw_head, sizeof(float) * (size_t)act * D, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(scatter_emb_kernel, dim3(64), dim3(256), 0, s, (const float*)F(w.dw_cat), pos.g, tokw.g, tokb.g, sigw.g,
                        sigb.g, actw.g, actb.g, D, obs, act, seq);
     TRY(hipGetLastError());
