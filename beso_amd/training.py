@@ -112,6 +112,9 @@ class HipTrainStep:
         if not inner.training:
             attn_p = resid_p = 0.0
         if seed is None:
+            if (attn_p > 0.0 or resid_p > 0.0) and torch.cuda.is_current_stream_capturing():
+                # the seed is a host scalar: a captured graph would replay one mask forever
+                raise RuntimeError("beso_amd: the HIP training step with dropout cannot be captured into a graph")
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,), device="cpu").item())
         precision = _lib.PRECISIONS[inner.precision]
         params = [p.detach() for p in inner.parameters()]

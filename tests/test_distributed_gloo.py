@@ -58,6 +58,10 @@ def _worker(rank, world, port, out):
     bucket.sync(async_op=True)
     bucket.wait()
     assert torch.allclose(p[0].grad, torch.full((3, 2), 15.0))
+    # --- C1 on the flat buffer the HIP training step writes (already scaled by 1/world by the kernels)
+    flat_g = torch.full((7,), float(rank + 1) / world)
+    bdist.all_reduce_sum(flat_g)
+    assert torch.allclose(flat_g, torch.full((7,), 1.5))
     # --- C2: broadcast makes replicas identical
     cfg, agent = _make_agent(seed=100 + rank)           # different init per rank on purpose
     bdist.broadcast_parameters(agent.model.get_params(), src=0)

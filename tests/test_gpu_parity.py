@@ -483,3 +483,217 @@ def test_no_writes_outside_output_and_workspace(cfg_name, precision):
             for big in (outbig, xbig):
                 assert bool((big[:1024] == -777.0).all()) and bool((big[1024 + n_out:] == -777.0).all()), (B, t, lam)
                 assert torch.isfinite(big[1024:1024 + n_out]).all()
+
+
+# -------------------------------------------------------------------------------------------------
+# training step in HIP (beso_loss_grad): row f1
+# -------------------------------------------------------------------------------------------------
+def _train_module(cfg, w, precision, attn_pdrop=0.0, resid_pdrop=0.0):
+    from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
+    from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser
+    inner = functools.partial(
+        DiffusionGPT, state_dim=cfg.obs_dim, device=DEV, goal_conditioned=cfg.goal_conditioned,
+        action_dim=cfg.act_dim, embed_dim=cfg.embed_dim, embed_pdrob=0.0, attn_pdrop=attn_pdrop,
+        resid_pdrop=resid_pdrop, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=cfg.goal_seq_len,
+        obs_seq_len=cfg.obs_seq_len, sigma_vocab_size=3, time_embedding_fn=None, goal_drop=0.0,
+        linear_output=cfg.linear_output, precision=precision)
+    m = GCDenoiser(inner, sigma_data=cfg.sigma_data)
+    sd = m.state_dict()
+    for k, v in w.items():
+        sd[k] = torch.from_numpy(v.copy())
+    m.load_state_dict(sd)
+    return m.to(DEV).train()
+
+
+def _train_inputs(cfg, B, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    return (r(B, cfg.obs_seq_len, cfg.obs_dim), r(B, cfg.obs_seq_len, cfg.act_dim), r(B, cfg.goal_seq_len, cfg.obs_dim),
+            r(B, cfg.obs_seq_len, cfg.act_dim), (torch.rand(B, generator=g) * 0.9 + 0.05).to(DEV))
+
+
+def _grad_errors(got, ref, floor=1e-4):
+    """per tensor ||got - ref|| / max(||ref||, floor): tensors whose exact gradient is zero (key.bias: softmax is
+    invariant to a shift of all scores of a row -- what is left is the rounding noise of the summands) are measured
+    against `floor` times the largest gradient entry"""
+    gmax = max(r.abs().max().item() for r in ref)
+    return [((g - r).norm() / max(r.norm().item(), floor * gmax * r.numel() ** 0.5)).item() for g, r in zip(got, ref)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_gemm_operand_layouts(precision):
+    """The one GEMM kernel of the training step with k-contiguous and contraction-major (k-slow) operands --
+    bf16 k-slow tiles come out of LDS through ds_read_b64_tr_b16 -- against fp64 matmul on ragged shapes,
+    with and without split-K."""
+    import ctypes as C
+    from beso_amd import _lib
+    lib = _lib.load()
+    prec = _lib.PRECISIONS[precision]
+    dt = torch.float32 if precision == "fp32" else torch.bfloat16
+    tol = 3e-6                                            # (bf16 inputs are exact; products and sums are fp32)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for aks, bks in ((0, 0), (0, 1), (1, 1)):
+        for (M, N, K, S) in ((128, 128, 64, 1), (200, 136, 72, 1), (360, 1440, 1000, 3), (16, 360, 520, 2), (56, 360, 264, 1)):
+            A = torch.randn((K, M) if aks else (M, K), generator=g).to(DEV).to(dt)
+            B = torch.randn((K, N) if bks else (N, K), generator=g).to(DEV).to(dt)
+            Cm = torch.zeros(M, N, device=DEV)
+            st = lib.beso_debug_gemm(prec, aks, bks, A.data_ptr(), A.shape[1], B.data_ptr(), B.shape[1], Cm.data_ptr(), N, M, N,
+                                     K, S, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(st, "debug_gemm")
+            ref = (A.t() if aks else A).double() @ (B.t() if bks else B).double().t()
+            err = ((Cm.double() - ref).abs().max() / ref.abs().max()).item()
+            assert err < tol, (precision, aks, bks, M, N, K, S, err)
+    # unsupported layout pair and misaligned leading dimension are refused, not run
+    A = torch.zeros(64, 64, device=DEV)
+    with pytest.raises(ValueError):
+        _lib.check(lib.beso_debug_gemm(1, 1, 0, A.data_ptr(), 64, A.data_ptr(), 64, A.data_ptr(), 64, 64, 64, 64, 1, None))
+    with pytest.raises(_lib.BesoHipError):
+        _lib.check(lib.beso_debug_gemm(1, 0, 0, A.data_ptr(), 63, A.data_ptr(), 64, A.data_ptr(), 64, 64, 64, 64, 1, None))
+
+
+@pytest.mark.gpu
+def test_hip_training_step_matches_reference_gradients():
+    """beso_loss_grad (fp32 mode) against the loss and the per-parameter gradients that the REFERENCE's
+    loss.backward() produced (tests/golden/tiny_loss.npz), through GCDenoiser.loss + autograd's backward."""
+    fx = load_golden("tiny_loss.npz")
+    cfg = O.TINY
+    m = _train_module(cfg, _weights(fx, cfg), "fp32")
+    T = lambda k: G(fx[k])
+    loss = m.loss(T("state"), T("action"), T("goal"), T("noise"), T("sigma"))
+    assert "ScoreMatchingLoss" in type(loss.grad_fn).__name__          # the HIP step, not the autograd evaluation
+    assert abs(loss.item() - float(fx["loss"])) < 2e-5 * abs(float(fx["loss"]))
+    loss.backward()
+    gmax = max(float(fx["gnorm::" + n]) for n, _ in m.named_parameters())
+    for n, p in m.named_parameters():
+        ref_norm = float(fx["gnorm::" + n])
+        assert abs(p.grad.norm().item() - ref_norm) <= 5e-4 * ref_norm + 1e-6 * gmax, n
+        np.testing.assert_allclose(p.grad.reshape(-1)[:8].cpu().numpy(), fx["gslice::" + n], rtol=5e-3, atol=2e-6 * gmax)
+
+
+_LONG_WINDOW = O.ScoreGPTConfig(obs_dim=6, act_dim=4, embed_dim=64, n_layers=2, n_heads=4, goal_seq_len=3, obs_seq_len=9,
+                                linear_output=True, sigma_data=0.5)       # T = 22 tokens: the general attention kernels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("cfg_name,B", [("tiny", 5), ("kitchen", 48), ("block_push", 40), ("long_window", 7)])
+def test_hip_loss_and_gradients_match_autograd(cfg_name, B, precision, monkeypatch):
+    """Loss and every parameter gradient of the HIP training step against torch autograd on the same function
+    (itself pinned to the reference: tests/test_host_logic.py).  fp32 mode: 2e-4 per tensor; bf16 mode (bf16 GEMM
+    operands and kept activations, fp32 accumulation): 1e-1 per tensor, 3e-3 on the loss."""
+    cfg = {"tiny": O.TINY, "kitchen": O.KITCHEN, "block_push": O.BLOCK_PUSH, "long_window": _LONG_WINDOW}[cfg_name]
+    m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), precision)
+    state, action, goal, noise, sigma = _train_inputs(cfg, B, seed=1)
+    monkeypatch.setenv("BESO_AMD_HIP_TRAIN", "0")
+    ref_loss = m.loss(state, action, goal, noise.clone(), sigma)
+    assert "ScoreMatchingLoss" not in type(ref_loss.grad_fn).__name__
+    ref_loss.backward()
+    ref = [p.grad.clone() for p in m.parameters()]
+    for p in m.parameters():
+        p.grad = None
+    monkeypatch.setenv("BESO_AMD_HIP_TRAIN", "1")
+    loss = m.loss(state, action, goal, noise.clone(), sigma)
+    assert "ScoreMatchingLoss" in type(loss.grad_fn).__name__
+    loss.backward()
+    got = [p.grad for p in m.parameters()]
+    ltol, gtol = (2e-5, 2e-4) if precision == "fp32" else (3e-3, 1e-1)
+    assert abs(loss.item() - ref_loss.item()) < ltol * abs(ref_loss.item())
+    errs = _grad_errors(got, ref, 1e-4 if precision == "fp32" else 2e-3)
+    worst = max(range(len(errs)), key=lambda i: errs[i])
+    assert errs[worst] < gtol, (list(dict(m.named_parameters()))[worst], errs[worst])
+    # a second backward through a scaled loss scales the gradients (autograd contract of the custom node); bias and
+    # LayerNorm gradients are accumulated with fp32 atomics, so two runs agree to rounding, not bit for bit
+    got = [g.clone() for g in got]
+    for p in m.parameters():
+        p.grad = None
+    (3.0 * m.loss(state, action, goal, noise.clone(), sigma)).backward()
+    if precision == "fp32":
+        errs3 = _grad_errors([p.grad / 3.0 for p in m.parameters()], got)
+        assert max(errs3) < 1e-4, max(errs3)
+
+
+@pytest.mark.gpu
+def test_hip_training_dropout_masks():
+    """Dropout of the attention weights (kitchen: 0.3) and of the proj / MLP outputs (block-push: 0.05) inside the
+    HIP step: the counter-based masks are a function of the seed only (same seed -> same loss and gradients,
+    another seed -> another loss), the backward uses the forward's masks (directional derivative by central
+    differences at a fixed seed), and the expected loss is near the dropout-free one."""
+    from beso_amd.training import HipTrainStep
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=4, std=0.08)
+    m = _train_module(cfg, w, "fp32", attn_pdrop=0.3, resid_pdrop=0.1)
+    inner = m.inner_model
+    step = HipTrainStep(inner, cfg.sigma_data)
+    state, action, goal, noise, sigma = _train_inputs(cfg, 64, seed=2)
+    run = lambda seed: step.run(state, action, goal, noise, sigma, seed=seed, fresh_grads=True)
+    l1, f1, _ = run(11)
+    l2, f2, _ = run(11)
+    l3, _, _ = run(12)
+    assert abs(l1.item() - l2.item()) < 1e-6 * abs(l1.item())
+    assert (f1 - f2).abs().max().item() < 1e-5 * f1.abs().max().item()     # (atomics: rounding-level differences)
+    assert l3.item() != l1.item()
+    # eval mode switches the dropouts off
+    inner.eval()
+    l_eval, _, _ = run(11)
+    m0 = _train_module(cfg, w, "fp32")
+    l_ref, _, _ = HipTrainStep(m0.inner_model, cfg.sigma_data).run(state, action, goal, noise, sigma, seed=1, fresh_grads=True)
+    assert abs(l_eval.item() - l_ref.item()) < 1e-6 * abs(l_ref.item())
+    inner.train()
+    mean_drop = float(np.mean([run(s)[0].item() for s in range(20, 36)]))
+    assert abs(mean_drop - l_ref.item()) < 0.25 * abs(l_ref.item())
+    # directional derivative at seed 11
+    params = list(inner.parameters())
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    dirs = [torch.randn(p.shape, generator=gen).to(DEV) * p.detach().abs().mean().clamp_min(1e-3) for p in params]
+    _, flat, views = run(11)
+    analytic = sum((g.double() * d.double()).sum().item() for g, d in zip(views, dirs))
+    eps = 2e-2
+    with torch.no_grad():
+        for p, d in zip(params, dirs):
+            p.add_(eps * d)
+        lp = run(11)[0].item()
+        for p, d in zip(params, dirs):
+            p.sub_(2 * eps * d)
+        lm = run(11)[0].item()
+        for p, d in zip(params, dirs):
+            p.add_(eps * d)
+    numeric = (lp - lm) / (2 * eps)
+    assert abs(numeric - analytic) < 3e-2 * abs(analytic) + 1e-5, (numeric, analytic)
+
+
+@pytest.mark.gpu
+def test_train_step_runs_on_the_hip_step_and_matches_autograd(monkeypatch):
+    """BesoAgent.train_step: forward + backward through beso_loss_grad (gradients as views of one flat buffer that
+    the fused optimizer reads) == the same steps through torch autograd, with noise and sigma pinned."""
+    from test_host_logic import build_agent
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=2, std=0.05)
+    torch.manual_seed(11)
+    B = 16
+    noise = torch.randn(B, cfg.obs_seq_len, cfg.act_dim, device=DEV)
+    sigma = torch.rand(B, device=DEV) * 0.9 + 0.05
+    batches = [{"observation": torch.randn(B, cfg.obs_seq_len, cfg.obs_dim, device=DEV),
+                "action": torch.randn(B, cfg.obs_seq_len, cfg.act_dim, device=DEV),
+                "goal_observation": torch.randn(B, cfg.goal_seq_len, cfg.obs_dim, device=DEV)} for _ in range(4)]
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BESO_AMD_HIP_TRAIN", mode)
+        agent = build_agent(cfg, lambda: make_module(cfg, w, "fp32"), device=DEV)
+        agent.get_scaler(Scaler(np.random.default_rng(0).standard_normal((64, cfg.obs_dim)).astype(np.float32),
+                                np.random.default_rng(1).standard_normal((64, cfg.act_dim)).astype(np.float32), True, DEV))
+        agent.set_bounds(agent.scaler)
+        monkeypatch.setattr(agent, "make_sample_density", lambda: (lambda shape, device: sigma.clone()))
+        monkeypatch.setattr(torch, "randn_like", lambda t, *a, **k: noise.clone())
+        losses = [agent.train_step(b) for b in batches]
+        monkeypatch.undo()
+        hip = getattr(agent, "_hip_step", None)
+        assert (hip is not None) == (mode == "1")
+        if hip is not None:
+            flat = hip.flat_grads()
+            assert flat is not None and flat.numel() == sum(p.numel() for p in agent.model.parameters())
+        results[mode] = (losses, [p.detach().cpu().numpy().copy() for p in agent.model.parameters()])
+    assert np.allclose(results["1"][0], results["0"][0], rtol=2e-5, atol=1e-6), (results["1"][0], results["0"][0])
+    for a, b in zip(results["1"][1], results["0"][1]):
+        assert rel_err(a, b) < 5e-3            # Adam amplifies last-bit differences to O(lr), see above

@@ -321,3 +321,27 @@ def test_device_prefetcher_passthrough_and_order():
     assert all(g is b for g, b in zip(got, batches))
     assert len(DevicePrefetcher(batches, "cpu")) == 5
     assert list(DevicePrefetcher([], "cpu")) == []
+
+
+def test_hip_training_step_is_gpu_only_and_shape_gated():
+    """The HIP training step binds to HIP parameters only: on CPU GCDenoiser.loss stays on the autograd evaluation
+    (no library call), and shapes the kernels do not cover (MLP head, embedding dropout) are declared unsupported."""
+    from beso_amd.training import HipTrainStep
+    cfg = O.TINY
+    from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
+    kw = dict(state_dim=cfg.obs_dim, device="cpu", goal_conditioned=True, action_dim=cfg.act_dim, embed_dim=cfg.embed_dim,
+              attn_pdrop=0.1, resid_pdrop=0.1, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=cfg.goal_seq_len,
+              obs_seq_len=cfg.obs_seq_len)
+    assert HipTrainStep.supported(DiffusionGPT(embed_pdrob=0.0, linear_output=True, **kw))
+    assert not HipTrainStep.supported(DiffusionGPT(embed_pdrob=0.0, linear_output=False, **kw))
+    assert not HipTrainStep.supported(DiffusionGPT(embed_pdrob=0.1, linear_output=True, **kw))
+    from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser
+    den = GCDenoiser(DiffusionGPT(embed_pdrob=0.0, linear_output=True, **kw), sigma_data=0.5).train()
+    B = 3
+    state, action = torch.randn(B, cfg.obs_seq_len, cfg.obs_dim), torch.randn(B, cfg.obs_seq_len, cfg.act_dim)
+    goal, noise, sigma = torch.randn(B, cfg.goal_seq_len, cfg.obs_dim), torch.randn(B, cfg.obs_seq_len, cfg.act_dim), torch.rand(B) + 0.1
+    assert den.hip_train_step(state, action, goal, noise, sigma) is None
+    loss = den.loss(state, action, goal, noise, sigma)
+    assert "ScoreMatchingLoss" not in type(loss.grad_fn).__name__
+    loss.backward()
+    assert all(p.grad is not None for p in den.parameters())
