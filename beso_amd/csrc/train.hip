@@ -564,8 +564,7 @@ template <typename E, int kLnVec>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* dres_in, float* dres_out, E* __restrict__ dxb,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     float* __restrict__ dbias, int rows, int D, int rows_per_wave, float p,
+                                                     float* __restrict__ part, int rows, int D, int rows_per_wave, float p,
                                                      float inv_keep, uint32_t seed, uint32_t site) {
     __shared__ f32x4 red[3][4][64 * kLnVec];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -621,12 +620,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         red[0][wid][lane + i * 64] = ag[i]; red[1][wid][lane + i * 64] = ab[i]; red[2][wid][lane + i * 64] = ac[i];
     }
     __syncthreads();
+    // block partials [3][D] -> part[blockIdx.x]; ln_reduce_kernel sums them for all LayerNorms of the step at once
+    // (fp32 atomics from every block were the larger half of this kernel's time)
     const float* r0 = (const float*)red[0], *r1 = (const float*)red[1], *r2 = (const float*)red[2];
     constexpr int WS = 64 * kLnVec * 4;          // floats per wave slab
+    float* o = part + (size_t)blockIdx.x * 3 * D;
     for (int c = threadIdx.x; c < D; c += 256) {
-        unsafeAtomicAdd(dgamma + c, r0[c] + r0[WS + c] + r0[2 * WS + c] + r0[3 * WS + c]);
-        unsafeAtomicAdd(dbeta + c, r1[c] + r1[WS + c] + r1[2 * WS + c] + r1[3 * WS + c]);
-        if (dbias) unsafeAtomicAdd(dbias + c, r2[c] + r2[WS + c] + r2[2 * WS + c] + r2[3 * WS + c]);
+        o[c] = r0[c] + r0[WS + c] + r0[2 * WS + c] + r0[3 * WS + c];
+        o[D + c] = r1[c] + r1[WS + c] + r1[2 * WS + c] + r1[3 * WS + c];
+        o[2 * D + c] = r2[c] + r2[WS + c] + r2[2 * WS + c] + r2[3 * WS + c];
+    }
+}
+
+// sums the block partials of every LayerNorm backward of the step: call z -> gamma / beta gradient and the bias
+// gradient of the linear layer that consumed its output (assigned: each destination has exactly one source)
+struct LnRedCall { float* dgamma; float* dbeta; float* dbias; };
+struct LnRedTable { LnRedCall c[2 * kMaxLayers + 1]; };
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, LnRedTable t, int nblk, int D) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, which = blockIdx.y, call = blockIdx.z;
+    const int c = blockIdx.x * 64 + cx;
+    const float* src = part + ((size_t)call * nblk * 3 + which) * D;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;          // four loads in flight per thread
+    if (c < D) {
+        int b = ry;
+        for (; b + 12 < nblk; b += 16) {
+            a0 += src[(size_t)b * 3 * D + c]; a1 += src[(size_t)(b + 4) * 3 * D + c];
+            a2 += src[(size_t)(b + 8) * 3 * D + c]; a3 += src[(size_t)(b + 12) * 3 * D + c];
+        }
+        for (; b < nblk; b += 4) a0 += src[(size_t)b * 3 * D + c];
+    }
+    red[ry][cx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ry == 0 && c < D) {
+        const LnRedCall k = t.c[call];
+        float* dst = which == 0 ? k.dgamma : (which == 1 ? k.dbeta : k.dbias);
+        if (dst) dst[c] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
     }
 }
 
@@ -820,31 +849,43 @@ __device__ __forceinline__ float dot_rows(const float* a, const float* b, int hd
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-template <typename E, bool BWD>
+template <typename E, bool BWD, int TT>          // TT = T rounded up to a multiple of 4 (8, 12 or 16)
 __global__ __launch_bounds__(64) void attn_small_kernel(const E* __restrict__ qkv, const E* __restrict__ dy,
                                                         E* __restrict__ out, int T, int D, int H, int hd, float scale,
                                                         float p, float inv_keep, uint32_t seed, uint32_t site) {
-    __shared__ __attribute__((aligned(16))) float sq[kTP][kLdh], sk[kTP][kLdh], sv[BWD ? kTP : 1][kLdh],
-        sdy[BWD ? kTP : 1][kLdh];
-    __shared__ __attribute__((aligned(16))) float sP[kTP][kLdt], sdP[BWD ? kTP : 1][kLdt];
+    __shared__ __attribute__((aligned(16))) float sq[TT][kLdh], sk[TT][kLdh], sv[BWD ? TT : 1][kLdh],
+        sdy[BWD ? TT : 1][kLdh];
+    __shared__ __attribute__((aligned(16))) float sP[TT][kLdt], sdP[BWD ? TT : 1][kLdt];
     const int pair = blockIdx.x, b = pair / H, h = pair % H, lane = threadIdx.x;
     const size_t ldq = (size_t)3 * D;
     const bool act = lane < hd;
-    float qr[kTP], kr[kTP], vr[kTP], gr[kTP];
+    float qr[TT], kr[TT], vr[TT], gr[TT];
     {
-        const E* base = qkv + (size_t)b * T * ldq + (size_t)h * hd + lane;
-        const E* gbase = BWD ? dy + (size_t)b * T * D + (size_t)h * hd + lane : nullptr;
+        // branch-free: out-of-range rows / lanes read a clamped address and are zeroed afterwards (a load inside a
+        // divergent branch is waited for before the next one is issued: 48 serial round trips)
+        const int lc = act ? lane : 0;
+        const E* base = qkv + (size_t)b * T * ldq + (size_t)h * hd + lc;
+        const E* gbase = dy + (size_t)b * T * D + (size_t)h * hd + lc;
+        E qe[TT], ke[TT], ve[TT], ge[TT];
 #pragma unroll
-        for (int r = 0; r < kTP; ++r) {
+        for (int r = 0; r < TT; ++r) {
+            const int rc = r < T ? r : 0;
+            qe[r] = base[rc * ldq];
+            ke[r] = base[rc * ldq + D];
+            ve[r] = base[rc * ldq + 2 * D];
+            if (BWD) ge[r] = gbase[(size_t)rc * D];
+        }
+#pragma unroll
+        for (int r = 0; r < TT; ++r) {
             const bool ok = act && r < T;
-            qr[r] = ok ? Act<E>::to(base[r * ldq]) : 0.f;
-            kr[r] = ok ? Act<E>::to(base[r * ldq + D]) : 0.f;
-            vr[r] = ok ? Act<E>::to(base[r * ldq + 2 * D]) : 0.f;
-            gr[r] = (BWD && ok) ? Act<E>::to(gbase[(size_t)r * D]) : 0.f;
+            qr[r] = ok ? Act<E>::to(qe[r]) : 0.f;
+            kr[r] = ok ? Act<E>::to(ke[r]) : 0.f;
+            vr[r] = ok ? Act<E>::to(ve[r]) : 0.f;
+            gr[r] = (BWD && ok) ? Act<E>::to(ge[r]) : 0.f;
         }
     }
 #pragma unroll
-    for (int r = 0; r < kTP; ++r) {
+    for (int r = 0; r < TT; ++r) {
         sq[r][lane] = qr[r];
         sk[r][lane] = kr[r];
         if (BWD) { sv[r][lane] = vr[r]; sdy[r][lane] = gr[r]; }
@@ -853,45 +894,48 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const E* __restrict__ qk
     const int il = lane >> 4, j = lane & 15;
     // scores (and, backward, dPd = dy v^T) on the 4 x 16 lane grid
 #pragma unroll
-    for (int ib = 0; ib < kTP / 4; ++ib) {
+    for (int ib = 0; ib < TT / 4; ++ib) {
         const int i = ib * 4 + il;
         const bool in = i < T && j <= i;
-        sP[i][j] = in ? dot_rows(sq[i], sk[j], hd) * scale : -INFINITY;
-        if (BWD) sdP[i][j] = in ? dot_rows(sdy[i], sv[j], hd) : 0.f;
+        if (j < kLdt) {
+            sP[i][j] = in ? dot_rows(sq[i], sk[j < TT ? j : 0], hd) * scale : -INFINITY;
+            if (BWD) sdP[i][j] = in ? dot_rows(sdy[i], sv[j < TT ? j : 0], hd) : 0.f;
+        }
     }
     __syncthreads();
     // row softmax (lane i), dropout scale folded: sP <- Pd = P * keep-scale; backward also dS (pre-scaled by `scale`)
     if (lane < T) {
         const int i = lane;
-        float m = -INFINITY, pr[kTP], l = 0.f;
+        float m = -INFINITY, pr[TT], l = 0.f;
 #pragma unroll
-        for (int c = 0; c < kTP; ++c) m = fmaxf(m, sP[i][c]);
+        for (int c = 0; c < TT; ++c) m = fmaxf(m, sP[i][c]);
 #pragma unroll
-        for (int c = 0; c < kTP; ++c) { pr[c] = c <= i ? expf(sP[i][c] - m) : 0.f; l += pr[c]; }
+        for (int c = 0; c < TT; ++c) { pr[c] = c <= i ? expf(sP[i][c] - m) : 0.f; l += pr[c]; }
         const float inv = 1.0f / l;
-        float ks[kTP], dot = 0.f;
+        float ks[TT], dot = 0.f;
 #pragma unroll
-        for (int c = 0; c < kTP; ++c) {
+        for (int c = 0; c < TT; ++c) {
             pr[c] *= inv;
             ks[c] = (p > 0.f && c <= i) ? drop_scale(seed, site, (size_t)pair * T * T + (size_t)i * T + c, p, inv_keep) : 1.f;
             if (BWD) dot = fmaf(sdP[i][c] * ks[c], pr[c], dot);
         }
 #pragma unroll
-        for (int c = 0; c < kTP; ++c) {
+        for (int c = 0; c < TT; ++c) {
             if (BWD) sdP[i][c] = pr[c] * (sdP[i][c] * ks[c] - dot) * scale;       // dS
             sP[i][c] = pr[c] * ks[c];                                               // Pd
         }
     }
     __syncthreads();
     if (!act) return;
+    // the d-parallel products walk the lower triangle only: row i needs columns 0 .. i (in groups of four)
     if (!BWD) {
         E* o = out + (size_t)b * T * D + (size_t)h * hd + lane;
 #pragma unroll
-        for (int i = 0; i < kTP; ++i) {
+        for (int i = 0; i < TT; ++i) {
             if (i < T) {
                 float acc = 0.f;
 #pragma unroll
-                for (int c = 0; c < kTP; c += 4) {
+                for (int c = 0; c <= (i | 3) && c < TT; c += 4) {
                     const f32x4 pv = *(const f32x4*)&sP[i][c];
                     acc = fmaf(pv[0], vr[c], acc); acc = fmaf(pv[1], vr[c + 1], acc);
                     acc = fmaf(pv[2], vr[c + 2], acc); acc = fmaf(pv[3], vr[c + 3], acc);
@@ -900,16 +944,15 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const E* __restrict__ qk
             }
         }
     } else {
-        // dq[i] = sum_j dS[i][j] k[j];  dk[j] = sum_i dS[i][j] q[i];  dv[j] = sum_i Pd[i][j] dy[i]   (entries above the
-        // diagonal are zero in both matrices)
-        float dq[kTP], dk[kTP], dv[kTP];
+        // dq[i] = sum_j dS[i][j] k[j];  dk[j] = sum_i dS[i][j] q[i];  dv[j] = sum_i Pd[i][j] dy[i]
+        float dq[TT], dk[TT], dv[TT];
 #pragma unroll
-        for (int r = 0; r < kTP; ++r) { dq[r] = 0.f; dk[r] = 0.f; dv[r] = 0.f; }
+        for (int r = 0; r < TT; ++r) { dq[r] = 0.f; dk[r] = 0.f; dv[r] = 0.f; }
 #pragma unroll
-        for (int i = 0; i < kTP; ++i) {
+        for (int i = 0; i < TT; ++i) {
             if (i < T) {
 #pragma unroll
-                for (int c = 0; c < kTP; c += 4) {
+                for (int c = 0; c <= (i | 3) && c < TT; c += 4) {
                     const f32x4 ds = *(const f32x4*)&sdP[i][c], pd = *(const f32x4*)&sP[i][c];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -922,7 +965,7 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const E* __restrict__ qk
         }
         E* o = out + (size_t)b * T * ldq + (size_t)h * hd + lane;
 #pragma unroll
-        for (int r = 0; r < kTP; ++r) {
+        for (int r = 0; r < TT; ++r) {
             if (r < T) {
                 o[r * ldq] = Act<E>::from(dq[r]);
                 o[r * ldq + D] = Act<E>::from(dk[r]);
@@ -980,7 +1023,7 @@ struct TrainLayerWs {
 struct TrainWs {
     int M, T, Ke, ap;
     size_t noised, target, x0, xemb, stf, xf, pred, dpred, w_head, b_head, dw_cat, dw_head;
-    size_t dx, dx0b, dxn, dy;
+    size_t dx, dx0b, dxn, dy, ln_part;
     TrainLayerWs layer[kMaxLayers];
     size_t total;
 };
@@ -1004,6 +1047,7 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
     w->dw_cat = carve_t(cur, f * (size_t)w->Ke * D); w->dw_head = carve_t(cur, f * (size_t)w->ap * D);
     w->dx = carve_t(cur, f * M * D); w->dx0b = carve_t(cur, e * M * D); w->dxn = carve_t(cur, f * M * D);
     w->dy = carve_t(cur, e * M * D);
+    w->ln_part = carve_t(cur, f * (size_t)(2 * c->n_layers + 1) * ((M + 15) / 16) * 3 * D);     // LayerNorm backward block partials
     for (int l = 0; l < c->n_layers; ++l) {
         TrainLayerWs& y = w->layer[l];
         y.w_qkv = carve_t(cur, e * (size_t)3 * D * D); y.b_qkv = carve_t(cur, f * (size_t)3 * D);
@@ -1148,10 +1192,12 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(ln_fwd(x_in, lp[l].ln1w.p, lp[l].ln1b.p, P(y.xn1), F(y.st1)));
         TRY((tgemm<E, false, false>(P(y.xn1), D, P(y.w_qkv), D, M, D3, D, 1,
                                     EpiStore<E>{nullptr, P(y.qkv), F(y.b_qkv), D3}, s)));
-        if (attn_small)
-            hipLaunchKernelGGL((attn_small_kernel<E, false>), dim3(batch * H), dim3(64), 0, s, (const E*)P(y.qkv),
-                               (const E*)nullptr, P(y.y), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
-        else
+        if (attn_small) {
+#define ATT(TT) hipLaunchKernelGGL((attn_small_kernel<E, false, TT>), dim3(batch * H), dim3(64), 0, s, (const E*)P(y.qkv), \
+                                   (const E*)nullptr, P(y.y), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l))
+            if (T <= 8) ATT(8); else if (T <= 12) ATT(12); else ATT(16);
+#undef ATT
+        } else
             hipLaunchKernelGGL(attn_fwd_kernel<E>, dim3(batch * H), dim3(64), lds_f, s, (const E*)P(y.qkv), P(y.y), T, D, H,
                                hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
         TRY(hipGetLastError());
@@ -1185,12 +1231,16 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     };
     const int rpw = 4;                                    // rows per wave of the LayerNorm backward
     const int lnb_grid = (M + 4 * rpw - 1) / (4 * rpw);
+    LnRedTable lrt;
+    int ln_calls = 0;
     auto ln_bwd = [&](const float* x, size_t st, const float* gamma, bool have_res, E* dxb, float* dgam, float* dbet,
                       float* dbias, float p_site, uint32_t site) -> hipError_t {
+        float* part = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
+        lrt.c[ln_calls++] = LnRedCall{dgam, dbet, dbias};
 #define LNB(NV)                                                                                                     \
         hipLaunchKernelGGL((ln_bwd_kernel<E, NV>), dim3(lnb_grid), dim3(256), 0, s, (const float*)F(w.dxn), x,                \
-                           (const float*)F(st), gamma, have_res ? (const float*)F(w.dx) : nullptr, F(w.dx), dxb, dgam,       \
-                           dbet, dbias, M, D, rpw, p_site, p_site > 0.f ? 1.0f / (1.0f - p_site) : 1.f, seed, site)
+                           (const float*)F(st), gamma, have_res ? (const float*)F(w.dx) : nullptr, F(w.dx), dxb, part, M, D, \
+                           rpw, p_site, p_site > 0.f ? 1.0f / (1.0f - p_site) : 1.f, seed, site)
         if (nv == 1) LNB(1); else if (nv == 2) LNB(2); else LNB(4);
 #undef LNB
         return hipGetLastError();
@@ -1234,10 +1284,12 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         // proj: dWp = dym^T y, dy = dym Wp
         TRY(wgrad(P(y.dym), D, D, P(y.y), D, D, lp[l].pw.g));
         TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, M, D, D, 1, EpiStore<E>{nullptr, P(w.dy), nullptr, D}, s)));
-        if (attn_small)
-            hipLaunchKernelGGL((attn_small_kernel<E, true>), dim3(batch * H), dim3(64), 0, s, (const E*)P(y.qkv),
-                               (const E*)P(w.dy), P(y.dqkv), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
-        else
+        if (attn_small) {
+#define ATT(TT) hipLaunchKernelGGL((attn_small_kernel<E, true, TT>), dim3(batch * H), dim3(64), 0, s, (const E*)P(y.qkv), \
+                                   (const E*)P(w.dy), P(y.dqkv), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l))
+            if (T <= 8) ATT(8); else if (T <= 12) ATT(12); else ATT(16);
+#undef ATT
+        } else
             hipLaunchKernelGGL(attn_bwd_kernel<E>, dim3(batch * H), dim3(64), lds_b, s, (const E*)P(y.qkv), (const E*)P(w.dy),
                                P(y.dqkv), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
         TRY(hipGetLastError());
@@ -1254,6 +1306,9 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // embeddings: dWcat[Ke][D] = Xemb^T dx0, routed to pos_emb / tok_emb / action_emb / sigma_emb after the launch
     TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dx0b), D, D, F(w.dw_cat)));
     TRY(flush_group());
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls), dim3(256), 0, s, (const float*)F(w.ln_part), lrt,
+                       lnb_grid, D);
+    TRY(hipGetLastError());
     TRY(hipMemcpyAsync(hw.g, ws + w.dw_head, sizeof(float) * (size_t)act * D, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(scatter_emb_kernel, dim3(64), dim3(256), 0, s, (const float*)F(w.dw_cat), pos.g, tokw.g, tokb.g, sigw.g,
                        sigb.g, actw.g, actb.g, D, obs, act, seq);
