@@ -177,6 +177,14 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4
 
 typedef unsigned char TileLds[2][2][kOpBytes];
 
+// Workgroups are dealt to the 8 XCDs round robin by blockIdx.x, and every XCD has its own 4 MB L2.  Tiles that are
+// neighbours in the logical order share an operand panel (same rows of A, next columns of B), so each XCD takes a
+// CONTIGUOUS run of logical tiles: the panel is then fetched into one L2 instead of eight.
+__device__ __forceinline__ int xcd_tile(int b, int nb) {
+    const int per = nb >> 3, rem = nb & 7, x = b & 7, i = b >> 3;
+    return x * per + (x < rem ? x : rem) + i;
+}
+
 // One 128 x 128 output tile at (m0, n0), contraction over [k_begin, k_end).
 template <typename E, bool AKS, bool BKS, typename Epi, bool DEEP = false>
 __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A, int lda, const E* __restrict__ B, int ldb,
@@ -280,7 +288,8 @@ __global__ __launch_bounds__(kGT, 4) void tgemm_kernel(const E* __restrict__ A, 
                                                        int ldb, int M, int N, int K, int k_per_split, int nt_n,
                                                        Epi epi) {
     __shared__ __attribute__((aligned(16))) TileLds lds;
-    const int tile_n = blockIdx.x % nt_n, tile_m = blockIdx.x / nt_n;
+    const int bt = xcd_tile(blockIdx.x, gridDim.x);
+    const int tile_n = bt % nt_n, tile_m = bt / nt_n;
     const int k_begin = blockIdx.y * k_per_split;
     tgemm_tile<E, AKS, BKS, Epi>(lds, A, lda, B, ldb, M, N, tile_m * kTileMN, tile_n * kTileMN, k_begin,
                                  min(K, k_begin + k_per_split), epi);
@@ -388,7 +397,7 @@ struct EpiStoreF { float* out; int ld;
 template <typename E>
 __global__ __launch_bounds__(kGT, 4) void tgemm_wgrad_group_kernel(GTable t) {
     __shared__ __attribute__((aligned(16))) TileLds lds;
-    const int b = blockIdx.x;
+    const int b = xcd_tile(blockIdx.x, gridDim.x);
     int pi = 0;
     while (pi + 1 < t.n && b >= t.p[pi + 1].tile_begin) ++pi;
     const GProb g = t.p[pi];
