@@ -20,6 +20,7 @@ from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import
 from beso_amd.runtime import PackedWeights  # noqa: E402
 
 PAGE = 2 << 20            # allocation granule assumed for the tail placement (2 MiB fragments)
+_PREC = {"bf16": 0, "fp32": 1}
 
 
 def at_tail(x: np.ndarray, dev: str) -> torch.Tensor:
@@ -77,7 +78,36 @@ def main():
                 assert all(torch.isfinite(x).all() for x in (out, out_u, out_c, smp))
                 n_calls += 4
             scope.__exit__(None, None, None)
-    print(f"guard_check: {n_calls} calls with inputs, packed weights and workspace at the end of their allocations, no fault")
+    # --- the training step (beso_loss_grad): inputs, parameters, flat gradient buffer and workspace at allocation tails
+    import ctypes as C
+    from beso_amd.training import HipTrainStep
+    n_train = 0
+    for cfg_name, precisions in (("kitchen", ("bf16", "fp32")), ("block_push", ("bf16",)), ("tiny", ("bf16", "fp32"))):
+        cfg = O.CONFIGS[cfg_name]
+        w = O.make_weights(cfg, seed=1, std=0.03)
+        for precision in precisions:
+            model = build_model(cfg, w, precision, dev).train()
+            inner = model.inner_model
+            with torch.no_grad():
+                for prm in inner.parameters():                      # every parameter at the tail of its own allocation
+                    prm.data = at_tail(prm.detach().cpu().numpy(), dev)
+            step = HipTrainStep(inner, cfg.sigma_data)
+            for B, t in ((1, 1), (3, cfg.obs_seq_len), (17, cfg.obs_seq_len), (130, max(1, cfg.obs_seq_len - 1))):
+                s_np, g_np, a_np = O.make_inputs(cfg, B, seed=B * 5 + t, t=t)
+                s, g, a = at_tail(s_np, dev), at_tail(g_np, dev), at_tail(a_np, dev)
+                nz = at_tail(np.random.default_rng(B).standard_normal(a_np.shape).astype(np.float32), dev)
+                sg = at_tail(np.linspace(0.1, 0.9, B).astype(np.float32), dev)
+                need = int(step.lib.beso_train_workspace_bytes(C.byref(step.cfg), B, t, _PREC[precision]))
+                wtotal = ((need + PAGE - 1) // PAGE) * PAGE
+                step._ws = torch.empty(wtotal, dtype=torch.uint8, device=dev)[wtotal - need:]
+                gtotal = ((step.n_grad * 4 + PAGE - 1) // PAGE) * PAGE // 4
+                step._flat, step._views = torch.empty(gtotal, dtype=torch.float32, device=dev)[gtotal - step.n_grad:], None
+                loss = step.loss_backward(s, a, g, nz, sg, seed=3)
+                torch.cuda.synchronize()
+                assert torch.isfinite(loss) and all(torch.isfinite(prm.grad).all() for prm in inner.parameters())
+                n_train += 1
+    print(f"guard_check: {n_calls} forward / sampler calls and {n_train} training steps with inputs, weights, gradients and "
+          "workspace at the end of their allocations, no fault")
 
 
 if __name__ == "__main__":
