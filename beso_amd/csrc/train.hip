@@ -56,7 +56,7 @@ template <> __device__ __forceinline__ float gelu_grad_t<uint16_t>(float v) { re
 // sum means (EpiAtomic accumulates).
 // ---------------------------------------------------------------------------------------------
 constexpr int kOpBytes = 16896;        // LDS bytes of one operand stage (k-slow images carry padding)
-constexpr int kSubBytes = 2112;        // bf16 k-slow image: one 16-column subtile = 64 k-rows x 32 B + 64 B pad
+constexpr int kSubBytes = 2080;        // bf16 k-slow image: one 16-column subtile = 64 k-rows x 32 B + 32 B pad
 constexpr int kRowBytes32 = 528;       // fp32 k-slow image: one k-row = 128 columns x 4 B + 16 B pad
 
 // Global side of an operand: raw buffer loads with 32-bit per-lane byte offsets (computed once per tile) and the
@@ -65,15 +65,16 @@ constexpr int kRowBytes32 = 528;       // fp32 k-slow image: one k-row = 128 col
 // at a valid address and replaced by zeros.
 constexpr int kGT = 512;                   // threads of a tgemm workgroup (8 waves)
 constexpr int kGL = 1024 / kGT;            // 16-byte chunks per thread, operand and stage
-struct GOp { uint32_t voff[kGL]; };          // (the descriptor is rebuilt from the kernel argument at every use: a
+template <int NCH> struct GOp { uint32_t voff[NCH]; };          // (the descriptor is rebuilt from the kernel argument at every use: a
                                            //  descriptor carried in VGPRs makes every load a waterfall loop)
 
-template <typename E, bool KS>
-__device__ __forceinline__ GOp make_gop(const E* __restrict__ P, int ld, int r0, int R, int tid) {
+template <typename E, bool KS, int NCH>        // NCH = 2: 128 rows (columns) of the operand, 1: the first 64
+__device__ __forceinline__ GOp<NCH> make_gop(const E* __restrict__ P, int ld, int r0, int R, int tid) {
     constexpr int EPC = 16 / (int)sizeof(E);
-    GOp g;
+    static_assert(NCH == kGL || !KS, "a 64-wide tile is supported for k-contiguous operands only");
+    GOp<NCH> g;
 #pragma unroll
-    for (int i = 0; i < kGL; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int c = tid + kGT * i;
         if (!KS) {
             const int row = c >> 3, kc = c & 7, gr = r0 + row;
@@ -87,9 +88,9 @@ __device__ __forceinline__ GOp make_gop(const E* __restrict__ P, int ld, int r0,
     return g;
 }
 
-template <typename E, bool KS>
-__device__ __forceinline__ void op_gload(const E* __restrict__ P, const GOp& g, int ld, int k0, int k_end, int tid,
-                                         u32x4 (&r)[kGL]) {
+template <typename E, bool KS, int NCH>
+__device__ __forceinline__ void op_gload(const E* __restrict__ P, const GOp<NCH>& g, int ld, int k0, int k_end, int tid,
+                                         u32x4 (&r)[NCH]) {
     constexpr int EPC = 16 / (int)sizeof(E);
     // P and the k offset are wave-uniform; saying so keeps the descriptor and the scalar offset in SGPRs
     const uint64_t pv = (uint64_t)P;
@@ -102,7 +103,7 @@ __device__ __forceinline__ void op_gload(const E* __restrict__ P, const GOp& g, 
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(stage_ok ? (uint32_t)k0 * (uint32_t)sizeof(E) : 0u);
         const bool ok = k0 + (tid & 7) * EPC < k_end;        // the chunk index along k is the same for all loads of a thread
 #pragma unroll
-        for (int i = 0; i < kGL; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? g.voff[i] : 0u, soff, 0);
             r[i] = ok ? v : zero;
         }
@@ -110,7 +111,7 @@ __device__ __forceinline__ void op_gload(const E* __restrict__ P, const GOp& g, 
         constexpr int CPR = 128 / EPC;
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(stage_ok ? (uint32_t)k0 * (uint32_t)ld * (uint32_t)sizeof(E) : 0u);
 #pragma unroll
-        for (int i = 0; i < kGL; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const bool ok = k0 + (tid + kGT * i) / CPR < k_end;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? g.voff[i] : 0u, soff, 0);
             r[i] = ok ? v : zero;
@@ -118,10 +119,10 @@ __device__ __forceinline__ void op_gload(const E* __restrict__ P, const GOp& g, 
     }
 }
 
-template <typename E, bool KS>
-__device__ __forceinline__ void op_lstore(unsigned char* base, int tid, const u32x4 (&r)[kGL]) {
+template <typename E, bool KS, int NCH>
+__device__ __forceinline__ void op_lstore(unsigned char* base, int tid, const u32x4 (&r)[NCH]) {
 #pragma unroll
-    for (int i = 0; i < kGL; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int c = tid + kGT * i;
         int off;
         if (!KS) {
@@ -129,7 +130,11 @@ __device__ __forceinline__ void op_lstore(unsigned char* base, int tid, const u3
             off = row * 128 + ((kc ^ (row & 7)) << 4);
         } else if (sizeof(E) == 2) {
             const int krow = c >> 4, cc = c & 15;        // 8 columns per chunk: subtile cc/2, half cc%2
-            off = (cc >> 1) * kSubBytes + krow * 32 + (cc & 1) * 16;
+            // k-row r = 8g + 4h + j of a 32-row group is kept at row 16h + 4g + j: the four 16-lane groups of one
+            // transpose read (fixed h) then fetch 512 contiguous bytes (no bank conflict; with the rows in natural
+            // order groups 0/1 and 2/3 were 256 B apart = the same banks: half of all LDS cycles were conflicts)
+            const int prow = (krow & ~31) | ((krow & 4) << 2) | ((krow & 24) >> 1) | (krow & 3);
+            off = (cc >> 1) * kSubBytes + prow * 32 + (cc & 1) * 16;
         } else {
             const int krow = c >> 5, cc = c & 31;
             off = krow * kRowBytes32 + cc * 16;
@@ -149,11 +154,11 @@ __device__ __forceinline__ u32x4 op_frag(const unsigned char* base, int tile, in
         return *(const u32x4*)(base + row * 128 + ((kc ^ (row & 7)) << 4));
     } else if (sizeof(E) == 2) {
         // ds_read_b64_tr_b16: the 16 lanes of a group cover a [4 k][16 col] block (lane i: k-row i/4, columns
-        // 4(i%4)..+3) and receive column i of it, k-rows 0..3.  Two reads = 8 consecutive k of column i.
-        const unsigned char* p = base + tile * kSubBytes + (s * 32 + 8 * g + (i >> 2)) * 32 + (i & 3) * 8;
+        // 4(i%4)..+3) and receive column i of it, k-rows 0..3.  Two reads (h = 0, 1) = k 8g .. 8g+7 of column i.
+        const unsigned char* p = base + tile * kSubBytes + (s * 32 + 4 * g + (i >> 2)) * 32 + (i & 3) * 8;   // permuted rows
         typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * 32));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 16 * 32));
         const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
         return u32x4{l2.x, l2.y, h2.x, h2.y};
     } else {
@@ -185,24 +190,29 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
     return x * per + (x < rem ? x : rem) + i;
 }
 
-// One 128 x 128 output tile at (m0, n0), contraction over [k_begin, k_end).
-template <typename E, bool AKS, bool BKS, typename Epi, bool DEEP = false>
+// One BM x 128 output tile at (m0, n0), contraction over [k_begin, k_end).  BM = 128: 8 waves as 2 (m) x 4 (n), 64 x 32
+// each; BM = 64 (k-contiguous A only; GEMMs whose 128-row grid would not fill the chip): 1 x 8, 64 x 16 each.
+// Register-staged pipeline: stage kt+1 is fetched into registers while stage kt is multiplied out of LDS buffer
+// kt & 1, then written to the other buffer; four waves per SIMD cover the rest of the load latency.  (A second
+// register set, two stages ahead, measured no faster and spilled.)  Loads and LDS stores are unconditional -- a
+// stage past k_end is zeros -- so that the compiler's vmcnt bookkeeping stays exact.
+template <typename E, bool AKS, bool BKS, typename Epi, int BM = 128>
 __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A, int lda, const E* __restrict__ B, int ldb,
                                            int M, int N, int m0, int n0, int k_begin, int k_end, const Epi& epi) {
+    static_assert(BM == 128 || (BM == 64 && !AKS), "tile height");
     constexpr int KSTAGE = 128 / (int)sizeof(E);
+    constexpr int NA = BM / 64 * kGL / 2;              // 16-byte chunks of A per thread and stage
+    constexpr int NI = BM == 128 ? 2 : 1;              // 16-column MFMA tiles per wave
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;             // 8 waves as 2 (m) x 4 (n): 64 x 32 of the tile each
+    const int wm = BM == 128 ? wid >> 2 : 0, wn = BM == 128 ? wid & 3 : wid;
     const int nk = (k_end - k_begin + KSTAGE - 1) / KSTAGE;
 
-    f32x4 acc[4][2];
+    f32x4 acc[4][NI];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Register-staged pipeline, two stages ahead: while stage kt is multiplied out of LDS buffer kt&1, stage kt+1
-    // sits in one register set (loaded during the previous step, written to the other LDS buffer after the MFMAs)
-    // and stage kt+2 is being fetched into the other set -- a global load has two MFMA phases to land.
     auto compute = [&](const unsigned char* la, const unsigned char* lb) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -210,80 +220,49 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) af[mi] = op_frag<E, AKS>(la, wm * 4 + mi, s, lane);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const u32x4 bf = op_frag<E, BKS>(lb, wn * 2 + ni, s, lane);
+            for (int ni = 0; ni < NI; ++ni) {
+                const u32x4 bf = op_frag<E, BKS>(lb, wn * NI + ni, s, lane);
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) mma16<E>(acc[mi][ni], bf, af[mi]);   // D[n][m]: 4 consecutive n per lane
             }
         }
     };
-    if (DEEP && nk > 0) {
-        u32x4 ra0[kGL], rb0[kGL], ra1[kGL], rb1[kGL];
-        const GOp ga = make_gop<E, AKS>(A, lda, m0, M, tid), gb = make_gop<E, BKS>(B, ldb, n0, N, tid);
-        auto gload0 = [&](int kt) {
-            op_gload<E, AKS>(A, ga, lda, k_begin + kt * KSTAGE, k_end, tid, ra0);
-            op_gload<E, BKS>(B, gb, ldb, k_begin + kt * KSTAGE, k_end, tid, rb0);
-        };
-        auto gload1 = [&](int kt) {
-            op_gload<E, AKS>(A, ga, lda, k_begin + kt * KSTAGE, k_end, tid, ra1);
-            op_gload<E, BKS>(B, gb, ldb, k_begin + kt * KSTAGE, k_end, tid, rb1);
-        };
-        // Loads and LDS stores are UNCONDITIONAL (a stage past k_end is all out-of-range lanes: zeros, no memory
-        // traffic): a conditional load would make the compiler's vmcnt bookkeeping assume it was not issued, and the
-        // wait before the LDS store of the older register set would drain the newer one as well.
-        gload0(0);
-        gload1(1);
-        op_lstore<E, AKS>(lds[0][0], tid, ra0);
-        op_lstore<E, BKS>(lds[0][1], tid, rb0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
-            gload0(kt + 2);
-            compute(lds[0][0], lds[0][1]);
-            op_lstore<E, AKS>(lds[1][0], tid, ra1);
-            op_lstore<E, BKS>(lds[1][1], tid, rb1);
-            __syncthreads();
-            if (kt + 1 >= nk) break;
-            gload1(kt + 3);
-            compute(lds[1][0], lds[1][1]);
-            op_lstore<E, AKS>(lds[0][0], tid, ra0);
-            op_lstore<E, BKS>(lds[0][1], tid, rb0);
-            __syncthreads();
-        }
-    }
-    if (!DEEP && nk > 0) {
-        // one register set: stage kt+1 is fetched while stage kt is multiplied (4 waves per SIMD hide the rest)
-        u32x4 ra[kGL], rb[kGL];
-        const GOp ga = make_gop<E, AKS>(A, lda, m0, M, tid), gb = make_gop<E, BKS>(B, ldb, n0, N, tid);
-        op_gload<E, AKS>(A, ga, lda, k_begin, k_end, tid, ra);
-        op_gload<E, BKS>(B, gb, ldb, k_begin, k_end, tid, rb);
-        op_lstore<E, AKS>(lds[0][0], tid, ra);
-        op_lstore<E, BKS>(lds[0][1], tid, rb);
+    if (nk > 0) {
+        u32x4 ra[NA], rb[kGL];
+        const GOp<NA> ga = make_gop<E, AKS, NA>(A, lda, m0, M, tid);
+        const GOp<kGL> gb = make_gop<E, BKS, kGL>(B, ldb, n0, N, tid);
+        op_gload<E, AKS, NA>(A, ga, lda, k_begin, k_end, tid, ra);
+        op_gload<E, BKS, kGL>(B, gb, ldb, k_begin, k_end, tid, rb);
+        op_lstore<E, AKS, NA>(lds[0][0], tid, ra);
+        op_lstore<E, BKS, kGL>(lds[0][1], tid, rb);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            op_gload<E, AKS>(A, ga, lda, k_begin + (kt + 1) * KSTAGE, k_end, tid, ra);
-            op_gload<E, BKS>(B, gb, ldb, k_begin + (kt + 1) * KSTAGE, k_end, tid, rb);
+            op_gload<E, AKS, NA>(A, ga, lda, k_begin + (kt + 1) * KSTAGE, k_end, tid, ra);
+            op_gload<E, BKS, kGL>(B, gb, ldb, k_begin + (kt + 1) * KSTAGE, k_end, tid, rb);
             compute(lds[cur][0], lds[cur][1]);
-            op_lstore<E, AKS>(lds[cur ^ 1][0], tid, ra);
-            op_lstore<E, BKS>(lds[cur ^ 1][1], tid, rb);
+            op_lstore<E, AKS, NA>(lds[cur ^ 1][0], tid, ra);
+            op_lstore<E, BKS, kGL>(lds[cur ^ 1][1], tid, rb);
             __syncthreads();
         }
     }
     int te = tid;
     asm volatile("" : "+v"(te));          // epilogue addresses are formed HERE, not hoisted above the k loop (spills)
-    const int le = te & 63, wme = te >> 8, wne = (te >> 6) & 3;
+    // The MFMA ran as D = Bfrag x Afrag^T: the lane holds C[m][n..n+3] with m = lane & 15, n = 4*(lane >> 4) + reg,
+    // so every epilogue access is a 4-element vector (N % 4 == 0).
+    const int le = te & 63, wme = BM == 128 ? te >> 8 : 0, wne = BM == 128 ? (te >> 6) & 3 : te >> 6;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wme * 64 + mi * 16 + (le & 15);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int n = n0 + wne * 32 + ni * 16 + (le >> 4) * 4;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wne * (16 * NI) + ni * 16 + (le >> 4) * 4;
             if (m < M && n < N) epi(m, n, acc[mi][ni]);
         }
     }
 }
 
-template <typename E, bool AKS, bool BKS, typename Epi>
+template <typename E, bool AKS, bool BKS, typename Epi, int BM>
 __global__ __launch_bounds__(kGT, 4) void tgemm_kernel(const E* __restrict__ A, int lda, const E* __restrict__ B,
                                                        int ldb, int M, int N, int K, int k_per_split, int nt_n,
                                                        Epi epi) {
@@ -291,8 +270,8 @@ __global__ __launch_bounds__(kGT, 4) void tgemm_kernel(const E* __restrict__ A, 
     const int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tile_n = bt % nt_n, tile_m = bt / nt_n;
     const int k_begin = blockIdx.y * k_per_split;
-    tgemm_tile<E, AKS, BKS, Epi>(lds, A, lda, B, ldb, M, N, tile_m * kTileMN, tile_n * kTileMN, k_begin,
-                                 min(K, k_begin + k_per_split), epi);
+    tgemm_tile<E, AKS, BKS, Epi, BM>(lds, A, lda, B, ldb, M, N, tile_m * BM, tile_n * kTileMN, k_begin,
+                                     min(K, k_begin + k_per_split), epi);
 }
 
 // ---- epilogues: (m, n, v) = C[m][n..n+3] ------------------------------------------------------
@@ -378,7 +357,9 @@ hipError_t tgemm(const void* A, int lda, const void* B, int ldb, int M, int N, i
     if (splits < 1) splits = 1;
     const int kps = ((K + splits - 1) / splits + KSTAGE - 1) / KSTAGE * KSTAGE;
     splits = (K + kps - 1) / kps;
-    hipLaunchKernelGGL((tgemm_kernel<E, AKS, BKS, Epi>), dim3(nt_n * nt_m, splits), dim3(kGT), 0, s, (const E*)A, lda,
+    // (64-row tiles for the GEMMs whose 128-row grid is under one round of workgroups measured 20 % SLOWER: the
+    //  kernel is bound by operand traffic per FLOP, not by idle CUs; tgemm_tile keeps the BM = 64 instance for tests)
+    hipLaunchKernelGGL((tgemm_kernel<E, AKS, BKS, Epi, 128>), dim3(nt_n * nt_m, splits), dim3(kGT), 0, s, (const E*)A, lda,
                        (const E*)B, ldb, M, N, K, kps, nt_n, epi);
     return hipGetLastError();
 }
@@ -402,7 +383,7 @@ __global__ __launch_bounds__(kGT, 4) void tgemm_wgrad_group_kernel(GTable t) {
     while (pi + 1 < t.n && b >= t.p[pi + 1].tile_begin) ++pi;
     const GProb g = t.p[pi];
     const int local = b - g.tile_begin, tile_n = local % g.nt_n, tile_m = local / g.nt_n;
-    tgemm_tile<E, true, true, EpiStoreF, false>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
+    tgemm_tile<E, true, true, EpiStoreF>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
                                          tile_n * kTileMN, 0, t.K, EpiStoreF{g.out, g.No});
 }
 
