@@ -11,10 +11,13 @@
 //              (contraction over `out`), wgrad reads dY[m][n] and X[m][k] as they lie (contraction over the
 //              token index m).  k-slow bf16 tiles are fetched from LDS with ds_read_b64_tr_b16 (the gfx950
 //              transpose read), k-slow fp32 tiles with plain ds_read_b32 (v_mfma_f32_16x16x4_f32 takes one
-//              element per lane), so nothing is ever transposed through HBM.  Weight gradients are split over
-//              the token dimension and accumulated with fp32 atomics into the caller's (zeroed) flat buffer.
+//              element per lane), so nothing is ever transposed through HBM.  The weight gradients of the whole
+//              step run as ONE grouped launch after the data-gradient chain (every tile contracts over all token
+//              rows and stores its result: no split-K, no atomics).
 //   LayerNorm backward also carries the residual gradient and emits its operand-typed copy (with the
-//   dropout mask of the consuming linear layer), GELU' is the epilogue of the FC2 dgrad GEMM.
+//   dropout mask of the consuming linear layer) and that layer's bias gradient; GELU' is the epilogue of the FC2
+//   dgrad GEMM.  Bias / LayerNorm-affine gradients are the only accumulations (block partials + one reduction,
+//   or a handful of atomics per block): the flat gradient buffer is zeroed first.
 // Dropout masks come from a counter-based hash of (seed, site, element index): the backward recomputes them.
 #include <string.h>
 #include "common.h"
@@ -68,10 +71,9 @@ constexpr int kGL = 1024 / kGT;            // 16-byte chunks per thread, operand
 template <int NCH> struct GOp { uint32_t voff[NCH]; };          // (the descriptor is rebuilt from the kernel argument at every use: a
                                            //  descriptor carried in VGPRs makes every load a waterfall loop)
 
-template <typename E, bool KS, int NCH>        // NCH = 2: 128 rows (columns) of the operand, 1: the first 64
+template <typename E, bool KS, int NCH>
 __device__ __forceinline__ GOp<NCH> make_gop(const E* __restrict__ P, int ld, int r0, int R, int tid) {
     constexpr int EPC = 16 / (int)sizeof(E);
-    static_assert(NCH == kGL || !KS, "a 64-wide tile is supported for k-contiguous operands only");
     GOp<NCH> g;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -190,21 +192,19 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
     return x * per + (x < rem ? x : rem) + i;
 }
 
-// One BM x 128 output tile at (m0, n0), contraction over [k_begin, k_end).  BM = 128: 8 waves as 2 (m) x 4 (n), 64 x 32
-// each; BM = 64 (k-contiguous A only; GEMMs whose 128-row grid would not fill the chip): 1 x 8, 64 x 16 each.
+// One 128 x 128 output tile at (m0, n0), contraction over [k_begin, k_end): 8 waves as 2 (m) x 4 (n), 64 x 32 each.
 // Register-staged pipeline: stage kt+1 is fetched into registers while stage kt is multiplied out of LDS buffer
 // kt & 1, then written to the other buffer; four waves per SIMD cover the rest of the load latency.  (A second
 // register set, two stages ahead, measured no faster and spilled.)  Loads and LDS stores are unconditional -- a
 // stage past k_end is zeros -- so that the compiler's vmcnt bookkeeping stays exact.
-template <typename E, bool AKS, bool BKS, typename Epi, int BM = 128>
+template <typename E, bool AKS, bool BKS, typename Epi>
 __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A, int lda, const E* __restrict__ B, int ldb,
                                            int M, int N, int m0, int n0, int k_begin, int k_end, const Epi& epi) {
-    static_assert(BM == 128 || (BM == 64 && !AKS), "tile height");
     constexpr int KSTAGE = 128 / (int)sizeof(E);
-    constexpr int NA = BM / 64 * kGL / 2;              // 16-byte chunks of A per thread and stage
-    constexpr int NI = BM == 128 ? 2 : 1;              // 16-column MFMA tiles per wave
+    constexpr int NA = kGL;                            // 16-byte chunks of A per thread and stage
+    constexpr int NI = 2;                              // 16-column MFMA tiles per wave
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = BM == 128 ? wid >> 2 : 0, wn = BM == 128 ? wid & 3 : wid;
+    const int wm = wid >> 2, wn = wid & 3;
     const int nk = (k_end - k_begin + KSTAGE - 1) / KSTAGE;
 
     f32x4 acc[4][NI];
@@ -250,7 +250,7 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
     asm volatile("" : "+v"(te));          // epilogue addresses are formed HERE, not hoisted above the k loop (spills)
     // The MFMA ran as D = Bfrag x Afrag^T: the lane holds C[m][n..n+3] with m = lane & 15, n = 4*(lane >> 4) + reg,
     // so every epilogue access is a 4-element vector (N % 4 == 0).
-    const int le = te & 63, wme = BM == 128 ? te >> 8 : 0, wne = BM == 128 ? (te >> 6) & 3 : te >> 6;
+    const int le = te & 63, wme = te >> 8, wne = (te >> 6) & 3;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wme * 64 + mi * 16 + (le & 15);
@@ -262,7 +262,7 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
     }
 }
 
-template <typename E, bool AKS, bool BKS, typename Epi, int BM>
+template <typename E, bool AKS, bool BKS, typename Epi>
 __global__ __launch_bounds__(kGT, 4) void tgemm_kernel(const E* __restrict__ A, int lda, const E* __restrict__ B,
                                                        int ldb, int M, int N, int K, int k_per_split, int nt_n,
                                                        Epi epi) {
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(kGT, 4) void tgemm_kernel(const E* __restrict__ A, 
     const int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tile_n = bt % nt_n, tile_m = bt / nt_n;
     const int k_begin = blockIdx.y * k_per_split;
-    tgemm_tile<E, AKS, BKS, Epi, BM>(lds, A, lda, B, ldb, M, N, tile_m * BM, tile_n * kTileMN, k_begin,
-                                     min(K, k_begin + k_per_split), epi);
+    tgemm_tile<E, AKS, BKS, Epi>(lds, A, lda, B, ldb, M, N, tile_m * kTileMN, tile_n * kTileMN, k_begin,
+                                 min(K, k_begin + k_per_split), epi);
 }
 
 // ---- epilogues: (m, n, v) = C[m][n..n+3] ------------------------------------------------------
@@ -357,9 +357,9 @@ hipError_t tgemm(const void* A, int lda, const void* B, int ldb, int M, int N, i
     if (splits < 1) splits = 1;
     const int kps = ((K + splits - 1) / splits + KSTAGE - 1) / KSTAGE * KSTAGE;
     splits = (K + kps - 1) / kps;
-    // (64-row tiles for the GEMMs whose 128-row grid is under one round of workgroups measured 20 % SLOWER: the
-    //  kernel is bound by operand traffic per FLOP, not by idle CUs; tgemm_tile keeps the BM = 64 instance for tests)
-    hipLaunchKernelGGL((tgemm_kernel<E, AKS, BKS, Epi, 128>), dim3(nt_n * nt_m, splits), dim3(kGT), 0, s, (const E*)A, lda,
+    // (64-row tiles for the GEMMs whose 128-row grid is under one round of workgroups measured 20 % SLOWER: the kernel
+    //  is bound by operand bytes per FLOP through LDS, not by idle CUs)
+    hipLaunchKernelGGL((tgemm_kernel<E, AKS, BKS, Epi>), dim3(nt_n * nt_m, splits), dim3(kGT), 0, s, (const E*)A, lda,
                        (const E*)B, ldb, M, N, K, kps, nt_n, epi);
     return hipGetLastError();
 }
