@@ -697,3 +697,38 @@ def test_train_step_runs_on_the_hip_step_and_matches_autograd(monkeypatch):
     assert np.allclose(results["1"][0], results["0"][0], rtol=2e-5, atol=1e-6), (results["1"][0], results["0"][0])
     for a, b in zip(results["1"][1], results["0"][1]):
         assert rel_err(a, b) < 5e-3            # Adam amplifies last-bit differences to O(lr), see above
+
+
+@pytest.mark.gpu
+def test_training_with_the_hip_step_converges_like_autograd(monkeypatch):
+    """300 train_steps on a fixed synthetic data set (kitchen-like dropouts on): the bf16 HIP step and the fp32
+    torch-autograd step start from the same weights and must both bring the score-matching loss down, to the same
+    level (the two use different dropout masks and the HIP one bf16 GEMM operands, so curves agree statistically)."""
+    from test_host_logic import build_agent
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=5, std=0.02)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    N, B = 512, 128
+    obs = torch.randn(N, cfg.obs_seq_len, cfg.obs_dim, generator=g)
+    goal = torch.randn(N, cfg.goal_seq_len, cfg.obs_dim, generator=g)
+    # actions are a fixed smooth function of the observations and goals: something the network can fit
+    proj = torch.randn(cfg.obs_dim, cfg.act_dim, generator=g) * 0.5
+    act = torch.tanh(obs @ proj + (goal.mean(1, keepdim=True) @ proj) * 0.5)
+    curves = {}
+    for mode, precision in (("1", "bf16"), ("0", "fp32")):
+        monkeypatch.setenv("BESO_AMD_HIP_TRAIN", mode)
+        torch.manual_seed(17)
+        agent = build_agent(cfg, lambda: _train_module(cfg, w, precision, attn_pdrop=0.3, resid_pdrop=0.05), device=DEV, lr=2e-3)
+        agent.get_scaler(Scaler(obs.reshape(-1, cfg.obs_dim).numpy(), act.reshape(-1, cfg.act_dim).numpy(), True, DEV))
+        agent.set_bounds(agent.scaler)
+        losses = []
+        for it in range(300):
+            idx = torch.randint(0, N, (B,), generator=g)
+            losses.append(agent.train_step({"observation": obs[idx].to(DEV), "action": act[idx].to(DEV),
+                                            "goal_observation": goal[idx].to(DEV)}))
+        assert (getattr(agent, "_hip_step", None) is not None) == (mode == "1")
+        curves[mode] = (float(np.mean(losses[:20])), float(np.mean(losses[-40:])))
+    (h0, h1), (a0, a1) = curves["1"], curves["0"]
+    assert h1 < 0.6 * h0 and a1 < 0.6 * a0, curves                 # both learn
+    assert abs(h1 - a1) < 0.2 * a1, curves                          # ... to the same level

@@ -193,12 +193,12 @@ def test_instantiate_shim():
 
 
 # ------------------------------------------------------------------------------------------------
-def build_agent(cfg, model_factory, device="cpu", sampler="ddim"):
+def build_agent(cfg, model_factory, device="cpu", sampler="ddim", lr=1e-4):
     return BesoAgent(
         model=model_factory,
         input_encoder=functools.partial(NoEncoder, device=device, state_modality="observation",
                                         goal_modality="goal_observation"),
-        optimization=lambda params: torch.optim.AdamW(params, lr=1e-4),
+        optimization=lambda params: torch.optim.AdamW(params, lr=lr),
         device=device, obs_modalities=["observation"], goal_modalities=["goal_observation"],
         target_modality="action", max_train_steps=10, max_epochs=1, train_method="steps", eval_every_n_steps=5,
         use_ema=True, goal_conditioned=True, pred_last_action_only=False, rho=5.0, num_sampling_steps=3,
