@@ -1062,7 +1062,8 @@ int train_validate(const beso_config* c, int batch, int t) {
     if (c->embed_dim % 8 != 0) return BESO_ERR_UNSUPPORTED;        // 16-byte operand chunks, float4 LayerNorm rows
     const int T = 1 + c->goal_seq_len + 2 * t;
     if (attn_lds_bytes(T, c->embed_dim / c->n_heads, true) > 150 * 1024) return BESO_ERR_UNSUPPORTED;
-    if ((size_t)batch * T > (size_t)1 << 24) return BESO_ERR_BAD_SHAPE;
+    // operands are addressed with 32-bit byte offsets (raw buffer loads): the widest one is [M][4D] in fp32
+    if ((size_t)batch * T * 4 * c->embed_dim * sizeof(float) >= ((size_t)1 << 31)) return BESO_ERR_BAD_SHAPE;
     return BESO_OK;
 }
 
