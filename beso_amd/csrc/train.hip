@@ -90,7 +90,7 @@ __device__ __forceinline__ GOp<NCH> make_gop(const E* __restrict__ P, int ld, in
     return g;
 }
 
-template <typename E, bool KS, int NCH>
+template <typename E, bool KS, int NCH, bool RAW = false>      // RAW: lanes past k_end are zeroed by op_lstore_masked
 __device__ __forceinline__ void op_gload(const E* __restrict__ P, const GOp<NCH>& g, int ld, int k0, int k_end, int tid,
                                          u32x4 (&r)[NCH]) {
     constexpr int EPC = 16 / (int)sizeof(E);
@@ -107,7 +107,7 @@ __device__ __forceinline__ void op_gload(const E* __restrict__ P, const GOp<NCH>
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? g.voff[i] : 0u, soff, 0);
-            r[i] = ok ? v : zero;
+            r[i] = (RAW || ok) ? v : zero;
         }
     } else {
         constexpr int CPR = 128 / EPC;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void op_gload(const E* __restrict__ P, const GOp<NCH>
         for (int i = 0; i < NCH; ++i) {
             const bool ok = k0 + (tid + kGT * i) / CPR < k_end;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? g.voff[i] : 0u, soff, 0);
-            r[i] = ok ? v : zero;
+            r[i] = (RAW || ok) ? v : zero;
         }
     }
 }
@@ -143,6 +143,24 @@ __device__ __forceinline__ void op_lstore(unsigned char* base, int tid, const u3
         }
         *(u32x4*)(base + off) = r[i];
     }
+}
+
+// op_lstore of a RAW-loaded stage that began at k0: the zeroing of the lanes past k_end happens here, when the data
+// is consumed, so that nothing touches the registers of a load in flight
+template <typename E, bool KS, int NCH>
+__device__ __forceinline__ void op_lstore_masked(unsigned char* base, int tid, const u32x4 (&r)[NCH], int k0, int k_end) {
+    constexpr int EPC = 16 / (int)sizeof(E), CPR = 128 / EPC, KSTAGE = 128 / (int)sizeof(E);
+    if (k0 + KSTAGE <= k_end) {                 // (wave-uniform) a whole stage: nothing to zero
+        op_lstore<E, KS, NCH>(base, tid, r);
+        return;
+    }
+    u32x4 m[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const bool ok = KS ? (k0 + (tid + kGT * i) / CPR < k_end) : (k0 + (tid & 7) * EPC < k_end);
+        m[i] = ok ? r[i] : u32x4{0u, 0u, 0u, 0u};
+    }
+    op_lstore<E, KS, NCH>(base, tid, m);
 }
 
 // MFMA operand fragment of 16-row tile `tile` (0..7 of the block tile), half-stage s (0/1).
@@ -197,7 +215,7 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
 // kt & 1, then written to the other buffer; four waves per SIMD cover the rest of the load latency.  (A second
 // register set, two stages ahead, measured no faster and spilled.)  Loads and LDS stores are unconditional -- a
 // stage past k_end is zeros -- so that the compiler's vmcnt bookkeeping stays exact.
-template <typename E, bool AKS, bool BKS, typename Epi>
+template <typename E, bool AKS, bool BKS, typename Epi, bool EARLY = true>
 __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A, int lda, const E* __restrict__ B, int ldb,
                                            int M, int N, int m0, int n0, int k_begin, int k_end, const Epi& epi) {
     constexpr int KSTAGE = 128 / (int)sizeof(E);
@@ -216,18 +234,19 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
     auto compute = [&](const unsigned char* la, const unsigned char* lb) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            u32x4 af[4];
+            u32x4 bf[NI];                                 // (the two B fragments stay, the four A fragments pass through)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) af[mi] = op_frag<E, AKS>(la, wm * 4 + mi, s, lane);
+            for (int ni = 0; ni < NI; ++ni) bf[ni] = op_frag<E, BKS>(lb, wn * NI + ni, s, lane);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const u32x4 bf = op_frag<E, BKS>(lb, wn * NI + ni, s, lane);
+            for (int mi = 0; mi < 4; ++mi) {
+                const u32x4 af = op_frag<E, AKS>(la, wm * 4 + mi, s, lane);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) mma16<E>(acc[mi][ni], bf, af[mi]);   // D[n][m]: 4 consecutive n per lane
+                for (int ni = 0; ni < NI; ++ni) mma16<E>(acc[mi][ni], bf[ni], af);   // D[n][m]: 4 consecutive n per lane
             }
+            if (EARLY) __builtin_amdgcn_sched_barrier(0);   // keeps the second half-stage's fragment reads out of the first (VGPRs)
         }
     };
-    if (nk > 0) {
+    if (!EARLY && nk > 0) {
         u32x4 ra[NA], rb[kGL];
         const GOp<NA> ga = make_gop<E, AKS, NA>(A, lda, m0, M, tid);
         const GOp<kGL> gb = make_gop<E, BKS, kGL>(B, ldb, n0, N, tid);
@@ -243,6 +262,42 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
             compute(lds[cur][0], lds[cur][1]);
             op_lstore<E, AKS, NA>(lds[cur ^ 1][0], tid, ra);
             op_lstore<E, BKS, kGL>(lds[cur ^ 1][1], tid, rb);
+            __syncthreads();
+        }
+    }
+    if (EARLY && nk > 0) {
+        // Long contractions (the weight gradients: hundreds of stages).  Two register sets, ping-pong: the stage that
+        // landed during the previous iteration is written to LDS BEFORE the MFMAs of the current one while the stage
+        // after it is being fetched -- no wait for memory inside the loop, LDS writes under the matrix pipe.
+        u32x4 a0[NA], b0[kGL], a1[NA], b1[kGL];
+        const GOp<NA> ga = make_gop<E, AKS, NA>(A, lda, m0, M, tid);
+        const GOp<kGL> gb = make_gop<E, BKS, kGL>(B, ldb, n0, N, tid);
+        auto load0 = [&](int kt) {
+            op_gload<E, AKS, NA, true>(A, ga, lda, k_begin + kt * KSTAGE, k_end, tid, a0);
+            op_gload<E, BKS, kGL, true>(B, gb, ldb, k_begin + kt * KSTAGE, k_end, tid, b0);
+        };
+        auto load1 = [&](int kt) {
+            op_gload<E, AKS, NA, true>(A, ga, lda, k_begin + kt * KSTAGE, k_end, tid, a1);
+            op_gload<E, BKS, kGL, true>(B, gb, ldb, k_begin + kt * KSTAGE, k_end, tid, b1);
+        };
+        load0(0);
+        load1(1);
+        op_lstore_masked<E, AKS, NA>(lds[0][0], tid, a0, k_begin, k_end);
+        op_lstore_masked<E, BKS, kGL>(lds[0][1], tid, b0, k_begin, k_end);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            load0(kt + 2);
+            __builtin_amdgcn_sched_barrier(0);          // the loads are issued HERE (the scheduler sinks them below the MFMAs)
+            op_lstore_masked<E, AKS, NA>(lds[1][0], tid, a1, k_begin + (kt + 1) * KSTAGE, k_end);
+            op_lstore_masked<E, BKS, kGL>(lds[1][1], tid, b1, k_begin + (kt + 1) * KSTAGE, k_end);
+            compute(lds[0][0], lds[0][1]);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            load1(kt + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            op_lstore_masked<E, AKS, NA>(lds[0][0], tid, a0, k_begin + (kt + 2) * KSTAGE, k_end);
+            op_lstore_masked<E, BKS, kGL>(lds[0][1], tid, b0, k_begin + (kt + 2) * KSTAGE, k_end);
+            compute(lds[1][0], lds[1][1]);
             __syncthreads();
         }
     }
@@ -383,7 +438,7 @@ __global__ __launch_bounds__(kGT, 4) void tgemm_wgrad_group_kernel(GTable t) {
     while (pi + 1 < t.n && b >= t.p[pi + 1].tile_begin) ++pi;
     const GProb g = t.p[pi];
     const int local = b - g.tile_begin, tile_n = local % g.nt_n, tile_m = local / g.nt_n;
-    tgemm_tile<E, true, true, EpiStoreF>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
+    tgemm_tile<E, true, true, EpiStoreF, true>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
                                          tile_n * kTileMN, 0, t.K, EpiStoreF{g.out, g.No});
 }
 
