@@ -211,11 +211,11 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
 }
 
 // One 128 x 128 output tile at (m0, n0), contraction over [k_begin, k_end): 8 waves as 2 (m) x 4 (n), 64 x 32 each.
-// Register-staged pipeline: stage kt+1 is fetched into registers while stage kt is multiplied out of LDS buffer
-// kt & 1, then written to the other buffer; four waves per SIMD cover the rest of the load latency.  (A second
-// register set, two stages ahead, measured no faster and spilled.)  Loads and LDS stores are unconditional -- a
-// stage past k_end is zeros -- so that the compiler's vmcnt bookkeeping stays exact.
-template <typename E, bool AKS, bool BKS, typename Epi, bool EARLY = true>
+// Register-staged pipeline with two register sets (see the loop).  Loads and LDS stores are unconditional -- a
+// stage past k_end is read at a valid address and stored as zeros -- so that the compiler's vmcnt bookkeeping
+// stays exact.  (Measured without effect on the six-stage GEMMs of the step: persistent workgroups that keep the
+// pipeline filled across tiles, 128-byte aligned leading dimensions.)
+template <typename E, bool AKS, bool BKS, typename Epi>
 __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A, int lda, const E* __restrict__ B, int ldb,
                                            int M, int N, int m0, int n0, int k_begin, int k_end, const Epi& epi) {
     constexpr int KSTAGE = 128 / (int)sizeof(E);
@@ -243,32 +243,13 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) mma16<E>(acc[mi][ni], bf[ni], af);   // D[n][m]: 4 consecutive n per lane
             }
-            if (EARLY) __builtin_amdgcn_sched_barrier(0);   // keeps the second half-stage's fragment reads out of the first (VGPRs)
+            __builtin_amdgcn_sched_barrier(0);              // keeps the second half-stage's fragment reads out of the first (VGPRs)
         }
     };
-    if (!EARLY && nk > 0) {
-        u32x4 ra[NA], rb[kGL];
-        const GOp<NA> ga = make_gop<E, AKS, NA>(A, lda, m0, M, tid);
-        const GOp<kGL> gb = make_gop<E, BKS, kGL>(B, ldb, n0, N, tid);
-        op_gload<E, AKS, NA>(A, ga, lda, k_begin, k_end, tid, ra);
-        op_gload<E, BKS, kGL>(B, gb, ldb, k_begin, k_end, tid, rb);
-        op_lstore<E, AKS, NA>(lds[0][0], tid, ra);
-        op_lstore<E, BKS, kGL>(lds[0][1], tid, rb);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            op_gload<E, AKS, NA>(A, ga, lda, k_begin + (kt + 1) * KSTAGE, k_end, tid, ra);
-            op_gload<E, BKS, kGL>(B, gb, ldb, k_begin + (kt + 1) * KSTAGE, k_end, tid, rb);
-            compute(lds[cur][0], lds[cur][1]);
-            op_lstore<E, AKS, NA>(lds[cur ^ 1][0], tid, ra);
-            op_lstore<E, BKS, kGL>(lds[cur ^ 1][1], tid, rb);
-            __syncthreads();
-        }
-    }
-    if (EARLY && nk > 0) {
-        // Long contractions (the weight gradients: hundreds of stages).  Two register sets, ping-pong: the stage that
-        // landed during the previous iteration is written to LDS BEFORE the MFMAs of the current one while the stage
-        // after it is being fetched -- no wait for memory inside the loop, LDS writes under the matrix pipe.
+    if (nk > 0) {
+        // Two register sets, ping-pong: the stage that landed during the previous iteration is written to LDS BEFORE
+        // the MFMAs of the current one while the stage after it is being fetched -- no wait for memory inside the
+        // loop, LDS writes under the matrix pipe (the weight-gradient launch, hundreds of stages per tile: -29 %).
         u32x4 a0[NA], b0[kGL], a1[NA], b1[kGL];
         const GOp<NA> ga = make_gop<E, AKS, NA>(A, lda, m0, M, tid);
         const GOp<kGL> gb = make_gop<E, BKS, kGL>(B, ldb, n0, N, tid);
@@ -438,7 +419,7 @@ __global__ __launch_bounds__(kGT, 4) void tgemm_wgrad_group_kernel(GTable t) {
     while (pi + 1 < t.n && b >= t.p[pi + 1].tile_begin) ++pi;
     const GProb g = t.p[pi];
     const int local = b - g.tile_begin, tile_n = local % g.nt_n, tile_m = local / g.nt_n;
-    tgemm_tile<E, true, true, EpiStoreF, true>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
+    tgemm_tile<E, true, true, EpiStoreF>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
                                          tile_n * kTileMN, 0, t.K, EpiStoreF{g.out, g.No});
 }
 
