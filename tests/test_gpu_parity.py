@@ -732,3 +732,16 @@ def test_training_with_the_hip_step_converges_like_autograd(monkeypatch):
     (h0, h1), (a0, a1) = curves["1"], curves["0"]
     assert h1 < 0.6 * h0 and a1 < 0.6 * a0, curves                 # both learn
     assert abs(h1 - a1) < 0.2 * a1, curves                          # ... to the same level
+
+
+@pytest.mark.gpu
+def test_training_step_random_shapes():
+    """tools/fuzz_train.py for a few seconds: random model shapes (heads, head dims, windows, goal lengths incl. none,
+    layer counts, ragged batches; short- and general-sequence attention kernels) against autograd, fp32 mode."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_train.py"), "8", "11"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "fuzz_train:" in r.stdout
