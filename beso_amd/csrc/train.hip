@@ -66,8 +66,14 @@ constexpr int kRowBytes32 = 528;       // fp32 k-slow image: one k-row = 128 col
 // k advance in the scalar offset.  Nothing relies on the descriptor's range check: rows / columns outside the
 // operand are read at offset 0 (their products land in outputs that are never stored), lanes past k_end are read
 // at a valid address and replaced by zeros.
-constexpr int kGT = 512;                   // threads of a tgemm workgroup (8 waves)
+#ifndef BESO_TGEMM_WAVES
+#define BESO_TGEMM_WAVES 8                 // 8: waves as 2 x 4, 64 x 32 each; 4: 2 x 2, 64 x 64 each (A/B builds)
+#endif
+constexpr int kNW = BESO_TGEMM_WAVES;
+constexpr int kGT = 64 * kNW;              // threads of a tgemm workgroup
 constexpr int kGL = 1024 / kGT;            // 16-byte chunks per thread, operand and stage
+constexpr int kWN = kNW == 8 ? 4 : 2;      // waves along n
+constexpr int kOcc = kNW == 8 ? 4 : 2;     // waves per SIMD asked of the compiler (two workgroups per CU)
 template <int NCH> struct GOp { uint32_t voff[NCH]; };          // (the descriptor is rebuilt from the kernel argument at every use: a
                                            //  descriptor carried in VGPRs makes every load a waterfall loop)
 
@@ -220,9 +226,9 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
                                            int M, int N, int m0, int n0, int k_begin, int k_end, const Epi& epi) {
     constexpr int KSTAGE = 128 / (int)sizeof(E);
     constexpr int NA = kGL;                            // 16-byte chunks of A per thread and stage
-    constexpr int NI = 2;                              // 16-column MFMA tiles per wave
+    constexpr int NI = 128 / (16 * kWN);               // 16-column MFMA tiles per wave
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;
+    const int wm = wid / kWN, wn = wid % kWN;
     const int nk = (k_end - k_begin + KSTAGE - 1) / KSTAGE;
 
     f32x4 acc[4][NI];
@@ -286,7 +292,7 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
     asm volatile("" : "+v"(te));          // epilogue addresses are formed HERE, not hoisted above the k loop (spills)
     // The MFMA ran as D = Bfrag x Afrag^T: the lane holds C[m][n..n+3] with m = lane & 15, n = 4*(lane >> 4) + reg,
     // so every epilogue access is a 4-element vector (N % 4 == 0).
-    const int le = te & 63, wme = te >> 8, wne = (te >> 6) & 3;
+    const int le = te & 63, wme = (te >> 6) / kWN, wne = (te >> 6) % kWN;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wme * 64 + mi * 16 + (le & 15);
@@ -299,7 +305,7 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
 }
 
 template <typename E, bool AKS, bool BKS, typename Epi>
-__global__ __launch_bounds__(kGT, 4) void tgemm_kernel(const E* __restrict__ A, int lda, const E* __restrict__ B,
+__global__ __launch_bounds__(kGT, kOcc) void tgemm_kernel(const E* __restrict__ A, int lda, const E* __restrict__ B,
                                                        int ldb, int M, int N, int K, int k_per_split, int nt_n,
                                                        Epi epi) {
     __shared__ __attribute__((aligned(16))) TileLds lds;
@@ -415,13 +421,13 @@ struct EpiStoreF { float* out; int ld;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const { *(f32x4*)(out + (size_t)m * ld + n) = v; } };
 
 template <typename E>
-__global__ __launch_bounds__(kGT, 4) void tgemm_wgrad_group_kernel(GTable t) {
-    __shared__ __attribute__((aligned(16))) TileLds lds;
+__global__ __launch_bounds__(kGT, kOcc) void tgemm_wgrad_group_kernel(GTable t) {
     const int b = xcd_tile(blockIdx.x, gridDim.x);
     int pi = 0;
     while (pi + 1 < t.n && b >= t.p[pi + 1].tile_begin) ++pi;
     const GProb g = t.p[pi];
     const int local = b - g.tile_begin, tile_n = local % g.nt_n, tile_m = local / g.nt_n;
+    __shared__ __attribute__((aligned(16))) TileLds lds;
     tgemm_tile<E, true, true, EpiStoreF>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
                                          tile_n * kTileMN, 0, t.K, EpiStoreF{g.out, g.No});
 }
