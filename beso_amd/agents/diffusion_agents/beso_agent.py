@@ -306,6 +306,8 @@ class BesoAgent(BaseAgent):
             self.lr_scheduler.step()
             if do_ema:
                 self.ema_helper.update(self.model.parameters())
+        if bdist.is_distributed():
+            loss = bdist.all_reduce_mean(loss.detach().clone())      # C3: the logged loss is the global-batch mean
         return loss.item()
 
     @torch.no_grad()

@@ -106,6 +106,14 @@ def all_reduce_sum(flat: torch.Tensor) -> None:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
 
+def all_reduce_mean(x: torch.Tensor) -> torch.Tensor:
+    """C3: mean over the ranks of a small tensor (the logged loss of equal-sized shards), in place."""
+    if is_distributed():
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        x /= world_size()
+    return x
+
+
 def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0) -> None:
     """C2: make every replica start from rank ``src``'s weights (one flat broadcast)."""
     if not is_distributed():

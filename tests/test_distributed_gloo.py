@@ -109,9 +109,10 @@ def test_two_rank_gloo_training_step_matches_single_process(tmp_path):
     torch.randn_like = lambda t: dp["noise"].clone()
     agent.make_sample_density = lambda: (lambda shape, device: dp["sigma"].clone())
     try:
-        agent.train_step(full)
+        single_loss = agent.train_step(full)
     finally:
         torch.randn_like = real_randn_like
+    assert abs(single_loss - dp["loss"]) < 1e-5 * abs(single_loss)          # the data-parallel step reports the global mean
     single = torch.cat([q.detach().reshape(-1) for q in agent.model.get_params()])
     # mean of per-shard gradients == gradient of the global mean loss (equal shard sizes); AdamW sees the same grads
     # (the first AdamW step is lr * g / (|g| + eps): fp32 summation-order noise in g shows up at the 1e-7 level)
