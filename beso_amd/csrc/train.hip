@@ -414,9 +414,9 @@ hipError_t tgemm(const void* A, int lda, const void* B, int ldb, int M, int N, i
 // the whole token range and stores its result -- no split-K, no atomics (fp32 atomics sustain ~35 G/s on this
 // part: a split-K version spent more time adding partial sums than multiplying), no reduction pass; a few hundred
 // tiles of equal length fill the chip by themselves.
-struct GProb { const void* A; const void* B; float* out; int lda, ldb, Mo, No, tile_begin, nt_n; };
-constexpr int kMaxGroup = 72;                          // 6 per layer + 2: up to 11 layers per launch, more launches beyond
-struct GTable { GProb p[kMaxGroup]; int n; int K; };
+struct GProb { const void* A; const void* B; float* out; int lda, ldb, Mo, No, tile_begin, nt_n, K; };
+constexpr int kMaxGroup = 64;                          // 6 per layer + 2: up to 11 layers per launch, more launches beyond
+struct GTable { GProb p[kMaxGroup]; int n; };
 struct EpiStoreF { float* out; int ld;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const { *(f32x4*)(out + (size_t)m * ld + n) = v; } };
 
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kGT, kOcc) void tgemm_wgrad_group_kernel(GTable t) 
     const int local = b - g.tile_begin, tile_n = local % g.nt_n, tile_m = local / g.nt_n;
     __shared__ __attribute__((aligned(16))) TileLds lds;
     tgemm_tile<E, true, true, EpiStoreF>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
-                                         tile_n * kTileMN, 0, t.K, EpiStoreF{g.out, g.No});
+                                         tile_n * kTileMN, 0, g.K, EpiStoreF{g.out, g.No});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1011,23 +1011,49 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const E* __restrict__ qk
 }
 
 // ---------------------------------------------------------------------------------------------
-// squared-error loss over the action-token rows (score_wrappers.py:70-79 with pred_last_action_only False:
-// per-sample mean over (t, act), then the batch mean = the mean over all B*t*act elements), its gradient
-// with respect to the prediction, operand typed, zero on every other row and on the padding columns.
+// The last layer's out-projection, MLP, ln_f and head only matter on the action-token rows (nothing else reaches the
+// loss: score_gpts.py:341-353), so they run on a COMPACT copy of those rows: compact row c = b*t + i <-> token row
+// b*T + G + 2 + 2i.  gather: full -> compact; scatter: compact -> full with zeros on every other row (the gradient
+// that enters the attention of the last layer).  Four elements per thread (D % 8 == 0).
+// ---------------------------------------------------------------------------------------------
+template <typename V>     // V: float or the operand type
+__global__ void gather_rows_kernel(const V* __restrict__ src, V* __restrict__ dst, int n_compact, int t, int T, int G, int D) {
+    const int d4 = D / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n_compact * d4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / d4), k = (int)(i % d4), b = c / t, j = c % t;
+        const size_t m = (size_t)b * T + G + 2 + 2 * j;
+        Vec4<V>::store(dst + (size_t)c * D + 4 * k, Vec4<V>::load(src + m * D + 4 * k));
+    }
+}
+template <typename V>
+__global__ void scatter_rows_kernel(const V* __restrict__ src, V* __restrict__ dst, int M, int t, int T, int G, int D) {
+    const int d4 = D / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * d4; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / d4), k = (int)(i % d4), b = m / T, idx = m % T - 1 - G;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (idx >= 0 && (idx & 1)) v = Vec4<V>::load(src + ((size_t)b * t + (idx >> 1)) * D + 4 * k);
+        Vec4<V>::store(dst + (size_t)m * D + 4 * k, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// squared-error loss over the (compact) action-token rows (score_wrappers.py:70-79 with pred_last_action_only
+// False: per-sample mean over (t, act), then the batch mean = the mean over all B*t*act elements), its gradient
+// with respect to the prediction, operand typed, zero on the padding columns.
 // ---------------------------------------------------------------------------------------------
 template <typename E>
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
-                                                   E* __restrict__ dpred, float* __restrict__ loss, int M, int T, int G,
-                                                   int t, int act, int ap, float inv_count, float grad_scale) {
+                                                   E* __restrict__ dpred, float* __restrict__ loss, int M, int act, int ap,
+                                                   float inv_count, float grad_scale) {
     __shared__ float part[4];
     float acc = 0.f;
     const size_t n = (size_t)M * ap;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int m = (int)(i / ap), a = (int)(i % ap);
-        const int b = m / T, idx = m % T - 1 - G;
+        const size_t m = i / ap;                     // compact action row b*t + i: the layout of `target`
+        const int a = (int)(i % ap);
         float g = 0.f;
-        if (a < act && idx >= 0 && (idx & 1)) {
-            const float diff = pred[i] - target[((size_t)b * t + (idx >> 1)) * act + a];
+        if (a < act) {
+            const float diff = pred[i] - target[m * act + a];
             acc = fmaf(diff, diff, acc);
             g = 2.0f * diff * inv_count * grad_scale;
         }
@@ -1059,6 +1085,7 @@ struct TrainWs {
     int M, T, Ke, ap;
     size_t noised, target, x0, xemb, stf, xf, pred, dpred, w_head, b_head, dw_cat, dw_head;
     size_t dx, dx0b, dxn, dy, ln_part;
+    size_t ya, xa, dxa, dya;                                        // compact action rows of the last layer
     TrainLayerWs layer[kMaxLayers];
     size_t total;
 };
@@ -1082,6 +1109,11 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
     w->dw_cat = carve_t(cur, f * (size_t)w->Ke * D); w->dw_head = carve_t(cur, f * (size_t)w->ap * D);
     w->dx = carve_t(cur, f * M * D); w->dx0b = carve_t(cur, e * M * D); w->dxn = carve_t(cur, f * M * D);
     w->dy = carve_t(cur, e * M * D);
+    {
+        const size_t Ma = (size_t)batch * t;
+        w->ya = carve_t(cur, e * Ma * D); w->xa = carve_t(cur, f * Ma * D);
+        w->dxa = carve_t(cur, f * Ma * D); w->dya = carve_t(cur, e * Ma * D);
+    }
     w->ln_part = carve_t(cur, f * (size_t)(2 * c->n_layers + 1) * ((M + 15) / 16) * 3 * D);     // LayerNorm backward block partials
     for (int l = 0; l < c->n_layers; ++l) {
         TrainLayerWs& y = w->layer[l];
@@ -1206,14 +1238,16 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
                            actb.p, F(w.x0), P(w.xemb), t, T, G, D, obs, act, Ke, c->sigma_data);
         TRY(hipGetLastError());
     }
-    const int ln_grid = (M + 3) / 4;
     const int nv = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
-    auto ln_fwd = [&](const float* x, const float* gw, const float* gb, E* out, float* st) -> hipError_t {
-        if (nv == 1) hipLaunchKernelGGL((ln_fwd_kernel<E, 1>), dim3(ln_grid), dim3(256), 0, s, x, gw, gb, out, st, M, D);
-        else if (nv == 2) hipLaunchKernelGGL((ln_fwd_kernel<E, 2>), dim3(ln_grid), dim3(256), 0, s, x, gw, gb, out, st, M, D);
-        else hipLaunchKernelGGL((ln_fwd_kernel<E, 4>), dim3(ln_grid), dim3(256), 0, s, x, gw, gb, out, st, M, D);
+    const int Ma = batch * t;                             // compact action rows (last layer's projection, MLP, ln_f, head)
+    auto ln_fwd = [&](const float* x, const float* gw, const float* gb, E* out, float* st, int rows) -> hipError_t {
+        const int grid = (rows + 3) / 4;
+        if (nv == 1) hipLaunchKernelGGL((ln_fwd_kernel<E, 1>), dim3(grid), dim3(256), 0, s, x, gw, gb, out, st, rows, D);
+        else if (nv == 2) hipLaunchKernelGGL((ln_fwd_kernel<E, 2>), dim3(grid), dim3(256), 0, s, x, gw, gb, out, st, rows, D);
+        else hipLaunchKernelGGL((ln_fwd_kernel<E, 4>), dim3(grid), dim3(256), 0, s, x, gw, gb, out, st, rows, D);
         return hipGetLastError();
     };
+    auto gs_grid = [&](size_t n4) { const size_t g = (n4 + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); };
     const size_t lds_f = attn_lds_bytes(T, hd, false), lds_b = attn_lds_bytes(T, hd, true);
     const bool attn_small = T <= kTP && hd <= 64 && hd % 4 == 0;
     if (lds_f > 64 * 1024) {
@@ -1225,7 +1259,8 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     for (int l = 0; l < L; ++l) {
         const TrainLayerWs& y = w.layer[l];
         const float* x_in = l == 0 ? F(w.x0) : F(w.layer[l - 1].x_out);
-        TRY(ln_fwd(x_in, lp[l].ln1w.p, lp[l].ln1b.p, P(y.xn1), F(y.st1)));
+        const bool last = l == L - 1;
+        TRY(ln_fwd(x_in, lp[l].ln1w.p, lp[l].ln1b.p, P(y.xn1), F(y.st1), M));
         TRY((tgemm<E, false, false>(P(y.xn1), D, P(y.w_qkv), D, M, D3, D, 1,
                                     EpiStore<E>{nullptr, P(y.qkv), F(y.b_qkv), D3}, s)));
         if (attn_small) {
@@ -1237,45 +1272,57 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
             hipLaunchKernelGGL(attn_fwd_kernel<E>, dim3(batch * H), dim3(64), lds_f, s, (const E*)P(y.qkv), P(y.y), T, D, H,
                                hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
         TRY(hipGetLastError());
-        TRY((tgemm<E, false, false>(P(y.y), D, P(y.w_proj), D, M, D, D, 1,
-                                    EpiResid{x_in, F(y.x_mid), lp[l].pb.p, D, resid_p, resid_ik, seed, (uint32_t)(4 * l + 1)}, s)));
-        TRY(ln_fwd(F(y.x_mid), lp[l].ln2w.p, lp[l].ln2b.p, P(y.xn2), F(y.st2)));
-        TRY((tgemm<E, false, false>(P(y.xn2), D, P(y.w_fc1), D, M, D4, D, 1, EpiFc1<E>{P(y.h), P(y.g), lp[l].f1b.p, D4}, s)));
-        TRY((tgemm<E, false, false>(P(y.g), D4, P(y.w_fc2), D4, M, D, D4, 1,
+        // the last layer continues on the compact action rows only (its buffers hold Ma rows from here on)
+        const int rows = last ? Ma : M;
+        const E* y_in = P(y.y);
+        const float* res_in = x_in;
+        if (last) {
+            const size_t n4 = (size_t)Ma * (D / 4);
+            hipLaunchKernelGGL(gather_rows_kernel<E>, dim3(gs_grid(n4)), dim3(256), 0, s, (const E*)P(y.y), P(w.ya), Ma, t, T, G, D);
+            hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(gs_grid(n4)), dim3(256), 0, s, x_in, F(w.xa), Ma, t, T, G, D);
+            TRY(hipGetLastError());
+            y_in = P(w.ya); res_in = F(w.xa);
+        }
+        TRY((tgemm<E, false, false>(y_in, D, P(y.w_proj), D, rows, D, D, 1,
+                                    EpiResid{res_in, F(y.x_mid), lp[l].pb.p, D, resid_p, resid_ik, seed, (uint32_t)(4 * l + 1)}, s)));
+        TRY(ln_fwd(F(y.x_mid), lp[l].ln2w.p, lp[l].ln2b.p, P(y.xn2), F(y.st2), rows));
+        TRY((tgemm<E, false, false>(P(y.xn2), D, P(y.w_fc1), D, rows, D4, D, 1, EpiFc1<E>{P(y.h), P(y.g), lp[l].f1b.p, D4}, s)));
+        TRY((tgemm<E, false, false>(P(y.g), D4, P(y.w_fc2), D4, rows, D, D4, 1,
                                     EpiResid{(const float*)F(y.x_mid), F(y.x_out), lp[l].f2b.p, D, resid_p, resid_ik, seed,
                                              (uint32_t)(4 * l + 2)}, s)));
     }
-    const float* x_last = F(w.layer[L - 1].x_out);
-    TRY(ln_fwd(x_last, lnfw.p, lnfb.p, P(w.xf), F(w.stf)));
-    TRY((tgemm<E, false, false>(P(w.xf), D, P(w.w_head), D, M, ap, D, 1, EpiStore<E>{F(w.pred), nullptr, F(w.b_head), ap}, s)));
+    const float* x_last = F(w.layer[L - 1].x_out);       // [Ma][D]
+    TRY(ln_fwd(x_last, lnfw.p, lnfb.p, P(w.xf), F(w.stf), Ma));
+    TRY((tgemm<E, false, false>(P(w.xf), D, P(w.w_head), D, Ma, ap, D, 1, EpiStore<E>{F(w.pred), nullptr, F(w.b_head), ap}, s)));
     {
-        const size_t n = (size_t)M * ap;
+        const size_t n = (size_t)Ma * ap;
         int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
         hipLaunchKernelGGL(loss_kernel<E>, dim3(grid), dim3(256), 0, s, (const float*)F(w.pred), (const float*)F(w.target),
-                           P(w.dpred), loss_out, M, T, G, t, act, ap, 1.0f / (float)((size_t)batch * t * act), grad_scale);
+                           P(w.dpred), loss_out, Ma, act, ap, 1.0f / (float)((size_t)batch * t * act), grad_scale);
         TRY(hipGetLastError());
     }
 
     // ---- backward
     const int rpb = 128;                                  // rows per block of the column sums
     constexpr int EPC = 16 / (int)sizeof(E);
-    auto colsum = [&](const E* a, int ld, int cols, float* o0, float* o1 = nullptr, float* o2 = nullptr,
+    auto colsum = [&](const E* a, int ld, int cols, int rows, float* o0, float* o1 = nullptr, float* o2 = nullptr,
                       int seg = 1 << 30) -> hipError_t {
-        hipLaunchKernelGGL(colsum_kernel<E>, dim3((cols + 64 * EPC - 1) / (64 * EPC), (M + rpb - 1) / rpb), dim3(256), 0, s, a,
-                           ld, M, cols, o0, o1 ? o1 : o0, o2 ? o2 : o0, seg, rpb);
+        hipLaunchKernelGGL(colsum_kernel<E>, dim3((cols + 64 * EPC - 1) / (64 * EPC), (rows + rpb - 1) / rpb), dim3(256), 0, s, a,
+                           ld, rows, cols, o0, o1 ? o1 : o0, o2 ? o2 : o0, seg, rpb);
         return hipGetLastError();
     };
     const int rpw = 4;                                    // rows per wave of the LayerNorm backward
     const int lnb_grid = (M + 4 * rpw - 1) / (4 * rpw);
     LnRedTable lrt;
     int ln_calls = 0;
-    auto ln_bwd = [&](const float* x, size_t st, const float* gamma, bool have_res, E* dxb, float* dgam, float* dbet,
-                      float* dbias, float p_site, uint32_t site) -> hipError_t {
+    // (every call launches lnb_grid blocks so that the partial slabs have one shape; blocks past `rows` write zeros)
+    auto ln_bwd = [&](const float* x, size_t st, const float* gamma, const float* dres_in, float* dres_out, E* dxb, int rows,
+                      float* dgam, float* dbet, float* dbias, float p_site, uint32_t site) -> hipError_t {
         float* part = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
         lrt.c[ln_calls++] = LnRedCall{dgam, dbet, dbias};
 #define LNB(NV)                                                                                                     \
         hipLaunchKernelGGL((ln_bwd_kernel<E, NV>), dim3(lnb_grid), dim3(256), 0, s, (const float*)F(w.dxn), x,                \
-                           (const float*)F(st), gamma, have_res ? (const float*)F(w.dx) : nullptr, F(w.dx), dxb, part, M, D, \
+                           (const float*)F(st), gamma, dres_in, dres_out, dxb, part, rows, D,                               \
                            rpw, p_site, p_site > 0.f ? 1.0f / (1.0f - p_site) : 1.f, seed, site)
         if (nv == 1) LNB(1); else if (nv == 2) LNB(2); else LNB(4);
 #undef LNB
@@ -1284,7 +1331,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // The weight gradients are collected and run as one grouped launch after the chain of data gradients: every
     // output gradient they need stays in its own buffer until then.
     GTable gt;
-    gt.n = 0; gt.K = M;
+    gt.n = 0;
     int g_tiles = 0;
     auto flush_group = [&]() -> hipError_t {
         if (gt.n == 0) return hipSuccess;
@@ -1292,34 +1339,46 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         gt.n = 0; g_tiles = 0;
         return hipGetLastError();
     };
-    auto wgrad = [&](const E* A, int lda, int Mo, const E* B, int ldb, int No, float* out) -> hipError_t {
+    auto wgrad = [&](const E* A, int lda, int Mo, const E* B, int ldb, int No, int rows, float* out) -> hipError_t {
         if (gt.n == kMaxGroup) { hipError_t e = flush_group(); if (e != hipSuccess) return e; }
         const int nt_n = (No + kTileMN - 1) / kTileMN, nt_m = (Mo + kTileMN - 1) / kTileMN;
-        gt.p[gt.n++] = GProb{A, B, out, lda, ldb, Mo, No, g_tiles, nt_n};
+        gt.p[gt.n++] = GProb{A, B, out, lda, ldb, Mo, No, g_tiles, nt_n, rows};
         g_tiles += nt_n * nt_m;
         return hipSuccess;
     };
-    // head: dW = dpred^T xf (padded rows, copied out below), db = colsum(dpred), dxf = dpred W
-    TRY(wgrad(P(w.dpred), ap, ap, P(w.xf), D, D, F(w.dw_head)));
-    TRY(colsum(P(w.dpred), ap, act, hb.g));
-    TRY((tgemm<E, false, true>(P(w.dpred), ap, P(w.w_head), D, M, D, ap, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
-    TRY(ln_bwd(x_last, w.stf, lnfw.p, false, P(w.layer[L - 1].dyo), lnfw.g, lnfb.g, lp[L - 1].f2b.g, resid_p,
+    // head (compact rows): dW = dpred^T xf (padded rows, copied out below), db = colsum(dpred), dxf = dpred W
+    TRY(wgrad(P(w.dpred), ap, ap, P(w.xf), D, D, Ma, F(w.dw_head)));
+    TRY(colsum(P(w.dpred), ap, act, Ma, hb.g));
+    TRY((tgemm<E, false, true>(P(w.dpred), ap, P(w.w_head), D, Ma, D, ap, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+    TRY(ln_bwd(x_last, w.stf, lnfw.p, nullptr, F(w.dxa), P(w.layer[L - 1].dyo), Ma, lnfw.g, lnfb.g, lp[L - 1].f2b.g, resid_p,
                (uint32_t)(4 * (L - 1) + 2)));
     for (int l = L - 1; l >= 0; --l) {
         const TrainLayerWs& y = w.layer[l];
         const float* x_in = l == 0 ? F(w.x0) : F(w.layer[l - 1].x_out);
+        const bool last = l == L - 1;
+        const int rows = last ? Ma : M;
+        float* dres = last ? F(w.dxa) : F(w.dx);          // residual gradient of this layer's second half
         // FC2: dW2 = dyo^T g, dh = (dyo W2) * GELU'(h)
-        TRY(wgrad(P(y.dyo), D, D, P(y.g), D4, D4, lp[l].f2w.g));
-        TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, M, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), D4}, s)));
+        TRY(wgrad(P(y.dyo), D, D, P(y.g), D4, D4, rows, lp[l].f2w.g));
+        TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), D4}, s)));
         // FC1: dW1 = dh^T xn2, db1, dxn2 = dh W1
-        TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, lp[l].f1w.g));
-        TRY(colsum(P(y.dh), D4, D4, lp[l].f1b.g));
-        TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, M, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
-        TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, true, P(y.dym), lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
+        TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, rows, lp[l].f1w.g));
+        TRY(colsum(P(y.dh), D4, D4, rows, lp[l].f1b.g));
+        TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, rows, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+        TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, dres, dres, P(y.dym), rows, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
                    (uint32_t)(4 * l + 1)));
         // proj: dWp = dym^T y, dy = dym Wp
-        TRY(wgrad(P(y.dym), D, D, P(y.y), D, D, lp[l].pw.g));
-        TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, M, D, D, 1, EpiStore<E>{nullptr, P(w.dy), nullptr, D}, s)));
+        TRY(wgrad(P(y.dym), D, D, last ? P(w.ya) : P(y.y), D, D, rows, lp[l].pw.g));
+        TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, rows, D, D, 1,
+                                   EpiStore<E>{nullptr, last ? P(w.dya) : P(w.dy), nullptr, D}, s)));
+        if (last) {
+            // back to all token rows: dy and the residual gradient are zero off the action rows
+            const size_t n4 = (size_t)M * (D / 4);
+            hipLaunchKernelGGL(scatter_rows_kernel<E>, dim3(gs_grid(n4)), dim3(256), 0, s, (const E*)P(w.dya), P(w.dy), M, t, T, G, D);
+            hipLaunchKernelGGL(scatter_rows_kernel<float>, dim3(gs_grid(n4)), dim3(256), 0, s, (const float*)F(w.dxa), F(w.dx), M, t, T,
+                               G, D);
+            TRY(hipGetLastError());
+        }
         if (attn_small) {
 #define ATT(TT) hipLaunchKernelGGL((attn_small_kernel<E, true, TT>), dim3(batch * H), dim3(64), 0, s, (const E*)P(y.qkv), \
                                    (const E*)P(w.dy), P(y.dqkv), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l))
@@ -1330,17 +1389,18 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
                                P(y.dqkv), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
         TRY(hipGetLastError());
         // q/k/v: three weight gradients from the column blocks of dqkv, bias gradients, dxn1 = dqkv Wqkv
-        TRY(wgrad(P(y.dqkv), D3, D, P(y.xn1), D, D, lp[l].qw.g));
-        TRY(wgrad(P(y.dqkv) + D, D3, D, P(y.xn1), D, D, lp[l].kw.g));
-        TRY(wgrad(P(y.dqkv) + 2 * D, D3, D, P(y.xn1), D, D, lp[l].vw.g));
-        TRY(colsum(P(y.dqkv), D3, D3, lp[l].qb.g, lp[l].kb.g, lp[l].vb.g, D));
+        TRY(wgrad(P(y.dqkv), D3, D, P(y.xn1), D, D, M, lp[l].qw.g));
+        TRY(wgrad(P(y.dqkv) + D, D3, D, P(y.xn1), D, D, M, lp[l].kw.g));
+        TRY(wgrad(P(y.dqkv) + 2 * D, D3, D, P(y.xn1), D, D, M, lp[l].vw.g));
+        TRY(colsum(P(y.dqkv), D3, D3, M, lp[l].qb.g, lp[l].kb.g, lp[l].vb.g, D));
         TRY((tgemm<E, false, true>(P(y.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
         const bool first = l == 0;
-        TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, true, first ? P(w.dx0b) : P(w.layer[l - 1].dyo), lp[l].ln1w.g, lp[l].ln1b.g,
-                   first ? nullptr : lp[l - 1].f2b.g, first ? 0.f : resid_p, first ? 0u : (uint32_t)(4 * (l - 1) + 2)));
+        TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, F(w.dx), F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo), M, lp[l].ln1w.g,
+                   lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? 0.f : resid_p,
+                   first ? 0u : (uint32_t)(4 * (l - 1) + 2)));
     }
     // embeddings: dWcat[Ke][D] = Xemb^T dx0, routed to pos_emb / tok_emb / action_emb / sigma_emb after the launch
-    TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dx0b), D, D, F(w.dw_cat)));
+    TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dx0b), D, D, M, F(w.dw_cat)));
     TRY(flush_group());
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls), dim3(256), 0, s, (const float*)F(w.ln_part), lrt,
                        lnb_grid, D);
