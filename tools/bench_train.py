@@ -2,7 +2,7 @@
 """BASELINE config 3 on one GPU's share: kitchen train_step (score-matching loss, backward, AdamW, EMA) at
 1024 samples per step, through BesoAgent.train_step: HIP forward + backward (beso_loss_grad) and the fused
 Adam(W) + EMA launch; BESO_AMD_HIP_TRAIN=0 times the torch-autograd evaluation of the same step beside it.
-    python tools/bench_train.py [batch]"""
+    python tools/bench_train.py [batch] [kitchen|block_push]"""
 import json
 import os
 import sys
@@ -23,10 +23,26 @@ from beso_amd.networks.scaler.scaler_class import Scaler  # noqa: E402
 
 def main():
     dev = "cuda:0"
-    cfg = O.KITCHEN
+    name = sys.argv[2] if len(sys.argv) > 2 else "kitchen"
+    cfg = O.CONFIGS[name]
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     w = O.make_weights(cfg, seed=0, std=0.02)
-    agent = build_agent(cfg, lambda: build_model(cfg, w, "bf16", dev), device=dev)
+    # the shipped dropouts (configs/franka_kitchen_main_config.yaml:56-57, configs/block_push_main_config.yaml:57-58)
+    attn_p, resid_p = {"kitchen": (0.3, 0.0), "block_push": (0.05, 0.05)}.get(name, (0.0, 0.0))
+
+    def model():
+        m = build_model(cfg, w, "bf16", dev)
+        inner = m.inner_model
+        inner._pdrops = (0.0, attn_p, resid_p)
+        for blk in inner.blocks:
+            blk.attn.attn_drop.p = attn_p
+            blk.attn.resid_drop.p = resid_p
+            for mod in blk.mlp:
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = resid_p
+        return m
+
+    agent = build_agent(cfg, model, device=dev)
     rng = np.random.default_rng(0)
     agent.get_scaler(Scaler(rng.standard_normal((256, cfg.obs_dim)).astype(np.float32),
                             rng.standard_normal((256, cfg.act_dim)).astype(np.float32), True, dev))
@@ -44,7 +60,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     flops = 3.0 * cfg.flops_per_sample() * B
-    print(json.dumps({"config": "3: kitchen train_step, one GPU's share", "batch": B, "seconds_per_step": dt,
+    print(json.dumps({"config": ("3: kitchen train_step, one GPU's share" if name == "kitchen" else name + " train_step"), "batch": B, "attn_pdrop": attn_p, "resid_pdrop": resid_p, "seconds_per_step": dt,
                       "samples_per_s": B / dt, "tflops_fwd_bwd": flops / dt / 1e12, "loss": loss,
                       "path": ("HIP forward/backward (bf16 operands)" if getattr(agent, "_hip_step", None) is not None
                                else "torch autograd fp32 forward/backward") + " + " + type(agent.optimizer).__name__ + " (+EMA)"}))
