@@ -22,8 +22,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with `hipIpcGetMemHandle: invalid argument`
+# otherwise); the launcher normally exports it -- set it before the HIP runtime comes up in case it did not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
