@@ -3,7 +3,6 @@
 import ctypes as C
 import os
 import sys
-import time
 
 import torch
 
