@@ -293,13 +293,35 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
     // The MFMA ran as D = Bfrag x Afrag^T: the lane holds C[m][n..n+3] with m = lane & 15, n = 4*(lane >> 4) + reg,
     // so every epilogue access is a 4-element vector (N % 4 == 0).
     const int le = te & 63, wme = (te >> 6) / kWN, wne = (te >> 6) % kWN;
+    f32x4 cs[NI];                         // column sums of what this lane stored (epilogues with a bias gradient)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) cs[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wme * 64 + mi * 16 + (le & 15);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int n = n0 + wne * (16 * NI) + ni * 16 + (le >> 4) * 4;
-            if (m < M && n < N) epi(m, n, acc[mi][ni]);
+            if (m < M && n < N) {
+                if constexpr (Epi::kColSum) cs[ni] += epi(m, n, acc[mi][ni]);
+                else epi(m, n, acc[mi][ni]);
+            }
+        }
+    }
+    if constexpr (Epi::kColSum) {
+        // the 16 lanes with the same lane >> 4 hold the same four columns for 16 different rows: butterfly over
+        // lane & 15, then one atomic per column, wave and tile (64 rows each)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs[ni][r] += __shfl_xor(cs[ni][r], o, 64);
+            const int n = n0 + wne * (16 * NI) + ni * 16 + (le >> 4) * 4;
+            if ((le & 15) == 0 && n < N) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) unsafeAtomicAdd(epi.colsum + n + r, cs[ni][r]);
+            }
         }
     }
 }
@@ -321,6 +343,7 @@ template <typename E> struct Vec4;
 template <> struct Vec4<float> {
     __device__ static __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
     __device__ static __forceinline__ void store(float* p, const f32x4& v) { *(f32x4*)p = v; }
+    __device__ static __forceinline__ f32x4 rounded(const f32x4& v) { return v; }
 };
 template <> struct Vec4<uint16_t> {
     __device__ static __forceinline__ f32x4 load(const uint16_t* p) {
@@ -334,9 +357,13 @@ template <> struct Vec4<uint16_t> {
         u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
         *(uint2*)p = u;
     }
+    __device__ static __forceinline__ f32x4 rounded(const f32x4& v) {
+        return f32x4{bf2f(f2bf(v[0])), bf2f(f2bf(v[1])), bf2f(f2bf(v[2])), bf2f(f2bf(v[3]))};
+    }
 };
 
 template <typename E> struct EpiStore {          // out = acc + bias  (fp32 and / or operand-typed copy)
+    static constexpr bool kColSum = false;
     float* o32; E* oe; const float* bias; int ld;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         if (bias) v += *(const f32x4*)(bias + n);
@@ -349,6 +376,7 @@ template <typename E> struct EpiStore {          // out = acc + bias  (fp32 and 
     }
 };
 template <typename E> struct EpiFc1 {            // h = acc + bias (kept for GELU'), g = GELU(h)   (score_gpts.py:105-108)
+    static constexpr bool kColSum = false;
     E* h; E* g; const float* bias; int ld;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         v += *(const f32x4*)(bias + n);
@@ -358,6 +386,7 @@ template <typename E> struct EpiFc1 {            // h = acc + bias (kept for GEL
     }
 };
 struct EpiResid {                                // x_out = x_in + dropout(acc + bias)              (:79,:109,:113-114)
+    static constexpr bool kColSum = false;
     const float* xin; float* xout; const float* bias; int ld; float p, inv_keep; uint32_t seed, site;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         v += *(const f32x4*)(bias + n);
@@ -369,16 +398,20 @@ struct EpiResid {                                // x_out = x_in + dropout(acc +
         *(f32x4*)(xout + i) = *(const f32x4*)(xin + i) + v;
     }
 };
-template <typename E> struct EpiGeluBwd {        // dh = dg * GELU'(h)
-    const E* h; E* dh; int ld;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+template <typename E> struct EpiGeluBwd {        // dh = dg * GELU'(h); its column sums are the FC1 bias gradient
+    static constexpr bool kColSum = true;
+    const E* h; E* dh; float* colsum; int ld;
+    __device__ __forceinline__ f32x4 operator()(int m, int n, f32x4 v) const {
         const size_t i = (size_t)m * ld + n;
         const f32x4 hv = Vec4<E>::load(h + i);
-        Vec4<E>::store(dh + i, f32x4{v[0] * gelu_grad_t<E>(hv[0]), v[1] * gelu_grad_t<E>(hv[1]), v[2] * gelu_grad_t<E>(hv[2]),
-                                     v[3] * gelu_grad_t<E>(hv[3])});
+        const f32x4 d = {v[0] * gelu_grad_t<E>(hv[0]), v[1] * gelu_grad_t<E>(hv[1]), v[2] * gelu_grad_t<E>(hv[2]),
+                         v[3] * gelu_grad_t<E>(hv[3])};
+        Vec4<E>::store(dh + i, d);
+        return Vec4<E>::rounded(d);      // the sum is taken over the values as stored (what the weight gradient sees)
     }
 };
 struct EpiAtomic {                               // split-K partial sums accumulated with atomics (debug entry point)
+    static constexpr bool kColSum = false;
     float* out; int ld;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         float* o = out + (size_t)m * ld + n;
@@ -417,7 +450,7 @@ hipError_t tgemm(const void* A, int lda, const void* B, int ldb, int M, int N, i
 struct GProb { const void* A; const void* B; float* out; int lda, ldb, Mo, No, tile_begin, nt_n, K; };
 constexpr int kMaxGroup = 64;                          // 6 per layer + 2: up to 11 layers per launch, more launches beyond
 struct GTable { GProb p[kMaxGroup]; int n; };
-struct EpiStoreF { float* out; int ld;
+struct EpiStoreF { static constexpr bool kColSum = false; float* out; int ld;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const { *(f32x4*)(out + (size_t)m * ld + n) = v; } };
 
 template <typename E>
@@ -1360,10 +1393,9 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         float* dres = last ? F(w.dxa) : F(w.dx);          // residual gradient of this layer's second half
         // FC2: dW2 = dyo^T g, dh = (dyo W2) * GELU'(h)
         TRY(wgrad(P(y.dyo), D, D, P(y.g), D4, D4, rows, lp[l].f2w.g));
-        TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), D4}, s)));
+        TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), lp[l].f1b.g, D4}, s)));
         // FC1: dW1 = dh^T xn2, db1, dxn2 = dh W1
         TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, rows, lp[l].f1w.g));
-        TRY(colsum(P(y.dh), D4, D4, rows, lp[l].f1b.g));
         TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, rows, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
         TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, dres, dres, P(y.dym), rows, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
                    (uint32_t)(4 * l + 1)));
