@@ -793,12 +793,26 @@ template <typename E>
 __device__ __forceinline__ void attn_load_scores(const E* __restrict__ qkv, const AttnLds& a, int b, int h, int T,
                                                  int D, int hd, float scale, int lane) {
     const size_t ldq = (size_t)3 * D;
-    for (int u = lane; u < T * hd; u += 64) {
-        const int r = u / hd, d = u % hd;
-        const E* src = qkv + ((size_t)b * T + r) * ldq + (size_t)h * hd + d;
-        a.q[r * a.ldh + d] = Act<E>::to(src[0]);
-        a.k[r * a.ldh + d] = Act<E>::to(src[D]);
-        a.v[r * a.ldh + d] = Act<E>::to(src[2 * D]);
+    // four elements per lane in flight (12 loads issued before the first is used; clamped index, no branch)
+    const int n_el = T * hd;
+    for (int u0 = lane; u0 < n_el; u0 += 256) {
+        E qv[4], kv[4], vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = min(u0 + 64 * j, n_el - 1), r = u / hd, d = u - r * hd;
+            const E* src = qkv + ((size_t)b * T + r) * ldq + (size_t)h * hd + d;
+            qv[j] = src[0]; kv[j] = src[D]; vv[j] = src[2 * D];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = u0 + 64 * j;
+            if (u < n_el) {
+                const int r = u / hd, d = u - r * hd;
+                a.q[r * a.ldh + d] = Act<E>::to(qv[j]);
+                a.k[r * a.ldh + d] = Act<E>::to(kv[j]);
+                a.v[r * a.ldh + d] = Act<E>::to(vv[j]);
+            }
+        }
     }
     __syncthreads();
     for (int u = lane; u < T * T; u += 64) {
@@ -854,9 +868,18 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const E* __restrict__ qkv,
     const int pair = blockIdx.x, b = pair / H, h = pair % H, lane = threadIdx.x;
     const AttnLds a = attn_carve(smem_f, T, hd, true);
     attn_load_scores<E>(qkv, a, b, h, T, D, hd, scale, lane);
-    for (int u = lane; u < T * hd; u += 64) {
-        const int r = u / hd, d = u % hd;
-        a.dy[r * a.ldh + d] = Act<E>::to(dy[((size_t)b * T + r) * D + (size_t)h * hd + d]);
+    for (int u0 = lane; u0 < T * hd; u0 += 256) {
+        E gv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = min(u0 + 64 * j, T * hd - 1), r = u / hd, d = u - r * hd;
+            gv[j] = dy[((size_t)b * T + r) * D + (size_t)h * hd + d];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = u0 + 64 * j;
+            if (u < T * hd) { const int r = u / hd, d = u - r * hd; a.dy[r * a.ldh + d] = Act<E>::to(gv[j]); }
+        }
     }
     __syncthreads();
     // dP[i][j] = keep-scale * sum_d dy[i][d] v[j][d]   (gradient w.r.t. the pre-dropout probability)
