@@ -410,6 +410,35 @@ template <typename E> struct EpiGeluBwd {        // dh = dg * GELU'(h); its colu
         return Vec4<E>::rounded(d);      // the sum is taken over the values as stored (what the weight gradient sees)
     }
 };
+template <typename E> struct EpiSilu {           // z = acc + bias (kept for SiLU'), a = SiLU(z): the hidden layer of the MLP action head
+    static constexpr bool kColSum = false;       // (score_gpts.py:187-191: Linear(D,100) - SiLU - Linear(100,act))
+    E* z; E* a; const float* bias; int ld;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        v += *(const f32x4*)(bias + n);
+        const size_t i = (size_t)m * ld + n;
+        Vec4<E>::store(z + i, v);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = v[j] / (1.0f + expf(-v[j]));
+        Vec4<E>::store(a + i, o);
+    }
+};
+template <typename E> struct EpiSiluBwd {        // dz = da * SiLU'(z); column sums = bias gradient of the hidden layer
+    static constexpr bool kColSum = true;
+    const E* z; E* dz; float* colsum; int ld;
+    __device__ __forceinline__ f32x4 operator()(int m, int n, f32x4 v) const {
+        const size_t i = (size_t)m * ld + n;
+        const f32x4 zv = Vec4<E>::load(z + i);
+        f32x4 d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sg = 1.0f / (1.0f + expf(-zv[j]));
+            d[j] = v[j] * sg * (1.0f + zv[j] * (1.0f - sg));
+        }
+        Vec4<E>::store(dz + i, d);
+        return Vec4<E>::rounded(d);
+    }
+};
 struct EpiAtomic {                               // split-K partial sums accumulated with atomics (debug entry point)
     static constexpr bool kColSum = false;
     float* out; int ld;
@@ -1140,6 +1169,8 @@ struct TrainLayerWs {
 struct TrainWs {
     int M, T, Ke, ap;
     size_t noised, target, x0, xemb, stf, xf, pred, dpred, w_head, b_head, dw_cat, dw_head;
+    int Hp;                                                         // padded hidden width of the MLP head (0: linear head)
+    size_t w_hid, b_hid, hz, ha, hdz, dw_hid, db_hid;
     size_t dx, dx0b, dxn, dy, ln_part;
     size_t ya, xa, dxa, dya;                                        // compact action rows of the last layer
     TrainLayerWs layer[kMaxLayers];
@@ -1161,8 +1192,17 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
     w->x0 = carve_t(cur, f * M * D); w->xemb = carve_t(cur, e * M * w->Ke);
     w->stf = carve_t(cur, f * M * 2); w->xf = carve_t(cur, e * M * D);
     w->pred = carve_t(cur, f * M * w->ap); w->dpred = carve_t(cur, e * M * w->ap);
-    w->w_head = carve_t(cur, e * (size_t)w->ap * D); w->b_head = carve_t(cur, f * w->ap);
-    w->dw_cat = carve_t(cur, f * (size_t)w->Ke * D); w->dw_head = carve_t(cur, f * (size_t)w->ap * D);
+    w->b_head = carve_t(cur, f * w->ap);
+    w->dw_cat = carve_t(cur, f * (size_t)w->Ke * D);
+    w->Hp = c->linear_output ? 0 : round_up(kHeadHidden, 8);
+    {
+        // linear head: w_head [ap][D]; MLP head: w_hid [Hp][D] (first layer) and w_head [ap][Hp] (second layer)
+        const size_t Kh = w->Hp ? (size_t)w->Hp : (size_t)D, Ma = (size_t)batch * t;
+        w->w_head = carve_t(cur, e * (size_t)w->ap * Kh); w->dw_head = carve_t(cur, f * (size_t)w->ap * Kh);
+        w->w_hid = carve_t(cur, e * (size_t)w->Hp * D); w->b_hid = carve_t(cur, f * (size_t)(w->Hp + 8));
+        w->dw_hid = carve_t(cur, f * (size_t)w->Hp * D); w->db_hid = carve_t(cur, f * (size_t)(w->Hp + 8));
+        w->hz = carve_t(cur, e * Ma * w->Hp); w->ha = carve_t(cur, e * Ma * w->Hp); w->hdz = carve_t(cur, e * Ma * w->Hp);
+    }
     w->dx = carve_t(cur, f * M * D); w->dx0b = carve_t(cur, e * M * D); w->dxn = carve_t(cur, f * M * D);
     w->dy = carve_t(cur, e * M * D);
     {
@@ -1191,7 +1231,6 @@ int train_validate(const beso_config* c, int batch, int t) {
     int st = validate_config(c);
     if (st != BESO_OK) return st;
     if (batch < 1 || t < 1 || t > c->obs_seq_len) return BESO_ERR_BAD_SHAPE;
-    if (!c->linear_output) return BESO_ERR_UNSUPPORTED;           // every shipped config: linear_output True
     if (c->embed_dim % 8 != 0) return BESO_ERR_UNSUPPORTED;        // 16-byte operand chunks, float4 LayerNorm rows
     const int T = 1 + c->goal_seq_len + 2 * t;
     if (attn_lds_bytes(T, c->embed_dim / c->n_heads, true) > 150 * 1024) return BESO_ERR_UNSUPPORTED;
@@ -1250,7 +1289,11 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         y.f1w = take((size_t)D4 * D); y.f1b = take(D4); y.f2w = take((size_t)D * D4); y.f2b = take(D);
     }
     const PG lnfw = take(D), lnfb = take(D), sigw = take(D), sigb = take(D), actw = take((size_t)D * act), actb = take(D);
-    const PG hw = take((size_t)act * D), hb = take(act);
+    // action head: Linear(D, act), or Linear(D, 100) - SiLU - Linear(100, act)   (score_gpts.py:184-191)
+    const int Hh = kHeadHidden, Hp = w.Hp;
+    const bool mlp_head = !c->linear_output;
+    const PG h0w = mlp_head ? take((size_t)Hh * D) : PG{nullptr, nullptr}, h0b = mlp_head ? take(Hh) : PG{nullptr, nullptr};
+    const PG hw = take((size_t)act * (mlp_head ? Hh : D)), hb = take(act);
     const size_t n_grad = (size_t)(g - gflat);
 
     TRY(hipMemsetAsync(gflat, 0, sizeof(float) * n_grad, s));
@@ -1278,7 +1321,15 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
                            s, t, total4);
         TRY(hipGetLastError());
     }
-    TRY(launch_pack_matrix(hw.p, act, D, ws + w.w_head, ap, D, precision, s));
+    if (mlp_head) {
+        TRY(launch_pack_matrix(h0w.p, Hh, D, ws + w.w_hid, Hp, D, precision, s));          // zero rows Hh..Hp
+        TRY(hipMemsetAsync(ws + w.b_hid, 0, sizeof(float) * Hp, s));
+        TRY(hipMemcpyAsync(ws + w.b_hid, h0b.p, sizeof(float) * Hh, hipMemcpyDeviceToDevice, s));
+        TRY(hipMemsetAsync(ws + w.db_hid, 0, sizeof(float) * Hp, s));
+        TRY(launch_pack_matrix(hw.p, act, Hh, ws + w.w_head, ap, Hp, precision, s));       // zero columns Hh..Hp, rows act..ap
+    } else {
+        TRY(launch_pack_matrix(hw.p, act, D, ws + w.w_head, ap, D, precision, s));
+    }
     TRY(hipMemcpyAsync(ws + w.b_head, hb.p, sizeof(float) * act, hipMemcpyDeviceToDevice, s));
 
     // ---- forward
@@ -1349,7 +1400,12 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     }
     const float* x_last = F(w.layer[L - 1].x_out);       // [Ma][D]
     TRY(ln_fwd(x_last, lnfw.p, lnfb.p, P(w.xf), F(w.stf), Ma));
-    TRY((tgemm<E, false, false>(P(w.xf), D, P(w.w_head), D, Ma, ap, D, 1, EpiStore<E>{F(w.pred), nullptr, F(w.b_head), ap}, s)));
+    if (mlp_head) {
+        TRY((tgemm<E, false, false>(P(w.xf), D, P(w.w_hid), D, Ma, Hp, D, 1, EpiSilu<E>{P(w.hz), P(w.ha), F(w.b_hid), Hp}, s)));
+        TRY((tgemm<E, false, false>(P(w.ha), Hp, P(w.w_head), Hp, Ma, ap, Hp, 1, EpiStore<E>{F(w.pred), nullptr, F(w.b_head), ap}, s)));
+    } else {
+        TRY((tgemm<E, false, false>(P(w.xf), D, P(w.w_head), D, Ma, ap, D, 1, EpiStore<E>{F(w.pred), nullptr, F(w.b_head), ap}, s)));
+    }
     {
         const size_t n = (size_t)Ma * ap;
         int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
@@ -1403,9 +1459,18 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         return hipSuccess;
     };
     // head (compact rows): dW = dpred^T xf (padded rows, copied out below), db = colsum(dpred), dxf = dpred W
-    TRY(wgrad(P(w.dpred), ap, ap, P(w.xf), D, D, Ma, F(w.dw_head)));
     TRY(colsum(P(w.dpred), ap, act, Ma, hb.g));
-    TRY((tgemm<E, false, true>(P(w.dpred), ap, P(w.w_head), D, Ma, D, ap, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+    if (mlp_head) {
+        // second layer: dW1 = dpred^T a, da = dpred W1 -> dz = da * SiLU'(z) (+ its column sums = db0); first layer:
+        // dW0 = dz^T xf, dxf = dz W0.  Padded rows / columns are zeros all the way.
+        TRY(wgrad(P(w.dpred), ap, ap, P(w.ha), Hp, Hp, Ma, F(w.dw_head)));
+        TRY((tgemm<E, false, true>(P(w.dpred), ap, P(w.w_head), Hp, Ma, Hp, ap, 1, EpiSiluBwd<E>{P(w.hz), P(w.hdz), F(w.db_hid), Hp}, s)));
+        TRY(wgrad(P(w.hdz), Hp, Hp, P(w.xf), D, D, Ma, F(w.dw_hid)));
+        TRY((tgemm<E, false, true>(P(w.hdz), Hp, P(w.w_hid), D, Ma, D, Hp, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+    } else {
+        TRY(wgrad(P(w.dpred), ap, ap, P(w.xf), D, D, Ma, F(w.dw_head)));
+        TRY((tgemm<E, false, true>(P(w.dpred), ap, P(w.w_head), D, Ma, D, ap, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+    }
     TRY(ln_bwd(x_last, w.stf, lnfw.p, nullptr, F(w.dxa), P(w.layer[L - 1].dyo), Ma, lnfw.g, lnfb.g, lp[L - 1].f2b.g, resid_p,
                (uint32_t)(4 * (L - 1) + 2)));
     for (int l = L - 1; l >= 0; --l) {
@@ -1460,7 +1525,14 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls), dim3(256), 0, s, (const float*)F(w.ln_part), lrt,
                        lnb_grid, D);
     TRY(hipGetLastError());
-    TRY(hipMemcpyAsync(hw.g, ws + w.dw_head, sizeof(float) * (size_t)act * D, hipMemcpyDeviceToDevice, s));
+    if (mlp_head) {
+        TRY(hipMemcpy2DAsync(hw.g, sizeof(float) * Hh, ws + w.dw_head, sizeof(float) * Hp, sizeof(float) * Hh, act,
+                             hipMemcpyDeviceToDevice, s));                                    // [act][Hp] -> [act][100]
+        TRY(hipMemcpyAsync(h0w.g, ws + w.dw_hid, sizeof(float) * (size_t)Hh * D, hipMemcpyDeviceToDevice, s));
+        TRY(hipMemcpyAsync(h0b.g, ws + w.db_hid, sizeof(float) * Hh, hipMemcpyDeviceToDevice, s));
+    } else {
+        TRY(hipMemcpyAsync(hw.g, ws + w.dw_head, sizeof(float) * (size_t)act * D, hipMemcpyDeviceToDevice, s));
+    }
     hipLaunchKernelGGL(scatter_emb_kernel, dim3(64), dim3(256), 0, s, (const float*)F(w.dw_cat), pos.g, tokw.g, tokb.g, sigw.g,
                        sigb.g, actw.g, actb.g, D, obs, act, seq);
     TRY(hipGetLastError());
@@ -1476,7 +1548,7 @@ int train_loss_grad(const beso_config* c, const float* const* params, int n_para
     if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32) return BESO_ERR_BAD_ARG;
     if (!params || !grads_flat || !state || !action || !noise || !sigma || !loss_out || !workspace) return BESO_ERR_BAD_ARG;
     if (c->goal_seq_len > 0 && !goal) return BESO_ERR_BAD_ARG;
-    if (n_params != 3 + 16 * c->n_layers + 6 + 2) return BESO_ERR_BAD_ARG;
+    if (n_params != 3 + 16 * c->n_layers + 6 + (c->linear_output ? 2 : 4)) return BESO_ERR_BAD_ARG;
     for (int i = 0; i < n_params; ++i) if (!params[i]) return BESO_ERR_BAD_ARG;
     if (!(attn_pdrop >= 0.f && attn_pdrop < 1.f && resid_pdrop >= 0.f && resid_pdrop < 1.f)) return BESO_ERR_BAD_ARG;
     TrainWs w;

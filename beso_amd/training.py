@@ -12,8 +12,9 @@ Two ways in:
   persistent flat buffer (stable addresses for the fused optimizer's chunk table, one flat tensor for the
   data-parallel all-reduce) and returns the loss.
 
-There is no CPU implementation; shapes the kernels do not cover (``linear_output=False``, ``embed_pdrob > 0``,
-``pred_last_action_only``) stay on the torch-autograd evaluation of the same function.
+There is no CPU implementation; what the kernels do not cover (``embed_pdrob > 0``, ``pred_last_action_only``,
+``embed_dim`` not a multiple of 8: none of the shipped configs) stays on the torch-autograd evaluation of the same
+function.
 """
 from __future__ import annotations
 
@@ -43,7 +44,7 @@ class HipTrainStep:
     @staticmethod
     def supported(inner) -> bool:
         embed_p, _, _ = inner._pdrops
-        return bool(inner.linear_output) and embed_p == 0.0 and inner.embed_dim % 8 == 0
+        return embed_p == 0.0 and inner.embed_dim % 8 == 0
 
     def eligible(self, state, action, goal, noise, sigma) -> bool:
         params = list(self.inner.parameters())

@@ -161,7 +161,7 @@ int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg,
 /* Training step, forward + backward: GCDenoiser.loss (score_wrappers.py:45-79, pred_last_action_only False) of the
  * training-mode network (score_gpts.py:272-358 with the dropouts of :41,:79,:109) and the gradient of that loss with
  * respect to every parameter -- what `loss = model.loss(...); loss.backward()` leaves in `.grad`
- * (beso_agent.py:228-233).  linear_output = 1 only (all shipped configs), embed_pdrob = 0 (all shipped configs).
+ * (beso_agent.py:228-233).  Both action heads (linear_output 1 / 0); embed_pdrob = 0 (all shipped configs).
  *   params      host array of n_params DEVICE pointers, order of beso_pack_weights (fp32, torch layouts)
  *   grads_flat  device fp32 buffer of beso_grad_floats(cfg) values: the gradients of all parameters back to back in
  *               the same order, each tensor contiguous.  OVERWRITTEN (zeroed, then accumulated with atomics).

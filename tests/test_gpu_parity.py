@@ -577,12 +577,13 @@ _LONG_WINDOW = O.ScoreGPTConfig(obs_dim=6, act_dim=4, embed_dim=64, n_layers=2, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("cfg_name,B", [("tiny", 5), ("kitchen", 48), ("block_push", 40), ("long_window", 7)])
+@pytest.mark.parametrize("cfg_name,B", [("tiny", 5), ("kitchen", 48), ("block_push", 40), ("long_window", 7), ("tiny_mlp_head", 9)])
 def test_hip_loss_and_gradients_match_autograd(cfg_name, B, precision, monkeypatch):
     """Loss and every parameter gradient of the HIP training step against torch autograd on the same function
     (itself pinned to the reference: tests/test_host_logic.py).  fp32 mode: 2e-4 per tensor; bf16 mode (bf16 GEMM
     operands and kept activations, fp32 accumulation): 1e-1 per tensor, 3e-3 on the loss."""
-    cfg = {"tiny": O.TINY, "kitchen": O.KITCHEN, "block_push": O.BLOCK_PUSH, "long_window": _LONG_WINDOW}[cfg_name]
+    cfg = {"tiny": O.TINY, "kitchen": O.KITCHEN, "block_push": O.BLOCK_PUSH, "long_window": _LONG_WINDOW,
+           "tiny_mlp_head": O.TINY_MLP_HEAD}[cfg_name]         # (the last: Linear(D,100) - SiLU - Linear(100,act) action head)
     m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), precision)
     state, action, goal, noise, sigma = _train_inputs(cfg, B, seed=1)
     monkeypatch.setenv("BESO_AMD_HIP_TRAIN", "0")

@@ -28,9 +28,10 @@ def main():
         W, G = rng.randint(1, 9), rng.randint(0, 3)
         obs, act, L, B = rng.randint(1, 40), rng.randint(1, 12), rng.randint(1, 4), rng.randint(1, 70)
         t = rng.randint(1, W)
+        linear = rng.random() < 0.7
         inner = DiffusionGPT(state_dim=obs, device="cuda", goal_conditioned=G > 0, action_dim=act, embed_dim=D, embed_pdrob=0,
                              attn_pdrop=0.0, resid_pdrop=0.0, n_layers=L, n_heads=H, goal_seq_len=G, obs_seq_len=W,
-                             linear_output=True, precision="fp32").cuda()
+                             linear_output=linear, precision="fp32").cuda()
         with torch.no_grad():
             for p in inner.parameters():
                 p.add_(0.05 * torch.randn_like(p))
@@ -53,7 +54,7 @@ def main():
                 for p, r in zip(inner.parameters(), ref)]
         e = max(max(errs), abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()))
         worst = max(worst, e)
-        assert e < 5e-4, ("mismatch", e, dict(D=D, H=H, W=W, G=G, obs=obs, act=act, L=L, B=B, t=t))
+        assert e < 5e-4, ("mismatch", e, dict(D=D, H=H, W=W, G=G, obs=obs, act=act, L=L, B=B, t=t, linear=linear))
         n += 1
     print(f"fuzz_train: {n} random shapes in {time.time() - t0:.0f} s, worst error vs autograd {worst:.2e}")
 
