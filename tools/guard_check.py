@@ -82,7 +82,8 @@ def main():
     import ctypes as C
     from beso_amd.training import HipTrainStep
     n_train = 0
-    for cfg_name, precisions in (("kitchen", ("bf16", "fp32")), ("block_push", ("bf16",)), ("tiny", ("bf16", "fp32"))):
+    for cfg_name, precisions in (("kitchen", ("bf16", "fp32")), ("block_push", ("bf16",)), ("tiny", ("bf16", "fp32")),
+                                 ("tiny_mlp_head", ("bf16", "fp32"))):
         cfg = O.CONFIGS[cfg_name]
         w = O.make_weights(cfg, seed=1, std=0.03)
         for precision in precisions:
