@@ -51,10 +51,13 @@ def build_model(cfg, w, precision, dev):
 
 
 def cpu_baseline(cfg, w, batch, budget_s=15.0):
-    """The oracle (numpy fp32 port of the reference path) on the host cores, bounded to ~budget_s."""
+    """The oracle (numpy fp32 port of the reference path) on the host cores, bounded to ~budget_s.  The ONLY place
+    where bench.py touches oracle/: it is the thing timed here, on the same synthetic workload."""
     from oracle import beso_oracle as O
+    from beso_amd import synthetic as S
     sample_b = 256
-    s, g, a = O.make_inputs(cfg, sample_b, seed=0)
+    s, g, a = S.make_inputs(cfg, sample_b, seed=0)
+    cfg = O.ScoreGPTConfig(**cfg.as_dict())
     sig = np.full(sample_b, 0.3, np.float32)
     O.denoise(w, cfg, s[:8], a[:8], g[:8], sig[:8])           # warm-up
     t0 = time.perf_counter()
@@ -91,7 +94,7 @@ def main():
     args = ap.parse_args()
 
     from beso_amd import distributed as bdist
-    from oracle import beso_oracle as O           # cpu_baseline leg + shared synthetic-input recipe
+    from beso_amd import synthetic as S           # shipped shapes, seeded weights and inputs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -101,13 +104,13 @@ def main():
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(dev)
 
-    cfg = O.CONFIGS[args.config]
-    w = O.make_weights(cfg, seed=0, std=0.02)
+    cfg = S.SHAPES[args.config]
+    w = S.make_weights(cfg, seed=0, std=0.02)
     model = build_model(cfg, w, args.precision, dev)
     inner = model.inner_model
     B = args.batch
     # every rank owns its own shard of the job: different samples per rank, seeded
-    s_np, g_np, a_np = O.make_inputs(cfg, B, seed=1000 + rank)
+    s_np, g_np, a_np = S.make_inputs(cfg, B, seed=1000 + rank)
     state, goal, action = (torch.from_numpy(v).to(dev) for v in (s_np, g_np, a_np))
     sigma = torch.full((B,), 0.3, device=dev)
     rt = inner.runtime(cfg.sigma_data)

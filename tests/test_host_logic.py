@@ -345,3 +345,19 @@ def test_hip_training_step_is_gpu_only_and_shape_gated():
     assert "ScoreMatchingLoss" not in type(loss.grad_fn).__name__
     loss.backward()
     assert all(p.grad is not None for p in den.parameters())
+
+
+def test_synthetic_workload_recipe_matches_the_oracles():
+    """beso_amd/synthetic.py (what bench.py and the tools time) and the oracle's own copy of the recipe: same shapes,
+    same seeded weights and inputs, same FLOP count."""
+    from beso_amd import synthetic as S
+    assert set(S.SHAPES) == set(O.CONFIGS)
+    for name, shape in S.SHAPES.items():
+        cfg = O.CONFIGS[name]
+        assert shape.as_dict() == cfg.as_dict() and shape.flops_per_sample() == cfg.flops_per_sample()
+        assert (shape.G, shape.block_size, shape.seq_size) == (cfg.G, cfg.block_size, cfg.seq_size)
+        if name in ("kitchen", "long_horizon"):
+            continue                                            # (same code path, 10 M parameters each)
+        a, b = S.make_weights(shape, seed=3, std=0.05), O.make_weights(cfg, seed=3, std=0.05)
+        assert list(a) == list(b) and all(np.array_equal(a[k], b[k]) for k in a)
+        assert all(np.array_equal(x, y) for x, y in zip(S.make_inputs(shape, 5, seed=2, t=1), O.make_inputs(cfg, 5, seed=2, t=1)))

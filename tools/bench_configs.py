@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from bench import build_model  # noqa: E402
-from oracle import beso_oracle as O  # noqa: E402   (synthetic-input and weight recipes only)
+from beso_amd import synthetic as O  # noqa: E402   (synthetic-input and weight recipes only)
 from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks  # noqa: E402
 from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel  # noqa: E402
 
@@ -58,9 +58,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    res = [run("1: kitchen B=64 DDIM-10", O.KITCHEN, 64, "ddim", 10, 0.005, 1.0, reps=20),
-           run("4: block-push B=2048 Heun-50 CFG lambda=2", O.BLOCK_PUSH, 2048, "heun", 50, 0.05, 1.0, lam=2.0, reps=3),
-           run("5: long-horizon B=256 Euler-100 (one GPU's shard)", O.LONG_HORIZON, 256, "euler", 100, 0.005, 1.0, reps=2)]
+    res = [run("1: kitchen B=64 DDIM-10", O.SHAPES["kitchen"], 64, "ddim", 10, 0.005, 1.0, reps=20),
+           run("4: block-push B=2048 Heun-50 CFG lambda=2", O.SHAPES["block_push"], 2048, "heun", 50, 0.05, 1.0, lam=2.0, reps=3),
+           run("5: long-horizon B=256 Euler-100 (one GPU's shard)", O.SHAPES["long_horizon"], 256, "euler", 100, 0.005, 1.0, reps=2)]
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
 

@@ -10,21 +10,21 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from bench import build_model  # noqa: E402
-from oracle import beso_oracle as O  # noqa: E402
-from test_host_logic import build_agent  # noqa: E402
+from beso_amd import synthetic as O  # noqa: E402
+from _agent import build_agent  # noqa: E402
 from beso_amd.networks.scaler.scaler_class import Scaler  # noqa: E402
 
 
 def main():
     dev = "cuda:0"
     name = sys.argv[2] if len(sys.argv) > 2 else "kitchen"
-    cfg = O.CONFIGS[name]
+    cfg = O.SHAPES[name]
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     w = O.make_weights(cfg, seed=0, std=0.02)
     # the shipped dropouts (configs/franka_kitchen_main_config.yaml:56-57, configs/block_push_main_config.yaml:57-58)

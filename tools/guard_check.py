@@ -14,7 +14,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from bench import build_model  # noqa: E402
-from oracle import beso_oracle as O  # noqa: E402
+from beso_amd import synthetic as O  # noqa: E402
 from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks  # noqa: E402
 from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel  # noqa: E402
 from beso_amd.runtime import PackedWeights  # noqa: E402
@@ -38,7 +38,7 @@ def main():
     n_calls = 0
     for cfg_name, precisions in (("kitchen", ("bf16", "fp32")), ("block_push", ("bf16",)), ("long_horizon", ("bf16",)),
                                  ("tiny", ("bf16", "fp32")), ("tiny_mlp_head", ("fp32",))):
-        cfg = O.CONFIGS[cfg_name]
+        cfg = O.SHAPES[cfg_name]
         w = O.make_weights(cfg, seed=1, std=0.03)
         for precision in precisions:
             model = build_model(cfg, w, precision, dev)
@@ -84,7 +84,7 @@ def main():
     n_train = 0
     for cfg_name, precisions in (("kitchen", ("bf16", "fp32")), ("block_push", ("bf16",)), ("tiny", ("bf16", "fp32")),
                                  ("tiny_mlp_head", ("bf16", "fp32"))):
-        cfg = O.CONFIGS[cfg_name]
+        cfg = O.SHAPES[cfg_name]
         w = O.make_weights(cfg, seed=1, std=0.03)
         for precision in precisions:
             model = build_model(cfg, w, precision, dev).train()

@@ -14,10 +14,10 @@ def child(min_batch):
     sys.path.insert(0, ROOT)
     import torch
     from bench import build_model
-    from oracle import beso_oracle as O
+    from beso_amd import synthetic as O
     from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
     dev = "cuda:0"
-    cfg = O.KITCHEN
+    cfg = O.SHAPES["kitchen"]
     model = build_model(cfg, O.make_weights(cfg, seed=0, std=0.02), "bf16", dev)
     sig3 = ks.get_sigmas_exponential(3, 0.005, 1.0)
     for B in (1, 8, 32, 64, 128, 256, 512, 1024, 4096):

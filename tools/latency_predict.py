@@ -8,21 +8,21 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from bench import build_model  # noqa: E402
-from oracle import beso_oracle as O  # noqa: E402
-from test_host_logic import build_agent  # noqa: E402
+from beso_amd import synthetic as O  # noqa: E402
+from _agent import build_agent  # noqa: E402
 from beso_amd.networks.scaler.scaler_class import Scaler  # noqa: E402
 from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks  # noqa: E402
 
 
 def main():
     dev = "cuda:0"
-    cfg = O.KITCHEN
+    cfg = O.SHAPES["kitchen"]
     w = O.make_weights(cfg, seed=0, std=0.02)
     agent = build_agent(cfg, lambda: build_model(cfg, w, "bf16", dev), device=dev)
     rng = np.random.default_rng(0)

@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import build_model          # noqa: E402
 from beso_amd import _lib              # noqa: E402
-from oracle import beso_oracle as O    # noqa: E402
+from beso_amd import synthetic as O    # noqa: E402
 
 NAMES = {40: "emb_prologue", 41: "emb_loads_issued", 42: "emb_bias", 43: "emb_mfma", 1: "start", 2: "layer_start", 7: "ln1_done", 10: "pair_start(proj B)", 11: "qkv_gemm(pair)+write(A)", 12: "bar_qkv",
          13: "proj(A)+write(B)", 14: "bar_B", 15: "core(B)", 18: "bar_coreB", 16: "core(A)", 17: "bar_coreA", 3: "attn_done(proj B)",
@@ -22,7 +22,7 @@ NAMES = {40: "emb_prologue", 41: "emb_loads_issued", 42: "emb_bias", 43: "emb_mf
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     dev = "cuda:0"
-    cfg = O.KITCHEN
+    cfg = O.SHAPES["kitchen"]
     model = build_model(cfg, O.make_weights(cfg, seed=0, std=0.02), "bf16", dev)
     s, g, a = (torch.from_numpy(v).to(dev) for v in O.make_inputs(cfg, B, seed=1))
     sig = torch.full((B,), 0.3, device=dev)

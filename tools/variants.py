@@ -65,9 +65,9 @@ def build(specs):
 def time_one(batch, steps=30):
     import torch
     from bench import build_model
-    from oracle import beso_oracle as O
+    from beso_amd import synthetic as O
     dev = "cuda:0"
-    cfg = O.KITCHEN
+    cfg = O.SHAPES["kitchen"]
     model = build_model(cfg, O.make_weights(cfg, seed=0, std=0.02), "bf16", dev)
     s, g, a = (torch.from_numpy(v).to(dev) for v in O.make_inputs(cfg, batch, seed=1))
     sig = torch.full((batch,), 0.3, device=dev)
