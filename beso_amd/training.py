@@ -164,5 +164,9 @@ class ScoreMatchingLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        ctx.flat.mul_(grad_out)
-        return (None,) * 6 + tuple(ctx.views)
+        scaled = ctx.flat * grad_out               # out of place: a second backward through a retained graph stays right
+        grads, off = [], 0
+        for v in ctx.views:
+            grads.append(scaled[off:off + v.numel()].view_as(v))
+            off += v.numel()
+        return (None,) * 6 + tuple(grads)

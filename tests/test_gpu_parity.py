@@ -746,3 +746,18 @@ def test_training_step_random_shapes():
                        timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "fuzz_train:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_hip_loss_node_backward_twice():
+    """The autograd node of the HIP training step keeps its gradients intact: two backward passes through a retained
+    graph accumulate twice the gradient."""
+    cfg = O.TINY
+    m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), "fp32")
+    state, action, goal, noise, sigma = _train_inputs(cfg, 6, seed=4)
+    loss = m.loss(state, action, goal, noise, sigma)
+    loss.backward(retain_graph=True)
+    g1 = [p.grad.clone() for p in m.parameters()]
+    loss.backward()
+    for p, g in zip(m.parameters(), g1):
+        assert torch.allclose(p.grad, 2 * g, rtol=1e-6, atol=1e-9)
