@@ -309,6 +309,9 @@ def main():
     save("tiny_euler_ancestral.npz", **fixture_euler_ancestral("tiny", 4, seed=23, n=5))
     save("block_push_cfg.npz", **fixture_cfg("block_push", 5, seed=30))
     save("tiny_loss.npz", **fixture_loss("tiny", 6, seed=40))
+    save("kitchen_loss.npz", **fixture_loss("kitchen", 6, seed=41))
+    save("block_push_loss.npz", **fixture_loss("block_push", 6, seed=42))
+    save("tiny_mlp_head_loss.npz", **fixture_loss("tiny_mlp_head", 5, seed=43))
     save("schedules.npz", **fixture_schedules())
     save("tiny_agent_trace.npz", **fixture_agent_trace())
 

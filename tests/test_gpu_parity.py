@@ -553,11 +553,14 @@ def test_training_gemm_operand_layouts(precision):
 
 
 @pytest.mark.gpu
-def test_hip_training_step_matches_reference_gradients():
+@pytest.mark.parametrize("fixture,cfg_name", [("tiny_loss.npz", "tiny"), ("kitchen_loss.npz", "kitchen"),
+                                              ("block_push_loss.npz", "block_push"), ("tiny_mlp_head_loss.npz", "tiny_mlp_head")])
+def test_hip_training_step_matches_reference_gradients(fixture, cfg_name):
     """beso_loss_grad (fp32 mode) against the loss and the per-parameter gradients that the REFERENCE's
-    loss.backward() produced (tests/golden/tiny_loss.npz), through GCDenoiser.loss + autograd's backward."""
-    fx = load_golden("tiny_loss.npz")
-    cfg = O.TINY
+    loss.backward() produced (tests/golden/*_loss.npz: norm and first eight entries of every parameter's gradient, at
+    the kitchen and block-push shapes too), through GCDenoiser.loss + autograd's backward."""
+    fx = load_golden(fixture)
+    cfg = O.CONFIGS[cfg_name]
     m = _train_module(cfg, _weights(fx, cfg), "fp32")
     T = lambda k: G(fx[k])
     loss = m.loss(T("state"), T("action"), T("goal"), T("noise"), T("sigma"))

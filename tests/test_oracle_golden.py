@@ -91,6 +91,16 @@ def test_classifier_free_guidance():
         assert rel_err(out, fx[f"lam{float(lam)}"]) < TOL
 
 
+@pytest.mark.parametrize("fixture,cfg_name", [("kitchen_loss.npz", "kitchen"), ("block_push_loss.npz", "block_push"),
+                                              ("tiny_mlp_head_loss.npz", "tiny_mlp_head")])
+def test_loss_at_the_shipped_shapes(fixture, cfg_name):
+    fx = load_golden(fixture)
+    cfg = O.CONFIGS[cfg_name]
+    w = _weights(fx, cfg)
+    loss = O.score_matching_loss(w, cfg, fx["state"], fx["action"], fx["goal"], fx["noise"], fx["sigma"])
+    assert abs(float(loss) - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
+
+
 def test_loss_and_sigma_density():
     fx = load_golden("tiny_loss.npz")
     cfg = O.TINY
