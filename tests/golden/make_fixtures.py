@@ -232,10 +232,8 @@ def fixture_schedules():
     return out
 
 
-def fixture_agent_trace(seed=3, n_calls=6):
-    """A rollout-style BesoAgent.predict trace (kitchen_workspace_manager.py:286-294 call shape)."""
-    cfg = O.TINY
-    w = O.make_weights(cfg, seed=seed, std=0.05)
+def _reference_agent(cfg, w, seed):
+    """The reference BesoAgent around the reference model with the seeded weights, scaler fitted on seeded data."""
     model_partial = functools.partial(
         GCDenoiser,
         functools.partial(DiffusionGPT, state_dim=cfg.obs_dim, device="cpu", goal_conditioned=True,
@@ -267,6 +265,41 @@ def fixture_agent_trace(seed=3, n_calls=6):
     scaler = Scaler(x_data, y_data, True, "cpu")
     agent.get_scaler(scaler)
     agent.set_bounds(scaler)
+    return agent, rng, x_data, y_data
+
+
+def fixture_train_trace(seed=5, n_steps=4, batch=8):
+    """Four BesoAgent.train_step calls of the reference (beso_agent.py:215-248: AdamW, StepLR, EMA with warm-up) on seeded
+    batches; the noise and sigma each step draws are recorded by replaying the generator."""
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=seed, std=0.05)
+    agent, rng, x_data, y_data = _reference_agent(cfg, w, seed)
+    out = {"seed": seed, "std": 0.05, "x_data": x_data, "y_data": y_data, "n_steps": n_steps, "wsum": wsum(w)}
+    for i in range(n_steps):
+        obs = rng.standard_normal((batch, cfg.obs_seq_len, cfg.obs_dim)).astype(np.float32)
+        act = rng.uniform(-1, 1, size=(batch, cfg.obs_seq_len, cfg.act_dim)).astype(np.float32)
+        goal = rng.standard_normal((batch, cfg.goal_seq_len, cfg.obs_dim)).astype(np.float32)
+        torch.manual_seed(300 + i)
+        noise = torch.randn((batch, cfg.obs_seq_len, cfg.act_dim))                  # torch.randn_like(action), :226
+        sigma = agent.make_sample_density()(shape=(batch,), device="cpu")            # :227
+        torch.manual_seed(300 + i)
+        with torch.enable_grad():
+            loss = agent.train_step({"observation": T(obs), "action": T(act), "goal_observation": T(goal)})
+        out[f"step{i}::obs"], out[f"step{i}::action"], out[f"step{i}::goal"] = obs, act, goal
+        out[f"step{i}::noise"], out[f"step{i}::sigma"], out[f"step{i}::loss"] = noise.numpy(), sigma.numpy(), np.float32(loss)
+    for (n, p), sh in zip(agent.model.named_parameters(), agent.ema_helper.shadow_params):
+        out["final::" + n] = p.detach().reshape(-1)[:256].numpy().copy()
+        out["final_norm::" + n] = np.float64(p.detach().double().norm().item())
+        out["ema::" + n] = sh.detach().reshape(-1)[:256].numpy().copy()
+        out["ema_norm::" + n] = np.float64(sh.detach().double().norm().item())
+    return out
+
+
+def fixture_agent_trace(seed=3, n_calls=6):
+    """A rollout-style BesoAgent.predict trace (kitchen_workspace_manager.py:286-294 call shape)."""
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=seed, std=0.05)
+    agent, rng, x_data, y_data = _reference_agent(cfg, w, seed)
     agent.reset()
     goal = rng.standard_normal((cfg.goal_seq_len, cfg.obs_dim)).astype(np.float32)
     out = {"seed": seed, "std": 0.05, "x_data": x_data, "y_data": y_data, "goal": goal, "n_calls": n_calls}
@@ -314,6 +347,7 @@ def main():
     save("tiny_mlp_head_loss.npz", **fixture_loss("tiny_mlp_head", 5, seed=43))
     save("schedules.npz", **fixture_schedules())
     save("tiny_agent_trace.npz", **fixture_agent_trace())
+    save("tiny_train_trace.npz", **fixture_train_trace())
 
 
 if __name__ == "__main__":

@@ -764,3 +764,22 @@ def test_hip_loss_node_backward_twice():
     loss.backward()
     for p, g in zip(m.parameters(), g1):
         assert torch.allclose(p.grad, 2 * g, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_hip_train_steps_match_the_reference_agent_trace():
+    """BesoAgent.train_step x 4 entirely in HIP (beso_loss_grad + beso_adam_step with the EMA warm-up rule, fp32 mode)
+    against the trace that the REFERENCE's own agent produced on the same batches, noise and sigma
+    (tests/golden/tiny_train_trace.npz): losses, final parameters and EMA shadow."""
+    from test_host_logic import build_agent, replay_train_trace
+    from beso_amd.optim import FusedAdam
+    fx = load_golden("tiny_train_trace.npz")
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    agent = build_agent(cfg, lambda: make_module(cfg, w, "fp32"), device=DEV)
+    agent.ema_helper.load_shadow_params(agent.model.get_params())
+    assert isinstance(agent.optimizer, FusedAdam)
+    loss_err, p_err, e_err = replay_train_trace(agent, fx, device=DEV)
+    assert getattr(agent, "_hip_step", None) is not None
+    assert max(loss_err) < 5e-5, loss_err
+    assert p_err < 5e-3 and e_err < 5e-3, (p_err, e_err)      # Adam amplifies last-bit gradient differences to O(lr)

@@ -361,3 +361,57 @@ def test_synthetic_workload_recipe_matches_the_oracles():
         a, b = S.make_weights(shape, seed=3, std=0.05), O.make_weights(cfg, seed=3, std=0.05)
         assert list(a) == list(b) and all(np.array_equal(a[k], b[k]) for k in a)
         assert all(np.array_equal(x, y) for x, y in zip(S.make_inputs(shape, 5, seed=2, t=1), O.make_inputs(cfg, 5, seed=2, t=1)))
+
+
+def replay_train_trace(agent, fx, device="cpu"):
+    """Replays tests/golden/tiny_train_trace.npz (four train_step calls of the REFERENCE agent with the noise and sigma
+    it drew injected): returns (per-step relative loss error, worst parameter error, worst EMA error), parameter and
+    EMA errors relative to the largest entry of the stored slice / the stored norm."""
+    agent.get_scaler(Scaler(fx["x_data"], fx["y_data"], True, device))
+    agent.set_bounds(agent.scaler)
+    loss_err = []
+    real_randn_like, real_density = torch.randn_like, agent.make_sample_density
+    try:
+        for i in range(int(fx["n_steps"])):
+            noise = torch.from_numpy(fx[f"step{i}::noise"]).to(device)
+            sigma = torch.from_numpy(fx[f"step{i}::sigma"]).to(device)
+            torch.randn_like = lambda t, *a, **k: noise.clone()
+            agent.make_sample_density = lambda: (lambda shape, device: sigma.clone())
+            loss = agent.train_step({"observation": torch.from_numpy(fx[f"step{i}::obs"].copy()),
+                                     "action": torch.from_numpy(fx[f"step{i}::action"].copy()),
+                                     "goal_observation": torch.from_numpy(fx[f"step{i}::goal"].copy())})
+            ref = float(fx[f"step{i}::loss"])
+            loss_err.append(abs(loss - ref) / abs(ref))
+    finally:
+        torch.randn_like, agent.make_sample_density = real_randn_like, real_density
+    p_err = e_err = 0.0
+    for (n, p), sh in zip(agent.model.named_parameters(), agent.ema_helper.shadow_params):
+        for got, key, nkey in ((p.detach(), "final::" + n, "final_norm::" + n), (sh.detach(), "ema::" + n, "ema_norm::" + n)):
+            ref = fx[key]
+            err = float(np.abs(got.reshape(-1)[:256].cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-6))
+            err = max(err, abs(float(got.double().norm()) - float(fx[nkey])) / max(float(fx[nkey]), 1e-6))
+            if key.startswith("final"):
+                p_err = max(p_err, err)
+            else:
+                e_err = max(e_err, err)
+    return loss_err, p_err, e_err
+
+
+def test_train_steps_match_the_reference_agent_trace():
+    """BesoAgent.train_step x 4 on CPU (autograd evaluation, torch AdamW, StepLR, the EMA helper with its warm-up rule)
+    against the trace the reference's own agent produced."""
+    fx = load_golden("tiny_train_trace.npz")
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    def model():
+        m = make_module(cfg)
+        load_weights(m, w)
+        return m
+
+    agent = build_agent(cfg, model, device="cpu")
+    agent.ema_helper.load_shadow_params(agent.model.get_params())
+    loss_err, p_err, e_err = replay_train_trace(agent, fx)
+    assert max(loss_err) < 2e-5, loss_err
+    # AdamW's first steps move every weight by ~lr whatever the gradient's size: last-bit differences in tiny
+    # gradients flip to O(lr) differences, so parameters are compared at a few lr relative to their largest entry
+    assert p_err < 5e-3 and e_err < 5e-3, (p_err, e_err)
