@@ -37,6 +37,8 @@ __device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t site, size_t
     return ((float)(h >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.f;
 }
 
+constexpr uint32_t kEmbedSite = 4 * kMaxLayers + 16;     // dropout site of the embeddings (layer sites are 4 l + {0, 1, 2})
+
 // GELU and its derivative (nn.GELU(), score_gpts.py:107): exact erf / exp in the fp32 mode, the fitted polynomial of
 // the inference kernels (max |error| 1.9e-4, below the bf16 rounding of the stored value) in the bf16 mode
 template <typename E> __device__ __forceinline__ float gelu_t(float v);
@@ -543,7 +545,8 @@ __global__ void train_embed_kernel(const float* __restrict__ state, const float*
                                    const float* __restrict__ tok_b, const float* __restrict__ sig_w,
                                    const float* __restrict__ sig_b, const float* __restrict__ act_w,
                                    const float* __restrict__ act_b, float* __restrict__ x, E* __restrict__ xemb,
-                                   int t, int T, int G, int D, int obs, int act, int Ke, float sigma_data) {
+                                   int t, int T, int G, int D, int obs, int act, int Ke, float sigma_data, float p_drop,
+                                   uint32_t seed) {
     extern __shared__ float in_vec[];
     const int row = blockIdx.x, b = row / T, j = row % T;
     const float sg = sigma[b];
@@ -586,6 +589,8 @@ __global__ void train_embed_kernel(const float* __restrict__ state, const float*
             float acc = 0.f;
             for (int c = 0; c < len; ++c) acc = fmaf(in_vec[c], w[c], acc);
             v = acc + (kind == 1 ? tok_b[d] : act_b[d]) + pos[(size_t)posrow * D + d];
+            // self.drop(tok_emb(..) + pos) / self.drop(action_emb(..) + pos): score_gpts.py:321-325 (the sigma token has none)
+            if (p_drop > 0.f) v *= drop_scale(seed, kEmbedSite, (size_t)row * D + d, p_drop, 1.0f / (1.0f - p_drop));
         }
         x[(size_t)row * D + d] = v;
     }
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* dres_in, float* dres_out, E* __restrict__ dxb,
                                                      float* __restrict__ part, int rows, int D, int rows_per_wave, float p,
-                                                     float inv_keep, uint32_t seed, uint32_t site) {
+                                                     float inv_keep, uint32_t seed, uint32_t site, int skip_mod) {
     __shared__ f32x4 red[3][4][64 * kLnVec];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + wid;
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 if (dres_in) tot += *(const f32x4*)(dres_in + idx);
                 *(f32x4*)(dres_out + idx) = tot;
                 f32x4 op = tot;
-                if (p > 0.f) {
+                if (p > 0.f && !(skip_mod > 0 && row % skip_mod == 0)) {      // (the sigma token's embedding has no dropout)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) op[j] *= drop_scale(seed, site, idx + j, p, inv_keep);
                 }
@@ -1263,7 +1268,7 @@ size_t train_grad_floats(const beso_config* c) {
 template <typename E>
 static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat, int precision, const float* state,
                        const float* action, const float* goal, const float* noise, const float* sigma, float* loss_out,
-                       int batch, int t, float attn_p, float resid_p, uint32_t seed, float grad_scale, char* ws,
+                       int batch, int t, float embed_p, float attn_p, float resid_p, uint32_t seed, float grad_scale, char* ws,
                        const TrainWs& w, hipStream_t s, hipError_t* err, int* err_line) {
     const int D = c->embed_dim, H = c->n_heads, hd = D / H, L = c->n_layers, G = c->goal_seq_len;
     const int obs = c->obs_dim, act = c->act_dim, seq = G + c->obs_seq_len + 1;
@@ -1342,7 +1347,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         const int threads = D >= 256 ? 256 : round_up(D, 64);
         hipLaunchKernelGGL(train_embed_kernel<E>, dim3(M), dim3(threads), sizeof(float) * (size_t)(obs > act ? obs : act), s,
                            state, (const float*)F(w.noised), goal, sigma, pos.p, tokw.p, tokb.p, sigw.p, sigb.p, actw.p,
-                           actb.p, F(w.x0), P(w.xemb), t, T, G, D, obs, act, Ke, c->sigma_data);
+                           actb.p, F(w.x0), P(w.xemb), t, T, G, D, obs, act, Ke, c->sigma_data, embed_p, seed);
         TRY(hipGetLastError());
     }
     const int nv = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
@@ -1429,13 +1434,13 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     int ln_calls = 0;
     // (every call launches lnb_grid blocks so that the partial slabs have one shape; blocks past `rows` write zeros)
     auto ln_bwd = [&](const float* x, size_t st, const float* gamma, const float* dres_in, float* dres_out, E* dxb, int rows,
-                      float* dgam, float* dbet, float* dbias, float p_site, uint32_t site) -> hipError_t {
+                      float* dgam, float* dbet, float* dbias, float p_site, uint32_t site, int skip_mod = 0) -> hipError_t {
         float* part = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
         lrt.c[ln_calls++] = LnRedCall{dgam, dbet, dbias};
 #define LNB(NV)                                                                                                     \
         hipLaunchKernelGGL((ln_bwd_kernel<E, NV>), dim3(lnb_grid), dim3(256), 0, s, (const float*)F(w.dxn), x,                \
                            (const float*)F(st), gamma, dres_in, dres_out, dxb, part, rows, D,                               \
-                           rpw, p_site, p_site > 0.f ? 1.0f / (1.0f - p_site) : 1.f, seed, site)
+                           rpw, p_site, p_site > 0.f ? 1.0f / (1.0f - p_site) : 1.f, seed, site, skip_mod)
         if (nv == 1) LNB(1); else if (nv == 2) LNB(2); else LNB(4);
 #undef LNB
         return hipGetLastError();
@@ -1516,8 +1521,8 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY((tgemm<E, false, true>(P(y.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
         const bool first = l == 0;
         TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, F(w.dx), F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo), M, lp[l].ln1w.g,
-                   lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? 0.f : resid_p,
-                   first ? 0u : (uint32_t)(4 * (l - 1) + 2)));
+                   lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? embed_p : resid_p,
+                   first ? kEmbedSite : (uint32_t)(4 * (l - 1) + 2), first ? T : 0));
     }
     // embeddings: dWcat[Ke][D] = Xemb^T dx0, routed to pos_emb / tok_emb / action_emb / sigma_emb after the launch
     TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dx0b), D, D, M, F(w.dw_cat)));
@@ -1541,7 +1546,8 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
 
 int train_loss_grad(const beso_config* c, const float* const* params, int n_params, float* grads_flat, int precision,
                     const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
-                    float* loss_out, int batch, int t, float attn_pdrop, float resid_pdrop, uint32_t seed, float grad_scale,
+                    float* loss_out, int batch, int t, float embed_pdrop, float attn_pdrop, float resid_pdrop, uint32_t seed,
+                    float grad_scale,
                     void* workspace, size_t workspace_bytes, hipStream_t s, hipError_t* err, int* err_line) {
     int st = train_validate(c, batch, t);
     if (st != BESO_OK) return st;
@@ -1550,15 +1556,17 @@ int train_loss_grad(const beso_config* c, const float* const* params, int n_para
     if (c->goal_seq_len > 0 && !goal) return BESO_ERR_BAD_ARG;
     if (n_params != 3 + 16 * c->n_layers + 6 + (c->linear_output ? 2 : 4)) return BESO_ERR_BAD_ARG;
     for (int i = 0; i < n_params; ++i) if (!params[i]) return BESO_ERR_BAD_ARG;
-    if (!(attn_pdrop >= 0.f && attn_pdrop < 1.f && resid_pdrop >= 0.f && resid_pdrop < 1.f)) return BESO_ERR_BAD_ARG;
+    if (!(attn_pdrop >= 0.f && attn_pdrop < 1.f && resid_pdrop >= 0.f && resid_pdrop < 1.f && embed_pdrop >= 0.f &&
+          embed_pdrop < 1.f))
+        return BESO_ERR_BAD_ARG;
     TrainWs w;
     make_train_ws(c, batch, t, precision, &w);
     if (workspace_bytes < w.total) return BESO_ERR_WORKSPACE;
     if (precision == BESO_PREC_FP32)
         return loss_grad_e<float>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
-                                  attn_pdrop, resid_pdrop, seed, grad_scale, (char*)workspace, w, s, err, err_line);
+                                  embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale, (char*)workspace, w, s, err, err_line);
     return loss_grad_e<uint16_t>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
-                                 attn_pdrop, resid_pdrop, seed, grad_scale, (char*)workspace, w, s, err, err_line);
+                                 embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale, (char*)workspace, w, s, err, err_line);
 }
 
 // development aid: C[M][N] = op(A) op(B)^T through tgemm (fp32 output), for the layout tests

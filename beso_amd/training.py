@@ -12,9 +12,9 @@ Two ways in:
   persistent flat buffer (stable addresses for the fused optimizer's chunk table, one flat tensor for the
   data-parallel all-reduce) and returns the loss.
 
-There is no CPU implementation; what the kernels do not cover (``embed_pdrob > 0``, ``pred_last_action_only``,
-``embed_dim`` not a multiple of 8: none of the shipped configs) stays on the torch-autograd evaluation of the same
-function.
+There is no CPU implementation; what the kernels do not cover (the ``pred_last_action_only`` keyword, which the
+reference's ``train_step`` never passes, and ``embed_dim`` not a multiple of 8) stays on the torch-autograd evaluation of
+the same function.
 """
 from __future__ import annotations
 
@@ -43,8 +43,7 @@ class HipTrainStep:
     # ------------------------------------------------------------------ eligibility
     @staticmethod
     def supported(inner) -> bool:
-        embed_p, _, _ = inner._pdrops
-        return embed_p == 0.0 and inner.embed_dim % 8 == 0
+        return inner.embed_dim % 8 == 0
 
     def eligible(self, state, action, goal, noise, sigma) -> bool:
         params = list(self.inner.parameters())
@@ -109,11 +108,11 @@ class HipTrainStep:
                 goal = goal.unsqueeze(0)
             goal = goal.expand(B, G, inner.obs_dim).contiguous()
             gptr = goal.data_ptr()
-        _, attn_p, resid_p = inner._pdrops
+        embed_p, attn_p, resid_p = inner._pdrops
         if not inner.training:
-            attn_p = resid_p = 0.0
+            embed_p = attn_p = resid_p = 0.0
         if seed is None:
-            if (attn_p > 0.0 or resid_p > 0.0) and torch.cuda.is_current_stream_capturing():
+            if (embed_p > 0.0 or attn_p > 0.0 or resid_p > 0.0) and torch.cuda.is_current_stream_capturing():
                 # the seed is a host scalar: a captured graph would replay one mask forever
                 raise RuntimeError("beso_amd: the HIP training step with dropout cannot be captured into a graph")
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,), device="cpu").item())
@@ -126,7 +125,7 @@ class HipTrainStep:
         with torch.cuda.device(dev):
             st = self.lib.beso_loss_grad(C.byref(self.cfg), arr, len(params), flat.data_ptr(), precision,
                                          state.data_ptr(), action.data_ptr(), gptr, noise.data_ptr(), sigma.data_ptr(),
-                                         loss.data_ptr(), B, t, float(attn_p), float(resid_p), C.c_uint(seed & 0xFFFFFFFF),
+                                         loss.data_ptr(), B, t, float(embed_p), float(attn_p), float(resid_p), C.c_uint(seed & 0xFFFFFFFF),
                                          float(grad_scale), ws.data_ptr(), ws.numel(),
                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         _lib.check(st, "loss_grad")

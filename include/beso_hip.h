@@ -161,13 +161,14 @@ int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg,
 /* Training step, forward + backward: GCDenoiser.loss (score_wrappers.py:45-79, pred_last_action_only False) of the
  * training-mode network (score_gpts.py:272-358 with the dropouts of :41,:79,:109) and the gradient of that loss with
  * respect to every parameter -- what `loss = model.loss(...); loss.backward()` leaves in `.grad`
- * (beso_agent.py:228-233).  Both action heads (linear_output 1 / 0); embed_pdrob = 0 (all shipped configs).
+ * (beso_agent.py:228-233).  Both action heads (linear_output 1 / 0).
  *   params      host array of n_params DEVICE pointers, order of beso_pack_weights (fp32, torch layouts)
  *   grads_flat  device fp32 buffer of beso_grad_floats(cfg) values: the gradients of all parameters back to back in
  *               the same order, each tensor contiguous.  OVERWRITTEN (zeroed, then accumulated with atomics).
  *   state [batch,t,obs], action [batch,t,act] (clean), goal [batch,G,obs] (already masked by DiffusionGPT.mask_cond),
  *   noise [batch,t,act], sigma [batch];  loss_out: one device float.
- *   attn_pdrop / resid_pdrop: dropout probabilities of the attention weights and of the proj / MLP outputs; the
+ *   embed_pdrop / attn_pdrop / resid_pdrop: dropout probabilities of the token embeddings (not the sigma token), of
+ *   the attention weights and of the proj / MLP outputs (DiffusionGPT's embed_pdrob, attn_pdrop, resid_pdrop); the
  *   masks are a counter-based hash of (seed, site, element), recomputed in the backward.  0 disables.
  *   grad_scale multiplies every gradient (1/world_size for data-parallel averaging); the loss is unscaled.
  *   precision   BESO_PREC_BF16: bf16 GEMM operands (weights, kept activations, gradient operands), fp32 accumulation,
@@ -176,7 +177,7 @@ size_t beso_train_workspace_bytes(const beso_config* cfg, int batch, int t, int 
 size_t beso_grad_floats(const beso_config* cfg);
 int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
                    const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
-                   float* loss_out, int batch, int t, float attn_pdrop, float resid_pdrop, unsigned int seed,
+                   float* loss_out, int batch, int t, float embed_pdrop, float attn_pdrop, float resid_pdrop, unsigned int seed,
                    float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
 /* Development aid (tests of the operand layouts of the training GEMM): C[M][N] (fp32, ldc) = sum_k A(m,k) B(n,k);
  * a_kslow / b_kslow = 1: the operand is stored [K][ld] (contraction index slow), 0: [rows][ld] (k contiguous).

@@ -488,12 +488,12 @@ def test_no_writes_outside_output_and_workspace(cfg_name, precision):
 # -------------------------------------------------------------------------------------------------
 # training step in HIP (beso_loss_grad): row f1
 # -------------------------------------------------------------------------------------------------
-def _train_module(cfg, w, precision, attn_pdrop=0.0, resid_pdrop=0.0):
+def _train_module(cfg, w, precision, attn_pdrop=0.0, resid_pdrop=0.0, embed_pdrop=0.0):
     from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
     from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser
     inner = functools.partial(
         DiffusionGPT, state_dim=cfg.obs_dim, device=DEV, goal_conditioned=cfg.goal_conditioned,
-        action_dim=cfg.act_dim, embed_dim=cfg.embed_dim, embed_pdrob=0.0, attn_pdrop=attn_pdrop,
+        action_dim=cfg.act_dim, embed_dim=cfg.embed_dim, embed_pdrob=embed_pdrop, attn_pdrop=attn_pdrop,
         resid_pdrop=resid_pdrop, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=cfg.goal_seq_len,
         obs_seq_len=cfg.obs_seq_len, sigma_vocab_size=3, time_embedding_fn=None, goal_drop=0.0,
         linear_output=cfg.linear_output, precision=precision)
@@ -619,14 +619,14 @@ def test_hip_loss_and_gradients_match_autograd(cfg_name, B, precision, monkeypat
 
 @pytest.mark.gpu
 def test_hip_training_dropout_masks():
-    """Dropout of the attention weights (kitchen: 0.3) and of the proj / MLP outputs (block-push: 0.05) inside the
-    HIP step: the counter-based masks are a function of the seed only (same seed -> same loss and gradients,
+    """Dropout of the token embeddings, of the attention weights (kitchen: 0.3) and of the proj / MLP outputs
+    (block-push: 0.05) inside the HIP step: the counter-based masks are a function of the seed only (same seed -> same loss and gradients,
     another seed -> another loss), the backward uses the forward's masks (directional derivative by central
     differences at a fixed seed), and the expected loss is near the dropout-free one."""
     from beso_amd.training import HipTrainStep
     cfg = O.TINY
     w = O.make_weights(cfg, seed=4, std=0.08)
-    m = _train_module(cfg, w, "fp32", attn_pdrop=0.3, resid_pdrop=0.1)
+    m = _train_module(cfg, w, "fp32", attn_pdrop=0.3, resid_pdrop=0.1, embed_pdrop=0.1)
     inner = m.inner_model
     step = HipTrainStep(inner, cfg.sigma_data)
     state, action, goal, noise, sigma = _train_inputs(cfg, 64, seed=2)

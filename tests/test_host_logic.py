@@ -325,7 +325,8 @@ def test_device_prefetcher_passthrough_and_order():
 
 def test_hip_training_step_is_gpu_only_and_shape_gated():
     """The HIP training step binds to HIP parameters only: on CPU GCDenoiser.loss stays on the autograd evaluation
-    (no library call), and what the kernels do not cover (embedding dropout) is declared unsupported."""
+    (no library call); both action heads and all three dropouts are covered, an embedding width that is not a multiple
+    of 8 is not."""
     from beso_amd.training import HipTrainStep
     cfg = O.TINY
     from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
@@ -334,7 +335,9 @@ def test_hip_training_step_is_gpu_only_and_shape_gated():
               obs_seq_len=cfg.obs_seq_len)
     assert HipTrainStep.supported(DiffusionGPT(embed_pdrob=0.0, linear_output=True, **kw))
     assert HipTrainStep.supported(DiffusionGPT(embed_pdrob=0.0, linear_output=False, **kw))
-    assert not HipTrainStep.supported(DiffusionGPT(embed_pdrob=0.1, linear_output=True, **kw))
+    assert HipTrainStep.supported(DiffusionGPT(embed_pdrob=0.1, linear_output=True, **kw))
+    kw12 = dict(kw, embed_dim=36)
+    assert not HipTrainStep.supported(DiffusionGPT(embed_pdrob=0.0, linear_output=True, **kw12))
     from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser
     den = GCDenoiser(DiffusionGPT(embed_pdrob=0.0, linear_output=True, **kw), sigma_data=0.5).train()
     B = 3
