@@ -96,8 +96,8 @@ def load() -> C.CDLL:
             lib.beso_grad_floats.restype = sz
             lib.beso_grad_floats.argtypes = [cfgp]
             lib.beso_loss_grad.restype = i32
-            lib.beso_loss_grad.argtypes = [cfgp, C.POINTER(vp), i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32,
-                                           C.c_uint, f32, vp, sz, vp]
+            lib.beso_loss_grad.argtypes = [cfgp, C.POINTER(vp), i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32,
+                                           f32, C.c_uint, f32, vp, sz, vp]
             lib.beso_debug_gemm.restype = i32
             lib.beso_debug_gemm.argtypes = [i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]
         lib.beso_profile_read.restype = i32

@@ -49,14 +49,14 @@ class GCDenoiser(nn.Module):
         """Score-matching objective (score_wrappers.py:45-79).  Mutates ``noise`` in place when
         ``pred_last_action_only`` is set, like the reference (:63)."""
         last_only = bool(kwargs.pop("pred_last_action_only", False))
-        step = None if (last_only or kwargs) else self.hip_train_step(state, action, goal, noise, sigma)
+        if last_only:
+            noise[:, :-1, :] = 0                                   # in place, like the reference (:63)
+        step = None if kwargs else self.hip_train_step(state, action, goal, noise, sigma)
         if step is not None:
             # forward + every parameter gradient in one enqueue of beso_loss_grad (beso_amd/training.py)
             inner = self.inner_model
             masked = inner.mask_cond(goal) if (inner.training and goal is not None) else goal
-            return ScoreMatchingLoss.apply(step, state, action, masked, noise, sigma, *inner.parameters())
-        if last_only:
-            noise[:, :-1, :] = 0
+            return ScoreMatchingLoss.apply(step, last_only, state, action, masked, noise, sigma, *inner.parameters())
         noised = action + noise * append_dims(sigma, action.ndim)
         c_skip, c_out, c_in = (append_dims(c, action.ndim) for c in self.get_scalings(sigma))
         out = self.inner_model(state, noised * c_in, goal, sigma, **kwargs)

@@ -459,12 +459,12 @@ size_t beso_grad_floats(const beso_config* cfg) { return train_grad_floats(cfg);
 
 int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
                    const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
-                   float* loss_out, int batch, int t, float embed_pdrop, float attn_pdrop, float resid_pdrop, unsigned int seed,
+                   float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop, unsigned int seed,
                    float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
     hipError_t e = hipSuccess;
     int line = 0;
     int st = train_loss_grad(cfg, params, n_params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch,
-                             t, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale, workspace, workspace_bytes, (hipStream_t)stream,
+                             t, flags, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale, workspace, workspace_bytes, (hipStream_t)stream,
                              &e, &line);
     if (st == BESO_ERR_HIP) {
         snprintf(g_last_error, sizeof(g_last_error), "%s (%d) at train.hip:%d", hipGetErrorName(e), (int)e, line);

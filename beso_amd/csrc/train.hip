@@ -1134,7 +1134,7 @@ __global__ void scatter_rows_kernel(const V* __restrict__ src, V* __restrict__ d
 template <typename E>
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                    E* __restrict__ dpred, float* __restrict__ loss, int M, int act, int ap,
-                                                   float inv_count, float grad_scale) {
+                                                   float inv_count, float grad_scale, int t, int last_only) {
     __shared__ float part[4];
     float acc = 0.f;
     const size_t n = (size_t)M * ap;
@@ -1142,7 +1142,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pre
         const size_t m = i / ap;                     // compact action row b*t + i: the layout of `target`
         const int a = (int)(i % ap);
         float g = 0.f;
-        if (a < act) {
+        // pred_last_action_only: only the last step of every window is scored (score_wrappers.py:76-77)
+        if (a < act && (!last_only || (int)(m % t) == t - 1)) {
             const float diff = pred[i] - target[m * act + a];
             acc = fmaf(diff, diff, acc);
             g = 2.0f * diff * inv_count * grad_scale;
@@ -1268,7 +1269,8 @@ size_t train_grad_floats(const beso_config* c) {
 template <typename E>
 static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat, int precision, const float* state,
                        const float* action, const float* goal, const float* noise, const float* sigma, float* loss_out,
-                       int batch, int t, float embed_p, float attn_p, float resid_p, uint32_t seed, float grad_scale, char* ws,
+                       int batch, int t, int last_only, float embed_p, float attn_p, float resid_p, uint32_t seed,
+                       float grad_scale, char* ws,
                        const TrainWs& w, hipStream_t s, hipError_t* err, int* err_line) {
     const int D = c->embed_dim, H = c->n_heads, hd = D / H, L = c->n_layers, G = c->goal_seq_len;
     const int obs = c->obs_dim, act = c->act_dim, seq = G + c->obs_seq_len + 1;
@@ -1415,7 +1417,8 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         const size_t n = (size_t)Ma * ap;
         int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
         hipLaunchKernelGGL(loss_kernel<E>, dim3(grid), dim3(256), 0, s, (const float*)F(w.pred), (const float*)F(w.target),
-                           P(w.dpred), loss_out, Ma, act, ap, 1.0f / (float)((size_t)batch * t * act), grad_scale);
+                           P(w.dpred), loss_out, Ma, act, ap,
+                           1.0f / (float)((size_t)batch * (last_only ? 1 : t) * act), grad_scale, t, last_only);
         TRY(hipGetLastError());
     }
 
@@ -1546,8 +1549,8 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
 
 int train_loss_grad(const beso_config* c, const float* const* params, int n_params, float* grads_flat, int precision,
                     const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
-                    float* loss_out, int batch, int t, float embed_pdrop, float attn_pdrop, float resid_pdrop, uint32_t seed,
-                    float grad_scale,
+                    float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
+                    uint32_t seed, float grad_scale,
                     void* workspace, size_t workspace_bytes, hipStream_t s, hipError_t* err, int* err_line) {
     int st = train_validate(c, batch, t);
     if (st != BESO_OK) return st;
@@ -1556,6 +1559,7 @@ int train_loss_grad(const beso_config* c, const float* const* params, int n_para
     if (c->goal_seq_len > 0 && !goal) return BESO_ERR_BAD_ARG;
     if (n_params != 3 + 16 * c->n_layers + 6 + (c->linear_output ? 2 : 4)) return BESO_ERR_BAD_ARG;
     for (int i = 0; i < n_params; ++i) if (!params[i]) return BESO_ERR_BAD_ARG;
+    if (flags & ~BESO_TRAIN_LAST_ACTION_ONLY) return BESO_ERR_BAD_ARG;
     if (!(attn_pdrop >= 0.f && attn_pdrop < 1.f && resid_pdrop >= 0.f && resid_pdrop < 1.f && embed_pdrop >= 0.f &&
           embed_pdrop < 1.f))
         return BESO_ERR_BAD_ARG;
@@ -1564,9 +1568,11 @@ int train_loss_grad(const beso_config* c, const float* const* params, int n_para
     if (workspace_bytes < w.total) return BESO_ERR_WORKSPACE;
     if (precision == BESO_PREC_FP32)
         return loss_grad_e<float>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
-                                  embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale, (char*)workspace, w, s, err, err_line);
+                                  flags & BESO_TRAIN_LAST_ACTION_ONLY, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale,
+                                  (char*)workspace, w, s, err, err_line);
     return loss_grad_e<uint16_t>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
-                                 embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale, (char*)workspace, w, s, err, err_line);
+                                 flags & BESO_TRAIN_LAST_ACTION_ONLY, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale,
+                                 (char*)workspace, w, s, err, err_line);
 }
 
 // development aid: C[M][N] = op(A) op(B)^T through tgemm (fp32 output), for the layout tests

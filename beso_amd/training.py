@@ -12,9 +12,8 @@ Two ways in:
   persistent flat buffer (stable addresses for the fused optimizer's chunk table, one flat tensor for the
   data-parallel all-reduce) and returns the loss.
 
-There is no CPU implementation; what the kernels do not cover (the ``pred_last_action_only`` keyword, which the
-reference's ``train_step`` never passes, and ``embed_dim`` not a multiple of 8) stays on the torch-autograd evaluation of
-the same function.
+There is no CPU implementation; what the kernels do not cover (``embed_dim`` not a multiple of 8) stays on the
+torch-autograd evaluation of the same function.
 """
 from __future__ import annotations
 
@@ -89,7 +88,7 @@ class HipTrainStep:
 
     # ------------------------------------------------------------------ the call
     def run(self, state, action, goal, noise, sigma, grad_scale: float = 1.0, seed: Optional[int] = None,
-            fresh_grads: bool = False):
+            fresh_grads: bool = False, last_action_only: bool = False):
         """-> (loss 0-d tensor, flat gradient tensor, list of per-parameter views).  Inputs are NOT modified."""
         inner = self.inner
         dev = action.device
@@ -125,7 +124,8 @@ class HipTrainStep:
         with torch.cuda.device(dev):
             st = self.lib.beso_loss_grad(C.byref(self.cfg), arr, len(params), flat.data_ptr(), precision,
                                          state.data_ptr(), action.data_ptr(), gptr, noise.data_ptr(), sigma.data_ptr(),
-                                         loss.data_ptr(), B, t, float(embed_p), float(attn_p), float(resid_p), C.c_uint(seed & 0xFFFFFFFF),
+                                         loss.data_ptr(), B, t, 1 if last_action_only else 0, float(embed_p), float(attn_p), float(resid_p),
+                                         C.c_uint(seed & 0xFFFFFFFF),
                                          float(grad_scale), ws.data_ptr(), ws.numel(),
                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         _lib.check(st, "loss_grad")
@@ -156,8 +156,8 @@ class ScoreMatchingLoss(torch.autograd.Function):
     """loss = GCDenoiser.loss(...) with the parameter gradients computed alongside (HIP); backward hands them over."""
 
     @staticmethod
-    def forward(ctx, step: HipTrainStep, state, action, goal, noise, sigma, *params):
-        loss, flat, views = step.run(state, action, goal, noise, sigma, fresh_grads=True)
+    def forward(ctx, step: HipTrainStep, last_action_only: bool, state, action, goal, noise, sigma, *params):
+        loss, flat, views = step.run(state, action, goal, noise, sigma, fresh_grads=True, last_action_only=last_action_only)
         ctx.flat, ctx.views = flat, views
         return loss
 
@@ -168,4 +168,4 @@ class ScoreMatchingLoss(torch.autograd.Function):
         for v in ctx.views:
             grads.append(scaled[off:off + v.numel()].view_as(v))
             off += v.numel()
-        return (None,) * 6 + tuple(grads)
+        return (None,) * 7 + tuple(grads)

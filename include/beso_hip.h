@@ -57,6 +57,12 @@ enum {
     BESO_PREC_BF16X3 = 2  /* split-bf16 (hi*hi + hi*lo + lo*hi), fp32-class accuracy            */
 };
 
+/* beso_loss_grad flags */
+enum {
+    BESO_TRAIN_LAST_ACTION_ONLY = 1  /* GCDenoiser.loss(pred_last_action_only=True): only the last step of every window
+                                        is scored (score_wrappers.py:59-63,76-77; the caller zeroes the other steps' noise) */
+};
+
 /* beso_denoise_fwd / beso_score_fwd flags */
 enum {
     BESO_FLAG_UNCOND = 1  /* DiffusionGPT.forward(uncond=True): goals := 0 (score_gpts.py:301-302) */
@@ -158,7 +164,7 @@ int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,
                    float ema_decay, void* stream);
 
-/* Training step, forward + backward: GCDenoiser.loss (score_wrappers.py:45-79, pred_last_action_only False) of the
+/* Training step, forward + backward: GCDenoiser.loss (score_wrappers.py:45-79; flags: BESO_TRAIN_LAST_ACTION_ONLY) of the
  * training-mode network (score_gpts.py:272-358 with the dropouts of :41,:79,:109) and the gradient of that loss with
  * respect to every parameter -- what `loss = model.loss(...); loss.backward()` leaves in `.grad`
  * (beso_agent.py:228-233).  Both action heads (linear_output 1 / 0).
@@ -177,7 +183,7 @@ size_t beso_train_workspace_bytes(const beso_config* cfg, int batch, int t, int 
 size_t beso_grad_floats(const beso_config* cfg);
 int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
                    const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
-                   float* loss_out, int batch, int t, float embed_pdrop, float attn_pdrop, float resid_pdrop, unsigned int seed,
+                   float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop, unsigned int seed,
                    float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
 /* Development aid (tests of the operand layouts of the training GEMM): C[M][N] (fp32, ldc) = sum_k A(m,k) B(n,k);
  * a_kslow / b_kslow = 1: the operand is stored [K][ld] (contraction index slow), 0: [rows][ld] (k contiguous).

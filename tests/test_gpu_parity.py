@@ -783,3 +783,25 @@ def test_hip_train_steps_match_the_reference_agent_trace():
     assert getattr(agent, "_hip_step", None) is not None
     assert max(loss_err) < 5e-5, loss_err
     assert p_err < 5e-3 and e_err < 5e-3, (p_err, e_err)      # Adam amplifies last-bit gradient differences to O(lr)
+
+
+@pytest.mark.gpu
+def test_hip_loss_pred_last_action_only(monkeypatch):
+    """GCDenoiser.loss(..., pred_last_action_only=True) (score_wrappers.py:59-63,76-77: the noise of all but the last
+    step is zeroed in place and only the last step is scored) through the HIP step against autograd."""
+    cfg = O.TINY
+    m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), "fp32")
+    state, action, goal, noise, sigma = _train_inputs(cfg, 7, seed=6)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BESO_AMD_HIP_TRAIN", mode)
+        for p in m.parameters():
+            p.grad = None
+        nz = noise.clone()
+        loss = m.loss(state, action, goal, nz, sigma, pred_last_action_only=True)
+        assert ("ScoreMatchingLoss" in type(loss.grad_fn).__name__) == (mode == "1")
+        assert float(nz[:, :-1].abs().max()) == 0.0 and float(nz[:, -1].abs().max()) > 0.0       # mutated like the reference
+        loss.backward()
+        out[mode] = (loss.item(), [p.grad.clone() for p in m.parameters()])
+    assert abs(out["1"][0] - out["0"][0]) < 2e-5 * abs(out["0"][0])
+    assert max(_grad_errors(out["1"][1], out["0"][1])) < 2e-4
