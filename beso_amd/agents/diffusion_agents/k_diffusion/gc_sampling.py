@@ -433,6 +433,274 @@ def sample_dpmpp_2s_ancestral(model, state, action, goal, sigmas, scaler=None, e
     return action
 
 
+# ------------------------------------------------------------------------------------------------
+# Brownian-path noise for the SDE sampler (:117-165)
+# ------------------------------------------------------------------------------------------------
+class BrownianTreeNoiseSampler:
+    """``sampler(sigma, sigma_next) -> (W(t1) - W(t0)) / sqrt|t1 - t0|`` with t = transform(sigma): increments of
+    ONE Brownian path per sample, so that overlapping intervals are correlated the way the reference's
+    torchsde-backed sampler makes them (:144-165).  torchsde is not a dependency here: the path is built lazily on
+    the action's device -- W is drawn at every time that is asked for, conditioned on the values already drawn at
+    its neighbours (Brownian bridge inside the known range, a free increment outside it).  Same law as a Brownian
+    tree, different random numbers; ``seed`` (an int, or one int per batch row) makes it repeatable."""
+
+    def __init__(self, x, sigma_min, sigma_max, seed=None, transform=lambda x: x):
+        self.transform = transform
+        self._like = x
+        t0, t1 = float(transform(torch.as_tensor(sigma_min))), float(transform(torch.as_tensor(sigma_max)))
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 63 - 1, []).item())
+        try:
+            seeds = [int(v) for v in seed]
+            if len(seeds) != x.shape[0]:
+                raise ValueError("one seed per batch row expected")
+        except TypeError:
+            seeds = None
+        self._gens = [torch.Generator(device=x.device).manual_seed(v) for v in (seeds if seeds is not None else [int(seed)])]
+        self._batched = seeds is not None
+        self._times = [min(t0, t1)]                       # sorted; W(first time) = 0
+        self._w = [torch.zeros_like(x)]
+        self._at(max(t0, t1))
+
+    def _randn(self):
+        x = self._like
+        if not self._batched:
+            return torch.randn(x.shape, generator=self._gens[0], device=x.device, dtype=x.dtype)
+        return torch.stack([torch.randn(x.shape[1:], generator=g, device=x.device, dtype=x.dtype) for g in self._gens])
+
+    def _at(self, t):
+        import bisect
+        k = bisect.bisect_left(self._times, t)
+        if k < len(self._times) and self._times[k] == t:
+            return self._w[k]
+        if k == 0:                                         # before the first known time
+            w = self._w[0] - self._randn() * math.sqrt(self._times[0] - t)
+        elif k == len(self._times):                        # beyond the last
+            w = self._w[-1] + self._randn() * math.sqrt(t - self._times[-1])
+        else:                                              # bridge between the neighbours
+            a, b = self._times[k - 1], self._times[k]
+            f = (t - a) / (b - a)
+            w = torch.lerp(self._w[k - 1], self._w[k], f) + self._randn() * math.sqrt((t - a) * (b - t) / (b - a))
+        self._times.insert(k, t)
+        self._w.insert(k, w)
+        return w
+
+    def __call__(self, sigma, sigma_next):
+        t0, t1 = float(self.transform(torch.as_tensor(sigma))), float(self.transform(torch.as_tensor(sigma_next)))
+        lo, hi = min(t0, t1), max(t0, t1)
+        w = self._at(hi) - self._at(lo)
+        return (w if t1 >= t0 else -w) / math.sqrt(abs(t1 - t0))
+
+
+# ------------------------------------------------------------------------------------------------
+# DPM-Solver (:498-672): eps-prediction steps of order 1/2/3 in t = -log(sigma), fixed and adaptive step size
+# ------------------------------------------------------------------------------------------------
+class PIDStepSizeController:
+    """Step-size controller of the adaptive solver (:498-524): h <- h * limiter(prod_k (1/err_k)^b_k)."""
+
+    def __init__(self, h, pcoeff, icoeff, dcoeff, order=1, accept_safety=0.81, eps=1e-8):
+        self.h = h
+        self.b = ((pcoeff + icoeff + dcoeff) / order, -(pcoeff + 2 * dcoeff) / order, dcoeff / order)
+        self.accept_safety = accept_safety
+        self.eps = eps
+        self.errs = []
+
+    @staticmethod
+    def limiter(x):
+        return 1 + math.atan(x - 1)
+
+    def propose_step(self, error):
+        inv = 1 / (float(error) + self.eps)
+        self.errs = [inv, inv, inv] if not self.errs else [inv] + self.errs[1:]
+        factor = self.limiter(math.prod(e ** b for e, b in zip(self.errs, self.b)))
+        accept = factor >= self.accept_safety
+        if accept:
+            self.errs = [self.errs[0], self.errs[0], self.errs[1]]
+        self.h *= factor
+        return accept
+
+
+def _sigma_of(t):
+    return f32(np.exp(-f32(t)))
+
+
+class DPMSolver:
+    """DPM-Solver steps (arXiv 2206.00927; reference :527-672).  All times are host fp32 scalars, the network is
+    evaluated through ``model`` (the HIP denoiser on a GPU), the state update is a handful of axpy's on the device."""
+
+    def __init__(self, model, extra_args=None, eps_callback=None, info_callback=None):
+        self.model = model
+        self.extra_args = {} if extra_args is None else extra_args
+        self.eps_callback = eps_callback
+        self.info_callback = info_callback
+
+    t = staticmethod(lambda sigma: _neg_log(sigma))
+    sigma = staticmethod(_sigma_of)
+
+    def eps(self, state, action, goal, t):
+        sig = _sigma_of(t)
+        out = (action - self.model(state, action, goal, _sig_vec(action, sig), **self.extra_args)) / float(sig)
+        if self.eps_callback is not None:
+            self.eps_callback()
+        return out
+
+    def steps(self, orders, state, action, goal, t, t_next, eps, r1=None):
+        """The updates of every order in ``orders`` from (action, t) to t_next, sharing the network evaluations
+        (the reference's eps_cache): eps at t is given; order 2 needs eps at t + r1 h, order 3 also at t + 2/3 h."""
+        h = f32(t_next - t)
+        sn, em1 = float(_sigma_of(t_next)), float(f32(np.expm1(h)))
+        out = {}
+        if 1 in orders:
+            out[1] = action - (sn * em1) * eps
+        if 2 in orders or 3 in orders:
+            r1 = f32(r1 if r1 is not None else (1 / 3 if 3 in orders else 1 / 2))
+            s1 = f32(t + r1 * h)
+            u1 = action - float(_sigma_of(s1) * f32(np.expm1(f32(r1 * h)))) * eps
+            d1 = self.eps(state, u1, goal, s1) - eps
+            if 2 in orders:
+                out[2] = action - (sn * em1) * eps - float(f32(sn) / (2 * r1) * f32(em1)) * d1
+            if 3 in orders:
+                r2 = f32(2 / 3)
+                s2 = f32(t + r2 * h)
+                e2 = f32(np.expm1(f32(r2 * h)))
+                u2 = action - float(_sigma_of(s2) * e2) * eps - float(_sigma_of(s2) * (r2 / r1) * (e2 / f32(r2 * h) - 1)) * d1
+                d2 = self.eps(state, u2, goal, s2) - eps
+                out[3] = action - (sn * em1) * eps - float(f32(sn) / r2 * (f32(em1) / h - 1)) * d2
+        return out
+
+    def _ancestral_target(self, t, t_next, t_end, eta):
+        """(t_next_, sigma_up) of a step with added noise (:614-619)."""
+        if not eta:
+            return t_next, 0.
+        sd, _ = get_ancestral_step(_sigma_of(t), _sigma_of(t_next), eta)
+        t_down = min(f32(t_end), _neg_log(sd))
+        return t_down, float((_sigma_of(t_next) ** 2 - _sigma_of(t_down) ** 2) ** f32(0.5))
+
+    def dpm_solver_fast(self, state, action, goal, t_start, t_end, nfe, eta=0., s_noise=1., noise_sampler=None):
+        # the reference draws from randn_like whatever sampler it is given (:604), also when the noise is scaled by 0
+        noise_sampler = default_noise_sampler(action)
+        t_start, t_end = f32(t_start), f32(t_end)
+        if not t_end > t_start and eta:
+            raise ValueError('eta must be 0 for reverse sampling')
+        m = nfe // 3 + 1
+        ts = torch.linspace(float(t_start), float(t_end), m + 1, dtype=torch.float32).numpy()
+        orders = [3] * (m - 2) + [2, 1] if nfe % 3 == 0 else [3] * (m - 1) + [nfe % 3]
+        for i, order in enumerate(orders):
+            t, t_next = ts[i], ts[i + 1]
+            t_next_, su = self._ancestral_target(t, t_next, t_end, eta)
+            eps = self.eps(state, action, goal, t)
+            if self.info_callback is not None:
+                self.info_callback({'x': action, 'i': i, 't': t, 't_up': t, 'denoised': action - float(_sigma_of(t)) * eps})
+            action = self.steps((order,), state, action, goal, t, t_next_, eps, r1=None if order == 3 else 0.5)[order]
+            action = action + (su * s_noise) * noise_sampler(_sigma_of(t), _sigma_of(t_next))
+        return action
+
+    def dpm_solver_adaptive(self, state, action, goal, t_start, t_end, order=3, rtol=0.05, atol=0.0078, h_init=0.05,
+                            pcoeff=0., icoeff=1., dcoeff=0., accept_safety=0.81, eta=0., s_noise=1.):
+        """Embedded pairs 1/2 or 2/3 with a PID step size (:629-672).  The error norm runs over the WHOLE batch, so
+        the accepted step sequence depends on which samples share a call: one device->host scalar per step."""
+        noise_sampler = default_noise_sampler(action)
+        if order not in {2, 3}:
+            raise ValueError('order should be 2 or 3')
+        t_start, t_end = f32(t_start), f32(t_end)
+        forward = t_end > t_start
+        if not forward and eta:
+            raise ValueError('eta must be 0 for reverse sampling')
+        pid = PIDStepSizeController(abs(h_init) * (1 if forward else -1), pcoeff, icoeff, dcoeff,
+                                    1.5 if eta else order, accept_safety)
+        info = {'steps': 0, 'nfe': 0, 'n_accept': 0, 'n_reject': 0}
+        s, action_prev = t_start, action
+        while (s < t_end - 1e-5) if forward else (s > t_end + 1e-5):
+            t = min(t_end, f32(s + f32(pid.h))) if forward else max(t_end, f32(s + f32(pid.h)))
+            t_, su = self._ancestral_target(s, t, t_end, eta)
+            eps = self.eps(state, action, goal, s)
+            cand = self.steps((order - 1, order), state, action, goal, s, t_, eps, r1=1 / 3 if order == 3 else 1 / 2)
+            low, high = cand[order - 1], cand[order]
+            delta = (rtol * torch.maximum(low.abs(), action_prev.abs())).clamp_min(atol)
+            error = torch.linalg.norm((low - high) / delta) / action.numel() ** 0.5
+            if pid.propose_step(error):
+                action_prev = low
+                action = high + (su * s_noise) * noise_sampler(_sigma_of(s), _sigma_of(t))
+                s = t
+                info['n_accept'] += 1
+            else:
+                info['n_reject'] += 1
+            info['nfe'] += order
+            info['steps'] += 1
+            if self.info_callback is not None:
+                self.info_callback({'x': action, 'i': info['steps'] - 1, 't': s, 't_up': s,
+                                    'denoised': action - float(_sigma_of(s)) * eps, 'error': error, 'h': pid.h, **info})
+        return action, info
+
+
+def _solver(model, extra_args, callback):
+    solver = DPMSolver(model, extra_args)
+    if callback is not None:
+        solver.info_callback = lambda info: callback({'sigma': _sigma_of(info['t']), 'sigma_hat': _sigma_of(info['t_up']), **info})
+    return solver
+
+
+@torch.no_grad()
+def sample_dpm_fast(model, state, action, goal, sigma_min, sigma_max, n, scaler=None, extra_args=None, callback=None,
+                    disable=None, eta=0., s_noise=1., noise_sampler=None):
+    """DPM-Solver-fast: ``n`` network evaluations in steps of order 3, 3, ..., (2, 1 | n mod 3), uniform in
+    log sigma from sigma_max to sigma_min (:675-699)."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError('sigma_min and sigma_max must not be 0')
+    return _solver(model, extra_args, callback).dpm_solver_fast(
+        state, action, goal, _neg_log(sigma_max), _neg_log(sigma_min), n, eta, s_noise, noise_sampler)
+
+
+@torch.no_grad()
+def sample_dpm_adaptive(model, state, action, goal, sigma_min, sigma_max, extra_args=None, callback=None, disable=None,
+                        order=3, rtol=0.05, atol=0.0078, h_init=0.05, pcoeff=0., icoeff=1., dcoeff=0.,
+                        accept_safety=0.81, eta=0., s_noise=1., return_info=False):
+    """DPM-Solver-12 / -23 with adaptive step size (:855-892)."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError('sigma_min and sigma_max must not be 0')
+    action, info = _solver(model, extra_args, callback).dpm_solver_adaptive(
+        state, action, goal, _neg_log(sigma_max), _neg_log(sigma_min), order, rtol, atol, h_init, pcoeff, icoeff,
+        dcoeff, accept_safety, eta, s_noise)
+    return (action, info) if return_info else action
+
+
+@torch.no_grad()
+def sample_dpmpp_sde(model, state, action, goal, sigmas, extra_args=None, callback=None, disable=None, eta=1.,
+                     s_noise=1., scaler=None, noise_sampler=None, r=1 / 2):
+    """Stochastic DPM-Solver++ (:739-795): two exponential-integrator half steps per sigma interval, each to the
+    ancestral sigma_down of its sub-interval followed by the matching amount of Brownian noise.  This is what
+    ``sampler_type='dpmpp_2m_sde'`` runs (beso_agent.py:452-453)."""
+    extra_args = {} if extra_args is None else extra_args
+    sig = _host_sigmas(sigmas)
+    if noise_sampler is None:
+        noise_sampler = BrownianTreeNoiseSampler(action, sig[sig > 0].min(), sig.max())
+    r = f32(r)
+    fac = float(1 / (2 * r))
+
+    def to(x, denoised, t, t_to):                          # x at t -> t_to along the denoised direction
+        return float(_sigma_of(t_to) / _sigma_of(t)) * x - float(f32(np.expm1(f32(t - t_to)))) * denoised
+
+    for i in range(len(sig) - 1):
+        denoised = model(state, action, goal, _sig_vec(action, sig[i]), **extra_args)
+        if callback is not None:
+            callback({'x': action, 'i': i, 'sigma': sig[i], 'sigma_hat': sig[i], 'denoised': denoised})
+        if sig[i + 1] == 0:
+            action = action + to_d(action, sig[i], denoised) * float(sig[i + 1] - sig[i])
+            continue
+        t, t_next = _neg_log(sig[i]), _neg_log(sig[i + 1])
+        s = f32(t + f32(t_next - t) * r)
+        sd, su = get_ancestral_step(_sigma_of(t), _sigma_of(s), eta)
+        x_2 = to(action, denoised, t, _neg_log(sd))
+        x_2 = x_2 + noise_sampler(_sigma_of(t), _sigma_of(s)) * (s_noise * float(su))
+        denoised_2 = model(state, x_2, goal, _sig_vec(action, _sigma_of(s)), **extra_args)
+        sd, su = get_ancestral_step(_sigma_of(t), _sigma_of(t_next), eta)
+        action = to(action, (1 - fac) * denoised + fac * denoised_2, t, _neg_log(sd))
+        action = action + noise_sampler(_sigma_of(t), _sigma_of(t_next)) * (s_noise * float(su))
+        if scaler is not None:
+            action = scaler.clip_output(action)
+    return action
+
+
 def _out_of_scope(name, why):
     def fn(*a, **k):
         raise NotImplementedError(f"{name} is outside the MI355X hot-path scope ({why}); see DESIGN.md")
@@ -440,6 +708,7 @@ def _out_of_scope(name, why):
     return fn
 
 
-sample_dpmpp_sde = _out_of_scope('sample_dpmpp_sde', 'needs torchsde Brownian trees')
-sample_dpm_fast = _out_of_scope('sample_dpm_fast', 'DPM-Solver-fast is not on the scope table')
-sample_dpm_adaptive = _out_of_scope('sample_dpm_adaptive', 'adaptive step-size control is host-driven')
+# the reference's sample_dpmpp_2m_sde cannot run (it reads undefined names, gc_sampling.py:817-820) and nothing
+# dispatches to it (beso_agent.py:452 maps 'dpmpp_2m_sde' to sample_dpmpp_sde): there is no behaviour to reproduce
+sample_dpmpp_2m_sde = _out_of_scope('sample_dpmpp_2m_sde', 'the reference function raises NameError; use sample_dpmpp_sde')
+log_likelihood = _out_of_scope('log_likelihood', 'needs the torchdiffeq ODE integrator')

@@ -178,6 +178,43 @@ def fixture_euler_ancestral(cfg_name, batch, seed, n):
             "noise": np.stack(draws), "seed": seed}
 
 
+def fixture_more_samplers(cfg_name, batch, seed):
+    """The samplers that draw noise or choose their own steps, run on the reference with the torch CPU generator
+    seeded: the host loops of the build consume the same stream, so outputs are comparable directly."""
+    cfg = O.CONFIGS[cfg_name]
+    w = O.make_weights(cfg, seed=seed, std=0.05)
+    m = build_ref(cfg, w)
+    state, goal, x_t = O.make_inputs(cfg, batch, seed=seed)
+    sig = ref_samp.get_sigmas_exponential(6, 0.005, 1.0)
+    out = {"state": state, "goal": goal, "x_t": x_t, "sigmas": sig.numpy(), "seed": seed, "std": 0.05}
+    args = (m, T(state), T(x_t), T(goal))
+    smin, smax = sig[-2].item(), sig[0].item()
+
+    def run(key, fn):
+        torch.manual_seed(999)
+        y = fn()
+        out[key] = (y[0] if isinstance(y, tuple) else y).numpy()
+        if isinstance(y, tuple):
+            out[key + "::info"] = np.array([y[1][k] for k in ("steps", "nfe", "n_accept", "n_reject")])
+
+    run("lms", lambda: ref_samp.sample_lms(*args, sig, disable=True))
+    run("ancestral", lambda: ref_samp.sample_dpm_2_ancestral(*args, sig, disable=True))
+    run("dpmpp_2s_ancestral", lambda: ref_samp.sample_dpmpp_2s_ancestral(*args, sig, disable=True))
+    for n in (6, 7, 8):
+        run(f"dpm_fast_{n}", lambda: ref_samp.sample_dpm_fast(*args, smin, smax, n, disable=True))
+    run("dpm_fast_7_eta", lambda: ref_samp.sample_dpm_fast(*args, smin, smax, 7, disable=True, eta=0.5))
+    for order in (2, 3):
+        run(f"dpm_adaptive_{order}", lambda: ref_samp.sample_dpm_adaptive(*args, smin, smax, disable=True, order=order,
+                                                                         return_info=True))
+    run("dpm_adaptive_3_eta", lambda: ref_samp.sample_dpm_adaptive(*args, smin, smax, disable=True, eta=0.3,
+                                                                   return_info=True))
+    run("dpm_adaptive_3_reject", lambda: ref_samp.sample_dpm_adaptive(*args, smin, smax, disable=True, h_init=4.0, rtol=0.005,
+                                                                      atol=0.001, return_info=True))
+    run("dpmpp_sde", lambda: ref_samp.sample_dpmpp_sde(*args, sig, disable=True,
+                                                       noise_sampler=ref_samp.default_noise_sampler(T(x_t))))
+    return out
+
+
 def fixture_cfg(cfg_name, batch, seed):
     cfg = O.CONFIGS[cfg_name]
     w = O.make_weights(cfg, seed=seed, std=0.05)
@@ -340,6 +377,7 @@ def main():
         "long_horizon", 2, seed=22, std=0.02, specs=[("euler", 10, "exponential")],
         sigma_min=0.005, sigma_max=1.0))
     save("tiny_euler_ancestral.npz", **fixture_euler_ancestral("tiny", 4, seed=23, n=5))
+    save("tiny_more_samplers.npz", **fixture_more_samplers("tiny", 4, seed=24))
     save("block_push_cfg.npz", **fixture_cfg("block_push", 5, seed=30))
     save("tiny_loss.npz", **fixture_loss("tiny", 6, seed=40))
     save("kitchen_loss.npz", **fixture_loss("kitchen", 6, seed=41))

@@ -114,6 +114,33 @@ def test_fused_sampler_loops_vs_reference_vectors(precision):
             assert err < tol, key
 
 
+def test_stochastic_and_adaptive_samplers_on_gpu():
+    """lms, dpm_fast, dpm_adaptive (incl. rejected steps), dpmpp_2s_ancestral and dpmpp_sde with the HIP denoiser
+    (fp32 mode) against the reference's outputs; the injected noise is drawn from the seeded CPU generator the
+    reference run used and copied to the device."""
+    from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+    from test_host_logic import _more_sampler_runs
+    fx = load_golden("tiny_more_samplers.npz")
+    cfg = O.TINY
+    m = make_module(cfg, O.make_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"])), "fp32")
+    cpu_noise = lambda s, sn: torch.randn(fx["x_t"].shape).to(DEV)      # noqa: E731
+    runs = _more_sampler_runs(m, fx, lambda k: G(fx[k]), cpu_noise)
+    sig = torch.from_numpy(fx["sigmas"])
+    runs["dpmpp_2s_ancestral"] = lambda: ks.sample_dpmpp_2s_ancestral(m, G(fx["state"]), G(fx["x_t"]), G(fx["goal"]), sig,
+                                                                      disable=True, noise_sampler=cpu_noise)
+    for key in ("ancestral", "dpm_fast_7_eta", "dpm_adaptive_3_eta"):    # these draw with randn_like on the device
+        runs.pop(key)
+    for key, fn in runs.items():
+        torch.manual_seed(999)
+        y = fn()
+        if isinstance(y, tuple):
+            y, info = y
+            assert [info[k] for k in ("steps", "nfe", "n_accept", "n_reject")] == list(fx[key + "::info"]), key
+        err = rel_err(y.cpu().numpy(), fx[key])
+        print(f"[parity] tiny_more_samplers:{key} fp32: {err:.3e}")
+        assert err < 5e-5, key
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_classifier_free_guidance(precision):
     from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel

@@ -143,6 +143,67 @@ def test_euler_ancestral_consumes_the_same_random_stream_as_the_reference():
     assert rel_err(out.numpy(), fx["out"]) < 2e-5
 
 
+def _more_sampler_runs(model, fx, T, noise_like):
+    """key -> thunk for every entry of tests/golden/tiny_more_samplers.npz (make_fixtures.fixture_more_samplers)."""
+    sig = torch.from_numpy(fx["sigmas"])
+    smin, smax = sig[-2].item(), sig[0].item()
+    a = lambda: (model, T("state"), T("x_t"), T("goal"))      # noqa: E731
+    runs = {"lms": lambda: ks.sample_lms(*a(), sig, disable=True),
+            "ancestral": lambda: ks.sample_dpm_2_ancestral(*a(), sig, disable=True),
+            "dpmpp_2s_ancestral": lambda: ks.sample_dpmpp_2s_ancestral(*a(), sig, disable=True),
+            "dpm_fast_7_eta": lambda: ks.sample_dpm_fast(*a(), smin, smax, 7, disable=True, eta=0.5),
+            "dpm_adaptive_3_eta": lambda: ks.sample_dpm_adaptive(*a(), smin, smax, disable=True, eta=0.3, return_info=True),
+            "dpm_adaptive_3_reject": lambda: ks.sample_dpm_adaptive(*a(), smin, smax, disable=True, h_init=4.0, rtol=0.005,
+                                                                    atol=0.001, return_info=True),
+            "dpmpp_sde": lambda: ks.sample_dpmpp_sde(*a(), sig, disable=True, noise_sampler=noise_like)}
+    for n in (6, 7, 8):
+        runs[f"dpm_fast_{n}"] = lambda n=n: ks.sample_dpm_fast(*a(), smin, smax, n, disable=True)
+    for order in (2, 3):
+        runs[f"dpm_adaptive_{order}"] = lambda order=order: ks.sample_dpm_adaptive(*a(), smin, smax, disable=True,
+                                                                                  order=order, return_info=True)
+    return runs
+
+
+def test_stochastic_and_adaptive_samplers_match_reference():
+    """lms, dpm_2_ancestral, dpmpp_2s_ancestral, dpm_fast, dpm_adaptive, dpmpp_sde (gc_sampling.py:379-468,498-699,
+    739-795,855-892,971-1016) against the reference's outputs; the torch CPU generator is seeded as in the fixture
+    run, so every randn the reference drew is drawn here too (including the ones DPM-Solver scales by zero)."""
+    fx = load_golden("tiny_more_samplers.npz")
+    cfg = O.TINY
+    model = OracleModel(O.make_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"])), cfg)
+    T = lambda k: torch.from_numpy(fx[k].copy())        # noqa: E731
+    runs = _more_sampler_runs(model, fx, T, ks.default_noise_sampler(T("x_t")))
+    assert set(runs) == {k for k in fx if "::" not in k} - {"state", "goal", "x_t", "sigmas", "seed", "std"}
+    for key, fn in runs.items():
+        torch.manual_seed(999)
+        y = fn()
+        if isinstance(y, tuple):
+            y, info = y
+            assert [info[k] for k in ("steps", "nfe", "n_accept", "n_reject")] == list(fx[key + "::info"]), key
+        assert rel_err(y.numpy(), fx[key]) < 5e-5, key
+
+
+def test_brownian_noise_sampler_is_one_path():
+    """Increments over adjacent intervals add up (one Brownian path per sample), are N(0, 1) after the 1/sqrt(dt)
+    normalisation, and a seed repeats them (the contract of gc_sampling.py:144-165)."""
+    x = torch.zeros(4000, 3)
+    s = ks.BrownianTreeNoiseSampler(x, 0.01, 1.0, seed=5)
+    a, b, c = 0.9, 0.5, 0.2
+    w_ab, w_bc, w_ac = s(a, b) * (a - b) ** 0.5, s(b, c) * (b - c) ** 0.5, s(a, c) * (a - c) ** 0.5
+    assert torch.allclose(w_ab + w_bc, w_ac, atol=1e-5)
+    assert torch.allclose(s(c, a), -s(a, c))
+    for v in (s(a, b), s(b, c), s(0.7, 0.6), s(1.0, 0.01)):
+        assert abs(float(v.mean())) < 0.05 and abs(float(v.std()) - 1.0) < 0.05
+    assert abs(float((s(a, b) * s(b, c)).mean())) < 0.05                        # independent increments
+    s2 = ks.BrownianTreeNoiseSampler(x, 0.01, 1.0, seed=5)
+    assert torch.equal(s2(a, b), s(a, b))
+    rows = ks.BrownianTreeNoiseSampler(x[:3], 0.01, 1.0, seed=[1, 2, 1])
+    v = rows(0.8, 0.3)
+    assert torch.equal(v[0], v[2]) and not torch.equal(v[0], v[1])
+    with pytest.raises(NotImplementedError):
+        ks.sample_dpmpp_2m_sde()
+
+
 def test_cfg_wrapper_semantics():
     fx = load_golden("block_push_cfg.npz")
     cfg = O.BLOCK_PUSH
