@@ -14,6 +14,7 @@ PREC_BF16, PREC_FP32, PREC_BF16X3 = 0, 1, 2
 PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
 FLAG_UNCOND = 1
 SAMPLER_IDS = {"ddim": 0, "euler": 1, "heun": 2}
+GOAL_RANDOM, GOAL_TAIL, GOAL_SEQ_END = 0, 1, 2
 STEP_DDIM, STEP_EULER, STEP_HEUN_PREDICT, STEP_HEUN_CORRECT = 0, 1, 2, 3
 SITES = {"off": 0, "gemm_qkv": 1, "gemm_proj": 2, "gemm_fc1": 3, "gemm_fc2": 4, "attention": 5,
          "layernorm": 6, "embed": 7, "head": 8, "forward": 9, "fused_layer": 10}
@@ -22,7 +23,7 @@ SITES = {"off": 0, "gemm_qkv": 1, "gemm_proj": 2, "gemm_fc1": 3, "gemm_fc2": 4, 
 EXPORTS = ["beso_version", "beso_status_string", "beso_last_error", "beso_num_params", "beso_packed_bytes", "beso_pack_weights",
            "beso_workspace_bytes", "beso_score_fwd", "beso_denoise_fwd", "beso_sampler_step", "beso_sample",
            "beso_profile_enable", "beso_profile_read", "beso_debug_set_stamps", "beso_adam_step",
-           "beso_train_workspace_bytes", "beso_grad_floats", "beso_loss_grad", "beso_debug_gemm"]
+           "beso_train_workspace_bytes", "beso_grad_floats", "beso_loss_grad", "beso_debug_gemm", "beso_gather_windows"]
 
 
 class BesoConfig(C.Structure):
@@ -100,6 +101,10 @@ def load() -> C.CDLL:
                                            f32, C.c_uint, f32, vp, sz, vp]
             lib.beso_debug_gemm.restype = i32
             lib.beso_debug_gemm.argtypes = [i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]
+        if hasattr(lib, "beso_gather_windows") or not os.environ.get("BESO_HIP_LIB"):
+            lib.beso_gather_windows.restype = i32
+            lib.beso_gather_windows.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, C.c_longlong, vp, vp, i32, i32, i32,
+                                                i32, i32, vp, vp, vp, vp]
         lib.beso_profile_read.restype = i32
         lib.beso_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
         _lib = lib

@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "build")
 LIB = os.path.join(LIBDIR, "libbeso_hip.so")
-UNITS = ["api", "elementwise", "attention", "gemm", "fused", "optim", "train"]
+UNITS = ["api", "elementwise", "attention", "gemm", "fused", "optim", "train", "feed"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -451,6 +451,26 @@ int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg,
     return BESO_OK;
 }
 
+int beso_gather_windows(const float* observations, const float* actions, const int* seq_len, int n_traj, int t_max,
+                        int obs_dim, int act_dim, const int* slice_traj, const int* slice_start, long long n_slices,
+                        const long long* batch_slices, const long long* draws, int batch, int window, int goal_len,
+                        int goal_mode, int min_future_sep, float* obs_out, float* act_out, float* goal_out, void* stream) {
+    if (!observations || !actions || !seq_len || !slice_traj || !slice_start || !batch_slices || !obs_out || !act_out)
+        return BESO_ERR_BAD_ARG;
+    if (n_traj < 1 || t_max < 1 || obs_dim < 1 || act_dim < 1 || n_slices < 1 || batch < 0 || window < 1 || window > t_max)
+        return BESO_ERR_BAD_ARG;
+    if (goal_len < 0 || goal_len > t_max || min_future_sep < 0) return BESO_ERR_BAD_ARG;
+    if (goal_mode != BESO_GOAL_RANDOM && goal_mode != BESO_GOAL_TAIL && goal_mode != BESO_GOAL_SEQ_END) return BESO_ERR_BAD_ARG;
+    if (goal_len > 0 && (!goal_out || (goal_mode == BESO_GOAL_RANDOM && !draws))) return BESO_ERR_BAD_ARG;
+    if ((long long)window * (obs_dim > act_dim ? obs_dim : act_dim) > 0x7fffffffLL) return BESO_ERR_BAD_ARG;
+    if (batch == 0) return BESO_OK;
+    hipError_t e = launch_gather_windows(observations, actions, seq_len, n_traj, t_max, obs_dim, act_dim, slice_traj,
+                                         slice_start, n_slices, batch_slices, draws, batch, window, goal_len, goal_mode,
+                                         min_future_sep, obs_out, act_out, goal_out, (hipStream_t)stream);
+    if (e != hipSuccess) return record_hip_error(e, "gather_windows_kernel", __LINE__);
+    return BESO_OK;
+}
+
 size_t beso_train_workspace_bytes(const beso_config* cfg, int batch, int t, int precision) {
     return train_workspace_bytes(cfg, batch, t, precision);
 }

@@ -153,6 +153,11 @@ hipError_t launch_sampler_step(int mode, float* out, float* aux, const float* x,
 void profile_begin(int site, hipStream_t s);
 void profile_end(int site, hipStream_t s);
 
+hipError_t launch_gather_windows(const float* observations, const float* actions, const int* seq_len, int n_traj,
+                                 int t_max, int obs, int act, const int* slice_traj, const int* slice_start,
+                                 long long n_slices, const long long* batch_slices, const long long* draws, int batch,
+                                 int window, int goal_len, int goal_mode, int min_future_sep, float* obs_out,
+                                 float* act_out, float* goal_out, hipStream_t s);
 hipError_t launch_adam_ema(const void* chunks, int n_chunks, float* m, float* v, float* ema, float lr, float beta1,
                            float beta2, float eps, float wd, int decoupled, int step, float ema_decay, hipStream_t s);
 

@@ -15,6 +15,7 @@
  *   beso_sample         <- sample_ddim / sample_euler / sample_heun    k_diffusion/gc_sampling.py:167-213,259-314,895-924
  *   beso_loss_grad      <- GCDenoiser.loss + loss.backward()           k_diffusion/score_wrappers.py:45-79, beso_agent.py:228-233
  *   beso_adam_step      <- optimizer.step() + ema_helper.update()      beso_agent.py:236-244
+ *   beso_gather_windows <- TrajectorySlicerDataset.__getitem__ x batch envs/dataloaders/trajectory_loader.py:160-197
  *
  * Conventions
  *   - plain C, plain pointers and sizes.  No torch types.  `stream` is a hipStream_t passed as void*.
@@ -185,6 +186,26 @@ int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_par
                    const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
                    float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop, unsigned int seed,
                    float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* The training feed on trajectories resident in HBM: one batch of TrajectorySlicerDataset.__getitem__
+ * (envs/dataloaders/trajectory_loader.py:160-197; the collate of torch's DataLoader included) as one launch.
+ *   observations [n_traj,t_max,obs_dim], actions [n_traj,t_max,act_dim]  padded trajectories (TensorDataset.tensors)
+ *   seq_len [n_traj] int32        valid length of each trajectory (get_seq_length)
+ *   slice_traj / slice_start [n_slices] int32   the slicer's table: window s = rows [start, start + window) (:128-135)
+ *   batch_slices [batch] int64    which windows make up this batch (a chunk of a permutation)
+ *   draws [batch] int64 >= 0      one random integer per sample; BESO_GOAL_RANDOM takes the future sequence at
+ *                                 lo + draws % (hi - lo), lo = end + min_future_sep, hi = seq_len - goal_len (:169-182);
+ *                                 may be NULL for the other modes or goal_len = 0
+ *   goal_mode   BESO_GOAL_RANDOM | BESO_GOAL_TAIL (only_sample_tail, :175-176) | BESO_GOAL_SEQ_END (only_sample_seq_end, :177-178)
+ *   goal_len    future_seq_len, 0 = not future conditional (goal_out may be NULL)
+ *   obs_out [batch,window,obs_dim], act_out [batch,window,act_dim], goal_out [batch,goal_len,obs_dim]
+ * Samples whose trajectory has no room for a future sequence get the reference's zeros placeholder (:185-186);
+ * out-of-range slice ids produce zero rows instead of a fault.                                                     */
+enum { BESO_GOAL_RANDOM = 0, BESO_GOAL_TAIL = 1, BESO_GOAL_SEQ_END = 2 };
+int beso_gather_windows(const float* observations, const float* actions, const int* seq_len, int n_traj, int t_max,
+                        int obs_dim, int act_dim, const int* slice_traj, const int* slice_start, long long n_slices,
+                        const long long* batch_slices, const long long* draws, int batch, int window, int goal_len,
+                        int goal_mode, int min_future_sep, float* obs_out, float* act_out, float* goal_out, void* stream);
+
 /* Development aid (tests of the operand layouts of the training GEMM): C[M][N] (fp32, ldc) = sum_k A(m,k) B(n,k);
  * a_kslow / b_kslow = 1: the operand is stored [K][ld] (contraction index slow), 0: [rows][ld] (k contiguous).
  * Supported pairs: (0,0), (0,1), (1,1).  splits > 1 accumulates split-K partial sums into a ZEROED C.      */

@@ -514,6 +514,46 @@ SAMPLERS = {"ddim": sample_ddim, "euler": sample_euler, "heun": sample_heun,
 
 
 # --------------------------------------------------------------------------------------------
+# training feed: TrajectorySlicerDataset (envs/dataloaders/trajectory_loader.py:77-197)
+# --------------------------------------------------------------------------------------------
+def window_table(lengths, window):
+    """The slicer's (trajectory, start, end) rows (:126-135)."""
+    rows = []
+    for i, n in enumerate(lengths):
+        if int(n) - window >= 0:
+            rows += [(i, start, start + window) for start in range(int(n) - window + 1)]
+    return np.asarray(rows, dtype=np.int32).reshape(-1, 3)
+
+
+def slice_windows(observations, actions, lengths, slices, ids, goal_len=0, min_future_sep=0, mode="random", draws=None):
+    """``[dataset[i] for i in ids]`` collated (:160-197).  ``draws[k]`` is the value np.random.randint(lo, hi) - lo
+    took for item k (the injected randomness of the random future-goal mode)."""
+    t_max = observations.shape[1]
+    obs_out, act_out, goal_out = [], [], []
+    for k, idx in enumerate(ids):
+        i, start, end = (int(v) for v in slices[int(idx)])
+        obs_out.append(observations[i, start:end])
+        act_out.append(actions[i, start:end])
+        if goal_len > 0:
+            lo, hi = end + min_future_sep, int(lengths[i]) - goal_len
+            if lo < hi:
+                if mode == "tail":
+                    g = observations[i, t_max - goal_len:]            # the PADDED tensor's tail (:176)
+                elif mode == "seq_end":
+                    g = observations[i, end:end + goal_len]
+                else:
+                    g0 = lo + int(draws[k]) % (hi - lo)
+                    g = observations[i, g0:g0 + goal_len]
+            else:
+                g = np.zeros((goal_len, observations.shape[2]), dtype=observations.dtype)
+            goal_out.append(g)
+    out = {"observation": np.stack(obs_out), "action": np.stack(act_out)}
+    if goal_len > 0:
+        out["goal_observation"] = np.stack(goal_out)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # training-side sigma density (utils.py:173-185)
 # --------------------------------------------------------------------------------------------
 def log_logistic_from_uniform(u, loc, scale, min_value, max_value):

@@ -215,6 +215,74 @@ def fixture_more_samplers(cfg_name, batch, seed):
     return out
 
 
+def fixture_trajectory_windows(seed=7):
+    """TrajectorySlicerDataset over a TrajectorySubset of a padded TensorDataset (trajectory_loader.py:44-272), the
+    way get_push_train_val builds it: the window table, and items in all three future-goal modes plus the
+    unconditional one.  The random mode's np.random draws are recovered by replaying the seeded stream."""
+    from torch.utils.data import TensorDataset
+    import importlib.util
+    # beso/envs/__init__.py registers gym environments (gym is absent here); the loader module itself only needs torch,
+    # so it is loaded from its file, unmodified, without running the package's __init__
+    spec = importlib.util.spec_from_file_location(
+        "ref_trajectory_loader", os.path.join(REF, "beso", "envs", "dataloaders", "trajectory_loader.py"))
+    TL = importlib.util.module_from_spec(spec)
+    import itertools
+    import torch._utils
+    if not hasattr(torch._utils, "_accumulate"):          # removed from torch 2.x; only random_split_traj uses it,
+        torch._utils._accumulate = itertools.accumulate   # which this fixture does not call (subset built directly)
+    spec.loader.exec_module(TL)
+
+    rng = np.random.default_rng(seed)
+    n, t_max, obs, act = 9, 26, 5, 3
+    lengths = rng.integers(4, t_max + 1, size=n)
+    lengths[0], lengths[1] = t_max, 5                     # one full-length trajectory, one shorter than the window
+    observations = rng.standard_normal((n, t_max, obs)).astype(np.float32)
+    actions = rng.standard_normal((n, t_max, act)).astype(np.float32)
+    masks = (np.arange(t_max)[None, :] < lengths[:, None]).astype(np.float32)
+    observations *= masks[..., None]
+    actions *= masks[..., None]
+
+    class Padded(TensorDataset, TL.TrajectoryDataset):
+        def __init__(self):
+            TensorDataset.__init__(self, T(observations), T(actions), T(masks))
+
+        def get_seq_length(self, idx):
+            return int(self.tensors[2][idx].sum().item())
+
+        def get_all_actions(self):
+            return torch.cat([self.tensors[1][i, :self.get_seq_length(i)] for i in range(len(self))])
+
+    window, glen, sep = 6, 2, 1
+    out = {"observations": observations, "actions": actions, "lengths": lengths.astype(np.int32),
+           "window": window, "future_seq_len": glen, "min_future_sep": sep}
+    for mode, kw in (("none", dict(future_conditional=False)),
+                     ("random", dict(future_conditional=True, future_seq_len=glen, min_future_sep=sep)),
+                     ("tail", dict(future_conditional=True, future_seq_len=glen, min_future_sep=sep, only_sample_tail=True)),
+                     ("seq_end", dict(future_conditional=True, future_seq_len=glen, min_future_sep=sep,
+                                      only_sample_seq_end=True))):
+        subset = np.array([4, 0, 7, 1, 8, 2, 5], dtype=np.int64)          # a TrajectorySubset like split_traj_datasets makes
+        train = TL.TrajectorySlicerDataset(TL.TrajectorySubset(Padded(), subset.tolist()), window=window, **kw)
+        out["subset"] = subset
+        out["slices"] = np.asarray(train.slices, dtype=np.int32)
+        ids = np.random.default_rng(seed + 1).permutation(len(train))[:40]
+        out["ids"] = ids.astype(np.int64)
+        np.random.seed(11)
+        items = [train[int(i)] for i in ids]
+        out[f"{mode}::observation"] = np.stack([it["observation"].numpy() for it in items])
+        out[f"{mode}::action"] = np.stack([it["action"].numpy() for it in items])
+        if mode != "none":
+            out[f"{mode}::goal_observation"] = np.stack([it["goal_observation"].numpy() for it in items])
+        if mode == "random":
+            np.random.seed(11)
+            draws = []
+            for i in ids:
+                tr, start, end = train.slices[int(i)]
+                lo, hi = end + sep, train.dataset.get_seq_length(tr) - glen
+                draws.append(np.random.randint(lo, hi) - lo if lo < hi else 0)
+            out["random::draws"] = np.asarray(draws, dtype=np.int64)
+    return out
+
+
 def fixture_cfg(cfg_name, batch, seed):
     cfg = O.CONFIGS[cfg_name]
     w = O.make_weights(cfg, seed=seed, std=0.05)
@@ -378,6 +446,7 @@ def main():
         sigma_min=0.005, sigma_max=1.0))
     save("tiny_euler_ancestral.npz", **fixture_euler_ancestral("tiny", 4, seed=23, n=5))
     save("tiny_more_samplers.npz", **fixture_more_samplers("tiny", 4, seed=24))
+    save("trajectory_windows.npz", **fixture_trajectory_windows())
     save("block_push_cfg.npz", **fixture_cfg("block_push", 5, seed=30))
     save("tiny_loss.npz", **fixture_loss("tiny", 6, seed=40))
     save("kitchen_loss.npz", **fixture_loss("kitchen", 6, seed=41))

@@ -832,3 +832,117 @@ def test_hip_loss_pred_last_action_only(monkeypatch):
         out[mode] = (loss.item(), [p.grad.clone() for p in m.parameters()])
     assert abs(out["1"][0] - out["0"][0]) < 2e-5 * abs(out["0"][0])
     assert max(_grad_errors(out["1"][1], out["0"][1])) < 2e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# training feed (beso_gather_windows)
+# ------------------------------------------------------------------------------------------------
+def _feed(fx, mode, batch_size=16, **kw):
+    from beso_amd.data.trajectory_feed import DeviceTrajectoryFeed
+    sub = fx["subset"]
+    cond = mode != "none"
+    return DeviceTrajectoryFeed(fx["observations"][sub], fx["actions"][sub], fx["lengths"][sub], int(fx["window"]), batch_size, DEV,
+                                future_conditional=cond, min_future_sep=int(fx["min_future_sep"]),
+                                future_seq_len=int(fx["future_seq_len"]) if cond else None,
+                                only_sample_tail=mode == "tail", only_sample_seq_end=mode == "seq_end", **kw)
+
+
+@pytest.mark.parametrize("mode", ["none", "random", "tail", "seq_end"])
+def test_feed_gather_vs_reference_items(mode):
+    """beso_gather_windows against items of the reference's TrajectorySlicerDataset (collated), bit for bit; the random
+    future-goal starts are the ones np.random gave the reference."""
+    fx = load_golden("trajectory_windows.npz")
+    feed = _feed(fx, mode)
+    np.testing.assert_array_equal(feed.slices, fx["slices"])
+    batch = feed.gather(torch.from_numpy(fx["ids"]), torch.from_numpy(fx["random::draws"]) if mode == "random" else None)
+    assert set(batch) == {"observation", "action"} | ({"goal_observation"} if mode != "none" else set())
+    for key, val in batch.items():
+        assert val.is_cuda and val.dtype == torch.float32
+        np.testing.assert_array_equal(val.cpu().numpy(), fx[f"{mode}::{key}"], err_msg=f"{mode}::{key}")
+
+
+def test_feed_epoch_and_oracle_at_size():
+    """A kitchen-sized dataset: every window exactly once per epoch (also split over two ranks), batches equal the
+    oracle's slicing of the same ids / draws, a new epoch is a new permutation, out-of-range ids give zero rows."""
+    from beso_amd.data.trajectory_feed import DeviceTrajectoryFeed
+    rng = np.random.default_rng(0)
+    n, t_max, obs, act, window, glen = 120, 200, 30, 9, 10, 1
+    lengths = rng.integers(5, t_max + 1, size=n).astype(np.int32)
+    observations = rng.standard_normal((n, t_max, obs)).astype(np.float32)
+    actions = rng.standard_normal((n, t_max, act)).astype(np.float32)
+    table = O.window_table(lengths, window)
+    kw = dict(future_conditional=True, future_seq_len=glen, min_future_sep=3, seed=5)
+    feed = DeviceTrajectoryFeed(observations, actions, lengths, window, 1024, DEV, **kw)
+    assert feed.n_windows == len(table) and len(feed) == -(-len(table) // 1024)
+    ids = torch.from_numpy(rng.integers(0, len(table), size=4096))
+    draws = torch.from_numpy(rng.integers(0, 2 ** 62, size=4096))
+    got = feed.gather(ids, draws)
+    want = O.slice_windows(observations, actions, lengths, table, ids.numpy(), glen, 3, "random", draws.numpy())
+    for key in want:
+        np.testing.assert_array_equal(got[key].cpu().numpy(), want[key], err_msg=key)
+    # an epoch covers every window once: the observation windows, as a multiset, are the table's
+    def epoch_keys(f):
+        rows = torch.cat([b["observation"][:, 0, :2] for b in f])          # (first row's first two features) identify a window
+        return rows.cpu().numpy()
+    all_first = np.stack([observations[i, s, :2] for i, s, _ in table])
+    e1, e2 = epoch_keys(feed), epoch_keys(feed)
+    assert e1.shape == all_first.shape and not np.array_equal(e1, e2)
+    order = lambda a: a[np.lexsort(a.T)]                                   # noqa: E731
+    np.testing.assert_array_equal(order(e1), order(all_first))
+    np.testing.assert_array_equal(order(e2), order(all_first))
+    halves = [epoch_keys(DeviceTrajectoryFeed(observations, actions, lengths, window, 256, DEV, rank=r, world_size=2, **kw))
+              for r in range(2)]
+    assert abs(len(halves[0]) - len(halves[1])) <= 1
+    np.testing.assert_array_equal(order(np.concatenate(halves)), order(all_first))
+    bad = feed.gather(torch.tensor([-1, len(table), 3]))
+    assert float(bad["observation"][:2].abs().max()) == 0.0 and float(bad["observation"][2].abs().max()) > 0.0
+    # drop_last and no shuffling
+    seq = DeviceTrajectoryFeed(observations, actions, lengths, window, 1000, DEV, shuffle=False, drop_last=True)
+    first = next(iter(seq))
+    assert len(seq) == len(table) // 1000 and first["observation"].shape == (1000, window, obs) and "goal_observation" not in first
+    np.testing.assert_array_equal(first["action"].cpu().numpy(), np.stack([actions[i, s:e] for i, s, e in table[:1000]]))
+
+
+def test_feed_from_sliced_and_train_step():
+    """from_sliced on an object with the reference slicer's attributes, and the dict batches drive train_step."""
+    from beso_amd.data.trajectory_feed import DeviceTrajectoryFeed
+    from test_host_logic import build_agent
+    fx = load_golden("trajectory_windows.npz")
+    cfg = O.TINY
+
+    class Base:
+        def __init__(self, obs, act, lengths):
+            self.obs, self.act, self.lengths = obs, act, lengths
+
+        def __len__(self):
+            return len(self.lengths)
+
+        def __getitem__(self, i):
+            return torch.from_numpy(self.obs[i]), torch.from_numpy(self.act[i]), torch.ones(self.obs.shape[1])
+
+        def get_seq_length(self, i):
+            return int(self.lengths[i])
+
+    rng = np.random.default_rng(1)
+    n, t_max = 12, 40
+    lengths = rng.integers(cfg.obs_seq_len, t_max + 1, size=n)
+    base = Base(rng.standard_normal((n, t_max, cfg.obs_dim)).astype(np.float32),
+                rng.standard_normal((n, t_max, cfg.act_dim)).astype(np.float32), lengths)
+    table = O.window_table(lengths, cfg.obs_seq_len)
+
+    class Sliced:
+        dataset, window, future_conditional, min_future_sep = base, cfg.obs_seq_len, True, 0
+        future_seq_len, only_sample_tail, only_sample_seq_end = cfg.goal_seq_len, False, False
+        slices = [tuple(r) for r in table]
+
+    feed = DeviceTrajectoryFeed.from_sliced(Sliced, 64, DEV, seed=1)
+    assert feed.n_windows == len(table)
+    agent = build_agent(cfg, lambda: make_module(cfg, O.make_weights(cfg, seed=1, std=0.05), "fp32"), device=DEV)
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    agent.get_scaler(Scaler(base.obs.reshape(-1, cfg.obs_dim), base.act.reshape(-1, cfg.act_dim), True, DEV))
+    agent.set_bounds(agent.scaler)
+    losses = [agent.train_step(b) for b in feed]
+    assert len(losses) == len(feed) and all(np.isfinite(v) for v in losses)
+    Sliced.slices = Sliced.slices[:-1]
+    with pytest.raises(ValueError):
+        DeviceTrajectoryFeed.from_sliced(Sliced, 64, DEV)

@@ -479,3 +479,16 @@ def test_train_steps_match_the_reference_agent_trace():
     # AdamW's first steps move every weight by ~lr whatever the gradient's size: last-bit differences in tiny
     # gradients flip to O(lr) differences, so parameters are compared at a few lr relative to their largest entry
     assert p_err < 5e-3 and e_err < 5e-3, (p_err, e_err)
+
+
+def test_feed_window_table_and_cpu_refusal():
+    """The feed's window table equals the reference slicer's; a CPU device is refused (the dataset lives in HBM)."""
+    from beso_amd.data.trajectory_feed import DeviceTrajectoryFeed, window_table
+    fx = load_golden("trajectory_windows.npz")
+    lengths = fx["lengths"][fx["subset"]]
+    traj, start = window_table(lengths, int(fx["window"]))
+    np.testing.assert_array_equal(np.stack([traj, start, start + int(fx["window"])], 1), fx["slices"])
+    np.testing.assert_array_equal(np.stack([traj, start, start + int(fx["window"])], 1), O.window_table(lengths, int(fx["window"])))
+    assert window_table([3, 2], 5)[0].size == 0
+    with pytest.raises((ValueError, RuntimeError)):
+        DeviceTrajectoryFeed(fx["observations"], fx["actions"], fx["lengths"], 6, 8, "cpu")

@@ -124,3 +124,19 @@ def test_schedules():
         mine = fns[name](int(n))
         assert mine.shape == ref.shape and mine[-1] == 0
         np.testing.assert_allclose(mine, ref, rtol=3e-6, atol=1e-9, err_msg=key)
+
+
+def test_trajectory_windows_match_reference():
+    """The feed's restatement against TrajectorySlicerDataset items of the reference, bit for bit."""
+    fx = load_golden("trajectory_windows.npz")
+    sub = fx["subset"]
+    obs, act, lengths = fx["observations"][sub], fx["actions"][sub], fx["lengths"][sub]
+    window, glen, sep = int(fx["window"]), int(fx["future_seq_len"]), int(fx["min_future_sep"])
+    table = O.window_table(lengths, window)
+    np.testing.assert_array_equal(table, fx["slices"])
+    for mode in ("none", "random", "tail", "seq_end"):
+        out = O.slice_windows(obs, act, lengths, table, fx["ids"], goal_len=0 if mode == "none" else glen,
+                              min_future_sep=sep, mode=mode, draws=fx["random::draws"])
+        for key, val in out.items():
+            np.testing.assert_array_equal(val, fx[f"{mode}::{key}"], err_msg=f"{mode}::{key}")
+        assert ("goal_observation" in out) == (mode != "none")
