@@ -90,6 +90,22 @@ def test_null_and_shape_errors_do_not_touch_the_device(lib):
     assert lib.beso_sampler_step(_lib.STEP_DDIM, one, None, one, None, one, 1.0, 1.0, 0, None) == 0
 
 
+def test_feed_argument_errors_do_not_touch_the_device(lib):
+    """beso_gather_windows rejects NULLs, a window longer than the trajectories, an unknown goal mode and a random goal
+    mode without draws before anything is enqueued (status -3), and an empty batch is a no-op."""
+    one = C.c_void_p(0x1000)
+    call = lambda **k: lib.beso_gather_windows(*[k.get(n, d) for n, d in (          # noqa: E731
+        ("observations", one), ("actions", one), ("seq_len", one), ("n_traj", 4), ("t_max", 20), ("obs", 5), ("act", 3),
+        ("slice_traj", one), ("slice_start", one), ("n_slices", 30), ("batch_slices", one), ("draws", one), ("batch", 8),
+        ("window", 6), ("goal_len", 2), ("goal_mode", _lib.GOAL_RANDOM), ("sep", 0), ("obs_out", one), ("act_out", one),
+        ("goal_out", one), ("stream", None))])
+    assert call(batch=0) == 0
+    for bad in (dict(observations=None), dict(batch_slices=None), dict(obs_out=None), dict(window=21), dict(window=0),
+                dict(goal_mode=3), dict(draws=None), dict(goal_out=None), dict(goal_len=-1), dict(n_slices=0), dict(batch=-1)):
+        assert call(**bad) == -3, bad
+    assert call(batch=0, goal_mode=_lib.GOAL_TAIL, draws=None) == 0
+
+
 def test_product_path_has_no_cpu_fallback():
     """CPU tensors must raise, not silently compute somewhere else."""
     import torch
