@@ -943,6 +943,14 @@ def test_feed_from_sliced_and_train_step():
     agent.set_bounds(agent.scaler)
     losses = [agent.train_step(b) for b in feed]
     assert len(losses) == len(feed) and all(np.isfinite(v) for v in losses)
+    # the reference's step loop, fed and evaluated from HBM, across an epoch boundary
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        agent.working_dir, agent.max_train_steps, agent.eval_every_n_steps = tmp, len(feed) + 2, len(feed)
+        test_feed = DeviceTrajectoryFeed.from_sliced(Sliced, 128, DEV, shuffle=False)
+        before = agent.steps
+        agent.train_agent_on_steps(feed, test_feed)
+        assert agent.steps == before + len(feed) + 2 and os.path.exists(os.path.join(tmp, "model_state_dict.pth"))
     Sliced.slices = Sliced.slices[:-1]
     with pytest.raises(ValueError):
         DeviceTrajectoryFeed.from_sliced(Sliced, 64, DEV)
