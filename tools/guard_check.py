@@ -107,8 +107,30 @@ def main():
                 torch.cuda.synchronize()
                 assert torch.isfinite(loss) and all(torch.isfinite(prm.grad).all() for prm in inner.parameters())
                 n_train += 1
-    print(f"guard_check: {n_calls} forward / sampler calls and {n_train} training steps with inputs, weights, gradients and "
-          "workspace at the end of their allocations, no fault")
+    # the training feed: dataset tensors and tables at the tails, windows and goal rows at the very end of the last trajectory
+    from beso_amd.data.trajectory_feed import DeviceTrajectoryFeed
+    n_feed = 0
+    rng = np.random.default_rng(0)
+    for obs_dim, act_dim, window, glen in ((30, 9, 4, 2), (5, 3, 6, 1), (16, 2, 10, 3)):
+        n, t_max = 7, 33
+        lengths = rng.integers(window, t_max + 1, size=n).astype(np.int32)
+        lengths[-1] = t_max
+        obs = rng.standard_normal((n, t_max, obs_dim)).astype(np.float32)
+        act = rng.standard_normal((n, t_max, act_dim)).astype(np.float32)
+        for mode in ({}, {"only_sample_tail": True}, {"only_sample_seq_end": True}):
+            feed = DeviceTrajectoryFeed(obs, act, lengths, window, 64, dev, future_conditional=True, future_seq_len=glen, seed=1, **mode)
+            feed.observations, feed.actions = at_tail(obs, dev), at_tail(act, dev)
+            for name in ("_traj", "_start", "_seq_len"):
+                v = getattr(feed, name).cpu().numpy()
+                setattr(feed, name, at_tail(v.view(np.float32), dev).view(torch.int32))
+            for batch in feed:
+                assert all(torch.isfinite(v).all() for v in batch.values())
+            last = torch.full((5,), feed.n_windows - 1, dtype=torch.int64)
+            feed.gather(last, torch.full((5,), 2 ** 62 - 1, dtype=torch.int64))
+            torch.cuda.synchronize()
+            n_feed += 1
+    print(f"guard_check: {n_calls} forward / sampler calls, {n_train} training steps and {n_feed} feed epochs with inputs, weights, "
+          "gradients, datasets and workspace at the end of their allocations, no fault")
 
 
 if __name__ == "__main__":
