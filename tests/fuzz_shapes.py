@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised soak of the HIP path: random batch sizes / window lengths / conditioning / samplers on the
 shipped shapes, inputs at the end of their allocations (run with PYTORCH_NO_CUDA_MEMORY_CACHING=1), small
-cases checked against the oracle.   python tools/fuzz_shapes.py [seconds] [seed]"""
+cases checked against the oracle.   python tests/fuzz_shapes.py [seconds] [seed]
+(a script, not collected by pytest; it lives under tests/ because it checks against the oracle)"""
 import os
 import sys
 import time
