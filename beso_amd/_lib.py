@@ -23,7 +23,8 @@ SITES = {"off": 0, "gemm_qkv": 1, "gemm_proj": 2, "gemm_fc1": 3, "gemm_fc2": 4, 
 EXPORTS = ["beso_version", "beso_status_string", "beso_last_error", "beso_num_params", "beso_packed_bytes", "beso_pack_weights",
            "beso_workspace_bytes", "beso_score_fwd", "beso_denoise_fwd", "beso_sampler_step", "beso_sample",
            "beso_profile_enable", "beso_profile_read", "beso_debug_set_stamps", "beso_adam_step",
-           "beso_train_workspace_bytes", "beso_grad_floats", "beso_loss_grad", "beso_debug_gemm", "beso_gather_windows"]
+           "beso_train_workspace_bytes", "beso_grad_floats", "beso_loss_grad", "beso_debug_gemm", "beso_gather_windows",
+           "beso_loss_grad_overlap", "beso_grad_early_range"]
 
 
 class BesoConfig(C.Structure):
@@ -99,6 +100,11 @@ def load() -> C.CDLL:
             lib.beso_loss_grad.restype = i32
             lib.beso_loss_grad.argtypes = [cfgp, C.POINTER(vp), i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32,
                                            f32, C.c_uint, f32, vp, sz, vp]
+            if hasattr(lib, "beso_loss_grad_overlap") or not os.environ.get("BESO_HIP_LIB"):
+                lib.beso_loss_grad_overlap.restype = i32
+                lib.beso_loss_grad_overlap.argtypes = lib.beso_loss_grad.argtypes + [vp]
+                lib.beso_grad_early_range.restype = i32
+                lib.beso_grad_early_range.argtypes = [cfgp, C.POINTER(sz), C.POINTER(sz)]
             lib.beso_debug_gemm.restype = i32
             lib.beso_debug_gemm.argtypes = [i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]
         if hasattr(lib, "beso_gather_windows") or not os.environ.get("BESO_HIP_LIB"):

@@ -217,7 +217,18 @@ class BesoAgent(BaseAgent):
             self.optimizer.zero_grad(set_to_none=True)
             masked = inner.mask_cond(goal) if goal is not None else goal
             self._hip_step = step
-            return step.loss_backward(state, action, masked, noise, sigma, grad_scale=1.0 / bdist.world_size())
+            # under data parallelism the all-reduce of the upper layers' gradients starts under the backward of the lower
+            # ones: the call orders self._c1_stream behind the completion of that range (BESO_AMD_C1_OVERLAP=0: one flat
+            # all-reduce after the backward)
+            early = None
+            if bdist.is_distributed() and state.is_cuda and os.environ.get("BESO_AMD_C1_OVERLAP", "1") == "1" \
+                    and not torch.cuda.is_current_stream_capturing():
+                if getattr(self, "_c1_stream", None) is None:
+                    self._c1_stream = torch.cuda.Stream(state.device)
+                early = self._c1_stream
+            self._c1_early = early
+            return step.loss_backward(state, action, masked, noise, sigma, grad_scale=1.0 / bdist.world_size(),
+                                      early_stream=early)
         self._hip_step = None
         loss = self.model.loss(state, action, goal, noise, sigma)
         self.optimizer.zero_grad()
@@ -283,13 +294,16 @@ class BesoAgent(BaseAgent):
         state, action, goal = self.process_batch(batch, predict=False)
         self.model.train()
         self.model.training = True
+        self._c1_early = None
         if self._use_train_graph(state):
             loss = self._graphed_loss_backward(state, action, goal)
         else:
             loss = self._loss_backward(state, action, goal)
         if bdist.is_distributed():
             flat = self._hip_step.flat_grads() if getattr(self, "_hip_step", None) is not None else None
-            if flat is not None:
+            if flat is not None and getattr(self, "_c1_early", None) is not None:
+                bdist.all_reduce_sum_overlapped(flat, self._hip_step.early_range(), self._c1_early)
+            elif flat is not None:
                 bdist.all_reduce_sum(flat)                    # C1 on the flat buffer the kernels wrote (pre-scaled)
             else:
                 if self._grad_bucket is None:

@@ -477,19 +477,37 @@ size_t beso_train_workspace_bytes(const beso_config* cfg, int batch, int t, int 
 
 size_t beso_grad_floats(const beso_config* cfg) { return train_grad_floats(cfg); }
 
-int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
-                   const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
-                   float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop, unsigned int seed,
-                   float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
+int beso_loss_grad_overlap(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
+                           const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
+                           float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
+                           unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes, void* stream,
+                           void* early_stream) {
     hipError_t e = hipSuccess;
     int line = 0;
     int st = train_loss_grad(cfg, params, n_params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch,
                              t, flags, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale, workspace, workspace_bytes, (hipStream_t)stream,
-                             &e, &line);
+                             (hipStream_t)early_stream, &e, &line);
     if (st == BESO_ERR_HIP) {
         snprintf(g_last_error, sizeof(g_last_error), "%s (%d) at train.hip:%d", hipGetErrorName(e), (int)e, line);
     }
     return st;
+}
+
+int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
+                   const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
+                   float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop, unsigned int seed,
+                   float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    return beso_loss_grad_overlap(cfg, params, n_params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
+                                  flags, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale, workspace, workspace_bytes, stream,
+                                  nullptr);
+}
+
+int beso_grad_early_range(const beso_config* cfg, size_t* begin, size_t* end) {
+    if (!cfg || !begin || !end) return BESO_ERR_BAD_ARG;
+    int st = train_validate(cfg, 1, 1);
+    if (st != BESO_OK) return st;
+    train_early_range(cfg, begin, end);
+    return BESO_OK;
 }
 
 int beso_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,

@@ -738,9 +738,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // gradient of the linear layer that consumed its output (assigned: each destination has exactly one source)
 struct LnRedCall { float* dgamma; float* dbeta; float* dbias; };
 struct LnRedTable { LnRedCall c[2 * kMaxLayers + 1]; };
-__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, LnRedTable t, int nblk, int D) {
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, LnRedTable t, int nblk, int D,
+                                                        int call0) {
     __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, which = blockIdx.y, call = blockIdx.z;
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, which = blockIdx.y, call = blockIdx.z + call0;
     const int c = blockIdx.x * 64 + cx;
     const float* src = part + ((size_t)call * nblk * 3 + which) * D;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;          // four loads in flight per thread
@@ -1253,6 +1254,30 @@ size_t train_workspace_bytes(const beso_config* c, int batch, int t, int precisi
     return w.total;
 }
 
+// The data-parallel exchange can start before the backward pass is over: the gradients of transformer layers
+// train_early_layer(c) .. L-1 and of ln_f form one contiguous range of the flat gradient buffer and are completed first.
+// Their weight gradients run as a grouped launch of their own, so the split is placed where that launch is one full
+// round of workgroups (256 CUs x 2): as many upper layers as fit into 512 tiles.  (An even split of the kitchen model,
+// 324 + 324 tiles, costs 0.15 ms per step -- two half-filled rounds; 432 + 216 costs nothing measurable.)
+int train_early_layer(const beso_config* c) {
+    const int L = c->n_layers;
+    if (L < 2) return 0;
+    const int td = (c->embed_dim + kTileMN - 1) / kTileMN, t4 = (4 * c->embed_dim + kTileMN - 1) / kTileMN;
+    const int per_layer = 4 * td * td + 2 * t4 * td;               // q, k, v, proj + fc1 + fc2
+    int n = 512 / per_layer;
+    if (n < 1) n = 1;
+    if (n > L - 1) n = L - 1;
+    return L - n;
+}
+void train_early_range(const beso_config* c, size_t* begin, size_t* end) {
+    const size_t D = (size_t)c->embed_dim, seq = (size_t)c->goal_seq_len + c->obs_seq_len + 1;
+    const size_t per_layer = 4 * D + 4 * (D * D + D) + (4 * D * D + 4 * D) + (4 * D * D + D);
+    const size_t layers0 = seq * D + D * (size_t)c->obs_dim + D;
+    const int l0 = train_early_layer(c);
+    if (l0 < 1) { *begin = *end = 0; return; }                     // fewer than two layers: nothing is early
+    *begin = layers0 + per_layer * (size_t)l0;
+    *end = layers0 + per_layer * (size_t)c->n_layers + 2 * D;      // ... + ln_f weight and bias
+}
 size_t train_grad_floats(const beso_config* c) {
     if (validate_config(c) != BESO_OK) return 0;
     const size_t D = c->embed_dim, seq = c->goal_seq_len + c->obs_seq_len + 1;
@@ -1271,7 +1296,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
                        const float* action, const float* goal, const float* noise, const float* sigma, float* loss_out,
                        int batch, int t, int last_only, float embed_p, float attn_p, float resid_p, uint32_t seed,
                        float grad_scale, char* ws,
-                       const TrainWs& w, hipStream_t s, hipError_t* err, int* err_line) {
+                       const TrainWs& w, hipStream_t s, hipStream_t early_stream, hipError_t* err, int* err_line) {
     const int D = c->embed_dim, H = c->n_heads, hd = D / H, L = c->n_layers, G = c->goal_seq_len;
     const int obs = c->obs_dim, act = c->act_dim, seq = G + c->obs_seq_len + 1;
     const int M = w.M, T = w.T, Ke = w.Ke, ap = w.ap, D3 = 3 * D, D4 = 4 * D;
@@ -1434,7 +1459,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     const int rpw = 4;                                    // rows per wave of the LayerNorm backward
     const int lnb_grid = (M + 4 * rpw - 1) / (4 * rpw);
     LnRedTable lrt;
-    int ln_calls = 0;
+    int ln_calls = 0, ln_reduced = 0;
     // (every call launches lnb_grid blocks so that the partial slabs have one shape; blocks past `rows` write zeros)
     auto ln_bwd = [&](const float* x, size_t st, const float* gamma, const float* dres_in, float* dres_out, E* dxb, int rows,
                       float* dgam, float* dbet, float* dbias, float p_site, uint32_t site, int skip_mod = 0) -> hipError_t {
@@ -1526,12 +1551,26 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, F(w.dx), F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo), M, lp[l].ln1w.g,
                    lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? embed_p : resid_p,
                    first ? kEmbedSite : (uint32_t)(4 * (l - 1) + 2), first ? T : 0));
+        if (early_stream && l == train_early_layer(c) && l > 0) {
+            // the gradients of layers l .. L-1 and ln_f are complete once their weight gradients and LayerNorm sums
+            // have run: do those now and order `early_stream` behind this point (the C1 exchange of that range can
+            // start under the backward of layers l-1 .. 0)
+            TRY(flush_group());
+            hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls), dim3(256), 0, s, (const float*)F(w.ln_part),
+                               lrt, lnb_grid, D, 0);
+            TRY(hipGetLastError());
+            ln_reduced = ln_calls;
+            static thread_local hipEvent_t ev = nullptr;
+            if (!ev) TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            TRY(hipEventRecord(ev, s));
+            TRY(hipStreamWaitEvent(early_stream, ev, 0));
+        }
     }
     // embeddings: dWcat[Ke][D] = Xemb^T dx0, routed to pos_emb / tok_emb / action_emb / sigma_emb after the launch
     TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dx0b), D, D, M, F(w.dw_cat)));
     TRY(flush_group());
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls), dim3(256), 0, s, (const float*)F(w.ln_part), lrt,
-                       lnb_grid, D);
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls - ln_reduced), dim3(256), 0, s,
+                       (const float*)F(w.ln_part), lrt, lnb_grid, D, ln_reduced);
     TRY(hipGetLastError());
     if (mlp_head) {
         TRY(hipMemcpy2DAsync(hw.g, sizeof(float) * Hh, ws + w.dw_head, sizeof(float) * Hp, sizeof(float) * Hh, act,
@@ -1551,7 +1590,8 @@ int train_loss_grad(const beso_config* c, const float* const* params, int n_para
                     const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
                     float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
                     uint32_t seed, float grad_scale,
-                    void* workspace, size_t workspace_bytes, hipStream_t s, hipError_t* err, int* err_line) {
+                    void* workspace, size_t workspace_bytes, hipStream_t s, hipStream_t early_stream, hipError_t* err,
+                    int* err_line) {
     int st = train_validate(c, batch, t);
     if (st != BESO_OK) return st;
     if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32) return BESO_ERR_BAD_ARG;
@@ -1569,10 +1609,10 @@ int train_loss_grad(const beso_config* c, const float* const* params, int n_para
     if (precision == BESO_PREC_FP32)
         return loss_grad_e<float>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
                                   flags & BESO_TRAIN_LAST_ACTION_ONLY, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale,
-                                  (char*)workspace, w, s, err, err_line);
+                                  (char*)workspace, w, s, early_stream, err, err_line);
     return loss_grad_e<uint16_t>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
                                  flags & BESO_TRAIN_LAST_ACTION_ONLY, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale,
-                                 (char*)workspace, w, s, err, err_line);
+                                 (char*)workspace, w, s, early_stream, err, err_line);
 }
 
 // development aid: C[M][N] = op(A) op(B)^T through tgemm (fp32 output), for the layout tests

@@ -106,6 +106,31 @@ def all_reduce_sum(flat: torch.Tensor) -> None:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
 
+def all_reduce_sum_overlapped(flat: torch.Tensor, early_range, early_stream=None, _single_rank_ok: bool = False) -> None:
+    """C1 in three collectives so that the first overlaps the backward pass: ``flat[begin:end]`` (the gradient range
+    ``beso_loss_grad_overlap`` completes first) is reduced from ``early_stream`` -- which the kernels' call has ordered
+    behind the completion of that range -- while the current stream still runs the backward of the lower layers; the two
+    remaining ranges follow on the current stream, which finally waits for the early collective.  RCCL executes each
+    collective on its own stream behind the stream it was issued from, so issuing from ``early_stream`` is what lets it
+    start early.  ``early_stream=None`` (CPU tensors / gloo): the same three reductions, in order."""
+    if not is_distributed() and not (_single_rank_ok and dist.is_initialized()):      # (one-rank groups: the tests)
+        return
+    begin, end = early_range
+    work = None
+    if end > begin:
+        if early_stream is not None:
+            with torch.cuda.stream(early_stream):
+                work = dist.all_reduce(flat[begin:end], op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            dist.all_reduce(flat[begin:end], op=dist.ReduceOp.SUM)
+    if begin > 0:
+        dist.all_reduce(flat[:begin], op=dist.ReduceOp.SUM)
+    if end < flat.numel():
+        dist.all_reduce(flat[end:], op=dist.ReduceOp.SUM)
+    if work is not None:
+        work.wait()                                   # the current stream waits for the early collective
+
+
 def all_reduce_mean(x: torch.Tensor) -> torch.Tensor:
     """C3: mean over the ranks of a small tensor (the logged loss of equal-sized shards), in place."""
     if is_distributed():

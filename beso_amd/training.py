@@ -87,9 +87,17 @@ class HipTrainStep:
         return self._ws
 
     # ------------------------------------------------------------------ the call
+    def early_range(self):
+        """[begin, end) floats of the flat gradient buffer that are complete first (the upper layers + ln_f):
+        what ``run(..., early_stream=...)`` releases to that stream while the rest of the backward still runs."""
+        b, e = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(self.lib.beso_grad_early_range(C.byref(self.cfg), C.byref(b), C.byref(e)), "grad_early_range")
+        return int(b.value), int(e.value)
+
     def run(self, state, action, goal, noise, sigma, grad_scale: float = 1.0, seed: Optional[int] = None,
-            fresh_grads: bool = False, last_action_only: bool = False):
-        """-> (loss 0-d tensor, flat gradient tensor, list of per-parameter views).  Inputs are NOT modified."""
+            fresh_grads: bool = False, last_action_only: bool = False, early_stream=None):
+        """-> (loss 0-d tensor, flat gradient tensor, list of per-parameter views).  Inputs are NOT modified.
+        ``early_stream`` (a torch.cuda.Stream): ordered behind the completion of ``early_range()`` by the call."""
         inner = self.inner
         dev = action.device
         f32 = lambda x: x.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -122,19 +130,22 @@ class HipTrainStep:
         ws = self._workspace(B, t, precision, dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            st = self.lib.beso_loss_grad(C.byref(self.cfg), arr, len(params), flat.data_ptr(), precision,
-                                         state.data_ptr(), action.data_ptr(), gptr, noise.data_ptr(), sigma.data_ptr(),
-                                         loss.data_ptr(), B, t, 1 if last_action_only else 0, float(embed_p), float(attn_p), float(resid_p),
-                                         C.c_uint(seed & 0xFFFFFFFF),
-                                         float(grad_scale), ws.data_ptr(), ws.numel(),
-                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            st = self.lib.beso_loss_grad_overlap(
+                C.byref(self.cfg), arr, len(params), flat.data_ptr(), precision,
+                state.data_ptr(), action.data_ptr(), gptr, noise.data_ptr(), sigma.data_ptr(),
+                loss.data_ptr(), B, t, 1 if last_action_only else 0, float(embed_p), float(attn_p), float(resid_p),
+                C.c_uint(seed & 0xFFFFFFFF), float(grad_scale), ws.data_ptr(), ws.numel(),
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+                C.c_void_p(early_stream.cuda_stream) if early_stream is not None else None)
         _lib.check(st, "loss_grad")
         return loss, flat, views
 
-    def loss_backward(self, state, action, goal, noise, sigma, grad_scale: float = 1.0, seed: Optional[int] = None):
+    def loss_backward(self, state, action, goal, noise, sigma, grad_scale: float = 1.0, seed: Optional[int] = None,
+                      early_stream=None):
         """The training step's ``loss = model.loss(...); loss.backward()``: returns the loss and leaves the
         gradients in ``p.grad`` (views of the persistent flat buffer; accumulated into an existing ``.grad``)."""
-        loss, flat, views = self.run(state, action, goal, noise, sigma, grad_scale, seed, fresh_grads=False)
+        loss, flat, views = self.run(state, action, goal, noise, sigma, grad_scale, seed, fresh_grads=False,
+                                     early_stream=early_stream)
         for p, v in zip(self.inner.parameters(), views):
             if p.grad is None or p.grad.data_ptr() == v.data_ptr():
                 p.grad = v

@@ -14,6 +14,7 @@
  *                                                                      k_diffusion/gc_sampling.py:205-210,296-310,921-923
  *   beso_sample         <- sample_ddim / sample_euler / sample_heun    k_diffusion/gc_sampling.py:167-213,259-314,895-924
  *   beso_loss_grad      <- GCDenoiser.loss + loss.backward()           k_diffusion/score_wrappers.py:45-79, beso_agent.py:228-233
+ *   beso_loss_grad_overlap  (same, with the early gradient range for the overlapped all-reduce: SURVEY 8(e) C1)
  *   beso_adam_step      <- optimizer.step() + ema_helper.update()      beso_agent.py:236-244
  *   beso_gather_windows <- TrajectorySlicerDataset.__getitem__ x batch envs/dataloaders/trajectory_loader.py:160-197
  *
@@ -206,6 +207,21 @@ int beso_gather_windows(const float* observations, const float* actions, const i
                         const long long* batch_slices, const long long* draws, int batch, int window, int goal_len,
                         int goal_mode, int min_future_sep, float* obs_out, float* act_out, float* goal_out, void* stream);
 
+/* The same call for data-parallel training, where the exchange of the gradients (one all-reduce per range) should start
+ * before the backward pass is over.  The gradients of the upper transformer layers l0 .. n_layers-1 and of ln_f are one
+ * contiguous range of grads_flat -- [*begin, *end) floats, beso_grad_early_range -- and are completed FIRST: their weight
+ * gradients and LayerNorm sums run as soon as the chain of data gradients has passed layer l0 (chosen so that those weight
+ * gradients fill one round of workgroups: 4 of the 6 kitchen layers), and `early_stream`
+ * (a second hipStream_t) is then made to wait for exactly that point (an event recorded on `stream`).  Work the caller
+ * enqueues on early_stream after the call returns -- the all-reduce of that range -- runs under the backward of the
+ * lower layers; everything else in grads_flat is final at the end of `stream` as before.  early_stream = NULL is
+ * beso_loss_grad.  With fewer than two layers the range is empty and early_stream is left alone.                    */
+int beso_grad_early_range(const beso_config* cfg, size_t* begin, size_t* end);
+int beso_loss_grad_overlap(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
+                           const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
+                           float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
+                           unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes, void* stream,
+                           void* early_stream);
 /* Development aid (tests of the operand layouts of the training GEMM): C[M][N] (fp32, ldc) = sum_k A(m,k) B(n,k);
  * a_kslow / b_kslow = 1: the operand is stored [K][ld] (contraction index slow), 0: [rows][ld] (k contiguous).
  * Supported pairs: (0,0), (0,1), (1,1).  splits > 1 accumulates split-K partial sums into a ZEROED C.      */

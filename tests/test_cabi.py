@@ -106,6 +106,33 @@ def test_feed_argument_errors_do_not_touch_the_device(lib):
     assert call(batch=0, goal_mode=_lib.GOAL_TAIL, draws=None) == 0
 
 
+def test_early_gradient_range_matches_parameter_layout(lib):
+    """beso_grad_early_range = [offset of blocks[l0].ln1.weight, end of ln_f.bias) in the order of the parameters, 1 <= l0 < L."""
+    import torch
+    from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
+    for kw in (dict(state_dim=7, action_dim=3, embed_dim=48, n_layers=4, n_heads=6, goal_seq_len=2, obs_seq_len=3, linear_output=True),
+               dict(state_dim=5, action_dim=2, embed_dim=32, n_layers=3, n_heads=4, goal_seq_len=1, obs_seq_len=4,
+                    linear_output=False),
+               dict(state_dim=5, action_dim=2, embed_dim=32, n_layers=1, n_heads=4, goal_seq_len=1, obs_seq_len=4, linear_output=True)):
+        net = DiffusionGPT(device="cpu", goal_conditioned=True, embed_pdrob=0.0, attn_pdrop=0.0, resid_pdrop=0.0, **kw)
+        cfg = net.shape(0.5).c_struct()
+        b, e = C.c_size_t(7), C.c_size_t(7)
+        assert lib.beso_grad_early_range(C.byref(cfg), C.byref(b), C.byref(e)) == 0
+        offs, off = {}, 0
+        for name, prm in net.named_parameters():
+            offs[name] = (off, off + prm.numel())
+            off += prm.numel()
+        assert off == lib.beso_grad_floats(C.byref(cfg))
+        L = kw["n_layers"]
+        if L < 2:
+            assert b.value == e.value
+            continue
+        starts = {offs[next(n for n in offs if n.startswith(f"blocks.{l}."))][0]: l for l in range(L)}
+        assert b.value in starts and 1 <= starts[b.value] <= L - 1, (b.value, starts)     # the first parameter of an upper layer
+        assert e.value == offs["ln_f.bias"][1]
+    assert lib.beso_grad_early_range(None, C.byref(b), C.byref(e)) == -3
+
+
 def test_product_path_has_no_cpu_fallback():
     """CPU tensors must raise, not silently compute somewhere else."""
     import torch

@@ -62,6 +62,11 @@ def _worker(rank, world, port, out):
     flat_g = torch.full((7,), float(rank + 1) / world)
     bdist.all_reduce_sum(flat_g)
     assert torch.allclose(flat_g, torch.full((7,), 1.5))
+    # --- the same exchange split into the early range and the rest (the overlapped form; no streams on the CPU)
+    for rng in ((3, 6), (0, 4), (2, 7), (0, 7), (5, 5)):
+        flat_g = torch.arange(7, dtype=torch.float32) * (rank + 1) / world
+        bdist.all_reduce_sum_overlapped(flat_g, rng, None)
+        assert torch.allclose(flat_g, torch.arange(7, dtype=torch.float32) * 1.5), rng
     # --- C2: broadcast makes replicas identical
     cfg, agent = _make_agent(seed=100 + rank)           # different init per rank on purpose
     bdist.broadcast_parameters(agent.model.get_params(), src=0)

@@ -954,3 +954,82 @@ def test_feed_from_sliced_and_train_step():
     Sliced.slices = Sliced.slices[:-1]
     with pytest.raises(ValueError):
         DeviceTrajectoryFeed.from_sliced(Sliced, 64, DEV)
+
+
+# ------------------------------------------------------------------------------------------------
+# overlapped gradient exchange (beso_loss_grad_overlap)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg_name,precision", [("kitchen", "bf16"), ("tiny", "fp32"), ("tiny_mlp_head", "fp32")])
+def test_early_gradient_range_is_final_when_the_early_stream_runs(cfg_name, precision):
+    """The gradients with the early range released to a second stream equal the plain call's, and a copy of the early
+    range enqueued on that stream right after the call already holds the final values (the stream was ordered behind
+    their completion, not behind the whole backward)."""
+    from beso_amd.training import HipTrainStep
+    cfg = O.CONFIGS[cfg_name]
+    m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.05), precision)
+    B = 256 if cfg_name == "kitchen" else 9
+    state, action, goal, noise, sigma = _train_inputs(cfg, B, seed=4)
+    step = HipTrainStep(m.inner_model, cfg.sigma_data)
+    b, e = step.early_range()
+    if cfg.n_layers < 2:
+        assert b == e                                                   # nothing is early; the call must still work
+    else:
+        assert 0 < b < e < step.n_grad
+    loss0, flat0, _ = step.run(state, action, goal, noise, sigma, seed=11, fresh_grads=True)
+    side = torch.cuda.Stream(DEV)
+    early = torch.empty(e - b, device=DEV)
+    for _ in range(3):                                                  # (repeat: the event object is reused across calls)
+        loss1, flat1, _ = step.run(state, action, goal, noise, sigma, seed=11, fresh_grads=True, early_stream=side)
+        with torch.cuda.stream(side):
+            early.copy_(flat1[b:e], non_blocking=True)
+        torch.cuda.synchronize()
+        assert torch.equal(early, flat1[b:e]), "the early range changed after the early stream was released"
+        assert e == b or float(early.abs().max()) > 0.0
+        scale = float(flat0.abs().max())
+        assert float((flat1 - flat0).abs().max()) <= 2e-6 * scale      # (bias sums accumulate with atomics)
+        assert abs(float(loss1) - float(loss0)) <= 1e-6 * abs(float(loss0))
+
+
+def test_overlapped_all_reduce_on_a_one_rank_group():
+    """all_reduce_sum_overlapped through RCCL (a one-rank group on this GPU: the collectives are identities, the stream
+    and work-handle choreography is the real one), driven by BesoAgent.train_step's data-parallel branch."""
+    import torch.distributed as dist
+    from beso_amd import distributed as bdist
+    from test_host_logic import build_agent
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    real = bdist.is_distributed
+    try:
+        cfg = O.TINY
+        w = O.make_weights(cfg, seed=1, std=0.05)
+        torch.manual_seed(3)
+        batch = {"observation": torch.randn(32, cfg.obs_seq_len, cfg.obs_dim, device=DEV),
+                 "action": torch.randn(32, cfg.obs_seq_len, cfg.act_dim, device=DEV),
+                 "goal_observation": torch.randn(32, cfg.goal_seq_len, cfg.obs_dim, device=DEV)}
+        params = {}
+        for overlap in ("1", "0"):
+            os.environ["BESO_AMD_C1_OVERLAP"] = overlap
+            bdist.is_distributed = lambda: True                         # one rank, but take the data-parallel branch
+            real_sum = bdist.all_reduce_sum_overlapped
+            calls = []
+            bdist.all_reduce_sum_overlapped = lambda f, r, st: (calls.append(r), real_sum(f, r, st, _single_rank_ok=True))
+            agent = build_agent(cfg, lambda: make_module(cfg, w, "fp32"), device=DEV)
+            agent.get_scaler(Scaler(np.random.default_rng(0).standard_normal((64, cfg.obs_dim)).astype(np.float32),
+                                    np.random.default_rng(1).standard_normal((64, cfg.act_dim)).astype(np.float32), True, DEV))
+            agent.set_bounds(agent.scaler)
+            torch.manual_seed(9)
+            losses = [agent.train_step(batch) for _ in range(3)]
+            bdist.all_reduce_sum_overlapped = real_sum
+            assert (len(calls) == 3) == (overlap == "1") and all(np.isfinite(v) for v in losses)
+            params[overlap] = (torch.cat([q.detach().reshape(-1) for q in agent.model.get_params()]), losses)
+        # same trajectory: equal losses; equal parameters except where the true gradient is zero (key biases: Adam turns
+        # the atomics' rounding noise into +-lr there)
+        assert np.allclose(params["1"][1], params["0"][1], rtol=1e-4), (params["1"][1], params["0"][1])
+        diff = (params["1"][0] - params["0"][0]).abs()
+        print(f"[overlap] losses {params['1'][1]} vs {params['0'][1]}; parameters differing by > 1e-6: {float((diff > 1e-6).float().mean()):.4f}")
+        assert float((diff > 1e-6).float().mean()) < 0.03 and float(diff.max()) < 1e-3
+    finally:
+        bdist.is_distributed = real
+        os.environ.pop("BESO_AMD_C1_OVERLAP", None)
+        dist.destroy_process_group()
