@@ -437,6 +437,7 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
 }
 
 void beso_debug_set_stamps(void* device_buf, int capacity_u64) { fused_set_stamps(device_buf, capacity_u64); }
+void beso_debug_set_small_batch_max(int n) { fused_set_small_batch_max(n); }
 
 int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg, float* exp_avg_sq, float* ema,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,

@@ -15,6 +15,7 @@ bool   fused_has_lin_blocks(const Layout& lay, int precision);
 int    fused_lin_block(const Layout& lay, const char* packed, int layer, int which, float* x, void* buf, int ld, int M,
                        hipStream_t s);
 void   fused_set_stamps(void* buf, int cap);
+void   fused_set_small_batch_max(int n);
 int    forward_fused(const Layout& lay, const Workspace& ws, const char* packed, int precision, const FwdArgs& a,
                      char* wsp, hipStream_t s);
 

@@ -1168,7 +1168,8 @@ __device__ __forceinline__ void attn_prefetch(u32x4 (&qE)[3], u32x4 (&qO)[3], co
 // the next pair before core(B); each head's projection weights (two k-steps: all of them) are requested
 // before the barrier that precedes its core.
 // HG > 1: a virtual head is HG real heads of `hd` dims side by side (FusedDims); H counts virtual heads.
-template <int RPW, int KS, int HG, int NTP = kNTT>      // NTP: token tiles that receive the out-projection (last layer: action tokens only)
+template <int RPW, int KS, int HG, int NTP = kNTT, int NTQ = kNTT>   // NTP: token tiles that receive the out-projection (last layer:
+                                                                     // action tokens only); NTQ: token tiles that hold tokens at all
 __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsigned char* u,
                                            const u32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
                                            const u32x4* __restrict__ wproj, int H, int hd, int Tn, int n_samples,
@@ -1183,17 +1184,17 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     // `ln` (= lane) is re-made opaque in every pair iteration: the LDS addresses below are loop invariant
     // and would otherwise be hoisted out of the pair loop and spilled (24 VGPRs).
     int ln = lane;
-    auto write_qkv = [&](const f32x4 (&qa)[3][kNTT]) {
+    auto write_qkv = [&](const f32x4 (&qa)[3][NTQ]) {
         const int n = ln & 15, g = ln >> 4;
-        int row[kNTT];                                    // natural q/k/v row of this lane's token in each token tile
+        int row[NTQ];                                     // natural q/k/v row of this lane's token in each token tile
 #pragma unroll
-        for (int t = 0; t < kNTT; ++t) row[t] = tb->row_of_slot[t * 16 + n];
+        for (int t = 0; t < NTQ; ++t) row[t] = tb->row_of_slot[t * 16 + n];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int rt = 3 * wa + i, part = rt >> 2, d0 = (rt & 3) * 16 + 4 * g;
             uint16_t* dst = qkv + (size_t)part * kQKVRows * kQKVRow + d0;
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) {
+            for (int t = 0; t < NTQ; ++t) {
                 uint2 pk;
                 pk.x = pack_bf16x2(qa[i][t][0], qa[i][t][1]);
                 pk.y = pack_bf16x2(qa[i][t][2], qa[i][t][3]);
@@ -1341,15 +1342,15 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         const int g = ln >> 4;
         stamp(st, 10);
         u32x4 aE[RPW], aO[RPW];
-        f32x4 qa[3][kNTT];
+        f32x4 qa[3][NTQ];
         // ---- q, k, v of both heads for all tokens of the tile
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const f32x4 bv = *(const f32x4*)(bqkv + ((hA + hsel) * 12 + 3 * wa + i) * 16 + 4 * g);
 #pragma unroll
-            for (int t = 0; t < kNTT; ++t) qa[i][t] = bv;
+            for (int t = 0; t < NTQ; ++t) qa[i][t] = bv;
         }
-        gemm_phase<3, kNTT, kt16(KS)>(qa, qE, qO, qkv_a(pair), 24, xnT + lane, KS * 64, 64, KS);
+        gemm_phase<3, NTQ, kt16(KS)>(qa, qE, qO, qkv_a(pair), 24, xnT + lane, KS * 64, 64, KS);
         prefetch_a<RPW>(aE, aO, proj_a(hA), kWaves * RPW);
         if (hsel == 0) write_qkv(qa);
         stamp(st, 11);
@@ -1500,7 +1501,11 @@ __global__ __launch_bounds__(512, 2) void proj_block_kernel(float* __restrict__ 
 // NTL: token tiles that hold the action tokens of a full tile (8 samples x window, rounded up to an even count):
 // in the LAST layer only those go through the out-projection, LayerNorm-2 and the MLP -- nothing else reaches
 // the head (score_gpts.py:344-354; SURVEY.md section 8 parity note 7: numerically identical per row).
-template <int RPW, int KS, int HG, int NTL>
+// SPW / NTA: samples and token tiles per workgroup.  8 / 6 is the throughput instance; 2 / 2 is the latency instance for
+// small batches (rollouts, BASELINE config 1): a workgroup carries two samples in two token tiles, so a batch of B
+// spreads over B/2 CUs and every phase runs a third of the MFMA / LDS / VALU work -- what is left is the L2 -> CU
+// stream of the weights.  Same phases, same per-sample arithmetic (results are bit-identical between the instances).
+template <int RPW, int KS, int HG, int NTL, int SPW = kSPW, int NTA = kNTT>
 __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, const char* __restrict__ lw0,
                                                         FusedDims d, int l0, int l1, int n_samples_total, int Tn,
                                                         EdgeArgs e, unsigned long long* stamps, int cap) {
@@ -1510,8 +1515,9 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
-    const int s0 = blockIdx.x * kSPW;
-    const int n_samples = min(kSPW, n_samples_total - s0);
+    constexpr int NTLa = NTL < NTA ? NTL : NTA;
+    const int s0 = blockIdx.x * SPW;
+    const int n_samples = min(SPW, n_samples_total - s0);
     const int m0 = s0 * Tn, m_end = m0 + n_samples * Tn;
     // LDS that is read but never written by the phases must be finite: the attention-output fragments of
     // padding tokens, and the 8 q/k/v rows past the last token slot (a sample's 16-row window reaches them)
@@ -1542,7 +1548,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     // The last layer (when this launch contains it and the action tokens of the tile fit NTL token tiles) runs its
     // out-projection, LayerNorm-2 and MLP on the action-token tiles only; it is peeled off the loop -- a branch
     // between the two variants INSIDE the loop costs 150 spilled VGPRs.
-    const bool peel = actions_first && l1 == d.L && l1 > l0 && n_samples * e.t <= 16 * NTL;
+    const bool peel = actions_first && l1 == d.L && l1 > l0 && n_samples * e.t <= 16 * NTLa;
     const int l_loop_end = peel ? l1 - 1 : l1;
     auto layer_weights = [&](int l) {
 #if BESO_FUSED_ABLATE == 4
@@ -1557,19 +1563,19 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         stamp(st, 2);
         u32x4 qE[3], qO[3];
         attn_prefetch<KS>(qE, qO, (const u32x4*)(lw + d.o_wqkv), w, lane);
-        layernorm_to_lds<RPW, KS, kWaves>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+        layernorm_to_lds<RPW, KS, kWaves, true, NTA>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                           (const float*)(lw + d.o_bproj), st);
         stamp(st, 7);
-        attn_phase<RPW, KS, HG>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
+        attn_phase<RPW, KS, HG, NTA, NTA>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
                                 (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
                                 lane, tb, qE, qO, st);
         stamp(st, 3);
         u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
         mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)lw, w, lane);
-        layernorm_to_lds<RPW, KS, kWaves>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+        layernorm_to_lds<RPW, KS, kWaves, true, NTA>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                           (const float*)(lw + d.o_b2), st);
         stamp(st, 6);
-        mlp_phase<RPW, KS, kWaves>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
+        mlp_phase<RPW, KS, kWaves, NTA>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
                                    (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
     }
     if (peel) {
@@ -1577,19 +1583,19 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         stamp(st, 2);
         u32x4 qE[3], qO[3];
         attn_prefetch<KS>(qE, qO, (const u32x4*)(lw + d.o_wqkv), w, lane);
-        layernorm_to_lds<RPW, KS, kWaves>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+        layernorm_to_lds<RPW, KS, kWaves, true, NTA>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                           (const float*)(lw + d.o_bproj), st);
         stamp(st, 7);
-        attn_phase<RPW, KS, HG, NTL>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
+        attn_phase<RPW, KS, HG, NTLa, NTA>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
                                      (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
                                      lane, tb, qE, qO, st);
         stamp(st, 3);
         u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
         mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)lw, w, lane);
-        layernorm_to_lds<RPW, KS, kWaves, true, NTL>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+        layernorm_to_lds<RPW, KS, kWaves, true, NTLa>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                                      (const float*)(lw + d.o_b2), st);
         stamp(st, 6);
-        mlp_phase<RPW, KS, kWaves, NTL>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
+        mlp_phase<RPW, KS, kWaves, NTLa>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
                                         (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
     }
     stamp(st, 4);
@@ -1639,10 +1645,23 @@ hipError_t launch_lin_blocks(int which, float* x, const char* lw, const FusedDim
     return hipGetLastError();
 }
 
+int g_small_batch_max = 512;           // batches up to this size take the latency instance (beso_debug_set_small_batch_max)
+
 template <int RPW, int KS, int HG, int NTL>
 hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
                          const EdgeArgs& edge, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS);
+    constexpr int kSmallSPW = 2, kSmallNT = 2;
+    // latency instance: two samples' tokens and the second sample's 16-row attention window must fit its token tiles
+    if (n_samples <= g_small_batch_max && kSmallSPW * Tn <= 16 * kSmallNT && (kSmallSPW - 1) * Tn + 16 <= 16 * kSmallNT) {
+        static bool attr_s = false;
+        hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL, kSmallSPW, kSmallNT>, L.total, &attr_s);
+        if (e != hipSuccess) return e;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL((layers_kernel<RPW, KS, HG, NTL, kSmallSPW, kSmallNT>), dim3((n_samples + kSmallSPW - 1) / kSmallSPW),
+                           dim3(512), L.total, s, x, lw0, d, l0, l1, n_samples, Tn, edge, g_stamps, g_stamps_cap);
+        return hipGetLastError();
+    }
     static bool attr = false;
     hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL>, L.total, &attr);
     if (e != hipSuccess) return e;
@@ -1826,6 +1845,8 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     else return BESO_ERR_UNSUPPORTED;
     return err == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
+
+void fused_set_small_batch_max(int n) { g_small_batch_max = n; }
 
 void fused_set_stamps(void* buf, int cap) {
     g_stamps = (unsigned long long*)buf;

@@ -413,12 +413,24 @@ def test_graphed_train_step_matches_eager(monkeypatch):
         assert rel_err(a, b) < 5e-3            # Adam amplifies last-bit differences to O(lr), see above
 
 
+@pytest.fixture
+def fused_instance(request):
+    """Selects the instance of the fused kernel small batches run on: 'latency' (two samples per workgroup, the default
+    up to 512 samples) or 'throughput' (eight per workgroup, what larger batches use)."""
+    from beso_amd import _lib
+    lib = _lib.load()
+    lib.beso_debug_set_small_batch_max(0 if request.param == "throughput" else 512)
+    yield request.param
+    lib.beso_debug_set_small_batch_max(512)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused_instance", ["latency", "throughput"], indirect=True)
 @pytest.mark.parametrize("cfg_name", ["kitchen", "block_push"])
-def test_fused_path_ragged_shapes_and_cfg(cfg_name):
+def test_fused_path_ragged_shapes_and_cfg(cfg_name, fused_instance):
     """The fused layers kernel (bf16) on what rollouts feed it: B = 1, batches that do not fill a workgroup's
-    8-sample tile (or leave its last tile ragged), every warm-up window t = 1 .. W, unconditional calls, and
-    classifier-free pairs with an odd batch -- each against the oracle."""
+    sample tile (or leave its last tile ragged), every warm-up window t = 1 .. W, unconditional calls, and
+    classifier-free pairs with an odd batch -- each against the oracle, through both instances of the kernel."""
     from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
     cfg = O.CONFIGS[cfg_name]
     w = O.make_weights(cfg, seed=21, std=0.03)
@@ -437,8 +449,36 @@ def test_fused_path_ragged_shapes_and_cfg(cfg_name):
             out_cfg = ClassifierFreeSampleModel(m, 2.0)(s, a, g, sg)
             ref_cfg = O.denoise_cfg(w, cfg, s_np, a_np, g_np, sg_np, 2.0)
             worst = max(worst, rel_err(out_cfg.cpu().numpy(), ref_cfg))
-    print(f"[parity] fused ragged/CFG {cfg_name} bf16: {worst:.3e}")
+    print(f"[parity] fused ragged/CFG {cfg_name} bf16 ({fused_instance} instance): {worst:.3e}")
     assert worst < TOL["bf16"]
+
+
+@pytest.mark.parametrize("cfg_name", ["kitchen", "block_push"])
+def test_fused_instances_are_bit_identical(cfg_name):
+    """The latency instance (two samples per workgroup) and the throughput instance (eight) of the fused kernel run the
+    same per-sample arithmetic: equal bits for every batch size, window, conditioning mode and through a sampler loop."""
+    from beso_amd import _lib
+    from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+    from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
+    lib = _lib.load()
+    cfg = O.CONFIGS[cfg_name]
+    m = make_module(cfg, O.make_weights(cfg, seed=5, std=0.04), "bf16")
+    cfgm = ClassifierFreeSampleModel(m, 1.5)
+    sig = ks.get_sigmas_exponential(4, 0.05, 1.0)
+    try:
+        with torch.no_grad():
+            for B, t in [(1, 1), (2, cfg.obs_seq_len), (5, 2), (64, cfg.obs_seq_len), (257, cfg.obs_seq_len - 1), (512, cfg.obs_seq_len)]:
+                s, g, a = (G(v) for v in O.make_inputs(cfg, B, seed=B + t, t=t))
+                sg = G(np.linspace(0.05, 1.0, B).astype(np.float32))
+                outs = []
+                for limit in (0, 512):
+                    lib.beso_debug_set_small_batch_max(limit)
+                    outs.append((m(s, a, g, sg), m(s, a, g, sg, uncond=True), cfgm(s, a, g, sg),
+                                 ks.sample_heun(cfgm, s, a, g, sig, disable=True)))
+                for x8, x2 in zip(*outs):
+                    assert torch.isfinite(x2).all() and torch.equal(x8, x2), (B, t)
+    finally:
+        lib.beso_debug_set_small_batch_max(512)
 
 
 @pytest.mark.gpu
