@@ -1651,14 +1651,24 @@ template <int RPW, int KS, int HG, int NTL>
 hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
                          const EdgeArgs& edge, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS);
-    constexpr int kSmallSPW = 2, kSmallNT = 2;
-    // latency instance: two samples' tokens and the second sample's 16-row attention window must fit its token tiles
+    constexpr int kSmallSPW = 2, kSmallNT = 2, kMidSPW = 4, kMidNT = 4;
+    // latency instances: the samples' tokens and the last sample's 16-row attention window must fit the token tiles
     if (n_samples <= g_small_batch_max && kSmallSPW * Tn <= 16 * kSmallNT && (kSmallSPW - 1) * Tn + 16 <= 16 * kSmallNT) {
         static bool attr_s = false;
         hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL, kSmallSPW, kSmallNT>, L.total, &attr_s);
         if (e != hipSuccess) return e;
         (void)hipGetLastError();
         hipLaunchKernelGGL((layers_kernel<RPW, KS, HG, NTL, kSmallSPW, kSmallNT>), dim3((n_samples + kSmallSPW - 1) / kSmallSPW),
+                           dim3(512), L.total, s, x, lw0, d, l0, l1, n_samples, Tn, edge, g_stamps, g_stamps_cap);
+        return hipGetLastError();
+    }
+    // up to one workgroup of four samples per CU: two thirds of the throughput instance's work per workgroup
+    if (n_samples <= 2 * g_small_batch_max && kMidSPW * Tn <= 16 * kMidNT && (kMidSPW - 1) * Tn + 16 <= 16 * kMidNT) {
+        static bool attr_m = false;
+        hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL, kMidSPW, kMidNT>, L.total, &attr_m);
+        if (e != hipSuccess) return e;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL((layers_kernel<RPW, KS, HG, NTL, kMidSPW, kMidNT>), dim3((n_samples + kMidSPW - 1) / kMidSPW),
                            dim3(512), L.total, s, x, lw0, d, l0, l1, n_samples, Tn, edge, g_stamps, g_stamps_cap);
         return hipGetLastError();
     }

@@ -242,7 +242,8 @@ void beso_profile_enable(int site);
  * kernels appends {phase id, shader clock} pairs to it (NULL / 0 switches it off).               */
 void beso_debug_set_stamps(void* device_buf, int capacity_u64);
 /* Development aid: batches of at most `n` (virtual) samples run the latency instance of the fused kernel (two samples per
- * workgroup); larger ones the throughput instance (eight).  Default 512; 0 switches the latency instance off.          */
+ * workgroup), up to 2n the four-sample instance, larger ones the throughput instance (eight).  Default 512; 0 switches
+ * both latency instances off.                                                                                          */
 void beso_debug_set_small_batch_max(int n);
 int  beso_profile_read(double* total_ms, int* launches);
 

@@ -455,8 +455,8 @@ def test_fused_path_ragged_shapes_and_cfg(cfg_name, fused_instance):
 
 @pytest.mark.parametrize("cfg_name", ["kitchen", "block_push"])
 def test_fused_instances_are_bit_identical(cfg_name):
-    """The latency instance (two samples per workgroup) and the throughput instance (eight) of the fused kernel run the
-    same per-sample arithmetic: equal bits for every batch size, window, conditioning mode and through a sampler loop."""
+    """The latency instances (two samples per workgroup up to 512 samples -- 256 with a classifier-free pair --, four up
+    to 1024) and the throughput instance (eight) of the fused kernel run the same per-sample arithmetic: equal bits for every batch size, window, conditioning mode and through a sampler loop."""
     from beso_amd import _lib
     from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
     from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
@@ -467,7 +467,8 @@ def test_fused_instances_are_bit_identical(cfg_name):
     sig = ks.get_sigmas_exponential(4, 0.05, 1.0)
     try:
         with torch.no_grad():
-            for B, t in [(1, 1), (2, cfg.obs_seq_len), (5, 2), (64, cfg.obs_seq_len), (257, cfg.obs_seq_len - 1), (512, cfg.obs_seq_len)]:
+            for B, t in [(1, 1), (2, cfg.obs_seq_len), (5, 2), (64, cfg.obs_seq_len), (257, cfg.obs_seq_len - 1), (512, cfg.obs_seq_len),
+                         (513, cfg.obs_seq_len), (771, 2), (1024, cfg.obs_seq_len)]:      # 2, then 4 samples per workgroup
                 s, g, a = (G(v) for v in O.make_inputs(cfg, B, seed=B + t, t=t))
                 sg = G(np.linspace(0.05, 1.0, B).astype(np.float32))
                 outs = []
