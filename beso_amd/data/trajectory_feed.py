@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .. import distributed as bdist
 
 
 def window_table(seq_lengths: Sequence[int], window: int):
@@ -43,7 +44,8 @@ class DeviceTrajectoryFeed:
     def __init__(self, observations, actions, seq_lengths, window: int, batch_size: int, device,
                  future_conditional: bool = False, min_future_sep: int = 0, future_seq_len: Optional[int] = None,
                  only_sample_tail: bool = False, only_sample_seq_end: bool = False, shuffle: bool = True,
-                 drop_last: bool = False, seed: Optional[int] = None, rank: int = 0, world_size: int = 1):
+                 drop_last: bool = False, seed: Optional[int] = None, rank: Optional[int] = None,
+                 world_size: Optional[int] = None):
         if future_conditional and future_seq_len is None:
             raise AssertionError("must specify a future_seq_len")                      # trajectory_loader.py:115
         self.lib = _lib.load()                                                         # no library, no feed
@@ -71,12 +73,19 @@ class DeviceTrajectoryFeed:
         self._traj = torch.from_numpy(traj).to(self.device)
         self._start = torch.from_numpy(start).to(self.device)
         self.shuffle, self.drop_last = bool(shuffle), bool(drop_last)
-        self.rank, self.world_size = int(rank), int(world_size)
-        # data-parallel ranks draw the SAME permutation (same seed) and take interleaved shares of it, so that one
-        # epoch of the job still sees every window once; the goal draws differ per rank
+        # data-parallel ranks (default: the initialised process group) draw the SAME permutation (same seed -- rank 0's is
+        # broadcast when none is given) and take interleaved shares of it, so that one epoch of the job still sees every
+        # window once; the goal draws differ per rank
+        self.rank = bdist.rank() if rank is None else int(rank)
+        self.world_size = bdist.world_size() if world_size is None else int(world_size)
         self._perm_gen = torch.Generator(device=self.device)
         self._draw_gen = torch.Generator(device=self.device)
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if seed is None else int(seed)
+        if seed is None:
+            box = [int(torch.randint(0, 2 ** 31 - 1, (1,)).item())]
+            if bdist.is_distributed() and world_size is None:
+                torch.distributed.broadcast_object_list(box, src=0)
+            seed = box[0]
+        seed = int(seed)
         self._perm_gen.manual_seed(seed)
         self._draw_gen.manual_seed(seed * 1000003 + 17 + self.rank)
 
