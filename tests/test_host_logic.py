@@ -492,3 +492,66 @@ def test_feed_window_table_and_cpu_refusal():
     assert window_table([3, 2], 5)[0].size == 0
     with pytest.raises((ValueError, RuntimeError)):
         DeviceTrajectoryFeed(fx["observations"], fx["actions"], fx["lengths"], 6, 8, "cpu")
+
+
+def _shipped_config(dev, task):
+    """The nested `_target_` config the reference ships (keys of configs/agents/beso_{kitchen,block_push}.yaml,
+    agents/model/diffusion_gpt.yaml, agents/input_encoder/no_encoder.yaml, interpolations resolved from
+    franka_kitchen_main_config.yaml:23-66 / block_push_main_config.yaml:27-67), `beso.` -> `beso_amd.` in the targets."""
+    k = task == "kitchen"
+    cfg = {
+        "_target_": "beso_amd.agents.diffusion_agents.beso_agent.BesoAgent", "_recursive_": False,
+        "model": {
+            "_target_": "beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers.GCDenoiser", "_recursive_": False,
+            "sigma_data": 0.5,
+            "inner_model": {
+                "_target_": "beso_amd.agents.diffusion_agents.k_diffusion.score_gpts.DiffusionGPT",
+                "state_dim": 30 if k else 10, "action_dim": 9 if k else 2, "goal_conditioned": True, "embed_dim": 360 if k else 240,
+                "n_layers": 6 if k else 4, "goal_seq_len": 2 if k else 1,
+                "obs_seq_len": 4 if k else 5, "sigma_vocab_size": 3, "embed_pdrob": 0, "goal_drop": 0.1, "attn_pdrop": 0.3 if k else 0.05,
+                "resid_pdrop": 0 if k else 0.05,
+                "time_embedding_fn": {"_target_": "beso_amd.agents.diffusion_agents.k_diffusion.utils.return_time_sigma_embedding_model",
+                                      "embedding_type": "Linear", "time_embed_dim": 360 if k else 240, "device": dev},
+                "n_heads": 6 if k else 12, "device": dev, "linear_output": True}},
+        "input_encoder": {"_target_": "beso_amd.agents.input_encoders.obs_encoder.NoEncoder", "device": dev,
+                          "state_modality": "observation", "goal_modality": "goal_observation"},
+        "optimization": ({"_target_": "torch.optim.AdamW", "lr": 1e-4, "betas": [0.9, 0.999]} if k
+                         else {"_target_": "torch.optim.Adam", "lr": 1e-4}),
+        "lr_scheduler": {"_target_": "torch.optim.lr_scheduler.StepLR", "step_size": 100, "gamma": 0.99},
+        "obs_modalities": ["observation"], "goal_modalities": ["goal_observation"], "target_modality": "action",
+        "train_method": "steps", "max_epochs": 500 if k else 100, "goal_conditioned": True, "pred_last_action_only": False,
+        "eval_every_n_steps": 4000, "max_train_steps": 40000 if k else 60000, "num_sampling_steps": 3, "sampler_type": "ddim", "sigma_data": 0.5,
+        "rho": 5.0, "sigma_min": 0.005 if k else 0.05, "sigma_max": 1, "sigma_sample_density_type": "loglogistic",
+        "sigma_sample_density_mean": -0.6, "sigma_sample_density_std": 1.6, "use_ema": True, "decay": 0.999, "device": dev,
+        "update_ema_every_n_steps": 1, "goal_window_size": 2 if k else 1, "window_size": 4 if k else 5, "patience": 80}
+    return cfg
+
+
+def test_shipped_kitchen_config_surface():
+    """The agent built from the kitchen config (device cpu: no GPU in this suite): 9,381,249 parameters, AdamW,
+    StepLR, the contexts sized by the window."""
+    dev = "cpu"
+    agent = instantiate(_shipped_config(dev, "kitchen"))
+    assert isinstance(agent, BesoAgent) and isinstance(agent.input_encoder, NoEncoder)
+    assert sum(p.numel() for p in agent.model.parameters()) == 9_381_249
+    inner = agent.model.inner_model
+    assert (inner.embed_dim, inner.goal_seq_len, inner.obs_seq_len) == (360, 2, 4) and inner._pdrops == (0, 0.3, 0)
+    assert type(agent.optimizer).__name__ in ("AdamW", "FusedAdam") and agent.optimizer.param_groups[0]["lr"] == 1e-4
+    assert isinstance(agent.lr_scheduler, torch.optim.lr_scheduler.StepLR) and agent.lr_scheduler.step_size == 100
+    assert agent.obs_context.maxlen == 4 and agent.goal_context.maxlen == 2 and agent.action_context.maxlen == 3
+    assert (agent.sampler_type, agent.num_sampling_steps, agent.sigma_min, agent.sigma_max) == ("ddim", 3, 0.005, 1)
+    sig = agent.make_sample_density()(shape=(64,), device=dev)
+    assert sig.shape == (64,) and float(sig.min()) >= 0.005 and float(sig.max()) <= 1.0
+    np.testing.assert_allclose(agent.get_noise_schedule(3, "exponential").numpy(),
+                               ks.get_sigmas_exponential(3, 0.005, 1, dev).numpy())
+
+
+def test_shipped_block_push_config_surface():
+    dev = "cpu"
+    agent = instantiate(_shipped_config(dev, "block_push"))
+    inner = agent.model.inner_model
+    assert (inner.embed_dim, inner.n_heads, inner.goal_seq_len, inner.obs_seq_len) == (240, 12, 1, 5)
+    assert inner._pdrops == (0, 0.05, 0.05) and len(inner.blocks) == 4
+    assert type(agent.optimizer).__name__ in ("Adam", "FusedAdam") and agent.sigma_min == 0.05
+    assert sum(p.numel() for p in agent.model.parameters()) == sum(int(np.prod(sh)) for _, sh in O.param_shapes(O.BLOCK_PUSH))
+    assert agent.obs_context.maxlen == 5 and agent.goal_context.maxlen == 1
