@@ -24,7 +24,8 @@ EXPORTS = ["beso_version", "beso_status_string", "beso_last_error", "beso_num_pa
            "beso_workspace_bytes", "beso_score_fwd", "beso_denoise_fwd", "beso_sampler_step", "beso_sample",
            "beso_profile_enable", "beso_profile_read", "beso_debug_set_stamps", "beso_adam_step",
            "beso_train_workspace_bytes", "beso_grad_floats", "beso_loss_grad", "beso_debug_gemm", "beso_gather_windows",
-           "beso_loss_grad_overlap", "beso_grad_early_range", "beso_debug_set_small_batch_max"]
+           "beso_loss_grad_overlap", "beso_grad_early_range", "beso_debug_set_small_batch_max",
+           "beso_sample_ancestral"]
 
 
 class BesoConfig(C.Structure):
@@ -85,6 +86,10 @@ def load() -> C.CDLL:
         lib.beso_sample.restype = i32
         lib.beso_sample.argtypes = [cfgp, vp, i32, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_float), i32, f32,
                                     vp, sz, vp]
+        if hasattr(lib, "beso_sample_ancestral") or not os.environ.get("BESO_HIP_LIB"):
+            lib.beso_sample_ancestral.restype = i32
+            lib.beso_sample_ancestral.argtypes = [cfgp, vp, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_float), i32, f32, f32, vp,
+                                                  vp, sz, vp]
         lib.beso_profile_enable.restype = None
         lib.beso_profile_enable.argtypes = [i32]
         if hasattr(lib, "beso_debug_set_small_batch_max") or not os.environ.get("BESO_HIP_LIB"):

@@ -11,8 +11,8 @@ MI355X-first differences that do not change results:
     as fp32 scalars, so the loop never branches on a device tensor (the reference syncs on every
     ``sigmas[i + 1] == 0`` / ``s_tmin <= sigmas[i]`` test: gc_sampling.py:198,289,301,360);
   * when ``model`` is a ``beso_amd`` GCDenoiser (optionally inside ClassifierFreeSampleModel) and the
-    call is the plain deterministic one (no churn, no callback, no scaler, no extra args),
-    ddim / euler / heun run as ONE enqueue of the whole loop through ``beso_sample``
+    call is the plain one (no churn, no callback, no scaler, no extra args),
+    ddim / euler / heun / euler_ancestral run as ONE enqueue of the whole loop through ``beso_sample`` / ``beso_sample_ancestral``
     (include/beso_hip.h) -- otherwise the generic loops below call ``model`` once per evaluation.
 """
 import math
@@ -187,8 +187,15 @@ def sample_euler(model, state, action, goal, sigmas, scaler=None, extra_args=Non
 @torch.no_grad()
 def sample_euler_ancestral(model, state, action, goal, sigmas, scaler=None, extra_args=None, callback=None,
                            disable=None, eta=1.):
-    """Euler steps to sigma_down, then fresh noise of scale sigma_up (:216-256)."""
+    """Euler steps to sigma_down, then fresh noise of scale sigma_up (:216-256).  The plain call on a ``beso_amd``
+    denoiser runs as one enqueue (``beso_sample_ancestral``) with the same sequence of ``randn_like`` draws."""
     extra_args = {} if extra_args is None else extra_args
+    if scaler is None and callback is None and not extra_args and eta >= 0:
+        den, lam = _fused_target(model)
+        if den is not None and action.is_cuda:
+            fused = den.fused_sampler('euler_ancestral', state, action, goal, _host_sigmas(sigmas), cond_lambda=lam, eta=eta)
+            if fused is not None:
+                return fused
     sig = _host_sigmas(sigmas)
     for i in range(len(sig) - 1):
         denoised = model(state, action, goal, _sig_vec(action, sig[i]), **extra_args)

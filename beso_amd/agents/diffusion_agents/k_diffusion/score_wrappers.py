@@ -92,10 +92,14 @@ class GCDenoiser(nn.Module):
             return False            # training-mode goal masking / dropout live in DiffusionGPT.forward
         return inner._hip_eligible(*tensors)
 
-    def fused_sampler(self, sampler: str, state, x_t, goal, sigmas, cond_lambda: float = 1.0):
-        """Whole ddim / euler / heun loop as one enqueue (``beso_sample``); None if not applicable."""
+    def fused_sampler(self, sampler: str, state, x_t, goal, sigmas, cond_lambda: float = 1.0, eta: float = 1.0, noise=None):
+        """Whole ddim / euler / heun / euler_ancestral loop as one enqueue (``beso_sample``, ``beso_sample_ancestral``); None
+        if not applicable."""
         inner = self.inner_model
         if not self._fused(inner, {}, state, x_t, goal) or x_t.dim() != 3 or state.dim() != 3:
             return None
+        if sampler == "euler_ancestral":
+            return inner.runtime(self.sigma_data).sample_ancestral(inner.packed_weights(), state, x_t, goal, sigmas,
+                                                                   cond_lambda=cond_lambda, eta=eta, noise=noise)
         return inner.runtime(self.sigma_data).sample(inner.packed_weights(), sampler, state, x_t, goal, sigmas,
                                                      cond_lambda=cond_lambda)

@@ -373,7 +373,8 @@ int beso_denoise_fwd(const beso_config* cfg, const void* packed, int precision, 
 
 int beso_sampler_step(int mode, float* out, float* aux, const float* x, const float* x2, const float* den,
                       float c0, float c1, size_t n, void* stream) {
-    if (mode < BESO_STEP_DDIM || mode > BESO_STEP_HEUN_CORRECT || !out || !x || !den) return BESO_ERR_BAD_ARG;
+    if (mode < BESO_STEP_DDIM || mode > BESO_STEP_ADD_NOISE || !out || !x || !den) return BESO_ERR_BAD_ARG;
+    if (mode == BESO_STEP_ADD_NOISE && !x2) return BESO_ERR_BAD_ARG;
     if ((mode == BESO_STEP_HEUN_PREDICT || mode == BESO_STEP_HEUN_CORRECT) && !aux) return BESO_ERR_BAD_ARG;
     if (mode == BESO_STEP_HEUN_CORRECT && !x2) return BESO_ERR_BAD_ARG;
     if (n == 0) return BESO_OK;
@@ -432,6 +433,46 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
             if (st != BESO_OK) return st;
             HIP_TRY(launch_sampler_step(BESO_STEP_HEUN_CORRECT, x, d1, x, x2, den, sn, sn - si, n, s));
         }
+    }
+    return BESO_OK;
+}
+
+int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precision, const float* state, const float* goal,
+                          float* x, int batch, int t, const float* sigmas, int n_sigmas, float cond_lambda, float eta,
+                          const float* noise, void* workspace, size_t workspace_bytes, void* stream) {
+    int st = validate_config(cfg);
+    if (st != BESO_OK) return st;
+    if (!sigmas || n_sigmas < 2 || !x || !workspace || !noise || !(eta >= 0.f)) return BESO_ERR_BAD_ARG;
+    if (batch < 1 || t < 1 || t > cfg->obs_seq_len) return BESO_ERR_BAD_SHAPE;
+    if (precision == BESO_PREC_BF16X3) return BESO_ERR_UNSUPPORTED;
+    Layout lay;
+    Workspace ws;
+    if (!make_layout(cfg, precision, &lay)) return BESO_ERR_BAD_ARG;
+    const int two = (cond_lambda != 0.f && cond_lambda != 1.f) ? 1 : 0;
+    if (!make_workspace(cfg, lay, batch, t, precision, two, &ws)) return BESO_ERR_BAD_SHAPE;
+    if (workspace_bytes < ws.total) return BESO_ERR_WORKSPACE;
+    for (int i = 0; i + 1 < n_sigmas; ++i) if (!(sigmas[i] > 0.f)) return BESO_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    char* wsp = (char*)workspace;
+    float* den = (float*)(wsp + ws.den);
+    float* sig = (float*)(wsp + ws.sig);
+    const size_t n = (size_t)batch * t * lay.act;
+    for (int i = 0; i + 1 < n_sigmas; ++i) {
+        const float sf = sigmas[i], sn = sigmas[i + 1];
+        // get_ancestral_step (:107-114) in fp32
+        float down = sn, up = 0.f;
+        if (eta != 0.f) {
+            up = eta * sqrtf(sn * sn * (sf * sf - sn * sn) / (sf * sf));
+            if (sn < up) up = sn;
+            down = sqrtf(sn * sn - up * up);
+        }
+        uint32_t bits; memcpy(&bits, &sf, 4);
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)sig, (int)bits, (size_t)batch, s));
+        st = beso_denoise_fwd(cfg, packed, precision, state, x, goal, sig, den, batch, t, 0, cond_lambda, workspace,
+                              workspace_bytes, stream);
+        if (st != BESO_OK) return st;
+        HIP_TRY(launch_sampler_step(BESO_STEP_EULER, x, nullptr, x, nullptr, den, sf, down - sf, n, s));     // :240-245
+        if (down > 0.f) HIP_TRY(launch_sampler_step(BESO_STEP_ADD_NOISE, x, nullptr, x, noise + (size_t)i * n, x, up, 0.f, n, s));
     }
     return BESO_OK;
 }

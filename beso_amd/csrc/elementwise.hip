@@ -289,6 +289,8 @@ __global__ void sampler_step_kernel(int mode, float* __restrict__ out, float* __
             float d = (xv - dv) / c0;
             aux[i] = d;
             r = xv + d * c1;
+        } else if (mode == BESO_STEP_ADD_NOISE) {
+            r = xv + x2[i] * c0;
         } else {
             float d2 = (x2[i] - dv) / c0;
             r = xv + ((aux[i] + d2) / 2.0f) * c1;

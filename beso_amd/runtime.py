@@ -198,6 +198,39 @@ class ScoreNetRuntime:
         _lib.check(st, f"sample[{sampler}]")
         return x
 
+    def sample_ancestral(self, packed: PackedWeights, state, x_t, goal, sigmas, cond_lambda: float = 1.0, eta: float = 1.0,
+                         noise=None) -> torch.Tensor:
+        """sample_euler_ancestral as ONE enqueue of all steps (``beso_sample_ancestral``).  The per-step noise is drawn
+        here, one ``torch.randn_like`` per step that adds noise and in the order of the steps -- the calls the reference's
+        loop makes, so a seeded generator gives the same draws as the step-by-step loop; ``noise`` [n_steps, B, t, act]
+        injects them instead."""
+        dev, B, t, state, x, goal, _ = self._prep(state, x_t, goal, None)
+        if x.data_ptr() == x_t.data_ptr():
+            x = x.clone()
+        sig = [float(s) for s in (sigmas.detach().cpu().tolist() if torch.is_tensor(sigmas) else sigmas)]
+        n_steps = len(sig) - 1
+        if noise is None:
+            noise = torch.zeros((n_steps,) + tuple(x.shape), dtype=torch.float32, device=dev)
+            for i in range(n_steps):
+                sf, sn = sig[i], sig[i + 1]
+                up = min(sn, eta * (sn ** 2 * (sf ** 2 - sn ** 2) / sf ** 2) ** 0.5) if eta else 0.0
+                if sn ** 2 - up ** 2 > 0:                # sigma_down > 0: the step draws (gc_sampling.py:246-247)
+                    noise[i] = torch.randn_like(x)
+        else:
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+            if noise.shape != (n_steps,) + tuple(x.shape):
+                raise ValueError("noise must be [len(sigmas) - 1, B, t, act]")
+        two = cond_lambda not in (0.0, 1.0)
+        ws = self._workspace(B, t, two, dev)
+        arr = (C.c_float * len(sig))(*sig)
+        gp = goal.data_ptr() if goal is not None else None
+        with torch.cuda.device(dev):
+            st = self.lib.beso_sample_ancestral(C.byref(self.cfg), packed.buf.data_ptr(), packed.precision, state.data_ptr(), gp,
+                                                x.data_ptr(), B, t, arr, len(sig), float(cond_lambda), float(eta),
+                                                noise.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        _lib.check(st, "sample[euler_ancestral]")
+        return x
+
     # ------------------------------------------------------------------ profiling hooks (bench.py)
     def profile_enable(self, site: str) -> None:
         self.lib.beso_profile_enable(_lib.SITES[site])

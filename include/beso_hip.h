@@ -13,6 +13,7 @@
  *   beso_sampler_step   <- the per-step update of sample_ddim/_euler/_heun
  *                                                                      k_diffusion/gc_sampling.py:205-210,296-310,921-923
  *   beso_sample         <- sample_ddim / sample_euler / sample_heun    k_diffusion/gc_sampling.py:167-213,259-314,895-924
+ *   beso_sample_ancestral <- sample_euler_ancestral                    k_diffusion/gc_sampling.py:216-256
  *   beso_loss_grad      <- GCDenoiser.loss + loss.backward()           k_diffusion/score_wrappers.py:45-79, beso_agent.py:228-233
  *   beso_loss_grad_overlap  (same, with the early gradient range for the overlapped all-reduce: SURVEY 8(e) C1)
  *   beso_adam_step      <- optimizer.step() + ema_helper.update()      beso_agent.py:236-244
@@ -134,7 +135,8 @@ int beso_denoise_fwd(const beso_config* cfg, const void* packed, int precision,
  *   BESO_STEP_HEUN_PREDICT d = (x - den)/c0; aux = d; out = x + d*c1        (out = action_2)                     :296-305
  *   BESO_STEP_HEUN_CORRECT d2 = (x2 - den)/c0; out = x + ((aux + d2)/2)*c1  c0 = sigma_{i+1}                     :306-310
  * out may alias x.  x2 / aux may be NULL for the modes that do not use them.                     */
-enum { BESO_STEP_DDIM = 0, BESO_STEP_EULER = 1, BESO_STEP_HEUN_PREDICT = 2, BESO_STEP_HEUN_CORRECT = 3 };
+enum { BESO_STEP_DDIM = 0, BESO_STEP_EULER = 1, BESO_STEP_HEUN_PREDICT = 2, BESO_STEP_HEUN_CORRECT = 3,
+       BESO_STEP_ADD_NOISE = 4 /* out = x + x2 * c0 (x2 = the randn of an ancestral step, c0 = sigma_up; den unused, may be x)  :246-247 */ };
 int beso_sampler_step(int mode, float* out, float* aux, const float* x, const float* x2, const float* den,
                       float c0, float c1, size_t n, void* stream);
 
@@ -145,6 +147,15 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
                 const float* state, const float* goal, float* x, int batch, int t,
                 const float* sigmas, int n_sigmas, float cond_lambda,
                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* sample_euler_ancestral (gc_sampling.py:216-256, scaler = None) as one enqueue: per step an Euler step to sigma_down and,
+ * while sigma_down > 0, x += noise_i * sigma_up (get_ancestral_step: :107-114, fp32).  `noise` is a DEVICE array of
+ * n_sigmas - 1 standard-normal tensors [batch,t,act] back to back -- the reference's `torch.randn_like(action)` of each
+ * step, drawn by the caller (the library has no random number generator); entries of steps with sigma_down = 0 are not
+ * read.  Everything else as beso_sample.                                                                            */
+int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precision, const float* state, const float* goal,
+                          float* x, int batch, int t, const float* sigmas, int n_sigmas, float cond_lambda, float eta,
+                          const float* noise, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One Adam / AdamW step over ALL parameter tensors in one launch, optionally followed by the EMA update
  * of the shadow copy on the updated parameters.  Replaces `self.optimizer.step()` + `self.ema_helper.update`
