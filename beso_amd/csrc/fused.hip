@@ -1006,19 +1006,23 @@ __device__ __forceinline__ void gelu_slot(const f32x4 (&h)[RC][NT], GeluChain& c
 //     for c:  [FC2(c-1) || GELU(c)]  barrier  hT <- GELU(c)  FC1(c+1)  barrier
 //     FC2(n-1)
 constexpr int kFc1PF = 2;                // k-steps of FC1 weight fragments in flight per wave
+#ifndef BESO_LAT_PF1
+#define BESO_LAT_PF1 4                   // ... in the latency instances (KS % BESO_LAT_PF1 == 0)
+#endif
 constexpr int kKC = kChunkTiles / 2;     // FC2 k-steps per hidden chunk
 // First k-steps of chunk 0's FC1 weights of a layer (issued before the LayerNorm that precedes the phase).
-template <int KS, int NW>
-__device__ __forceinline__ void mlp_prefetch(u32x4 (&a1r)[kFc1PF][kChunkTiles / NW], const u32x4* __restrict__ w1p, int w,
+template <int KS, int NW, int PF1 = kFc1PF>
+__device__ __forceinline__ void mlp_prefetch(u32x4 (&a1r)[PF1][kChunkTiles / NW], const u32x4* __restrict__ w1p, int w,
                                              int lane) {
     constexpr int RC = kChunkTiles / NW;
-    prefetch_ring<RC, kFc1PF>(a1r, wptr(w1p + (size_t)(RC * w) * 64, lane), kChunkTiles);
+    prefetch_ring<RC, PF1>(a1r, wptr(w1p + (size_t)(RC * w) * 64, lane), kChunkTiles);
 }
 
-template <int RPW, int KS, int NW, int NT = kNTT>          // NT: the first NT token tiles only (last layer)
+template <int RPW, int KS, int NW, int NT = kNTT, int PF1 = kFc1PF>   // NT: the first NT token tiles only (last layer);
+                                                                      // PF1: k-steps of FC1 weights in flight per wave
 __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
                                           const float* __restrict__ b1f, const u32x4* __restrict__ w2p, int HT,
-                                          int KS2p, int w, int lane, u32x4 (&a1r)[kFc1PF][kChunkTiles / NW],
+                                          int KS2p, int w, int lane, u32x4 (&a1r)[PF1][kChunkTiles / NW],
                                           Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
@@ -1034,7 +1038,6 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     auto pc = [&](int c) { return c; };
     auto fc1_a = [&](int c) { return ABL_PTR(wptr(w1p + (size_t)(RC * w) * 64, lane), (size_t)pc(c) * KS * kChunkTiles); };
     auto fc2_a = [&](int c) { return ABL_PTR(wptr(w2p + (size_t)(w * RPW) * 64, lane), (size_t)(pc(c) * kKC) * (NW * RPW)); };
-    constexpr int PF1 = kFc1PF;
     auto fc1 = [&](int c, f32x4 (&h)[RC][NT], u32x4 (&ar)[PF1][RC]) {
         const int R0 = pc(c) * kChunkTiles + RC * w, g = lane >> 4;
 #pragma unroll
@@ -1516,6 +1519,8 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
     constexpr int NTLa = NTL < NTA ? NTL : NTA;
+    // the latency instances are bound by the L2 -> CU weight stream: more FC1 weight fragments in flight per wave
+    constexpr int PF1 = NTA < kNTT ? BESO_LAT_PF1 : kFc1PF;
     const int s0 = blockIdx.x * SPW;
     const int n_samples = min(SPW, n_samples_total - s0);
     const int m0 = s0 * Tn, m_end = m0 + n_samples * Tn;
@@ -1570,12 +1575,12 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
                                 (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
                                 lane, tb, qE, qO, st);
         stamp(st, 3);
-        u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
-        mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)lw, w, lane);
+        u32x4 a1r[PF1][kChunkTiles / kWaves];
+        mlp_prefetch<KS, kWaves, PF1>(a1r, (const u32x4*)lw, w, lane);
         layernorm_to_lds<RPW, KS, kWaves, true, NTA>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                           (const float*)(lw + d.o_b2), st);
         stamp(st, 6);
-        mlp_phase<RPW, KS, kWaves, NTA>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
+        mlp_phase<RPW, KS, kWaves, NTA, PF1>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
                                    (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
     }
     if (peel) {
@@ -1590,12 +1595,12 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
                                      (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
                                      lane, tb, qE, qO, st);
         stamp(st, 3);
-        u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
-        mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)lw, w, lane);
+        u32x4 a1r[PF1][kChunkTiles / kWaves];
+        mlp_prefetch<KS, kWaves, PF1>(a1r, (const u32x4*)lw, w, lane);
         layernorm_to_lds<RPW, KS, kWaves, true, NTLa>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                                      (const float*)(lw + d.o_b2), st);
         stamp(st, 6);
-        mlp_phase<RPW, KS, kWaves, NTLa>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
+        mlp_phase<RPW, KS, kWaves, NTLa, PF1>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
                                         (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
     }
     stamp(st, 4);
