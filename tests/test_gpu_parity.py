@@ -1103,3 +1103,24 @@ def test_fused_euler_ancestral_loop():
             err = rel_err(fused.cpu().numpy(), loop.cpu().numpy())
             print(f"[parity] fused euler_ancestral vs loop {cfg_name} {precision}: {err:.3e}")
             assert err < (2e-6 if precision == "fp32" else 2e-2)
+
+
+def test_feed_takes_rank_and_seed_from_the_process_group():
+    """Under torchrun the feed reads rank / world size from the process group and shares rank 0's shuffling seed
+    (a one-rank RCCL group here: the broadcast really runs)."""
+    import torch.distributed as dist
+    from beso_amd import distributed as bdist
+    from beso_amd.data.trajectory_feed import DeviceTrajectoryFeed
+    fx = load_golden("trajectory_windows.npz")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29654", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    real = bdist.is_distributed
+    try:
+        bdist.is_distributed = lambda: True
+        sub = fx["subset"]
+        feed = DeviceTrajectoryFeed(fx["observations"][sub], fx["actions"][sub], fx["lengths"][sub], int(fx["window"]), 16, DEV)
+        assert (feed.rank, feed.world_size) == (0, 1) and len(feed) == -(-feed.n_windows // 16)
+        assert sum(b["observation"].shape[0] for b in feed) == feed.n_windows
+    finally:
+        bdist.is_distributed = real
+        dist.destroy_process_group()
