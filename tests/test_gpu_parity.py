@@ -997,6 +997,13 @@ def test_feed_from_sliced_and_train_step():
         DeviceTrajectoryFeed.from_sliced(Sliced, 64, DEV)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 # ------------------------------------------------------------------------------------------------
 # overlapped gradient exchange (beso_loss_grad_overlap)
 # ------------------------------------------------------------------------------------------------
@@ -1038,7 +1045,7 @@ def test_overlapped_all_reduce_on_a_one_rank_group():
     from beso_amd import distributed as bdist
     from test_host_logic import build_agent
     from beso_amd.networks.scaler.scaler_class import Scaler
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", RANK="0", WORLD_SIZE="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), RANK="0", WORLD_SIZE="1")
     dist.init_process_group("nccl", rank=0, world_size=1)
     real = bdist.is_distributed
     try:
@@ -1112,7 +1119,7 @@ def test_feed_takes_rank_and_seed_from_the_process_group():
     from beso_amd import distributed as bdist
     from beso_amd.data.trajectory_feed import DeviceTrajectoryFeed
     fx = load_golden("trajectory_windows.npz")
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29654", RANK="0", WORLD_SIZE="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), RANK="0", WORLD_SIZE="1")
     dist.init_process_group("nccl", rank=0, world_size=1)
     real = bdist.is_distributed
     try:
