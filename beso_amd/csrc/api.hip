@@ -33,7 +33,7 @@ static size_t carve(size_t& cur, size_t bytes) {
 
 bool make_layout(const beso_config* c, int precision, Layout* o) {
     if (validate_config(c) != BESO_OK) return false;
-    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32) return false;
+    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32 && precision != BESO_PREC_BF16X3) return false;
     memset(o, 0, sizeof(*o));
     o->D = c->embed_dim; o->H = c->n_heads; o->hd = o->D / o->H; o->L = c->n_layers;
     o->G = c->goal_seq_len; o->W = c->obs_seq_len; o->obs = c->obs_dim; o->act = c->act_dim;
@@ -149,7 +149,7 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
         // embed -> all transformer layers -> head as ONE launch: the residual tile of 8 samples never leaves
         // the CU's registers (shapes whose head cannot be fused store x and run the head kernel)
         profile_begin(BESO_SITE_FUSED_LAYER, s);
-        int st = fused_layers(lay, packed, a, x, &fused_edges, s);
+        int st = fused_layers(lay, packed, a, x, &fused_edges, precision, s);
         profile_end(BESO_SITE_FUSED_LAYER, s);
         if (st != BESO_OK) return st;
     } else {
@@ -221,8 +221,7 @@ static int forward(const beso_config* cfg, const void* packed, int precision, co
                    hipStream_t s) {
     int st = validate_config(cfg);
     if (st != BESO_OK) return st;
-    if (precision == BESO_PREC_BF16X3) return BESO_ERR_UNSUPPORTED;
-    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32) return BESO_ERR_BAD_ARG;
+    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32 && precision != BESO_PREC_BF16X3) return BESO_ERR_BAD_ARG;
     if (batch < 1 || t < 1 || t > cfg->obs_seq_len) return BESO_ERR_BAD_SHAPE;
     if (!packed || !state || !action || !sigma || !out || !workspace) return BESO_ERR_BAD_ARG;
     if (cfg->goal_seq_len > 0 && !goal) return BESO_ERR_BAD_ARG;
@@ -245,9 +244,11 @@ static int forward(const beso_config* cfg, const void* packed, int precision, co
     a.precondition = precondition;
     a.uncond_from = two ? batch : (uncond ? 0 : a.vbatch);
     a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
+    const int level = fused_level(lay, a, precision);
+    // BF16X3 is the split-bf16 instance of the fused kernel (layers_kernel) and has no per-op form
+    if (precision == BESO_PREC_BF16X3 && level != 2) return BESO_ERR_UNSUPPORTED;
     profile_begin(BESO_SITE_FORWARD, s);
-    int r = forward_generic(lay, ws, (const char*)packed, precision, a, (char*)workspace, s,
-                            fused_level(lay, a, precision));
+    int r = forward_generic(lay, ws, (const char*)packed, precision, a, (char*)workspace, s, level);
     profile_end(BESO_SITE_FORWARD, s);
     return r;
 }
@@ -290,9 +291,9 @@ int beso_pack_weights(const beso_config* cfg, const float* const* p, int n_param
                       size_t packed_bytes, int precision, void* stream) {
     int st = validate_config(cfg);
     if (st != BESO_OK) return st;
-    if (precision == BESO_PREC_BF16X3) return BESO_ERR_UNSUPPORTED;
     Layout lay;
     if (!make_layout(cfg, precision, &lay)) return BESO_ERR_BAD_ARG;
+    if (precision == BESO_PREC_BF16X3 && lay.fused == lay.total) return BESO_ERR_UNSUPPORTED;   // no fused instance for this shape
     if (!p || !packed_v) return BESO_ERR_BAD_ARG;
     if (n_params != beso_num_params(cfg)) return BESO_ERR_BAD_ARG;
     for (int i = 0; i < n_params; ++i) if (!p[i]) return BESO_ERR_BAD_ARG;
@@ -303,7 +304,9 @@ int beso_pack_weights(const beso_config* cfg, const float* const* p, int n_param
     int i = 0;
     // fp32 sections: precision -1
 #define PACK32(off, rows, cols, rp, cp) HIP_TRY(launch_pack_matrix(p[i++], rows, cols, pk + (off), rp, cp, -1, s))
-#define PACKW(src, off, rows, cols, rp, cp) HIP_TRY(launch_pack_matrix(src, rows, cols, pk + (off), rp, cp, precision, s))
+    // (the GEMM operands of the per-op path are not used by BF16X3: its weights live in the fused image only)
+#define PACKW(src, off, rows, cols, rp, cp) \
+    do { if (precision != BESO_PREC_BF16X3) HIP_TRY(launch_pack_matrix(src, rows, cols, pk + (off), rp, cp, precision, s)); } while (0)
     PACK32(lay.pos_emb, lay.seq_size, D, lay.seq_size, D);
     PACK32(lay.tok_w, D, lay.obs, D, lay.obs);
     PACK32(lay.tok_b, 1, D, 1, D);
@@ -390,7 +393,6 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
     if (sampler < BESO_SAMPLER_DDIM || sampler > BESO_SAMPLER_HEUN) return BESO_ERR_BAD_ARG;
     if (!sigmas || n_sigmas < 2 || !x || !workspace) return BESO_ERR_BAD_ARG;
     if (batch < 1 || t < 1 || t > cfg->obs_seq_len) return BESO_ERR_BAD_SHAPE;
-    if (precision == BESO_PREC_BF16X3) return BESO_ERR_UNSUPPORTED;
     Layout lay;
     Workspace ws;
     if (!make_layout(cfg, precision, &lay)) return BESO_ERR_BAD_ARG;
@@ -444,7 +446,6 @@ int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precis
     if (st != BESO_OK) return st;
     if (!sigmas || n_sigmas < 2 || !x || !workspace || !noise || !(eta >= 0.f)) return BESO_ERR_BAD_ARG;
     if (batch < 1 || t < 1 || t > cfg->obs_seq_len) return BESO_ERR_BAD_SHAPE;
-    if (precision == BESO_PREC_BF16X3) return BESO_ERR_UNSUPPORTED;
     Layout lay;
     Workspace ws;
     if (!make_layout(cfg, precision, &lay)) return BESO_ERR_BAD_ARG;

@@ -9,7 +9,8 @@ size_t fused_workspace_bytes(const Layout& lay, int vbatch, int T, int precision
 int    fused_pack(const Layout& lay, const float* const* params, char* packed, int precision, hipStream_t s);
 bool   fused_supported(const Layout& lay, const FwdArgs& a, int precision);
 int    fused_level(const Layout& lay, const FwdArgs& a, int precision);   // 0 none, 1 MLP block, 2 whole layers
-int    fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, hipStream_t s);
+int    fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, int precision,
+                    hipStream_t s);
 int    fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, int M, hipStream_t s);
 bool   fused_has_lin_blocks(const Layout& lay, int precision);
 int    fused_lin_block(const Layout& lay, const char* packed, int layer, int which, float* x, void* buf, int ld, int M,

@@ -73,6 +73,9 @@ struct FusedDims {
     // per-model image behind the L per-layer images (fp32): embeddings transposed to [in][Dp], head with ln_f folded
     int Dp, obs, act, seq, G, L, head_fused;
     uint32_t g_tokT, g_tokb, g_actT, g_actb, g_sigw, g_sigb, g_pos, g_headw, g_headb, global_bytes;
+    // BF16X3 image: a second copy of the L per-layer images holding the LOW halves of the split-bf16 weight fragments,
+    // x3_delta bytes behind the first (= L * layer_bytes + global_bytes); same offsets inside, biases not repeated
+    uint32_t x3_delta;
 };
 
 bool fused_dims(const Layout& lay, FusedDims* d) {
@@ -138,6 +141,7 @@ bool fused_dims(const Layout& lay, FusedDims* d) {
     d->g_pos = carve((size_t)lay.seq_size * d->Dp);
     d->g_headw = carve((size_t)16 * d->Dp); d->g_headb = carve(16);
     d->global_bytes = cur;
+    d->x3_delta = (uint32_t)((size_t)lay.L * d->layer_bytes + d->global_bytes);
     return true;
 }
 
@@ -159,8 +163,14 @@ bool shape_has_kernel(const FusedDims& d) {
 // Fragment (R, kk) lives at tile index ((R/grp)*kt + kk)*grp + R%grp: the `grp` row tiles a workgroup
 // consumes together in one k-step are contiguous (grp KiB), so a k-step's loads of all 8 waves spread
 // over the L2 channels instead of striding by a whole row of k-steps.
+// part: 0 = bf16(v); 1 = bf16(v - bf16(v)), the low half of the split-bf16 pair of the BF16X3 mode (hi + lo = v to 2^-16)
+__device__ __forceinline__ uint16_t f2bf_part(float v, int part) {
+    const uint16_t h = f2bf(v);
+    return part ? f2bf(v - bf2f(h)) : h;
+}
+
 __global__ void pack_mfma_a_kernel(const float* __restrict__ src, int rows, int cols, const float* __restrict__ colscale,
-                                   uint16_t* __restrict__ dst, int rt, int kt, int grp) {
+                                   uint16_t* __restrict__ dst, int rt, int kt, int grp, int part) {
     size_t total = (size_t)rt * kt * 512;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
@@ -175,7 +185,7 @@ __global__ void pack_mfma_a_kernel(const float* __restrict__ src, int rows, int 
             v = src[(size_t)r * cols + c];
             if (colscale) v *= colscale[c];
         }
-        dst[i] = f2bf(v);
+        dst[i] = f2bf_part(v, part);
     }
 }
 
@@ -184,7 +194,7 @@ __global__ void pack_mfma_a_kernel(const float* __restrict__ src, int rows, int 
 // LayerNorm-1 gamma folded in.  part 0 = query, 1 = key, 2 = value.
 __global__ void pack_qkv_kernel(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
                                 const float* __restrict__ gamma, uint16_t* __restrict__ dst, int D, int H, int hd,
-                                int kt) {
+                                int kt, int split) {
     size_t total = (size_t)H * 12 * kt * 512;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
@@ -200,7 +210,7 @@ __global__ void pack_qkv_kernel(const float* __restrict__ wq, const float* __res
             const float* w = part == 0 ? wq : (part == 1 ? wk : wv);
             v = w[(size_t)(h * hd + d) * D + c] * gamma[c];
         }
-        dst[i] = f2bf(v);
+        dst[i] = f2bf_part(v, split);
     }
 }
 
@@ -224,7 +234,8 @@ __global__ void fold_qkv_bias_kernel(const float* __restrict__ wq, const float* 
 }
 
 // out-projection: k-step (2h + kk) covers head h, head dims 32kk .. 32kk+31 (zero for d >= hd)
-__global__ void pack_proj_kernel(const float* __restrict__ wp, uint16_t* __restrict__ dst, int D, int H, int hd, int rt) {
+__global__ void pack_proj_kernel(const float* __restrict__ wp, uint16_t* __restrict__ dst, int D, int H, int hd, int rt,
+                                 int part) {
     const int kt = 2 * H;
     size_t total = (size_t)rt * kt * 512;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -236,7 +247,7 @@ __global__ void pack_proj_kernel(const float* __restrict__ wp, uint16_t* __restr
         int d = 32 * (kk & 1) + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
         float v = 0.f;
         if (o < D && d < hd) v = wp[(size_t)o * D + h * hd + d];
-        dst[i] = f2bf(v);
+        dst[i] = f2bf_part(v, part);
     }
 }
 
@@ -506,6 +517,76 @@ __device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)
 }
 
 // ---------------------------------------------------------------------------------------------
+// BF16X3: split-bf16 arithmetic on the same MFMA (`PX` = 1 instances of the phases).  Every GEMM operand is a pair
+// (hi, lo) of bf16 values with hi = bf16(v), lo = bf16(v - hi): hi + lo = v to 2^-16 relative, and
+//   acc += A_lo B_hi + A_hi B_lo + A_hi B_hi          (fp32 accumulate; the lo*lo term is below the representation error)
+// -- three v_mfma_f32_16x16x32_bf16 per fragment pair, fp32-class results from the bf16 matrix pipe at a third of its
+// rate (the fp32-input MFMA runs at 1/16).  Weight fragments: the low image lies x3_delta bytes behind the bf16 image
+// (FusedDims); activation fragments: the low fragment `b_lo` u32x4 behind the high one in LDS.
+// ---------------------------------------------------------------------------------------------
+struct SplitPair { uint32_t hi, lo; };
+__device__ __forceinline__ SplitPair split_bf16x2(float a, float b) {
+    SplitPair p;
+    p.hi = pack_bf16x2(a, b);
+    p.lo = pack_bf16x2(a - __uint_as_float(p.hi << 16), b - __uint_as_float(p.hi & 0xffff0000u));
+    return p;
+}
+
+// acc[r][t] += sum_kk A(r,kk) B(t,kk) as gemm_phase, operands split.  k-steps two at a time from two register sets;
+// a set is refilled as soon as its MFMAs are issued.  ksteps even; TAIL16: the last k-step is a half k-step.
+template <int R, int NT, bool TAIL16 = false, int NTA = NT>
+__device__ __forceinline__ void gemm_x3(f32x4 (&acc)[R][NTA], WPtr a, int a_ks, uint32_t x3_delta, const u32x4* b, int b_lo,
+                                        int b_ts, int b_ks, int ksteps) {
+    const WPtr al{a.rs, a.so + x3_delta, a.lo};
+    struct Set { u32x4 ah[R], al[R], bh[NT], bl[NT]; };
+    Set s0, s1;
+    auto load = [&](Set& s, int kk) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { s.ah[r] = a.at(r + kk * a_ks); s.al[r] = al.at(r + kk * a_ks); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { s.bh[t] = b[t * b_ts + kk * b_ks]; s.bl[t] = b[b_lo + t * b_ts + kk * b_ks]; }
+    };
+    auto mma = [&](const Set& s, bool half) {
+        // the small terms first; R*NT independent accumulators between two MFMAs on the same one
+        if (half) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(s.al[r], s.bh[t], acc[r][t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(s.ah[r], s.bl[t], acc[r][t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(s.ah[r], s.bh[t], acc[r][t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(s.al[r], s.bh[t], acc[r][t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(s.ah[r], s.bl[t], acc[r][t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(s.ah[r], s.bh[t], acc[r][t]);
+        }
+    };
+    load(s0, 0);
+    load(s1, 1);
+    for (int kk = 0; kk < ksteps; kk += 2) {
+        mma(s0, false);
+        load(s0, min(kk + 2, ksteps - 2));          // unconditional (the last refill is never used): a load under a
+        mma(s1, TAIL16 && kk + 2 >= ksteps);        // branch makes the compiler drain every load in flight behind it
+        load(s1, min(kk + 3, ksteps - 1));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // shared pieces of the kernels
 // ---------------------------------------------------------------------------------------------
 constexpr int kKCc = kChunkTiles / 2;      // FC2 k-steps per hidden chunk (= kKC below)
@@ -519,6 +600,32 @@ __host__ __device__ constexpr LdsMap lds_map(int KS, bool mlp_only = false) {
     m.xnT = 0;
     m.u = kNTT * KS * 1024;
     m.red = m.u + (mlp_only ? kNTT * kKCc * 1024 : 59648);
+    m.tab = m.red + 2 * kWaves * kMT * 4;
+    m.total = m.tab + 512;
+    return m;
+}
+
+// LDS of the BF16X3 instances (NT token tiles): every B-fragment region twice (hi | lo), q/k/v of one head as fp32 rows
+// (the attention core runs on the exact-fp32 MFMA there).  yT sits behind both phase-local regions, so that its
+// never-rewritten entries (padding tokens) keep the zeros of the prologue; the pad rows of q/k/v alias hT, i.e. pairs
+// of finite bf16 values = finite fp32 values, and only ever meet zero probabilities.
+constexpr int kQKVRowF = kHDP + 4;         // fp32 elements per q/k/v row: 272 B, conflict-free b128 reads down a column of rows
+struct LdsMapX3 {
+    int xn_lo, u, qkv_rows, yT, y_lo, h_lo, red, tab, total;     // *_lo: distance hi -> lo fragment in u32x4 units; rest bytes
+};
+__host__ __device__ constexpr LdsMapX3 lds_map_x3(int KS, int NT) {
+    LdsMapX3 m{};
+    const int xn_bytes = NT * KS * 1024, h_bytes = NT * kKCc * 1024, y_bytes = NT * 2 * 1024;
+    m.xn_lo = xn_bytes / 16;
+    m.h_lo = h_bytes / 16;
+    m.y_lo = y_bytes / 16;
+    m.u = 2 * xn_bytes;
+    m.qkv_rows = 16 * NT + 8;
+    const int qkv_bytes = 3 * m.qkv_rows * kQKVRowF * 4;
+    const int front = qkv_bytes > 2 * h_bytes ? qkv_bytes : 2 * h_bytes;
+    m.yT = (front + 1023) / 1024 * 1024;                          // relative to u
+    const int need = m.yT + 2 * y_bytes, head = kWaves * kMT * 16 * 4;
+    m.red = m.u + (need > head ? need : head);
     m.tab = m.red + 2 * kWaves * kMT * 4;
     m.total = m.tab + 512;
     return m;
@@ -638,9 +745,10 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
 // even are the two halves of one k-step fragment and go out as one 16-byte LDS write per lane.
 // NOTE: the red[] buffer is re-used by the next LayerNorm; the barrier at the end of this function (and
 // the phases in between) orders the reads above against those writes.
-template <int RPW, int KS, int NW, bool ADD_BIAS = true, int NT = kNTT>
+// PX = 1 (BF16X3): the normalised values go out as split-bf16 pairs, the low fragment `lo_off` u32x4 behind the high one.
+template <int RPW, int KS, int NW, bool ADD_BIAS = true, int NT = kNTT, int PX = 0>
 __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float* red, int D, int w, int lane,
-                                                 const float* __restrict__ bias, Stamps& st) {
+                                                 const float* __restrict__ bias, Stamps& st, int lo_off = 0) {
     // `lane` is made opaque at the top of every phase: otherwise the per-lane address arithmetic of ALL
     // phases is hoisted out of the layer loop and kept live across it (46 spilled VGPRs).
     asm volatile("" : "+v"(lane));
@@ -659,13 +767,28 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         pk.y = pack_bf16x2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
         return pk;
     };
+    auto half_x3 = [&](int i, int t, uint2& hi, uint2& lo) {
+        const float a = rstd[t], b = -mean[t] * rstd[t];
+        const SplitPair p0 = split_bf16x2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
+        const SplitPair p1 = split_bf16x2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
+        hi = make_uint2(p0.hi, p1.hi);
+        lo = make_uint2(p0.lo, p1.lo);
+    };
     auto write_pair = [&](int i) {          // row tiles i, i+1 of this wave: Rf = w*RPW + i is even
         const int ks = (w * RPW + i) >> 1;
         if (ks < KS) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const uint2 lo = half(i, t), hi = half(i + 1, t);
-                xnT[((size_t)t * KS + ks) * 64 + lane] = u32x4{lo.x, lo.y, hi.x, hi.y};
+                if constexpr (PX) {
+                    uint2 h0, l0, h1, l1;
+                    half_x3(i, t, h0, l0);
+                    half_x3(i + 1, t, h1, l1);
+                    xnT[((size_t)t * KS + ks) * 64 + lane] = u32x4{h0.x, h0.y, h1.x, h1.y};
+                    xnT[((size_t)t * KS + ks) * 64 + lane + lo_off] = u32x4{l0.x, l0.y, l1.x, l1.y};
+                } else {
+                    const uint2 lo = half(i, t), hi = half(i + 1, t);
+                    xnT[((size_t)t * KS + ks) * 64 + lane] = u32x4{lo.x, lo.y, hi.x, hi.y};
+                }
             }
         }
     };
@@ -673,8 +796,16 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         const int Rf = w * RPW + i;
         if ((Rf >> 1) < KS) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                *((uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane) + (Rf & 1)) = half(i, t);
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (PX) {
+                    uint2 h0, l0;
+                    half_x3(i, t, h0, l0);
+                    *((uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane) + (Rf & 1)) = h0;
+                    *((uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane + lo_off) + (Rf & 1)) = l0;
+                } else {
+                    *((uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane) + (Rf & 1)) = half(i, t);
+                }
+            }
         }
     };
     if constexpr (RPW % 2 == 0) {
@@ -1382,6 +1513,195 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
 }
 
 // ---------------------------------------------------------------------------------------------
+// BF16X3 instances of the two phases: same decomposition (wave = feature slice of the residual tile, weights as A
+// fragments from L2, activations as B fragments through LDS, accumulator -> operand chaining), split-bf16 GEMMs,
+// exact GELU (erff) and the attention core on the exact-fp32 MFMA.  No software pipelining across phases: this
+// mode exists for parity (north-star 1e-4), its speed is set by three MFMAs per fragment pair and two weight images.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_exact(float v) {            // nn.GELU(): v * Phi(v), erf form (score_gpts.py:107)
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+// MLP phase: per hidden chunk  FC1 -> GELU -> [barrier] -> hT (hi | lo) -> [barrier] -> FC2 into the residual.
+template <int RPW, int KS, int NW, int NT>
+__device__ __forceinline__ void mlp_phase_x3(Tile<RPW>& T, const u32x4* xnT, int xn_lo, u32x4* hT, int h_lo,
+                                             const u32x4* __restrict__ w1p, const float* __restrict__ b1f,
+                                             const u32x4* __restrict__ w2p, int HT, uint32_t x3_delta, int w, int lane) {
+    asm volatile("" : "+v"(lane));
+    const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
+    constexpr int RC = kChunkTiles / NW, KW = RC / 2;
+    constexpr int A2KS = NW * RPW;
+#pragma unroll 1
+    for (int c = 0; c < n_chunks; ++c) {
+        asm volatile("" : "+v"(lane));
+        const int g = lane >> 4;
+        const int tiles_here = min(kChunkTiles, HT - c * kChunkTiles);
+        const int R0 = c * kChunkTiles + RC * w;
+        f32x4 h[RC][NT];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            const f32x4 bias = *(const f32x4*)(b1f + 16 * (R0 + r) + 4 * g);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) h[r][t] = bias;
+        }
+        // waves whose rows of this chunk are all padding (zero weights, zero bias) skip the GEMM: GELU(0) = 0
+        if (RC * w < tiles_here)
+            gemm_x3<RC, NT, kt16(KS)>(h, wptr(w1p + (size_t)(RC * w) * 64, lane).adv((size_t)c * KS * kChunkTiles), kChunkTiles,
+                                      x3_delta, xnT + lane, xn_lo, KS * 64, 64, KS);
+        u32x4 hh[KW][NT], hl[KW][NT];
+#pragma unroll
+        for (int j2 = 0; j2 < KW; ++j2)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4& hv = h[2 * j2 + (q >> 1)][t];
+                    const SplitPair p = split_bf16x2(gelu_exact(hv[2 * (q & 1)]), gelu_exact(hv[2 * (q & 1) + 1]));
+                    hh[j2][t][q] = p.hi;
+                    hl[j2][t][q] = p.lo;
+                }
+        if (c > 0) __syncthreads();              // every wave is done reading hT(c-1)
+#pragma unroll
+        for (int j2 = 0; j2 < KW; ++j2)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                hT[((size_t)t * kKC + KW * w + j2) * 64 + lane] = hh[j2][t];
+                hT[((size_t)t * kKC + KW * w + j2) * 64 + lane + h_lo] = hl[j2][t];
+            }
+        __syncthreads();                         // hT(c) complete
+        gemm_x3<RPW, NT, false, kNTT>(T.acc, wptr(w2p + (size_t)(w * RPW) * 64, lane).adv((size_t)(c * kKC) * A2KS), A2KS, x3_delta,
+                                      hT + lane, h_lo, kKC * 64, 64, ((tiles_here >> 1) + 1) & ~1);
+    }
+    __syncthreads();
+}
+
+// Attention phase: head pairs as attn_phase; q/k/v of one head in LDS as fp32 rows [3][rows][kQKVRowF], the core
+// (score_gpts.py:69-73) on v_mfma_f32_16x16x4_f32, one sample per wave:
+//   S^T[j][i] = sum_d K[j][d] Q[i][d]     16 MFMAs: step (kk4, r) contracts d = 16 kk4 + 4 g + r, A and B read as one
+//                                         float4 per lane and kk4 (any assignment of d to contraction slots is a sum)
+//   softmax over j as in the bf16 core (D layout: lane (i = lane&15, g) holds keys 4g + r)
+//   Y^T[d][i] = sum_j V[j][d] P[i][j]     16 MFMAs: step r contracts j = 4 g + r, so B is the probability register r as
+//                                         it stands and A = V[4g + r][16 dt + n]
+// and Y (normalised) goes out as split-bf16 B fragments of the out-projection.
+template <int RPW, int KS, int HG, int NTP, int NTQ>
+__device__ __forceinline__ void attn_phase_x3(Tile<RPW>& T, const u32x4* xnT, int xn_lo, unsigned char* u, int qkv_rows,
+                                              int y_off, int y_lo, const u32x4* __restrict__ wqkv,
+                                              const float* __restrict__ bqkv, const u32x4* __restrict__ wproj, int H, int hd,
+                                              int Tn, int n_samples, uint32_t x3_delta, int w, int lane, const SlotTabs* tb) {
+    asm volatile("" : "+v"(lane));
+    float* qkv = (float*)u;                               // [3][qkv_rows][kQKVRowF]
+    u32x4* yT = (u32x4*)(u + y_off);                      // [(t*2 + kk)*64 + lane], low fragments y_lo behind
+    const int wa = w & 3, hsel = w >> 2;
+    const float scale_log2e = 1.4426950408889634f * __builtin_amdgcn_rsqf((float)hd);
+    auto qkv_a = [&](int pair) { return wptr(wqkv + (size_t)(3 * w) * 64, lane).adv((size_t)pair * KS * 24); };
+    auto proj_a = [&](int h) { return wptr(wproj + (size_t)(w * RPW) * 64, lane).adv((size_t)(2 * h) * (kWaves * RPW)); };
+    int ln = lane;
+    auto write_qkv = [&](const f32x4 (&qa)[3][NTQ]) {
+        const int n = ln & 15, g = ln >> 4;
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            const int row = tb->row_of_slot[t * 16 + n];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int rt = 3 * wa + i, part = rt >> 2, d0 = (rt & 3) * 16 + 4 * g;
+                *(f32x4*)(qkv + ((size_t)part * qkv_rows + row) * kQKVRowF + d0) = qa[i][t];
+            }
+        }
+    };
+    auto core = [&]() {
+        const int n = ln & 15, g = ln >> 4;
+        if (w >= n_samples) return;
+        const float* qb = qkv + ((size_t)0 * qkv_rows + w * Tn + n) * kQKVRowF + 4 * g;
+        const float* kb = qkv + ((size_t)1 * qkv_rows + w * Tn + n) * kQKVRowF + 4 * g;
+        const float* vb = qkv + ((size_t)2 * qkv_rows + w * Tn + 4 * g) * kQKVRowF + n;
+        f32x4 q4[4], k4[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { q4[kk] = *(const f32x4*)(qb + 16 * kk); k4[kk] = *(const f32x4*)(kb + 16 * kk); }
+        f32x4 y[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) y[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < HG; ++h) {
+            // HG > 1: head h of the group sees its own dims [lo_d, hi_d) only (hd % 4 == 0: whole float4s)
+            const int lo_d = h * hd, hi_d = lo_d + hd;
+            f32x4 sT = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (HG > 1 && (16 * kk >= hi_d || 16 * kk + 16 <= lo_d)) continue;      // wave-uniform
+                const int d0 = 16 * kk + 4 * g;
+                const bool in = HG == 1 || (d0 >= lo_d && d0 < hi_d);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sT = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[kk][r], in ? q4[kk][r] : 0.f, sT, 0, 0, 0);
+            }
+            float e[4], mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = (4 * g + r <= n) ? sT[r] * scale_log2e : -INFINITY;       // (q k^T)/sqrt(hd), causal, log2 units
+                mx = fmaxf(mx, e[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - mx); sum += e[r]; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                if (HG > 1 && (16 * dt >= hi_d || 16 * dt + 16 <= lo_d)) continue;      // wave-uniform
+                f32x4 yh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    yh = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[(size_t)r * kQKVRowF + 16 * dt], e[r], yh, 0, 0, 0);
+                const int d0 = 16 * dt + 4 * g;
+                const bool mine = HG == 1 || (d0 >= lo_d && d0 < hi_d);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[dt][r] = mine ? yh[r] * inv : y[dt][r];
+            }
+        }
+        if (n < Tn) {
+            const int tok = tb->slot_of_row[w * Tn + n];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const SplitPair p0 = split_bf16x2(y[2 * kk][0], y[2 * kk][1]), p1 = split_bf16x2(y[2 * kk][2], y[2 * kk][3]);
+                const SplitPair p2 = split_bf16x2(y[2 * kk + 1][0], y[2 * kk + 1][1]), p3 = split_bf16x2(y[2 * kk + 1][2], y[2 * kk + 1][3]);
+                const u32x4 yh = {p0.hi, p1.hi, p2.hi, p3.hi}, yl = {p0.lo, p1.lo, p2.lo, p3.lo};
+                const size_t at = ((size_t)(tok >> 4) * 2 + kk) * 64 + (g << 4) + (tok & 15);
+                yT[at] = yh;
+                yT[at + y_lo] = yl;
+            }
+        }
+    };
+#pragma unroll 1
+    for (int pair = 0; pair < H / 2; ++pair) {
+        const int hA = 2 * pair, hB = hA + 1;
+        asm volatile("" : "+v"(ln));
+        const int g = ln >> 4;
+        f32x4 qa[3][NTQ];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x4 bv = *(const f32x4*)(bqkv + ((hA + hsel) * 12 + 3 * wa + i) * 16 + 4 * g);
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t) qa[i][t] = bv;
+        }
+        gemm_x3<3, NTQ, kt16(KS)>(qa, qkv_a(pair), 24, x3_delta, xnT + lane, xn_lo, KS * 64, 64, KS);
+        if (hsel == 0) write_qkv(qa);
+        __syncthreads();
+        core();
+        __syncthreads();
+        gemm_x3<RPW, NTP, false, kNTT>(T.acc, proj_a(hA), kWaves * RPW, x3_delta, yT + lane, y_lo, 2 * 64, 64, 2);
+        if (hsel == 1) write_qkv(qa);
+        __syncthreads();
+        core();
+        __syncthreads();
+        gemm_x3<RPW, NTP, false, kNTT>(T.acc, proj_a(hB), kWaves * RPW, x3_delta, yT + lane, y_lo, 2 * 64, 64, 2);
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
 template <int RPW, int KS, int NW>
@@ -1508,13 +1828,16 @@ __global__ __launch_bounds__(512, 2) void proj_block_kernel(float* __restrict__ 
 // small batches (rollouts, BASELINE config 1): a workgroup carries two samples in two token tiles, so a batch of B
 // spreads over B/2 CUs and every phase runs a third of the MFMA / LDS / VALU work -- what is left is the L2 -> CU
 // stream of the weights.  Same phases, same per-sample arithmetic (results are bit-identical between the instances).
-template <int RPW, int KS, int HG, int NTL, int SPW = kSPW, int NTA = kNTT>
+// PX = 1: the BF16X3 instance (split-bf16 GEMMs, exact GELU, fp32 attention core): the parity mode of this kernel.
+template <int RPW, int KS, int HG, int NTL, int SPW = kSPW, int NTA = kNTT, int PX = 0>
 __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, const char* __restrict__ lw0,
                                                         FusedDims d, int l0, int l1, int n_samples_total, int Tn,
                                                         EdgeArgs e, unsigned long long* stamps, int cap) {
     Stamps st{stamps, cap, 0};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr LdsMap L = lds_map(KS);
+    constexpr LdsMap Lb = lds_map(KS);
+    constexpr LdsMapX3 X = lds_map_x3(KS, NTA);
+    constexpr LdsMap L = PX ? LdsMap{0, X.u, X.red, X.tab, X.total} : Lb;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
@@ -1526,10 +1849,14 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     const int m0 = s0 * Tn, m_end = m0 + n_samples * Tn;
     // LDS that is read but never written by the phases must be finite: the attention-output fragments of
     // padding tokens, and the 8 q/k/v rows past the last token slot (a sample's 16-row window reaches them)
+    if constexpr (PX) {
+        for (int i = threadIdx.x; i < (L.red - L.u) / 16; i += blockDim.x) ((u32x4*)(lds + L.u))[i] = u32x4{0, 0, 0, 0};
+    } else {
     for (int i = threadIdx.x; i < kNTT * 2 * 64; i += blockDim.x) ((u32x4*)(lds + L.u + kQKVBytes))[i] = u32x4{0, 0, 0, 0};
     for (int i = threadIdx.x; i < 3 * 8 * kQKVRow / 2; i += blockDim.x) {
         const int part = i / (8 * kQKVRow / 2), rem = i % (8 * kQKVRow / 2);
         ((uint32_t*)(lds + L.u))[((size_t)part * kQKVRows + kMT) * kQKVRow / 2 + rem] = 0u;
+    }
     }
     // action tokens first whenever both network edges are inside the kernel (otherwise x travels in natural order)
     SlotTabs* tb = (SlotTabs*)(lds + L.tab);
@@ -1553,7 +1880,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     // The last layer (when this launch contains it and the action tokens of the tile fit NTL token tiles) runs its
     // out-projection, LayerNorm-2 and MLP on the action-token tiles only; it is peeled off the loop -- a branch
     // between the two variants INSIDE the loop costs 150 spilled VGPRs.
-    const bool peel = actions_first && l1 == d.L && l1 > l0 && n_samples * e.t <= 16 * NTLa;
+    const bool peel = actions_first && l1 == d.L && l1 > l0 && n_samples * e.t <= 16 * NTLa && (!PX || NTLa < NTA);
     const int l_loop_end = peel ? l1 - 1 : l1;
     auto layer_weights = [&](int l) {
 #if BESO_FUSED_ABLATE == 4
@@ -1563,6 +1890,24 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         return lw0 + (size_t)l * d.layer_bytes;
 #endif
     };
+    if constexpr (PX) {
+        auto layer_x3 = [&](const char* lw, auto NTPc) {
+            constexpr int NTP = decltype(NTPc)::value;
+            u32x4* xnT = (u32x4*)(lds + L.xnT);
+            layernorm_to_lds<RPW, KS, kWaves, true, NTA, 1>(T, xnT, (float*)(lds + L.red), d.D, w, lane,
+                                                            (const float*)(lw + d.o_bproj), st, X.xn_lo);
+            attn_phase_x3<RPW, KS, HG, NTP, NTA>(T, xnT, X.xn_lo, lds + L.u, X.qkv_rows, X.yT, X.y_lo,
+                                                 (const u32x4*)(lw + d.o_wqkv), (const float*)(lw + d.o_bqkv),
+                                                 (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, d.x3_delta, w, lane, tb);
+            layernorm_to_lds<RPW, KS, kWaves, true, NTP, 1>(T, xnT, (float*)(lds + L.red), d.D, w, lane,
+                                                            (const float*)(lw + d.o_b2), st, X.xn_lo);
+            mlp_phase_x3<RPW, KS, kWaves, NTP>(T, xnT, X.xn_lo, (u32x4*)(lds + L.u), X.h_lo, (const u32x4*)lw,
+                                               (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.x3_delta, w, lane);
+        };
+#pragma unroll 1
+        for (int l = l0; l < l_loop_end; ++l) layer_x3(layer_weights(l), std::integral_constant<int, NTA>{});
+        if (peel) layer_x3(layer_weights(l1 - 1), std::integral_constant<int, NTLa>{});
+    } else {
     for (int l = l0; l < l_loop_end; ++l) {
         const char* lw = layer_weights(l);
         stamp(st, 2);
@@ -1602,6 +1947,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         stamp(st, 6);
         mlp_phase<RPW, KS, kWaves, NTLa, PF1>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
                                         (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
+    }
     }
     stamp(st, 4);
     if (e.fuse_head) head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
@@ -1654,9 +2000,22 @@ int g_small_batch_max = 512;           // batches up to this size take the laten
 
 template <int RPW, int KS, int HG, int NTL>
 hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
-                         const EdgeArgs& edge, hipStream_t s) {
+                         const EdgeArgs& edge, int precision, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS);
     constexpr int kSmallSPW = 2, kSmallNT = 2, kMidSPW = 4, kMidNT = 4;
+    if (precision == BESO_PREC_BF16X3) {
+        // the split-bf16 instance: two samples in two token tiles per workgroup at every batch size (both halves of
+        // every activation fragment have to fit the 160 KiB of LDS)
+        if (!(kSmallSPW * Tn <= 16 * kSmallNT && (kSmallSPW - 1) * Tn + 16 <= 16 * kSmallNT)) return hipErrorInvalidValue;
+        constexpr LdsMapX3 X = lds_map_x3(KS, kSmallNT);
+        static bool attr_x = false;
+        hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL, kSmallSPW, kSmallNT, 1>, X.total, &attr_x);
+        if (e != hipSuccess) return e;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL((layers_kernel<RPW, KS, HG, NTL, kSmallSPW, kSmallNT, 1>), dim3((n_samples + kSmallSPW - 1) / kSmallSPW),
+                           dim3(512), X.total, s, x, lw0, d, l0, l1, n_samples, Tn, edge, g_stamps, g_stamps_cap);
+        return hipGetLastError();
+    }
     // latency instances: the samples' tokens and the last sample's 16-row attention window must fit the token tiles
     if (n_samples <= g_small_batch_max && kSmallSPW * Tn <= 16 * kSmallNT && (kSmallSPW - 1) * Tn + 16 <= 16 * kSmallNT) {
         static bool attr_s = false;
@@ -1689,9 +2048,15 @@ hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, 
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
+static bool x3_shape(const FusedDims& d) {
+    // BF16X3 exists as an instance of layers_kernel only (the shipped shapes with the fused attention phase)
+    return d.attn && ((d.RPW == 3 && d.KS == 12 && d.HG == 1) || (d.RPW == 2 && d.KS == 8 && d.HG == 3));
+}
+
 size_t fused_packed_bytes(const Layout& lay, int precision) {
     FusedDims d;
-    if (precision != BESO_PREC_BF16 || !fused_dims(lay, &d) || !shape_has_kernel(d)) return 0;
+    if ((precision != BESO_PREC_BF16 && precision != BESO_PREC_BF16X3) || !fused_dims(lay, &d) || !shape_has_kernel(d)) return 0;
+    if (precision == BESO_PREC_BF16X3) return x3_shape(d) ? (size_t)d.x3_delta + (size_t)d.layer_bytes * lay.L : 0;
     return d.layer_bytes * lay.L + d.global_bytes;
 }
 
@@ -1701,8 +2066,11 @@ size_t fused_workspace_bytes(const Layout&, int, int, int) { return 0; }
 
 int fused_pack(const Layout& lay, const float* const* p, char* packed, int precision, hipStream_t s) {
     FusedDims d;
-    if (precision != BESO_PREC_BF16 || !fused_dims(lay, &d) || !shape_has_kernel(d)) return BESO_OK;
+    if ((precision != BESO_PREC_BF16 && precision != BESO_PREC_BF16X3) || !fused_dims(lay, &d) || !shape_has_kernel(d)) return BESO_OK;
+    if (precision == BESO_PREC_BF16X3 && !x3_shape(d)) return BESO_ERR_UNSUPPORTED;
     const int D = lay.D;
+    const int n_parts = precision == BESO_PREC_BF16X3 ? 2 : 1;
+    for (int half = 0; half < n_parts; ++half)               // 0: bf16(w); 1 (BF16X3 only): the low halves
     for (int l = 0; l < lay.L; ++l) {
         // parameter order (include/beso_hip.h): 3 leading tensors, then 16 per block:
         // ln1.w ln1.b ln2.w ln2.b key.w key.b query.w query.b value.w value.b proj.w proj.b fc1.w fc1.b fc2.w fc2.b
@@ -1710,25 +2078,29 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
         const float *ln1w = q[0], *ln1b = q[1], *ln2w = q[2], *ln2b = q[3];
         const float *kw = q[4], *kb = q[5], *qw = q[6], *qb = q[7], *vw = q[8], *vb = q[9], *pw = q[10], *pb = q[11];
         const float *f1w = q[12], *f1b = q[13], *f2w = q[14], *f2b = q[15];
-        char* base = packed + lay.fused + (size_t)l * d.layer_bytes;
+        char* base = packed + lay.fused + (size_t)l * d.layer_bytes + (half ? (size_t)d.x3_delta : 0);
         const int rt1 = d.NCH * kChunkTiles, rt2 = d.RPW * kWaves;
         (void)hipGetLastError();
         hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, f1w, 4 * D, D, ln2w, (uint16_t*)base, rt1,
-                           d.KS, kChunkTiles);
+                           d.KS, kChunkTiles, half);
+        hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, f2w, D, 4 * D, (const float*)nullptr,
+                           (uint16_t*)(base + d.o_w2), rt2, d.KS2p, rt2, half);
+        if (d.attn) {
+            hipLaunchKernelGGL(pack_qkv_kernel, dim3(1024), dim3(256), 0, s, qw, kw, vw, ln1w,
+                               (uint16_t*)(base + d.o_wqkv), D, d.Hv, d.hdv, d.KS, half);
+            hipLaunchKernelGGL(pack_proj_kernel, dim3(512), dim3(256), 0, s, pw, (uint16_t*)(base + d.o_wproj), D, d.Hv,
+                               d.hdv, rt2, half);
+        }
+        FTRY(hipGetLastError());
+        if (half) continue;                      // the low image holds weight fragments only
         hipLaunchKernelGGL(fold_bias_kernel, dim3((rt1 * 16 + 255) / 256), dim3(256), 0, s, f1w, f1b, ln2b,
                            (float*)(base + d.o_b1), 4 * D, D, rt1 * 16);
-        hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, f2w, D, 4 * D, (const float*)nullptr,
-                           (uint16_t*)(base + d.o_w2), rt2, d.KS2p, rt2);
         FTRY(hipGetLastError());
         FTRY(launch_pack_matrix(f2b, 1, D, base + d.o_b2, 1, rt2 * 16, -1, s));
         if (d.attn) {
             (void)hipGetLastError();
-            hipLaunchKernelGGL(pack_qkv_kernel, dim3(1024), dim3(256), 0, s, qw, kw, vw, ln1w,
-                               (uint16_t*)(base + d.o_wqkv), D, d.Hv, d.hdv, d.KS);
             hipLaunchKernelGGL(fold_qkv_bias_kernel, dim3((d.Hv * 3 * kHDP + 255) / 256), dim3(256), 0, s, qw, kw, vw,
                                qb, kb, vb, ln1b, (float*)(base + d.o_bqkv), D, d.Hv, d.hdv);
-            hipLaunchKernelGGL(pack_proj_kernel, dim3(512), dim3(256), 0, s, pw, (uint16_t*)(base + d.o_wproj), D, d.Hv,
-                               d.hdv, rt2);
             FTRY(hipGetLastError());
             FTRY(launch_pack_matrix(pb, 1, D, base + d.o_bproj, 1, rt2 * 16, -1, s));
         }
@@ -1736,14 +2108,14 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
             const float* ws3[3] = {qw, kw, vw};
             const float* bs3[3] = {qb, kb, vb};
             (void)hipGetLastError();
-            for (int part = 0; part < 3; ++part) {
+            for (int part = 0; part < 3; ++part) {      // q / k / v
                 hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, ws3[part], D, D, ln1w,
-                                   (uint16_t*)(base + d.o_wqkv_lin + (size_t)part * d.part_bytes), rt2, d.KS, rt2);
+                                   (uint16_t*)(base + d.o_wqkv_lin + (size_t)part * d.part_bytes), rt2, d.KS, rt2, 0);
                 hipLaunchKernelGGL(fold_bias_kernel, dim3((rt2 * 16 + 255) / 256), dim3(256), 0, s, ws3[part], bs3[part], ln1b,
                                    (float*)(base + d.o_bqkv_lin) + (size_t)part * rt2 * 16, D, D, rt2 * 16);
             }
             hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, pw, D, D, (const float*)nullptr,
-                               (uint16_t*)(base + d.o_wproj_lin), rt2, d.KS, rt2);
+                               (uint16_t*)(base + d.o_wproj_lin), rt2, d.KS, rt2, 0);
             FTRY(hipGetLastError());
             FTRY(launch_pack_matrix(pb, 1, D, base + d.o_bproj_lin, 1, rt2 * 16, -1, s));
         }
@@ -1793,13 +2165,14 @@ static int fused_min_batch() {
 int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     FusedDims d;
     if (a.vbatch < fused_min_batch()) return 0;
-    if (precision != BESO_PREC_BF16 || lay.fused == lay.total || !fused_dims(lay, &d) || !shape_has_kernel(d)) return 0;
+    if ((precision != BESO_PREC_BF16 && precision != BESO_PREC_BF16X3) || lay.fused == lay.total || !fused_dims(lay, &d) ||
+        !shape_has_kernel(d)) return 0;
+    const bool whole = x3_shape(d) && kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused) &&
+                       d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK;
+    if (precision == BESO_PREC_BF16X3) return whole ? 2 : 0;     // BF16X3 is an instance of layers_kernel and nothing else
     static const int level_max = getenv("BESO_FUSED_LEVEL_MAX") ? atoi(getenv("BESO_FUSED_LEVEL_MAX")) : 2;   // kernel experiments
     if (level_max < 2) return level_max;
-    if (d.attn && ((d.RPW == 3 && d.KS == 12 && d.HG == 1) || (d.RPW == 2 && d.KS == 8 && d.HG == 3)) &&
-        kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused) &&
-        d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK) return 2;
-    return 1;
+    return whole ? 2 : 1;
 }
 
 bool fused_supported(const Layout& lay, const FwdArgs& a, int precision) { return fused_level(lay, a, precision) > 0; }
@@ -1838,7 +2211,8 @@ int fused_lin_block(const Layout& lay, const char* packed, int layer, int which,
 
 // Whole network (embed -> all layers -> head) or layers only.  Returns in *fused_edges whether the token
 // embedding / action head ran inside the kernel (bit 0 / bit 1).
-int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, hipStream_t s) {
+int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, int precision,
+                 hipStream_t s) {
     FusedDims d;
     if (!fused_dims(lay, &d) || !d.attn) return BESO_ERR_UNSUPPORTED;
     const char* base = packed + lay.fused;
@@ -1855,8 +2229,8 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     if (e.two && !e.fuse_head) return BESO_ERR_UNSUPPORTED;
     if (fused_edges) *fused_edges = (e.fuse_embed ? 1 : 0) | (e.fuse_head ? 2 : 0);
     hipError_t err;
-    if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1, 2>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);    // kitchen: 8 x 4 action tokens
-    else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3, 4>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);   // block-push: 8 x 5
+    if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1, 2>(x, base, d, 0, lay.L, a.vbatch, a.T, e, precision, s);    // kitchen: 8 x 4 action tokens
+    else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3, 4>(x, base, d, 0, lay.L, a.vbatch, a.T, e, precision, s);   // block-push: 8 x 5
     else return BESO_ERR_UNSUPPORTED;
     return err == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }

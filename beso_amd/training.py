@@ -123,7 +123,8 @@ class HipTrainStep:
                 # the seed is a host scalar: a captured graph would replay one mask forever
                 raise RuntimeError("beso_amd: the HIP training step with dropout cannot be captured into a graph")
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,), device="cpu").item())
-        precision = _lib.PRECISIONS[inner.precision]
+        # the split-bf16 mode is an inference instance of the fused kernel; its training step is the fp32 one
+        precision = _lib.PRECISIONS["fp32" if inner.precision == "bf16x3" else inner.precision]
         params = [p.detach() for p in inner.parameters()]
         arr = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
         flat, views = self._grad_buffer(dev, fresh_grads)
