@@ -17,6 +17,7 @@ int    fused_lin_block(const Layout& lay, const char* packed, int layer, int whi
                        hipStream_t s);
 void   fused_set_stamps(void* buf, int cap);
 void   fused_set_small_batch_max(int n);
+void   fused_set_level_max(int n);
 int    forward_fused(const Layout& lay, const Workspace& ws, const char* packed, int precision, const FwdArgs& a,
                      char* wsp, hipStream_t s);
 

@@ -532,57 +532,72 @@ __device__ __forceinline__ SplitPair split_bf16x2(float a, float b) {
     return p;
 }
 
-// acc[r][t] += sum_kk A(r,kk) B(t,kk) as gemm_phase, operands split.  k-steps two at a time from two register sets;
-// a set is refilled as soon as its MFMAs are issued.  ksteps even; TAIL16: the last k-step is a half k-step.
-template <int R, int NT, bool TAIL16 = false, int NTA = NT>
+// acc[r][t] += sum_kk A(r,kk) B(t,kk) as gemm_phase_ring, operands split: a ring of PFA k-steps of weight fragments
+// (a lone workgroup's weight stream is latency bound: bytes in flight per wave are what sets its rate) and two sets of
+// B fragments.  Every refill is unconditional (a load under a branch makes the compiler drain every load in flight
+// behind it); the surplus ones at the end of the phase are made free.  ksteps even; TAIL16: the last k-step is a half k-step.
+template <int R, int NT, int PFA, bool TAIL16 = false, int NTA = NT>
 __device__ __forceinline__ void gemm_x3(f32x4 (&acc)[R][NTA], WPtr a, int a_ks, uint32_t x3_delta, const u32x4* b, int b_lo,
                                         int b_ts, int b_ks, int ksteps) {
+    static_assert(PFA % 2 == 0, "B fragments alternate between two sets");
     const WPtr al{a.rs, a.so + x3_delta, a.lo};
-    struct Set { u32x4 ah[R], al[R], bh[NT], bl[NT]; };
-    Set s0, s1;
-    auto load = [&](Set& s, int kk) {
+    u32x4 ah[PFA][R], alo[PFA][R], bh[2][NT], bl[2][NT];
+    auto load_a = [&](int p, int kk) {
+        // refills past the last k-step go out with a lane offset beyond the buffer's range: the load instruction
+        // is issued (the vmcnt bookkeeping stays static) but returns zeros without touching memory
+        const uint32_t vo = kk < ksteps ? a.lo : (a.lo | 0x80000000u);
 #pragma unroll
-        for (int r = 0; r < R; ++r) { s.ah[r] = a.at(r + kk * a_ks); s.al[r] = al.at(r + kk * a_ks); }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { s.bh[t] = b[t * b_ts + kk * b_ks]; s.bl[t] = b[b_lo + t * b_ts + kk * b_ks]; }
-    };
-    auto mma = [&](const Set& s, bool half) {
-        // the small terms first; R*NT independent accumulators between two MFMAs on the same one
-        if (half) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(s.al[r], s.bh[t], acc[r][t]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(s.ah[r], s.bl[t], acc[r][t]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(s.ah[r], s.bh[t], acc[r][t]);
-        } else {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(s.al[r], s.bh[t], acc[r][t]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(s.ah[r], s.bl[t], acc[r][t]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(s.ah[r], s.bh[t], acc[r][t]);
+        for (int r = 0; r < R; ++r) {
+            ah[p][r] = __builtin_amdgcn_raw_buffer_load_b128(a.rs, vo, a.so + (uint32_t)(r + kk * a_ks) * 1024u, 0);
+            alo[p][r] = __builtin_amdgcn_raw_buffer_load_b128(al.rs, vo, al.so + (uint32_t)(r + kk * a_ks) * 1024u, 0);
         }
     };
-    load(s0, 0);
-    load(s1, 1);
-    for (int kk = 0; kk < ksteps; kk += 2) {
-        mma(s0, false);
-        load(s0, min(kk + 2, ksteps - 2));          // unconditional (the last refill is never used): a load under a
-        mma(s1, TAIL16 && kk + 2 >= ksteps);        // branch makes the compiler drain every load in flight behind it
-        load(s1, min(kk + 3, ksteps - 1));
+    auto load_b = [&](int q, int kk) {
+        kk = min(kk, ksteps - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { bh[q][t] = b[t * b_ts + kk * b_ks]; bl[q][t] = b[b_lo + t * b_ts + kk * b_ks]; }
+    };
+#pragma unroll
+    for (int p = 0; p < PFA; ++p) load_a(p, p);
+    load_b(0, 0);
+    load_b(1, 1);
+    for (int k0 = 0; k0 < ksteps; k0 += PFA) {
+#pragma unroll
+        for (int p = 0; p < PFA; ++p) {
+            const int kk = k0 + p;
+            if (kk < ksteps) {
+                // the small terms first; R*NT independent accumulators between two MFMAs on the same one
+                if (TAIL16 && kk + 1 >= ksteps) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(alo[p][r], bh[p & 1][t], acc[r][t]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(ah[p][r], bl[p & 1][t], acc[r][t]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(ah[p][r], bh[p & 1][t], acc[r][t]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(alo[p][r], bh[p & 1][t], acc[r][t]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(ah[p][r], bl[p & 1][t], acc[r][t]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(ah[p][r], bh[p & 1][t], acc[r][t]);
+                }
+            }
+            load_b(p & 1, kk + 2);
+            load_a(p, kk + PFA);
+        }
     }
 }
 
@@ -1546,7 +1561,7 @@ __device__ __forceinline__ void mlp_phase_x3(Tile<RPW>& T, const u32x4* xnT, int
         }
         // waves whose rows of this chunk are all padding (zero weights, zero bias) skip the GEMM: GELU(0) = 0
         if (RC * w < tiles_here)
-            gemm_x3<RC, NT, kt16(KS)>(h, wptr(w1p + (size_t)(RC * w) * 64, lane).adv((size_t)c * KS * kChunkTiles), kChunkTiles,
+            gemm_x3<RC, NT, 2, kt16(KS)>(h, wptr(w1p + (size_t)(RC * w) * 64, lane).adv((size_t)c * KS * kChunkTiles), kChunkTiles,
                                       x3_delta, xnT + lane, xn_lo, KS * 64, 64, KS);
         u32x4 hh[KW][NT], hl[KW][NT];
 #pragma unroll
@@ -1569,7 +1584,7 @@ __device__ __forceinline__ void mlp_phase_x3(Tile<RPW>& T, const u32x4* xnT, int
                 hT[((size_t)t * kKC + KW * w + j2) * 64 + lane + h_lo] = hl[j2][t];
             }
         __syncthreads();                         // hT(c) complete
-        gemm_x3<RPW, NT, false, kNTT>(T.acc, wptr(w2p + (size_t)(w * RPW) * 64, lane).adv((size_t)(c * kKC) * A2KS), A2KS, x3_delta,
+        gemm_x3<RPW, NT, 2, false, kNTT>(T.acc, wptr(w2p + (size_t)(w * RPW) * 64, lane).adv((size_t)(c * kKC) * A2KS), A2KS, x3_delta,
                                       hT + lane, h_lo, kKC * 64, 64, ((tiles_here >> 1) + 1) & ~1);
     }
     __syncthreads();
@@ -1686,17 +1701,17 @@ __device__ __forceinline__ void attn_phase_x3(Tile<RPW>& T, const u32x4* xnT, in
 #pragma unroll
             for (int t = 0; t < NTQ; ++t) qa[i][t] = bv;
         }
-        gemm_x3<3, NTQ, kt16(KS)>(qa, qkv_a(pair), 24, x3_delta, xnT + lane, xn_lo, KS * 64, 64, KS);
+        gemm_x3<3, NTQ, 2, kt16(KS)>(qa, qkv_a(pair), 24, x3_delta, xnT + lane, xn_lo, KS * 64, 64, KS);
         if (hsel == 0) write_qkv(qa);
         __syncthreads();
         core();
         __syncthreads();
-        gemm_x3<RPW, NTP, false, kNTT>(T.acc, proj_a(hA), kWaves * RPW, x3_delta, yT + lane, y_lo, 2 * 64, 64, 2);
+        gemm_x3<RPW, NTP, 2, false, kNTT>(T.acc, proj_a(hA), kWaves * RPW, x3_delta, yT + lane, y_lo, 2 * 64, 64, 2);
         if (hsel == 1) write_qkv(qa);
         __syncthreads();
         core();
         __syncthreads();
-        gemm_x3<RPW, NTP, false, kNTT>(T.acc, proj_a(hB), kWaves * RPW, x3_delta, yT + lane, y_lo, 2 * 64, 64, 2);
+        gemm_x3<RPW, NTP, 2, false, kNTT>(T.acc, proj_a(hB), kWaves * RPW, x3_delta, yT + lane, y_lo, 2 * 64, 64, 2);
     }
     __syncthreads();
 }
@@ -2162,6 +2177,7 @@ static int fused_min_batch() {
 }
 
 // 0: no fused kernel, 1: MLP block only, 2: whole layers
+static int g_level_max = -1;           // bf16 only: cap for tests / kernel experiments (beso_debug_set_fused_level_max)
 int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     FusedDims d;
     if (a.vbatch < fused_min_batch()) return 0;
@@ -2170,10 +2186,12 @@ int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     const bool whole = x3_shape(d) && kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused) &&
                        d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK;
     if (precision == BESO_PREC_BF16X3) return whole ? 2 : 0;     // BF16X3 is an instance of layers_kernel and nothing else
-    static const int level_max = getenv("BESO_FUSED_LEVEL_MAX") ? atoi(getenv("BESO_FUSED_LEVEL_MAX")) : 2;   // kernel experiments
-    if (level_max < 2) return level_max;
+    if (g_level_max < 0) g_level_max = getenv("BESO_FUSED_LEVEL_MAX") ? atoi(getenv("BESO_FUSED_LEVEL_MAX")) : 2;   // kernel experiments
+    if (g_level_max < 2) return g_level_max;
     return whole ? 2 : 1;
 }
+
+void fused_set_level_max(int n) { g_level_max = n < 0 ? 2 : n; }
 
 bool fused_supported(const Layout& lay, const FwdArgs& a, int precision) { return fused_level(lay, a, precision) > 0; }
 

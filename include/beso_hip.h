@@ -57,7 +57,9 @@ typedef struct beso_config {
 enum {
     BESO_PREC_BF16 = 0,   /* bf16 MFMA inputs, fp32 accumulate: throughput mode                 */
     BESO_PREC_FP32 = 1,   /* fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32: parity mode  */
-    BESO_PREC_BF16X3 = 2  /* split-bf16 (hi*hi + hi*lo + lo*hi), fp32-class accuracy            */
+    BESO_PREC_BF16X3 = 2  /* split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate): fp32-class
+                             accuracy from the fused kernel (an instance of layers_kernel: the shipped shapes --
+                             kitchen, block-push -- only; other shapes return BESO_ERR_UNSUPPORTED); inference only */
 };
 
 /* beso_loss_grad flags */
@@ -256,6 +258,10 @@ void beso_debug_set_stamps(void* device_buf, int capacity_u64);
  * workgroup), up to 2n the four-sample instance, larger ones the throughput instance (eight).  Default 512; 0 switches
  * both latency instances off.                                                                                          */
 void beso_debug_set_small_batch_max(int n);
+/* Development aid (tests): cap what the BESO_PREC_BF16 forward may fuse -- 2 (default): one launch for the whole network
+ * where the shape has such a kernel; 1: LN2 + MLP blocks only; 0: the per-op kernels (LayerNorm, GEMMs, attention) only.
+ * The comparison "fused kernel against per-op kernels in the same arithmetic" is a test of the former.               */
+void beso_debug_set_fused_level_max(int n);
 int  beso_profile_read(double* total_ms, int* launches);
 
 #ifdef __cplusplus

@@ -18,8 +18,27 @@ from conftest import load_golden, weights_from_fixture, rel_err
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": 2e-5, "bf16": 3e-2}
+TOL = {"fp32": 2e-5, "bf16": 3e-2, "bf16x3": 1e-4}      # bf16x3: the north-star bound itself (measured 7e-6 .. 3e-5)
+# bf16 against the reference's vectors, per fixture: twice what the fused kernel measures on MI355X (round 2:
+# 7.3e-3, 1.02e-2, 9.3e-3; the per-op kernels of the non-fused shapes sit at 3e-3 .. 8e-3)
+TOL_BF16_FIXTURE = {"kitchen_forward_std002.npz": 1.5e-2, "kitchen_forward_std008.npz": 2.1e-2, "block_push_forward.npz": 1.9e-2}
 DEV = "cuda:0"
+
+
+def count_fused_launches(fn):
+    """Runs fn() with the launch-site timer on the fused kernel's site; returns the number of launches it recorded."""
+    from beso_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    lib.beso_profile_enable(_lib.SITES["fused_layer"])
+    try:
+        fn()
+        torch.cuda.synchronize()
+        ms, n = C.c_double(0.0), C.c_int(0)
+        assert lib.beso_profile_read(C.byref(ms), C.byref(n)) == 0
+    finally:
+        lib.beso_profile_enable(0)
+    return n.value
 
 
 def make_module(cfg, w=None, precision="fp32", **kw):
@@ -83,7 +102,113 @@ def test_forward_vs_reference_vectors(fixture, cfg_name, precision):
             e3 = rel_err(m.inner_model(s, a, g, sg).cpu().numpy(), fx[p + "inner"])
             worst = max(worst, e1, e2, e3)
     print(f"[parity] {fixture} {precision}: max rel err {worst:.3e}")
-    assert worst < TOL[precision]
+    assert worst < (TOL_BF16_FIXTURE.get(fixture, TOL[precision]) if precision == "bf16" else TOL[precision])
+
+
+@pytest.mark.parametrize("fixture,cfg_name", [("kitchen_forward_std002.npz", "kitchen"), ("kitchen_forward_std008.npz", "kitchen"),
+                                              ("block_push_forward.npz", "block_push")])
+def test_bf16x3_forward_through_the_fused_kernel(fixture, cfg_name):
+    """The north-star tolerance (1e-4 of the reference) met by the BENCHMARKED kernel: the split-bf16 instance of
+    layers_kernel (BESO_PREC_BF16X3) against the reference's own outputs (score_gpts.py:272-358, score_wrappers.py:81-96),
+    t in {1, W/2, W}, conditional and unconditional, with and without preconditioning -- and every call must be exactly
+    one launch at the fused kernel's launch site (the mode has no per-op form to fall back to)."""
+    fx = load_golden(fixture)
+    cfg = O.CONFIGS[cfg_name]
+    m = make_module(cfg, _weights(fx, cfg), "bf16x3")
+    worst, calls = 0.0, 0
+
+    def run():
+        nonlocal worst, calls
+        for t in fx["ts"]:
+            p = f"t{int(t)}::"
+            s, a, g, sg = (G(fx[p + k]) for k in ("state", "action", "goal", "sigma"))
+            e1 = rel_err(m(s, a, g, sg).cpu().numpy(), fx[p + "denoised"])
+            e2 = rel_err(m(s, a, g, sg, uncond=True).cpu().numpy(), fx[p + "denoised_uncond"])
+            e3 = rel_err(m.inner_model(s, a, g, sg).cpu().numpy(), fx[p + "inner"])
+            worst = max(worst, e1, e2, e3)
+            calls += 3
+
+    with torch.no_grad():
+        launches = count_fused_launches(run)
+    print(f"[parity] {fixture} bf16x3 (layers_kernel, {launches} launches for {calls} calls): max rel err {worst:.3e}")
+    assert launches == calls
+    assert worst < TOL["bf16x3"]
+
+
+def test_bf16x3_sampler_loops_and_cfg_through_the_fused_kernel():
+    """Sampler loops (DDIM 3 / 10, Euler 10, Heun 5, DPM variants; block-push Heun-50 x classifier-free guidance: 198
+    score-net forwards per sample) in the split-bf16 mode against the reference's sampler outputs: <= 1e-4."""
+    from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+    from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
+    fns = {"ddim": ks.sample_ddim, "euler": ks.sample_euler, "heun": ks.sample_heun, "dpmpp_2m": ks.sample_dpmpp_2m,
+           "dpm": ks.sample_dpm_2, "dpmpp_2s": ks.sample_dpmpp_2s}
+    for fixture, cfg_name in [("kitchen_samplers.npz", "kitchen"), ("block_push_heun_cfg.npz", "block_push"),
+                              ("block_push_cfg.npz", "block_push")]:
+        fx = load_golden(fixture)
+        cfg = O.CONFIGS[cfg_name]
+        m = make_module(cfg, _weights(fx, cfg), "bf16x3")
+        if fixture == "block_push_cfg.npz":
+            with torch.no_grad():
+                for lam in fx["lambdas"]:
+                    out = ClassifierFreeSampleModel(m, float(lam))(G(fx["state"]), G(fx["action"]), G(fx["goal"]), G(fx["sigma"]))
+                    err = rel_err(out.cpu().numpy(), fx[f"lam{float(lam)}"])
+                    print(f"[parity] {fixture}:lambda={float(lam):g} bf16x3: {err:.3e}")
+                    assert err < TOL["bf16x3"]
+            continue
+        lam = float(fx["cond_lambda"])
+        model = m if lam < 0 else ClassifierFreeSampleModel(m, lam)
+        for key in sorted(k[:-5] for k in fx if k.endswith("::out")):
+            n = int(key.split("_")[-2])
+            sampler = key[: key.index(f"_{n}_")]
+            with torch.no_grad():
+                out = fns[sampler](model, G(fx["state"]), G(fx["x_t"]), G(fx["goal"]), torch.from_numpy(fx[key + "::sigmas"]),
+                                   disable=True)
+            err = rel_err(out.cpu().numpy(), fx[key + "::out"])
+            print(f"[parity] {fixture}:{key} bf16x3: {err:.3e}")
+            assert err < TOL["bf16x3"], key
+
+
+def test_bf16x3_rejects_shapes_without_a_fused_instance():
+    """BF16X3 is an instance of the fused kernel only: shapes that kernel does not serve raise instead of silently
+    running something else."""
+    cfg = O.TINY
+    m = make_module(cfg, O.make_weights(cfg), "bf16x3")
+    s, g, a = (G(v) for v in O.make_inputs(cfg, 2, seed=0))
+    with torch.no_grad(), pytest.raises(ValueError):
+        m(s, a, g, G(np.full(2, 0.5, np.float32)))
+
+
+@pytest.mark.parametrize("cfg_name", ["kitchen", "block_push"])
+def test_fused_bf16_kernel_against_the_per_op_bf16_kernels(cfg_name):
+    """The one-launch bf16 kernel against the per-op bf16 path of the same library (LayerNorm, GEMM, attention kernels:
+    same arithmetic type, different rounding points -- the fused kernel folds LayerNorm's gamma into the weights before
+    the bf16 rounding and keeps the residual in fp32 accumulators).  Both carry independent bf16 rounding errors of the
+    same size: measured on MI355X (std 0.02) fused-vs-oracle 8.9e-4 / 5.9e-4, per-op-vs-oracle 8.6e-4 / 6.4e-4,
+    fused-vs-per-op 1.1e-3 / 8.4e-4 (kitchen / block-push).  Held to: the fused kernel is no less accurate than the
+    per-op path (x1.5), and the two differ by no more than twice the larger of their own errors."""
+    from beso_amd import _lib
+    lib = _lib.load()
+    cfg = O.CONFIGS[cfg_name]
+    for std, bound in ((0.02, 2e-3), (0.08, 2e-2)):
+        wts = O.make_weights(cfg, seed=3, std=std)
+        m = make_module(cfg, wts, "bf16")
+        s_np, g_np, a_np = O.make_inputs(cfg, 256, seed=9)
+        sg_np = np.linspace(0.05, 1.0, 256).astype(np.float32)
+        s, a, g, sg = G(s_np), G(a_np), G(g_np), G(sg_np)
+        ref = O.denoise(wts, cfg, s_np, a_np, g_np, sg_np)
+        outs = {}
+        try:
+            with torch.no_grad():
+                for lvl in (2, 0):
+                    lib.beso_debug_set_fused_level_max(lvl)
+                    n = count_fused_launches(lambda: outs.__setitem__(lvl, m(s, a, g, sg).cpu().numpy()))
+                    assert n == (1 if lvl == 2 else 0)
+        finally:
+            lib.beso_debug_set_fused_level_max(2)
+        e_f, e_p, e_fp = rel_err(outs[2], ref), rel_err(outs[0], ref), rel_err(outs[2], outs[0])
+        print(f"[parity] {cfg_name} std={std}: fused-vs-oracle {e_f:.3e} per-op-vs-oracle {e_p:.3e} fused-vs-per-op {e_fp:.3e}")
+        assert e_f < bound and e_f < 1.5 * e_p + 1e-4
+        assert e_fp < 2.0 * max(e_f, e_p)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -204,7 +329,7 @@ def test_autograd_training_path_equals_hip_forward():
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32", "bf16x3"])
 def test_full_batch_properties_kitchen_4096(precision):
     """Config 2 (kitchen, B=4096): samples are independent, so (i) any slice of the batch must equal
     the same samples run alone, bit for bit; (ii) a batch of copies returns copies; (iii) a few
@@ -454,6 +579,31 @@ def test_fused_path_ragged_shapes_and_cfg(cfg_name, fused_instance):
 
 
 @pytest.mark.parametrize("cfg_name", ["kitchen", "block_push"])
+def test_bf16x3_ragged_shapes_and_cfg(cfg_name):
+    """The split-bf16 instance on what rollouts feed the kernel (B = 1, ragged batches, every warm-up window, unconditional
+    calls, classifier-free pairs with an odd batch) against the oracle at the north-star bound."""
+    from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
+    cfg = O.CONFIGS[cfg_name]
+    w = O.make_weights(cfg, seed=21, std=0.03)
+    m = make_module(cfg, w, "bf16x3")
+    worst = 0.0
+    with torch.no_grad():
+        for B, t in [(1, 1), (1, cfg.obs_seq_len), (3, 2), (9, cfg.obs_seq_len - 1), (37, 3), (129, cfg.obs_seq_len)]:
+            s_np, g_np, a_np = O.make_inputs(cfg, B, seed=100 * B + t, t=t)
+            sg_np = np.linspace(0.06, 1.0, B).astype(np.float32)
+            s, a, g, sg = G(s_np), G(a_np), G(g_np), G(sg_np)
+            out = m(s, a, g, sg)
+            assert out.shape == (B, t, cfg.act_dim)
+            worst = max(worst, rel_err(out.cpu().numpy(), O.denoise(w, cfg, s_np, a_np, g_np, sg_np)))
+            out_u = m(s, a, g, sg, uncond=True)
+            worst = max(worst, rel_err(out_u.cpu().numpy(), O.denoise(w, cfg, s_np, a_np, g_np, sg_np, uncond=True)))
+            out_cfg = ClassifierFreeSampleModel(m, 2.0)(s, a, g, sg)
+            worst = max(worst, rel_err(out_cfg.cpu().numpy(), O.denoise_cfg(w, cfg, s_np, a_np, g_np, sg_np, 2.0)))
+    print(f"[parity] fused ragged/CFG {cfg_name} bf16x3: {worst:.3e}")
+    assert worst < TOL["bf16x3"]
+
+
+@pytest.mark.parametrize("cfg_name", ["kitchen", "block_push"])
 def test_fused_instances_are_bit_identical(cfg_name):
     """The latency instances (two samples per workgroup up to 512 samples -- 256 with a classifier-free pair --, four up
     to 1024) and the throughput instance (eight) of the fused kernel run the same per-sample arithmetic: equal bits for every batch size, window, conditioning mode and through a sampler loop."""
@@ -511,7 +661,7 @@ def test_no_reads_past_the_end_of_the_inputs():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg_name,precision", [("kitchen", "bf16"), ("kitchen", "fp32"), ("block_push", "bf16"),
-                                                ("long_horizon", "bf16")])
+                                                ("long_horizon", "bf16"), ("kitchen", "bf16x3"), ("block_push", "bf16x3")])
 def test_no_writes_outside_output_and_workspace(cfg_name, precision):
     """beso_denoise_fwd / beso_sample through the C ABI with the output, the in/out sample and the workspace
     embedded in larger buffers full of sentinel bytes: nothing outside [ptr, ptr + size) may change."""
