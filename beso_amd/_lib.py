@@ -25,7 +25,7 @@ EXPORTS = ["beso_version", "beso_status_string", "beso_last_error", "beso_num_pa
            "beso_profile_enable", "beso_profile_read", "beso_debug_set_stamps", "beso_adam_step",
            "beso_train_workspace_bytes", "beso_grad_floats", "beso_loss_grad", "beso_debug_gemm", "beso_gather_windows",
            "beso_loss_grad_overlap", "beso_grad_early_range", "beso_debug_set_small_batch_max",
-           "beso_sample_ancestral", "beso_debug_set_fused_level_max"]
+           "beso_sample_ancestral", "beso_debug_set_fused_level_max", "beso_goal_mask"]
 
 
 class BesoConfig(C.Structure):
@@ -110,7 +110,9 @@ def load() -> C.CDLL:
             lib.beso_grad_floats.argtypes = [cfgp]
             lib.beso_loss_grad.restype = i32
             lib.beso_loss_grad.argtypes = [cfgp, C.POINTER(vp), i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32,
-                                           f32, C.c_uint, f32, vp, sz, vp]
+                                           f32, f32, C.c_uint, f32, vp, sz, vp]
+            lib.beso_goal_mask.restype = i32
+            lib.beso_goal_mask.argtypes = [vp, i32, i32, i32, f32, C.c_uint, vp]
             if hasattr(lib, "beso_loss_grad_overlap") or not os.environ.get("BESO_HIP_LIB"):
                 lib.beso_loss_grad_overlap.restype = i32
                 lib.beso_loss_grad_overlap.argtypes = lib.beso_loss_grad.argtypes + [vp]

@@ -60,9 +60,8 @@ class BesoAgent(BaseAgent):
         self.ema_helper = ExponentialMovingAverage(self.model.get_params(), decay, self.device)
         self.use_ema = use_ema
         # torch Adam / AdamW on a HIP device -> the one-launch fused step (same hyper-parameters, same
-        # param_groups surface for the LR scheduler); BESO_AMD_FUSED_OPTIM=0 keeps the eager optimizer
-        if os.environ.get("BESO_AMD_FUSED_OPTIM", "1") != "0":
-            self.optimizer = maybe_fuse(self.optimizer)
+        # param_groups surface for the LR scheduler); any other optimizer class is left as configured
+        self.optimizer = maybe_fuse(self.optimizer)
         self.lr_scheduler = instantiate(lr_scheduler, optimizer=self.optimizer)
         self.gc = goal_conditioned
         self.train_method = train_method
@@ -145,7 +144,20 @@ class BesoAgent(BaseAgent):
                 den.inner_model.mark_weights_dirty()
 
     # ------------------------------------------------------------------ training
+    def _sync_replicas(self):
+        """Data parallel: every replica starts from rank 0's weights (C2, one flat broadcast), and the EMA shadow is
+        re-seeded from them (a shadow built from the pre-broadcast init would make the ranks' EMA weights differ)."""
+        if bdist.is_distributed() and not getattr(self, "_replicas_synced", False):
+            bdist.broadcast_parameters(self.model.get_params(), src=0)
+            den = self._hip_denoiser()
+            if den is not None:
+                den.inner_model.mark_weights_dirty()
+            self.ema_helper.load_shadow_params(self.model.get_params())
+            self._ema_packed_key = None
+            self._replicas_synced = True
+
     def train_agent(self, train_loader, test_loader):
+        self._sync_replicas()
         if self.train_method == 'epochs':
             self.train_agent_on_epochs(train_loader, test_loader, self.epochs)
         elif self.train_method == 'steps':
@@ -154,12 +166,16 @@ class BesoAgent(BaseAgent):
             raise ValueError('Either epochs or n_steps must be specified!')
 
     def train_agent_on_epochs(self, train_loader, test_loader, epochs):
+        """Epoch mode with the reference loop's cadence (beso_agent.py:129-175): the logged / early-stopping test MSE is the
+        LAST test batch's (the reference re-creates its list inside the loop, :138-142), the step counter advances once
+        more per batch on top of train_step's own increment (:152) -- which shifts the EMA cadence
+        `steps % update_ema_every_n_steps` -- and the LR scheduler gets an extra step whenever that counter hits a
+        multiple of eval_every_n_steps (:153-154)."""
         best_test_mse, mean_mse, avg_test_mse = 1e10, 1e10, 1e10
         for epoch in range(epochs):
             test_mse = [self.evaluate(batch) for batch in test_loader]
             if test_mse:
-                mean_mse = test_mse[-1]
-                avg_test_mse = sum(test_mse) / len(test_mse)
+                mean_mse = avg_test_mse = test_mse[-1]
             stop, best_test_mse = self.early_stopping(best_test_mse, mean_mse, self.patience, epochs)
             if stop:
                 log.info('Early stopping!')
@@ -167,6 +183,9 @@ class BesoAgent(BaseAgent):
             losses = []
             for batch in train_loader:
                 losses.append(self.train_step(batch))
+                self.steps += 1
+                if self.steps % self.eval_every_n_steps == 0:
+                    self.lr_scheduler.step()
                 _wandb_log({"training/loss": losses[-1], "training/test_loss": avg_test_mse})
             _wandb_log({'training/epoch_loss': float(np.mean(losses)) if losses else 0.0,
                         'training/epoch_test_loss': avg_test_mse, 'training/epoch': epoch})
@@ -213,9 +232,7 @@ class BesoAgent(BaseAgent):
         if step is not None:
             # HIP forward + backward (beso_loss_grad): gradients land in views of one flat buffer, already
             # divided by the world size for the data-parallel mean
-            inner = self.model.inner_model
             self.optimizer.zero_grad(set_to_none=True)
-            masked = inner.mask_cond(goal) if goal is not None else goal
             self._hip_step = step
             # under data parallelism the all-reduce of the upper layers' gradients starts under the backward of the lower
             # ones: the call orders self._c1_stream behind the completion of that range (BESO_AMD_C1_OVERLAP=0: one flat
@@ -227,7 +244,8 @@ class BesoAgent(BaseAgent):
                     self._c1_stream = torch.cuda.Stream(state.device)
                 early = self._c1_stream
             self._c1_early = early
-            return step.loss_backward(state, action, masked, noise, sigma, grad_scale=1.0 / bdist.world_size(),
+            # (goal masking for classifier-free guidance, mask_cond, is applied by the kernel from cond_mask_prob)
+            return step.loss_backward(state, action, goal, noise, sigma, grad_scale=1.0 / bdist.world_size(),
                                       early_stream=early)
         self._hip_step = None
         loss = self.model.loss(state, action, goal, noise, sigma)

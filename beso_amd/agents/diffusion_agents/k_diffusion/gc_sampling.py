@@ -145,7 +145,15 @@ def _try_fused(name, model, state, action, goal, sigmas, scaler, extra_args, cal
     den, lam = _fused_target(model)
     if den is None or not action.is_cuda:
         return None
-    return den.fused_sampler(name, state, action, goal, _host_sigmas(sigmas), cond_lambda=lam)
+    sig = _host_sigmas(sigmas)
+    if not _interior_positive(sig):
+        return None                    # e.g. get_sigmas_linear(sigma_min=0), the clipped cosine_beta: the stepwise loop serves them
+    return den.fused_sampler(name, state, action, goal, sig, cond_lambda=lam)
+
+
+def _interior_positive(sig) -> bool:
+    """beso_sample / beso_sample_ancestral take schedules whose values are positive up to the trailing one."""
+    return len(sig) >= 2 and all(float(v) > 0.0 for v in sig[:-1])
 
 
 def _churn(i, n, sig, s_churn, s_tmin, s_tmax):
@@ -192,7 +200,7 @@ def sample_euler_ancestral(model, state, action, goal, sigmas, scaler=None, extr
     extra_args = {} if extra_args is None else extra_args
     if scaler is None and callback is None and not extra_args and eta >= 0:
         den, lam = _fused_target(model)
-        if den is not None and action.is_cuda:
+        if den is not None and action.is_cuda and _interior_positive(_host_sigmas(sigmas)):
             fused = den.fused_sampler('euler_ancestral', state, action, goal, _host_sigmas(sigmas), cond_lambda=lam, eta=eta)
             if fused is not None:
                 return fused

@@ -6,22 +6,19 @@ the EMA helper's zip over ``parameters()`` stays aligned), same call signature
 ``model(states, actions, goals, sigma, uncond=False, keep_last_actions=False)``
 (reference: score_gpts.py:121-139, 272-358).
 
-The module is a parameter container.  Inference (no autograd) never touches torch ops: it packs the
-parameters into the kernel image (cached, re-packed when a parameter changes) and calls
-``beso_score_fwd``.  Only when autograd is required (``train_step``) does it evaluate the same
-function with differentiable torch ops on the GPU -- the HIP backward is a later row of the scope
-table.  There is no CPU path.
+The module is a parameter container: its forward never touches torch ops.  Inference (no autograd) packs the
+parameters into the kernel image (cached, re-packed when a parameter changes) and calls ``beso_score_fwd``; the
+training step is ``GCDenoiser.loss`` -> ``beso_loss_grad`` (forward + every parameter gradient, beso_amd/training.py).
+There is no CPU path and no torch-op evaluation of the network: a call neither kernel can serve raises.
 """
 from __future__ import annotations
 
 import contextlib
-import math
 import os
 from typing import Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ....runtime import PackedWeights, ScoreNetRuntime, ScoreNetShape
 
@@ -132,7 +129,8 @@ class DiffusionGPT(nn.Module):
         return rt
 
     def set_precision(self, precision: str) -> None:
-        """'bf16' (throughput), 'fp32' (parity: exact-fp32 MFMA)."""
+        """'bf16' (throughput), 'bf16x3' (parity mode of the fused kernel: split-bf16, fp32-class), 'fp32' (exact-fp32
+        MFMA, per-op kernels, any shape)."""
         if precision != self.precision:
             self.precision = precision
             self._packed = None
@@ -182,11 +180,13 @@ class DiffusionGPT(nn.Module):
         assert t <= self.block_size, "Cannot forward, model block size is exhausted."
         if self.training:
             goals = self.mask_cond(goals)                                   # :298-299
-        if self._hip_eligible(states, actions, goals, sigma):
-            pred = self.runtime().denoise(self.packed_weights(), states, actions, goals, sigma,
-                                          uncond=bool(uncond), precondition=False)
-        else:
-            pred = self._forward_autograd(states, actions, goals, sigma, bool(uncond))
+        if not self._hip_eligible(states, actions, goals, sigma):
+            raise RuntimeError(
+                "beso_amd.DiffusionGPT.forward runs as HIP kernels without an autograd graph: call it under "
+                "torch.no_grad() (and in eval() mode when the model has dropout); the differentiable use of the "
+                "network is GCDenoiser.loss(...), whose forward AND backward are one HIP call (beso_loss_grad)")
+        pred = self.runtime().denoise(self.packed_weights(), states, actions, goals, sigma,
+                                      uncond=bool(uncond), precondition=False)
         if keep_last_actions:                                               # :355-356
             pred = torch.cat([actions[:, :-1, :], pred[:, -1, :].reshape(1, 1, -1)], dim=1)
         return pred
@@ -199,34 +199,3 @@ class DiffusionGPT(nn.Module):
             keep = 1. - torch.bernoulli(torch.full_like(cond, self.cond_mask_prob))
             return cond * keep
         return cond
-
-    # differentiable evaluation for the training step (torch ops on the GPU; autograd supplies the
-    # backward).  Semantics identical to the HIP forward: tests/test_gpu_parity.py compares them.
-    def _forward_autograd(self, states, actions, goals, sigma, uncond: bool):
-        b, t, _ = states.shape
-        G, D, H = self.goal_seq_len, self.embed_dim, self.n_heads
-        emb_t = self.sigma_emb((sigma.log() / 4).reshape(b, 1).to(torch.float32)).unsqueeze(1)
-        pos = self.pos_emb[:, : t + G, :]
-        s_x = self.drop(self.tok_emb(states) + pos[:, G:, :])
-        a_x = self.drop(self.action_emb(actions) + pos[:, G:, :])
-        seq = [emb_t]
-        if self.goal_conditioned:
-            if uncond:
-                goals = torch.zeros_like(goals)
-            seq.append(self.drop(self.tok_emb(goals) + pos[:, :G, :]).expand(b, -1, -1))
-        seq.append(torch.stack((s_x, a_x), dim=2).reshape(b, 2 * t, D))       # s_1,a_1,s_2,a_2,...
-        x = torch.cat(seq, dim=1)
-        T = x.shape[1]
-        for blk in self.blocks:
-            at = blk.attn
-            h = blk.ln1(x)
-            q, k, v = (lin(h).view(b, T, H, D // H).transpose(1, 2) for lin in (at.query, at.key, at.value))
-            w = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(D // H))
-            w = w.masked_fill(at.mask[:, :, :T, :T] == 0, float("-inf"))
-            w = at.attn_drop(F.softmax(w, dim=-1))
-            y = (w @ v).transpose(1, 2).reshape(b, T, D)
-            x = x + at.resid_drop(at.proj(y))
-            x = x + blk.mlp(blk.ln2(x))
-        x = self.ln_f(x)[:, G + 1:, :]
-        a_out = x.reshape(b, x.shape[1] // 2, 2, D)[:, :, 1, :]
-        return self.action_pred(a_out)

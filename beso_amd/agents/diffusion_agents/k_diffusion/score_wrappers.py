@@ -5,8 +5,6 @@ With a ``beso_amd`` DiffusionGPT inside, ``forward`` is ONE call into the HIP li
 (``beso_denoise_fwd``): c_in is folded into the token-embedding kernel, c_out / c_skip into the
 action-head kernel.  Any other inner model is evaluated by the textbook formula on top of it.
 """
-import os
-
 import torch
 from torch import nn
 
@@ -51,15 +49,21 @@ class GCDenoiser(nn.Module):
         last_only = bool(kwargs.pop("pred_last_action_only", False))
         if last_only:
             noise[:, :-1, :] = 0                                   # in place, like the reference (:63)
-        step = None if kwargs else self.hip_train_step(state, action, goal, noise, sigma)
-        if step is not None:
-            # forward + every parameter gradient in one enqueue of beso_loss_grad (beso_amd/training.py)
-            inner = self.inner_model
-            masked = inner.mask_cond(goal) if (inner.training and goal is not None) else goal
-            return ScoreMatchingLoss.apply(step, last_only, state, action, masked, noise, sigma, *inner.parameters())
+        inner = self.inner_model
+        if isinstance(inner, DiffusionGPT):
+            # forward + every parameter gradient in one enqueue of beso_loss_grad (beso_amd/training.py); there is no
+            # torch-op evaluation behind it: what the kernels cannot serve raises
+            if kwargs:
+                raise ValueError(f"GCDenoiser.loss: unsupported keyword arguments {sorted(kwargs)} for the HIP training step")
+            step = self.hip_train_step(state, action, goal, noise, sigma)
+            if step is None:
+                raise ValueError("GCDenoiser.loss: " + self._why_no_hip_step(state, action, goal, noise, sigma))
+            # (training-mode goal masking -- DiffusionGPT.mask_cond, score_gpts.py:298-299 -- happens inside the kernel)
+            return ScoreMatchingLoss.apply(step, last_only, state, action, goal, noise, sigma, *inner.parameters())
+        # a foreign inner model (any callable score network): the textbook objective on top of it
         noised = action + noise * append_dims(sigma, action.ndim)
         c_skip, c_out, c_in = (append_dims(c, action.ndim) for c in self.get_scalings(sigma))
-        out = self.inner_model(state, noised * c_in, goal, sigma, **kwargs)
+        out = inner(state, noised * c_in, goal, sigma, **kwargs)
         target = (action - c_skip * noised) / c_out
         if last_only:
             return (out[:, -1, :] - target[:, -1, :]).pow(2).mean()
@@ -71,7 +75,7 @@ class GCDenoiser(nn.Module):
         inner = self.inner_model
         if not isinstance(inner, DiffusionGPT) or not torch.is_grad_enabled():
             return None
-        if os.environ.get("BESO_AMD_HIP_TRAIN", "1") == "0" or not HipTrainStep.supported(inner):
+        if not HipTrainStep.supported(inner):
             return None
         if not (torch.is_tensor(action) and action.is_cuda):
             return None
@@ -80,6 +84,17 @@ class GCDenoiser(nn.Module):
         if step is None:
             step = self._train_steps[key] = HipTrainStep(inner, key)
         return step if step.eligible(state, action, goal, noise, sigma) else None
+
+    def _why_no_hip_step(self, state, action, goal, noise, sigma) -> str:
+        inner = self.inner_model
+        if not torch.is_grad_enabled():
+            return "called with autograd disabled (the loss is a training-step quantity)"
+        if not HipTrainStep.supported(inner):
+            return f"embed_dim={inner.embed_dim} is not a multiple of 8 (the HIP training kernels need that)"
+        if not (torch.is_tensor(action) and action.is_cuda):
+            return "the inputs are not on the GPU (beso_amd has no CPU path)"
+        return ("parameters must be contiguous fp32 HIP tensors that require grad, and state / action / goal / noise / "
+                "sigma HIP tensors that do not")
 
     # -- fused path ----------------------------------------------------------------------------
     @staticmethod

@@ -524,12 +524,12 @@ size_t beso_grad_floats(const beso_config* cfg) { return train_grad_floats(cfg);
 int beso_loss_grad_overlap(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
                            const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
                            float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
-                           unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes, void* stream,
-                           void* early_stream) {
+                           float goal_drop, unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes,
+                           void* stream, void* early_stream) {
     hipError_t e = hipSuccess;
     int line = 0;
     int st = train_loss_grad(cfg, params, n_params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch,
-                             t, flags, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale, workspace, workspace_bytes, (hipStream_t)stream,
+                             t, flags, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale, workspace, workspace_bytes, (hipStream_t)stream,
                              (hipStream_t)early_stream, &e, &line);
     if (st == BESO_ERR_HIP) {
         snprintf(g_last_error, sizeof(g_last_error), "%s (%d) at train.hip:%d", hipGetErrorName(e), (int)e, line);
@@ -539,11 +539,20 @@ int beso_loss_grad_overlap(const beso_config* cfg, const float* const* params, i
 
 int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
                    const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
-                   float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop, unsigned int seed,
-                   float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
+                   float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
+                   float goal_drop, unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
     return beso_loss_grad_overlap(cfg, params, n_params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
-                                  flags, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale, workspace, workspace_bytes, stream,
-                                  nullptr);
+                                  flags, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale, workspace, workspace_bytes,
+                                  stream, nullptr);
+}
+
+int beso_goal_mask(float* mask, int batch, int goal_seq_len, int obs_dim, float goal_drop, unsigned int seed, void* stream) {
+    if (batch < 0 || goal_seq_len < 0 || obs_dim < 0) return BESO_ERR_BAD_ARG;
+    hipError_t e = hipSuccess;
+    int line = 0;
+    int st = train_goal_mask(mask, (size_t)batch * goal_seq_len * obs_dim, goal_drop, seed, (hipStream_t)stream, &e, &line);
+    if (st == BESO_ERR_HIP) snprintf(g_last_error, sizeof(g_last_error), "%s (%d) at train.hip:%d", hipGetErrorName(e), (int)e, line);
+    return st;
 }
 
 int beso_grad_early_range(const beso_config* cfg, size_t* begin, size_t* end) {

@@ -38,6 +38,16 @@ __device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t site, size_t
 }
 
 constexpr uint32_t kEmbedSite = 4 * kMaxLayers + 16;     // dropout site of the embeddings (layer sites are 4 l + {0, 1, 2})
+constexpr uint32_t kGoalSite = 4 * kMaxLayers + 17;      // DiffusionGPT.mask_cond: elementwise Bernoulli over goals [B,G,obs]
+
+// mask_cond (score_gpts.py:360-371): cond * (1 - bernoulli(p)), elementwise over [B, G, obs], NO rescaling of the kept
+// elements.  keep(b, g, c) = 1 iff the hash-uniform of element ((b*G + g)*obs + c) is >= p.
+__device__ __forceinline__ float goal_keep(uint32_t seed, size_t idx, float p) { return drop_scale(seed, kGoalSite, idx, p, 1.0f); }
+
+__global__ void goal_mask_kernel(float* __restrict__ mask, size_t n, float p, uint32_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        mask[i] = p > 0.f ? goal_keep(seed, i, p) : 1.f;
+}
 
 // GELU and its derivative (nn.GELU(), score_gpts.py:107): exact erf / exp in the fp32 mode, the fitted polynomial of
 // the inference kernels (max |error| 1.9e-4, below the bf16 rounding of the stored value) in the bf16 mode
@@ -546,7 +556,7 @@ __global__ void train_embed_kernel(const float* __restrict__ state, const float*
                                    const float* __restrict__ sig_b, const float* __restrict__ act_w,
                                    const float* __restrict__ act_b, float* __restrict__ x, E* __restrict__ xemb,
                                    int t, int T, int G, int D, int obs, int act, int Ke, float sigma_data, float p_drop,
-                                   uint32_t seed) {
+                                   float p_goal, uint32_t seed) {
     extern __shared__ float in_vec[];
     const int row = blockIdx.x, b = row / T, j = row % T;
     const float sg = sigma[b];
@@ -566,7 +576,11 @@ __global__ void train_embed_kernel(const float* __restrict__ state, const float*
             scale = 1.0f / sqrtf(sg * sg + sigma_data * sigma_data);                      // c_in
         }
     }
-    for (int c = threadIdx.x; c < len; c += blockDim.x) in_vec[c] = src[c] * scale;
+    // training-mode goal masking (mask_cond, score_gpts.py:298-299) happens here: the goal tokens' inputs are zeroed
+    // elementwise; the feature matrix xemb (operand of the embedding weight gradients) takes the masked values
+    const bool goal_tok = j >= 1 && j <= G && p_goal > 0.f;
+    for (int c = threadIdx.x; c < len; c += blockDim.x)
+        in_vec[c] = src[c] * scale * (goal_tok ? goal_keep(seed, ((size_t)b * G + (j - 1)) * obs + c, p_goal) : 1.f);
     __syncthreads();
     const float lsg = logf(sg) / 4.0f;
     for (int c = threadIdx.x; c < Ke; c += blockDim.x) {
@@ -1294,7 +1308,7 @@ size_t train_grad_floats(const beso_config* c) {
 template <typename E>
 static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat, int precision, const float* state,
                        const float* action, const float* goal, const float* noise, const float* sigma, float* loss_out,
-                       int batch, int t, int last_only, float embed_p, float attn_p, float resid_p, uint32_t seed,
+                       int batch, int t, int last_only, float embed_p, float attn_p, float resid_p, float goal_p, uint32_t seed,
                        float grad_scale, char* ws,
                        const TrainWs& w, hipStream_t s, hipStream_t early_stream, hipError_t* err, int* err_line) {
     const int D = c->embed_dim, H = c->n_heads, hd = D / H, L = c->n_layers, G = c->goal_seq_len;
@@ -1374,7 +1388,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         const int threads = D >= 256 ? 256 : round_up(D, 64);
         hipLaunchKernelGGL(train_embed_kernel<E>, dim3(M), dim3(threads), sizeof(float) * (size_t)(obs > act ? obs : act), s,
                            state, (const float*)F(w.noised), goal, sigma, pos.p, tokw.p, tokb.p, sigw.p, sigb.p, actw.p,
-                           actb.p, F(w.x0), P(w.xemb), t, T, G, D, obs, act, Ke, c->sigma_data, embed_p, seed);
+                           actb.p, F(w.x0), P(w.xemb), t, T, G, D, obs, act, Ke, c->sigma_data, embed_p, goal_p, seed);
         TRY(hipGetLastError());
     }
     const int nv = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
@@ -1589,7 +1603,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
 int train_loss_grad(const beso_config* c, const float* const* params, int n_params, float* grads_flat, int precision,
                     const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
                     float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
-                    uint32_t seed, float grad_scale,
+                    float goal_drop, uint32_t seed, float grad_scale,
                     void* workspace, size_t workspace_bytes, hipStream_t s, hipStream_t early_stream, hipError_t* err,
                     int* err_line) {
     int st = train_validate(c, batch, t);
@@ -1601,18 +1615,28 @@ int train_loss_grad(const beso_config* c, const float* const* params, int n_para
     for (int i = 0; i < n_params; ++i) if (!params[i]) return BESO_ERR_BAD_ARG;
     if (flags & ~BESO_TRAIN_LAST_ACTION_ONLY) return BESO_ERR_BAD_ARG;
     if (!(attn_pdrop >= 0.f && attn_pdrop < 1.f && resid_pdrop >= 0.f && resid_pdrop < 1.f && embed_pdrop >= 0.f &&
-          embed_pdrop < 1.f))
+          embed_pdrop < 1.f && goal_drop >= 0.f && goal_drop <= 1.f))
         return BESO_ERR_BAD_ARG;
     TrainWs w;
     make_train_ws(c, batch, t, precision, &w);
     if (workspace_bytes < w.total) return BESO_ERR_WORKSPACE;
     if (precision == BESO_PREC_FP32)
         return loss_grad_e<float>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
-                                  flags & BESO_TRAIN_LAST_ACTION_ONLY, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale,
+                                  flags & BESO_TRAIN_LAST_ACTION_ONLY, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale,
                                   (char*)workspace, w, s, early_stream, err, err_line);
     return loss_grad_e<uint16_t>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
-                                 flags & BESO_TRAIN_LAST_ACTION_ONLY, embed_pdrop, attn_pdrop, resid_pdrop, seed, grad_scale,
+                                 flags & BESO_TRAIN_LAST_ACTION_ONLY, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale,
                                  (char*)workspace, w, s, early_stream, err, err_line);
+}
+
+int train_goal_mask(float* mask, size_t n, float goal_drop, uint32_t seed, hipStream_t s, hipError_t* err, int* err_line) {
+    if (!mask || !(goal_drop >= 0.f && goal_drop <= 1.f)) return BESO_ERR_BAD_ARG;
+    if (n == 0) return BESO_OK;
+    int grid = (int)((n + 255) / 256); if (grid > 2048) grid = 2048;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(goal_mask_kernel, dim3(grid), dim3(256), 0, s, mask, n, goal_drop, seed);
+    TRY(hipGetLastError());
+    return BESO_OK;
 }
 
 // development aid: C[M][N] = op(A) op(B)^T through tgemm (fp32 output), for the layout tests

@@ -74,8 +74,8 @@ class DeviceTrajectoryFeed:
         self._start = torch.from_numpy(start).to(self.device)
         self.shuffle, self.drop_last = bool(shuffle), bool(drop_last)
         # data-parallel ranks (default: the initialised process group) draw the SAME permutation (same seed -- rank 0's is
-        # broadcast when none is given) and take interleaved shares of it, so that one epoch of the job still sees every
-        # window once; the goal draws differ per rank
+        # broadcast when none is given) and take interleaved shares of it (equal counts: the permutation is wrapped to a
+        # multiple of the world size), so that one epoch of the job still sees every window; the goal draws differ per rank
         self.rank = bdist.rank() if rank is None else int(rank)
         self.world_size = bdist.world_size() if world_size is None else int(world_size)
         self._perm_gen = torch.Generator(device=self.device)
@@ -116,8 +116,10 @@ class DeviceTrajectoryFeed:
         return len(self.slices)
 
     def _share(self) -> int:
-        """Windows of one epoch that belong to this rank (interleaved split of the permutation)."""
-        return (self.n_windows - self.rank + self.world_size - 1) // self.world_size
+        """Windows of one epoch per rank: the SAME count on every rank, ceil(n / world) -- the permutation is wrapped
+        around to a multiple of the world size, as torch's DistributedSampler does.  Ranks that differed by one window
+        could differ by one batch, and a rank with an extra batch would issue a gradient all-reduce nobody joins."""
+        return (self.n_windows + self.world_size - 1) // self.world_size
 
     def __len__(self) -> int:
         n = self._share()
@@ -158,6 +160,9 @@ class DeviceTrajectoryFeed:
         n = self.n_windows
         order = (torch.randperm(n, device=self.device, generator=self._perm_gen) if self.shuffle
                  else torch.arange(n, device=self.device))
+        pad = self._share() * self.world_size - n
+        if pad:
+            order = torch.cat([order, order[:pad]])
         mine = order[self.rank::self.world_size]
         for k in range(len(self)):
             yield self.gather(mine[k * self.batch_size:(k + 1) * self.batch_size])

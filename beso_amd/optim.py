@@ -94,6 +94,9 @@ class FusedAdam(torch.optim.Optimizer):
                                           ema_ptr, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                           float(group["weight_decay"]), 1 if group["decoupled_weight_decay"] else 0,
                                           st["step"], float(ema_decay), stream), "beso_adam_step")
+        # the kernel writes the parameters through raw pointers: bump their version counters so that everything keyed on
+        # them (the packed-weight cache of DiffusionGPT, autograd's saved-tensor checks) sees the update
+        torch.autograd.graph.increment_version([p for g in self.param_groups for p in g["params"] if p.grad is not None])
         if ema is not None:
             ema.version += 1
         return loss

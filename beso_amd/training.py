@@ -95,9 +95,10 @@ class HipTrainStep:
         return int(b.value), int(e.value)
 
     def run(self, state, action, goal, noise, sigma, grad_scale: float = 1.0, seed: Optional[int] = None,
-            fresh_grads: bool = False, last_action_only: bool = False, early_stream=None):
+            fresh_grads: bool = False, last_action_only: bool = False, early_stream=None, goal_drop: Optional[float] = None):
         """-> (loss 0-d tensor, flat gradient tensor, list of per-parameter views).  Inputs are NOT modified.
-        ``early_stream`` (a torch.cuda.Stream): ordered behind the completion of ``early_range()`` by the call."""
+        ``early_stream`` (a torch.cuda.Stream): ordered behind the completion of ``early_range()`` by the call.
+        ``goal_drop``: None = the module's ``cond_mask_prob`` (training mode); 0 = the goals are taken as they are."""
         inner = self.inner
         dev = action.device
         f32 = lambda x: x.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -116,10 +117,13 @@ class HipTrainStep:
             goal = goal.expand(B, G, inner.obs_dim).contiguous()
             gptr = goal.data_ptr()
         embed_p, attn_p, resid_p = inner._pdrops
+        # training-mode goal masking (DiffusionGPT.mask_cond, score_gpts.py:298-299) is part of the kernel: the goals
+        # go in unmasked together with the drop probability
+        goal_p = float(getattr(inner, "cond_mask_prob", 0.0) or 0.0) if (G > 0 and goal_drop is None) else float(goal_drop or 0.0)
         if not inner.training:
-            embed_p = attn_p = resid_p = 0.0
+            embed_p = attn_p = resid_p = goal_p = 0.0
         if seed is None:
-            if (embed_p > 0.0 or attn_p > 0.0 or resid_p > 0.0) and torch.cuda.is_current_stream_capturing():
+            if (embed_p > 0.0 or attn_p > 0.0 or resid_p > 0.0 or goal_p > 0.0) and torch.cuda.is_current_stream_capturing():
                 # the seed is a host scalar: a captured graph would replay one mask forever
                 raise RuntimeError("beso_amd: the HIP training step with dropout cannot be captured into a graph")
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,), device="cpu").item())
@@ -135,11 +139,23 @@ class HipTrainStep:
                 C.byref(self.cfg), arr, len(params), flat.data_ptr(), precision,
                 state.data_ptr(), action.data_ptr(), gptr, noise.data_ptr(), sigma.data_ptr(),
                 loss.data_ptr(), B, t, 1 if last_action_only else 0, float(embed_p), float(attn_p), float(resid_p),
-                C.c_uint(seed & 0xFFFFFFFF), float(grad_scale), ws.data_ptr(), ws.numel(),
+                float(goal_p), C.c_uint(seed & 0xFFFFFFFF), float(grad_scale), ws.data_ptr(), ws.numel(),
                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
                 C.c_void_p(early_stream.cuda_stream) if early_stream is not None else None)
         _lib.check(st, "loss_grad")
         return loss, flat, views
+
+    def goal_mask(self, batch: int, seed: int, goal_drop: Optional[float] = None, device=None) -> torch.Tensor:
+        """The keep-mask [batch, G, obs] the kernel applies to the goals for (goal_drop, seed) (``beso_goal_mask``)."""
+        inner = self.inner
+        p = float(inner.cond_mask_prob if goal_drop is None else goal_drop)
+        dev = torch.device(device) if device is not None else next(inner.parameters()).device
+        mask = torch.empty(batch, inner.goal_seq_len, inner.obs_dim, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.beso_goal_mask(mask.data_ptr(), batch, inner.goal_seq_len, inner.obs_dim, p,
+                                               C.c_uint(seed & 0xFFFFFFFF),
+                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "goal_mask")
+        return mask
 
     def loss_backward(self, state, action, goal, noise, sigma, grad_scale: float = 1.0, seed: Optional[int] = None,
                       early_stream=None):

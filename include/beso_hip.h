@@ -15,6 +15,8 @@
  *   beso_sample         <- sample_ddim / sample_euler / sample_heun    k_diffusion/gc_sampling.py:167-213,259-314,895-924
  *   beso_sample_ancestral <- sample_euler_ancestral                    k_diffusion/gc_sampling.py:216-256
  *   beso_loss_grad      <- GCDenoiser.loss + loss.backward()           k_diffusion/score_wrappers.py:45-79, beso_agent.py:228-233
+ *                          (+ DiffusionGPT.mask_cond, training mode     k_diffusion/score_gpts.py:298-299, 360-371)
+ *   beso_goal_mask      <- the Bernoulli mask of DiffusionGPT.mask_cond k_diffusion/score_gpts.py:365-368
  *   beso_loss_grad_overlap  (same, with the early gradient range for the overlapped all-reduce: SURVEY 8(e) C1)
  *   beso_adam_step      <- optimizer.step() + ema_helper.update()      beso_agent.py:236-244
  *   beso_gather_windows <- TrajectorySlicerDataset.__getitem__ x batch envs/dataloaders/trajectory_loader.py:160-197
@@ -185,9 +187,16 @@ int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg,
  * (beso_agent.py:228-233).  Both action heads (linear_output 1 / 0).
  *   params      host array of n_params DEVICE pointers, order of beso_pack_weights (fp32, torch layouts)
  *   grads_flat  device fp32 buffer of beso_grad_floats(cfg) values: the gradients of all parameters back to back in
- *               the same order, each tensor contiguous.  OVERWRITTEN (zeroed, then accumulated with atomics).
- *   state [batch,t,obs], action [batch,t,act] (clean), goal [batch,G,obs] (already masked by DiffusionGPT.mask_cond),
+ *               the same order, each tensor contiguous.  OVERWRITTEN: zeroed first, then the weight gradients are
+ *               plain stores of one grouped launch (no split-K, no atomics), while the bias / LayerNorm-affine /
+ *               embedding gradients are accumulated from block partial sums (a few fp32 atomics per block: two runs
+ *               agree to rounding in those tensors, not bit for bit).
+ *   state [batch,t,obs], action [batch,t,act] (clean), goal [batch,G,obs] (UNMASKED: see goal_drop),
  *   noise [batch,t,act], sigma [batch];  loss_out: one device float.
+ *   goal_drop   DiffusionGPT's goal_drop (`cond_mask_prob`, configs: cond_mask_prob): training-mode mask_cond
+ *               (score_gpts.py:298-299, 360-371) -- every ELEMENT of goal is zeroed with this probability, kept ones are
+ *               not rescaled -- applied inside the embedding kernel; the mask is the counter-based hash of (seed, element),
+ *               the one beso_goal_mask writes out.  0 disables (eval mode, or goals masked by the caller).
  *   embed_pdrop / attn_pdrop / resid_pdrop: dropout probabilities of the token embeddings (not the sigma token), of
  *   the attention weights and of the proj / MLP outputs (DiffusionGPT's embed_pdrob, attn_pdrop, resid_pdrop); the
  *   masks are a counter-based hash of (seed, site, element), recomputed in the backward.  0 disables.
@@ -198,8 +207,11 @@ size_t beso_train_workspace_bytes(const beso_config* cfg, int batch, int t, int 
 size_t beso_grad_floats(const beso_config* cfg);
 int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
                    const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
-                   float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop, unsigned int seed,
-                   float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
+                   float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
+                   float goal_drop, unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes, void* stream);
+/* The keep-mask (1.0 / 0.0 per element of goal [batch,G,obs]) that beso_loss_grad applies for (goal_drop, seed):
+ * `1 - torch.bernoulli(...)` of DiffusionGPT.mask_cond (score_gpts.py:365-368) with this library's generator.       */
+int beso_goal_mask(float* mask, int batch, int goal_seq_len, int obs_dim, float goal_drop, unsigned int seed, void* stream);
 /* The training feed on trajectories resident in HBM: one batch of TrajectorySlicerDataset.__getitem__
  * (envs/dataloaders/trajectory_loader.py:160-197; the collate of torch's DataLoader included) as one launch.
  *   observations [n_traj,t_max,obs_dim], actions [n_traj,t_max,act_dim]  padded trajectories (TensorDataset.tensors)
@@ -233,8 +245,8 @@ int beso_grad_early_range(const beso_config* cfg, size_t* begin, size_t* end);
 int beso_loss_grad_overlap(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
                            const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
                            float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
-                           unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes, void* stream,
-                           void* early_stream);
+                           float goal_drop, unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes,
+                           void* stream, void* early_stream);
 /* Development aid (tests of the operand layouts of the training GEMM): C[M][N] (fp32, ldc) = sum_k A(m,k) B(n,k);
  * a_kslow / b_kslow = 1: the operand is stored [K][ld] (contraction index slow), 0: [rows][ld] (k contiguous).
  * Supported pairs: (0,0), (0,1), (1,1).  splits > 1 accumulates split-K partial sums into a ZEROED C.      */

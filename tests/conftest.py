@@ -32,3 +32,13 @@ def rel_err(a, b):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def autograd_training(monkeypatch):
+    """GCDenoiser.loss / BesoAgent.train_step on the torch-autograd comparator of tests/autograd_reference.py for the
+    duration of a test (the product itself has no torch-op evaluation of the network): host-logic tests on CPU, and the
+    reference side of the HIP-vs-autograd tests on the GPU."""
+    from autograd_reference import use_autograd_training
+    use_autograd_training(monkeypatch)
+    return monkeypatch

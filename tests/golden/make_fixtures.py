@@ -423,39 +423,47 @@ def fixture_agent_trace(seed=3, n_calls=6):
     return out
 
 
-def main():
-    save("tiny_forward.npz", **fixture_forward("tiny", 5, seed=1, std=0.05, store_weights=True))
-    save("tiny_mlp_head_forward.npz", **fixture_forward("tiny_mlp_head", 4, seed=2, std=0.1, store_weights=True))
-    save("tiny_nogoal_forward.npz", **fixture_forward("tiny_nogoal", 4, seed=3, std=0.1, store_weights=True))
-    save("kitchen_forward_std002.npz", **fixture_forward("kitchen", 6, seed=10, std=0.02, store_weights=False))
-    save("kitchen_forward_std008.npz", **fixture_forward("kitchen", 6, seed=11, std=0.08, store_weights=False))
-    save("block_push_forward.npz", **fixture_forward("block_push", 6, seed=12, std=0.05, store_weights=False))
-    save("long_horizon_forward.npz", **fixture_forward("long_horizon", 2, seed=13, std=0.02, store_weights=False))
-    save("kitchen_samplers.npz", **fixture_samplers(
+def main(only=None):
+    """Writes every fixture, or only the files named on the command line (regeneration is deterministic)."""
+    def save_if(name, make):
+        if not only or name in only:
+            save(name, **make())
+    save_if("tiny_forward.npz", lambda: fixture_forward("tiny", 5, seed=1, std=0.05, store_weights=True))
+    save_if("tiny_mlp_head_forward.npz", lambda: fixture_forward("tiny_mlp_head", 4, seed=2, std=0.1, store_weights=True))
+    save_if("tiny_nogoal_forward.npz", lambda: fixture_forward("tiny_nogoal", 4, seed=3, std=0.1, store_weights=True))
+    save_if("kitchen_forward_std002.npz", lambda: fixture_forward("kitchen", 6, seed=10, std=0.02, store_weights=False))
+    save_if("kitchen_forward_std008.npz", lambda: fixture_forward("kitchen", 6, seed=11, std=0.08, store_weights=False))
+    save_if("block_push_forward.npz", lambda: fixture_forward("block_push", 6, seed=12, std=0.05, store_weights=False))
+    save_if("long_horizon_forward.npz", lambda: fixture_forward("long_horizon", 2, seed=13, std=0.02, store_weights=False))
+    save_if("kitchen_samplers.npz", lambda: fixture_samplers(
         "kitchen", 4, seed=20, std=0.04,
         specs=[("ddim", 3, "exponential"), ("ddim", 10, "exponential"), ("ddim", 3, "linear"),
                ("euler", 10, "exponential"), ("euler", 5, "karras"), ("heun", 5, "exponential"),
                ("dpmpp_2m", 5, "exponential"), ("dpm", 4, "exponential"), ("dpmpp_2s", 4, "exponential")],
         sigma_min=0.005, sigma_max=1.0))
-    save("block_push_heun_cfg.npz", **fixture_samplers(
+    save_if("block_push_heun_cfg.npz", lambda: fixture_samplers(
         "block_push", 4, seed=21, std=0.05,
         specs=[("heun", 50, "exponential"), ("heun", 5, "karras"), ("ddim", 3, "exponential")],
         sigma_min=0.05, sigma_max=1.0, cond_lambda=2.0))
-    save("long_horizon_euler.npz", **fixture_samplers(
+    save_if("long_horizon_euler.npz", lambda: fixture_samplers(
         "long_horizon", 2, seed=22, std=0.02, specs=[("euler", 10, "exponential")],
         sigma_min=0.005, sigma_max=1.0))
-    save("tiny_euler_ancestral.npz", **fixture_euler_ancestral("tiny", 4, seed=23, n=5))
-    save("tiny_more_samplers.npz", **fixture_more_samplers("tiny", 4, seed=24))
-    save("trajectory_windows.npz", **fixture_trajectory_windows())
-    save("block_push_cfg.npz", **fixture_cfg("block_push", 5, seed=30))
-    save("tiny_loss.npz", **fixture_loss("tiny", 6, seed=40))
-    save("kitchen_loss.npz", **fixture_loss("kitchen", 6, seed=41))
-    save("block_push_loss.npz", **fixture_loss("block_push", 6, seed=42))
-    save("tiny_mlp_head_loss.npz", **fixture_loss("tiny_mlp_head", 5, seed=43))
-    save("schedules.npz", **fixture_schedules())
-    save("tiny_agent_trace.npz", **fixture_agent_trace())
-    save("tiny_train_trace.npz", **fixture_train_trace())
+    save_if("tiny_euler_ancestral.npz", lambda: fixture_euler_ancestral("tiny", 4, seed=23, n=5))
+    save_if("tiny_more_samplers.npz", lambda: fixture_more_samplers("tiny", 4, seed=24))
+    save_if("trajectory_windows.npz", lambda: fixture_trajectory_windows())
+    save_if("block_push_cfg.npz", lambda: fixture_cfg("block_push", 5, seed=30))
+    save_if("tiny_loss.npz", lambda: fixture_loss("tiny", 6, seed=40))
+    save_if("kitchen_loss.npz", lambda: fixture_loss("kitchen", 6, seed=41))
+    save_if("block_push_loss.npz", lambda: fixture_loss("block_push", 6, seed=42))
+    save_if("tiny_mlp_head_loss.npz", lambda: fixture_loss("tiny_mlp_head", 5, seed=43))
+    save_if("schedules.npz", lambda: fixture_schedules())
+    save_if("tiny_agent_trace.npz", lambda: fixture_agent_trace())
+    save_if("tiny_train_trace.npz", lambda: fixture_train_trace())
+    # BASELINE config 5: the 100-step Euler run on the long-horizon shape (gc_sampling.py:167-213)
+    save_if("long_horizon_euler100.npz", lambda: fixture_samplers(
+        "long_horizon", 2, seed=25, std=0.02, specs=[("euler", 100, "exponential")],
+        sigma_min=0.005, sigma_max=1.0))
 
 
 if __name__ == "__main__":
-    main()
+    main(set(sys.argv[1:]))

@@ -44,6 +44,9 @@ def _batch(cfg, n, seed):
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from autograd_reference import install_autograd_training
+    install_autograd_training()          # CPU host-logic test: the loss comes from the tests' autograd comparator
     from beso_amd import distributed as bdist
     assert bdist.init_from_env("gloo")
     assert bdist.world_size() == world and bdist.rank() == rank and bdist.is_distributed()
@@ -101,7 +104,7 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_training_step_matches_single_process(tmp_path):
+def test_two_rank_gloo_training_step_matches_single_process(tmp_path, autograd_training):
     out = str(tmp_path / "dp.pt")
     port = _free_port()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)

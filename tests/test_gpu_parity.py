@@ -219,7 +219,7 @@ def test_fused_sampler_loops_vs_reference_vectors(precision):
     fns = {"ddim": ks.sample_ddim, "euler": ks.sample_euler, "heun": ks.sample_heun, "dpmpp_2m": ks.sample_dpmpp_2m,
            "dpm": ks.sample_dpm_2, "dpmpp_2s": ks.sample_dpmpp_2s}
     for fixture, cfg_name in [("kitchen_samplers.npz", "kitchen"), ("block_push_heun_cfg.npz", "block_push"),
-                              ("long_horizon_euler.npz", "long_horizon")]:
+                              ("long_horizon_euler.npz", "long_horizon"), ("long_horizon_euler100.npz", "long_horizon")]:
         fx = load_golden(fixture)
         cfg = O.CONFIGS[cfg_name]
         m = make_module(cfg, _weights(fx, cfg), precision)
@@ -235,7 +235,7 @@ def test_fused_sampler_loops_vs_reference_vectors(precision):
             assert torch.equal(x_t, keep), "sampler must not overwrite the caller's x_T"
             err = rel_err(out.cpu().numpy(), fx[key + "::out"])
             print(f"[parity] {fixture}:{key} {precision}: {err:.3e}")
-            tol = TOL[precision] * (1 if n <= 10 else 8) if precision == "fp32" else 0.1
+            tol = TOL[precision] * (1 if n <= 10 else 8) if precision == "fp32" else 2e-2      # bf16 loops: measured 2.1e-3 .. 6.4e-3
             assert err < tol, key
 
 
@@ -315,14 +315,17 @@ def test_repack_when_parameters_change():
     assert not torch.allclose(y0, y1)
 
 
-def test_autograd_training_path_equals_hip_forward():
+def test_autograd_comparator_equals_hip_forward():
+    """The tests' torch-autograd comparator (tests/autograd_reference.py, pinned to the reference in the CPU suite)
+    and the HIP forward agree: what the training-step tests compare against is the same function."""
+    from autograd_reference import forward_autograd
     cfg = O.KITCHEN
     m = make_module(cfg, O.make_weights(cfg, seed=3, std=0.04), "fp32")
     s, g, a = (G(v) for v in O.make_inputs(cfg, 8, seed=2))
     sg = G(np.exp(np.random.default_rng(0).uniform(np.log(0.005), 0, 8)).astype(np.float32))
     with torch.no_grad():
         hip = m.inner_model(s, a, g, sg)
-    ref = m.inner_model._forward_autograd(s, a, g, sg, False)
+    ref = forward_autograd(m.inner_model, s, a, g, sg, False)
     assert rel_err(hip.cpu().numpy(), ref.detach().cpu().numpy()) < TOL["fp32"]
 
 
@@ -482,8 +485,10 @@ def test_train_step_with_fused_optimizer_matches_eager(monkeypatch):
     cfg = O.TINY
     w = O.make_weights(cfg, seed=2, std=0.05)
     losses, finals, shadows = {}, {}, {}
+    import beso_amd.agents.diffusion_agents.beso_agent as agent_mod
     for mode in ("1", "0"):
-        monkeypatch.setenv("BESO_AMD_FUSED_OPTIM", mode)
+        if mode == "0":                                   # the eager torch optimizer + EMA helper: keep what Hydra configured
+            monkeypatch.setattr(agent_mod, "maybe_fuse", lambda opt: opt)
         agent = build_agent(cfg, lambda: make_module(cfg, w, "fp32"), device=DEV)
         assert isinstance(agent.optimizer, FusedAdam) == (mode == "1")
         agent.get_scaler(Scaler(np.random.default_rng(0).standard_normal((64, cfg.obs_dim)).astype(np.float32),
@@ -706,14 +711,14 @@ def test_no_writes_outside_output_and_workspace(cfg_name, precision):
 # -------------------------------------------------------------------------------------------------
 # training step in HIP (beso_loss_grad): row f1
 # -------------------------------------------------------------------------------------------------
-def _train_module(cfg, w, precision, attn_pdrop=0.0, resid_pdrop=0.0, embed_pdrop=0.0):
+def _train_module(cfg, w, precision, attn_pdrop=0.0, resid_pdrop=0.0, embed_pdrop=0.0, goal_drop=0.0):
     from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
     from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser
     inner = functools.partial(
         DiffusionGPT, state_dim=cfg.obs_dim, device=DEV, goal_conditioned=cfg.goal_conditioned,
         action_dim=cfg.act_dim, embed_dim=cfg.embed_dim, embed_pdrob=embed_pdrop, attn_pdrop=attn_pdrop,
         resid_pdrop=resid_pdrop, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=cfg.goal_seq_len,
-        obs_seq_len=cfg.obs_seq_len, sigma_vocab_size=3, time_embedding_fn=None, goal_drop=0.0,
+        obs_seq_len=cfg.obs_seq_len, sigma_vocab_size=3, time_embedding_fn=None, goal_drop=goal_drop,
         linear_output=cfg.linear_output, precision=precision)
     m = GCDenoiser(inner, sigma_data=cfg.sigma_data)
     sd = m.state_dict()
@@ -807,14 +812,12 @@ def test_hip_loss_and_gradients_match_autograd(cfg_name, B, precision, monkeypat
            "tiny_mlp_head": O.TINY_MLP_HEAD}[cfg_name]         # (the last: Linear(D,100) - SiLU - Linear(100,act) action head)
     m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), precision)
     state, action, goal, noise, sigma = _train_inputs(cfg, B, seed=1)
-    monkeypatch.setenv("BESO_AMD_HIP_TRAIN", "0")
-    ref_loss = m.loss(state, action, goal, noise.clone(), sigma)
-    assert "ScoreMatchingLoss" not in type(ref_loss.grad_fn).__name__
+    from autograd_reference import loss_autograd
+    ref_loss = loss_autograd(m, state, action, goal, noise.clone(), sigma)
     ref_loss.backward()
     ref = [p.grad.clone() for p in m.parameters()]
     for p in m.parameters():
         p.grad = None
-    monkeypatch.setenv("BESO_AMD_HIP_TRAIN", "1")
     loss = m.loss(state, action, goal, noise.clone(), sigma)
     assert "ScoreMatchingLoss" in type(loss.grad_fn).__name__
     loss.backward()
@@ -885,6 +888,187 @@ def test_hip_training_dropout_masks():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name,B,precision", [("kitchen", 64, "fp32"), ("block_push", 48, "fp32"), ("kitchen", 64, "bf16")])
+def test_hip_training_goal_masking(cfg_name, B, precision):
+    """DiffusionGPT.mask_cond in training mode (score_gpts.py:298-299, 360-371; BASELINE configs 3 / 4: cond_mask_prob =
+    0.1) inside the HIP step: goals are zeroed ELEMENTWISE over [B, G, obs] with probability goal_drop, kept elements are
+    not rescaled.  The kernel's mask for (goal_drop, seed) is read back through beso_goal_mask and injected into the
+    torch-autograd comparator: loss and every parameter gradient must agree (fp32 2e-4 / bf16 1e-1 per tensor)."""
+    from autograd_reference import loss_autograd
+    cfg = O.CONFIGS[cfg_name]
+    m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), precision, goal_drop=0.1)
+    inner = m.inner_model
+    assert inner.cond_mask_prob == 0.1 and inner.training
+    state, action, goal, noise, sigma = _train_inputs(cfg, B, seed=4)
+    step = m.hip_train_step(state, action, goal, noise, sigma)
+    assert step is not None
+    seed = 20240
+    mask = step.goal_mask(B, seed)
+    assert mask.shape == goal.shape and bool(((mask == 0) | (mask == 1)).all())
+    frac = 1.0 - mask.mean().item()
+    n = mask.numel()
+    assert abs(frac - 0.1) < 4 * (0.09 / n) ** 0.5 + 1e-3, frac                    # Bernoulli(0.1) over B*G*obs elements
+    per_sample = mask.reshape(B, -1)
+    assert bool(((per_sample.min(1).values == 0) & (per_sample.max(1).values == 1)).any())   # elementwise, not per sample
+    assert not torch.equal(mask, step.goal_mask(B, seed + 1)) and torch.equal(mask, step.goal_mask(B, seed))
+    assert torch.equal(step.goal_mask(B, seed, goal_drop=0.0), torch.ones_like(mask))
+    loss, flat, views = step.run(state, action, goal, noise, sigma, seed=seed, fresh_grads=True)
+    got = [v.clone() for v in views]
+    # the comparator with the SAME mask injected (its own mask_cond switched off)
+    inner.cond_mask_prob = 0.0
+    try:
+        ref_loss = loss_autograd(m, state, action, goal * mask, noise.clone(), sigma)
+        ref_loss.backward()
+        ref = [p.grad.clone() for p in m.parameters()]
+        # ... and goal_drop = 0 on the pre-masked goals is the same step
+        loss0, _, views0 = step.run(state, action, goal * mask, noise, sigma, seed=seed, fresh_grads=True, goal_drop=0.0)
+    finally:
+        inner.cond_mask_prob = 0.1
+        for p in m.parameters():
+            p.grad = None
+    ltol, gtol, floor = (2e-5, 2e-4, 1e-4) if precision == "fp32" else (3e-3, 1e-1, 2e-3)
+    assert abs(loss.item() - ref_loss.item()) < ltol * abs(ref_loss.item())
+    errs = _grad_errors(got, ref, floor)
+    worst = max(range(len(errs)), key=lambda i: errs[i])
+    print(f"[parity] goal masking {cfg_name} {precision}: masked fraction {frac:.4f}, loss rel err "
+          f"{abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()):.2e}, worst gradient {errs[worst]:.2e}")
+    assert errs[worst] < gtol, (list(dict(m.named_parameters()))[worst], errs[worst])
+    assert abs(loss0.item() - loss.item()) < 1e-6 * abs(loss.item())
+    assert max(_grad_errors([v for v in views0], got, floor)) < 1e-5
+    # the unmasked step is a different one
+    loss_plain, _, _ = step.run(state, action, goal, noise, sigma, seed=seed, fresh_grads=True, goal_drop=0.0)
+    assert abs(loss_plain.item() - loss.item()) > 1e-6 * abs(loss.item())
+    # eval mode: no masking whatever cond_mask_prob says (mask_cond is training-only, :364)
+    m.eval()
+    loss_eval, _, _ = step.run(state, action, goal, noise, sigma, seed=seed, fresh_grads=True)
+    m.train()
+    assert abs(loss_eval.item() - loss_plain.item()) < 1e-6 * abs(loss_plain.item())
+
+
+@pytest.mark.gpu
+def test_agent_train_step_with_goal_drop_runs_the_hip_step():
+    """BesoAgent.train_step on a model built with goal_drop = 0.1 and the kitchen dropouts (configs[2] / [3]): the HIP step
+    serves it (no host-side masking, no torch-op network), losses are finite and decrease over a few steps."""
+    from test_host_logic import build_agent
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    cfg = O.KITCHEN
+    w = O.make_weights(cfg, seed=5, std=0.02)
+    agent = build_agent(cfg, lambda: _train_module(cfg, w, "bf16", attn_pdrop=0.3, goal_drop=0.1), device=DEV, lr=1e-3)
+    rng = np.random.default_rng(0)
+    agent.get_scaler(Scaler(rng.standard_normal((64, cfg.obs_dim)).astype(np.float32),
+                            rng.standard_normal((64, cfg.act_dim)).astype(np.float32), True, DEV))
+    agent.set_bounds(agent.scaler)
+    torch.manual_seed(3)
+    batch = {"observation": torch.randn(256, cfg.obs_seq_len, cfg.obs_dim, device=DEV),
+             "action": torch.tanh(torch.randn(256, cfg.obs_seq_len, cfg.act_dim, device=DEV)),
+             "goal_observation": torch.randn(256, cfg.goal_seq_len, cfg.obs_dim, device=DEV)}
+    losses = [agent.train_step(batch) for _ in range(30)]
+    assert getattr(agent, "_hip_step", None) is not None
+    assert all(np.isfinite(l) for l in losses) and np.mean(losses[-5:]) < 0.9 * np.mean(losses[:5]), losses
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_step_kitchen_1024_is_the_mean_of_its_slices(precision):
+    """BASELINE config 3 per-GPU size (kitchen, 1024 samples per step): the loss is the mean over samples
+    (score_wrappers.py:79), so loss and gradients of the whole batch must equal the mean of those of its four 256-sample
+    slices (also what makes the data-parallel average of per-rank gradients the global gradient); plus a spot check of
+    the first 48 samples' step against torch autograd."""
+    from autograd_reference import loss_autograd
+    cfg = O.KITCHEN
+    m = _train_module(cfg, O.make_weights(cfg, seed=8, std=0.04), precision)
+    state, action, goal, noise, sigma = _train_inputs(cfg, 1024, seed=2)
+    step = m.hip_train_step(state, action, goal, noise, sigma)
+    loss, flat, _ = step.run(state, action, goal, noise, sigma, seed=1, fresh_grads=True)
+    acc, lsum = torch.zeros_like(flat), 0.0
+    for k in range(4):
+        sl = slice(256 * k, 256 * (k + 1))
+        l_k, f_k, _ = step.run(state[sl], action[sl], goal[sl], noise[sl], sigma[sl], seed=1, fresh_grads=True)
+        acc += f_k / 4
+        lsum += l_k.item() / 4
+    rel = ((flat - acc).norm() / flat.norm()).item()
+    print(f"[parity] kitchen 1024-sample step vs mean of 4 slices ({precision}): loss {abs(loss.item() - lsum) / lsum:.2e}, "
+          f"gradient {rel:.2e}")
+    ltol, gtol = (1e-5, 1e-4) if precision == "fp32" else (1e-4, 2e-2)
+    assert abs(loss.item() - lsum) < ltol * lsum and rel < gtol
+    if precision == "fp32":
+        sl = slice(0, 48)
+        l_s, _, v_s = step.run(state[sl], action[sl], goal[sl], noise[sl], sigma[sl], seed=1, fresh_grads=True)
+        got = [v.clone() for v in v_s]
+        ref_loss = loss_autograd(m, state[sl], action[sl], goal[sl], noise[sl].clone(), sigma[sl])
+        ref_loss.backward()
+        ref = [p.grad.clone() for p in m.parameters()]
+        assert abs(l_s.item() - ref_loss.item()) < 2e-5 * abs(ref_loss.item())
+        assert max(_grad_errors(got, ref)) < 2e-4
+
+
+@pytest.mark.gpu
+def test_inference_on_live_weights_follows_the_fused_optimizer():
+    """use_ema = False: evaluate() / model() read the LIVE parameters, which the fused Adam launch updates through raw
+    pointers -- the packed-weight cache (keyed on the parameters' version counters) must notice.  After N train_steps the
+    HIP forward equals the oracle on the parameters' current values, and differs from the initial ones."""
+    from test_host_logic import build_agent
+    from beso_amd.optim import FusedAdam
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=2, std=0.05)
+    agent = build_agent(cfg, lambda: make_module(cfg, w, "fp32"), device=DEV, lr=5e-3)
+    agent.use_ema = False
+    assert isinstance(agent.optimizer, FusedAdam)
+    rng = np.random.default_rng(0)
+    agent.get_scaler(Scaler(rng.standard_normal((64, cfg.obs_dim)).astype(np.float32),
+                            rng.standard_normal((64, cfg.act_dim)).astype(np.float32), True, DEV))
+    agent.set_bounds(agent.scaler)
+    s_np, g_np, a_np = O.make_inputs(cfg, 8, seed=1)
+    sg_np = np.linspace(0.1, 0.9, 8).astype(np.float32)
+    agent.model.eval()
+    with torch.no_grad():
+        y0 = agent.model(G(s_np), G(a_np), G(g_np), G(sg_np)).cpu().numpy()       # packs the initial weights
+    torch.manual_seed(7)
+    batch = {"observation": torch.randn(16, cfg.obs_seq_len, cfg.obs_dim, device=DEV),
+             "action": torch.randn(16, cfg.obs_seq_len, cfg.act_dim, device=DEV),
+             "goal_observation": torch.randn(16, cfg.goal_seq_len, cfg.obs_dim, device=DEV)}
+    for _ in range(5):
+        agent.train_step(batch)
+    agent.model.eval()
+    now = {k: v.detach().cpu().numpy() for k, v in agent.model.state_dict().items() if not k.endswith("attn.mask")}
+    with torch.no_grad():
+        y1 = agent.model(G(s_np), G(a_np), G(g_np), G(sg_np)).cpu().numpy()
+    assert rel_err(y1, O.denoise(now, cfg, s_np, a_np, g_np, sg_np)) < TOL["fp32"]
+    assert rel_err(y1, y0) > 1e-3, "the forward still ran on the first-packed weights"
+    mse0 = agent.evaluate(batch)
+    for _ in range(5):
+        agent.train_step(batch)
+    assert agent.evaluate(batch) != mse0
+
+
+@pytest.mark.gpu
+def test_schedules_with_interior_zeros_take_the_stepwise_loop():
+    """get_sigmas_linear(sigma_min = 0) ends in [.., 0, 0]: beso_sample rejects non-positive interior values
+    (BESO_ERR_BAD_ARG), so the Python samplers must keep such schedules on the step-by-step loop (where the reference's
+    arithmetic handles them) instead of raising."""
+    from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+    cfg = O.TINY
+    w = O.make_weights(cfg, seed=2, std=0.05)
+    m = make_module(cfg, w, "fp32")
+    s_np, g_np, x_np = O.make_inputs(cfg, 4, seed=1)
+    sig = ks.get_sigmas_linear(5, 0.0, 1.0)
+    assert float(sig[-2]) == 0.0 and float(sig[-1]) == 0.0
+    with torch.no_grad():
+        out = ks.sample_ddim(m, G(s_np), G(x_np), G(g_np), sig[:-1], disable=True)           # [1 .. 0]: plain fused call
+        ref = O.sample_ddim(O.make_model(w, cfg), s_np, x_np, g_np, sig[:-1].numpy())
+        assert rel_err(out.cpu().numpy(), ref) < TOL["fp32"]
+        good = ks.get_sigmas_linear(5, 0.01, 1.0)
+        fused = ks.sample_euler(m, G(s_np), G(x_np), G(g_np), good, disable=True)
+        step = ks.sample_euler(m, G(s_np), G(x_np), G(g_np), good, disable=True, callback=lambda info: None)
+        assert rel_err(fused.cpu().numpy(), step.cpu().numpy()) < 1e-5
+        # interior zero: the fused entry would raise ValueError; the sampler falls back to the loop, which (like the
+        # reference's, gc_sampling.py:205-210) divides by sigma = 0 on the last step -- no exception either way
+        out0 = ks.sample_euler(m, G(s_np), G(x_np), G(g_np), sig, disable=True)
+        assert out0.shape == (4, cfg.obs_seq_len, cfg.act_dim)
+
+
+@pytest.mark.gpu
 def test_train_step_runs_on_the_hip_step_and_matches_autograd(monkeypatch):
     """BesoAgent.train_step: forward + backward through beso_loss_grad (gradients as views of one flat buffer that
     the fused optimizer reads) == the same steps through torch autograd, with noise and sigma pinned."""
@@ -900,8 +1084,10 @@ def test_train_step_runs_on_the_hip_step_and_matches_autograd(monkeypatch):
                 "action": torch.randn(B, cfg.obs_seq_len, cfg.act_dim, device=DEV),
                 "goal_observation": torch.randn(B, cfg.goal_seq_len, cfg.obs_dim, device=DEV)} for _ in range(4)]
     results = {}
+    from autograd_reference import use_autograd_training
     for mode in ("1", "0"):
-        monkeypatch.setenv("BESO_AMD_HIP_TRAIN", mode)
+        if mode == "0":
+            use_autograd_training(monkeypatch)
         agent = build_agent(cfg, lambda: make_module(cfg, w, "fp32"), device=DEV)
         agent.get_scaler(Scaler(np.random.default_rng(0).standard_normal((64, cfg.obs_dim)).astype(np.float32),
                                 np.random.default_rng(1).standard_normal((64, cfg.act_dim)).astype(np.float32), True, DEV))
@@ -938,8 +1124,10 @@ def test_training_with_the_hip_step_converges_like_autograd(monkeypatch):
     proj = torch.randn(cfg.obs_dim, cfg.act_dim, generator=g) * 0.5
     act = torch.tanh(obs @ proj + (goal.mean(1, keepdim=True) @ proj) * 0.5)
     curves = {}
+    from autograd_reference import use_autograd_training
     for mode, precision in (("1", "bf16"), ("0", "fp32")):
-        monkeypatch.setenv("BESO_AMD_HIP_TRAIN", mode)
+        if mode == "0":
+            use_autograd_training(monkeypatch)
         torch.manual_seed(17)
         agent = build_agent(cfg, lambda: _train_module(cfg, w, precision, attn_pdrop=0.3, resid_pdrop=0.05), device=DEV, lr=2e-3)
         agent.get_scaler(Scaler(obs.reshape(-1, cfg.obs_dim).numpy(), act.reshape(-1, cfg.act_dim).numpy(), True, DEV))
@@ -1011,12 +1199,15 @@ def test_hip_loss_pred_last_action_only(monkeypatch):
     m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), "fp32")
     state, action, goal, noise, sigma = _train_inputs(cfg, 7, seed=6)
     out = {}
+    from autograd_reference import loss_autograd
     for mode in ("0", "1"):
-        monkeypatch.setenv("BESO_AMD_HIP_TRAIN", mode)
         for p in m.parameters():
             p.grad = None
         nz = noise.clone()
-        loss = m.loss(state, action, goal, nz, sigma, pred_last_action_only=True)
+        if mode == "0":
+            loss = loss_autograd(m, state, action, goal, nz, sigma, pred_last_action_only=True)
+        else:
+            loss = m.loss(state, action, goal, nz, sigma, pred_last_action_only=True)
         assert ("ScoreMatchingLoss" in type(loss.grad_fn).__name__) == (mode == "1")
         assert float(nz[:, :-1].abs().max()) == 0.0 and float(nz[:, -1].abs().max()) > 0.0       # mutated like the reference
         loss.backward()
@@ -1081,10 +1272,18 @@ def test_feed_epoch_and_oracle_at_size():
     order = lambda a: a[np.lexsort(a.T)]                                   # noqa: E731
     np.testing.assert_array_equal(order(e1), order(all_first))
     np.testing.assert_array_equal(order(e2), order(all_first))
-    halves = [epoch_keys(DeviceTrajectoryFeed(observations, actions, lengths, window, 256, DEV, rank=r, world_size=2, **kw))
-              for r in range(2)]
-    assert abs(len(halves[0]) - len(halves[1])) <= 1
-    np.testing.assert_array_equal(order(np.concatenate(halves)), order(all_first))
+    # data-parallel shares: the same number of windows AND of batches on every rank (a rank with one batch more would
+    # all-reduce alone), every window covered, the surplus (world * ceil(n / world) - n) wrapped from the front
+    for world in (2, 3, 8):
+        feeds = [DeviceTrajectoryFeed(observations, actions, lengths, window, 256, DEV, rank=r, world_size=world, **kw)
+                 for r in range(world)]
+        assert len({len(f) for f in feeds}) == 1
+        parts = [epoch_keys(f) for f in feeds]
+        assert len({len(p) for p in parts}) == 1 and len(parts[0]) == -(-len(table) // world)
+        both = np.concatenate(parts)
+        uniq = np.unique(both, axis=0)
+        np.testing.assert_array_equal(order(uniq), order(np.unique(all_first, axis=0)))
+        assert len(both) - len(all_first) == world * len(parts[0]) - len(table) < world
     bad = feed.gather(torch.tensor([-1, len(table), 3]))
     assert float(bad["observation"][:2].abs().max()) == 0.0 and float(bad["observation"][2].abs().max()) > 0.0
     # drop_last and no shuffling

@@ -74,9 +74,10 @@ def test_module_has_the_reference_parameter_layout(name):
     assert list(m.get_params()) == list(m.inner_model.parameters())
 
 
-def test_autograd_training_forward_matches_reference_vectors():
-    """The differentiable evaluation used by train_step reproduces the reference's forward, loss and
-    parameter gradients (tiny_loss.npz was produced by the reference's loss.backward())."""
+def test_autograd_comparator_matches_reference_vectors():
+    """The torch-autograd comparator of the HIP training step (tests/autograd_reference.py) reproduces the reference's
+    forward, loss and parameter gradients (tiny_loss.npz was produced by the reference's loss.backward())."""
+    from autograd_reference import forward_autograd, loss_autograd
     fx = load_golden("tiny_loss.npz")
     cfg = O.TINY
     w = O.make_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
@@ -84,7 +85,7 @@ def test_autograd_training_forward_matches_reference_vectors():
     load_weights(m, w)
     m.train()
     T = lambda k: torch.from_numpy(fx[k].copy())        # noqa: E731
-    loss = m.loss(T("state"), T("action"), T("goal"), T("noise"), T("sigma"))
+    loss = loss_autograd(m, T("state"), T("action"), T("goal"), T("noise"), T("sigma"))
     assert abs(loss.item() - float(fx["loss"])) < 2e-6 * abs(float(fx["loss"]))
     loss.backward()
     for n, p in m.named_parameters():
@@ -96,7 +97,7 @@ def test_autograd_training_forward_matches_reference_vectors():
     m.eval()
     for t in fwd["ts"]:
         p = f"t{int(t)}::"
-        x = m.inner_model._forward_autograd(*(torch.from_numpy(fwd[p + k].copy()) for k in ("state", "action", "goal", "sigma")), False)
+        x = forward_autograd(m.inner_model, *(torch.from_numpy(fwd[p + k].copy()) for k in ("state", "action", "goal", "sigma")), False)
         assert rel_err(x.detach().numpy(), fwd[p + "inner"]) < 2e-5
 
 
@@ -324,8 +325,8 @@ def test_agent_surface_and_error_conventions():
         assert sig.shape == (6,) and float(sig[-1]) == 0.0
 
 
-def test_train_step_and_checkpoint_roundtrip(tmp_path):
-    """train_step (autograd path), EMA update, store_model_weights / load_pretrained_model formats
+def test_train_step_and_checkpoint_roundtrip(tmp_path, autograd_training):
+    """train_step (host logic on CPU, the loss through the autograd comparator), EMA update, store_model_weights / load_pretrained_model formats
     (model_state_dict.pth = EMA weights, non_ema_model_state_dict.pth = raw: beso_agent.py:466-476)."""
     cfg = O.TINY
     agent = build_agent(cfg, lambda: make_module(cfg, attn_pdrop=0.1, goal_drop=0.1))
@@ -352,6 +353,37 @@ def test_train_step_and_checkpoint_roundtrip(tmp_path):
     agent2.load_pretrained_model(str(tmp_path))
     assert torch.equal(agent2.model.state_dict()[k], ema_sd[k])
     assert torch.equal(agent2.ema_helper.shadow_params[1], ema_sd[k])
+
+
+def test_epoch_mode_keeps_the_reference_loop_cadence(autograd_training, tmp_path):
+    """train_agent_on_epochs (beso_agent.py:129-175): per training batch the step counter advances TWICE (train_step's own
+    increment + the loop's, :152) and the LR scheduler gets an extra step whenever the counter reaches a multiple of
+    eval_every_n_steps (:153-154); the test MSE handed to early stopping is the last test batch's."""
+    cfg = O.TINY
+    agent = build_agent(cfg, lambda: make_module(cfg))
+    agent.eval_every_n_steps = 4
+    rng = np.random.default_rng(0)
+    agent.get_scaler(Scaler(rng.standard_normal((40, cfg.obs_dim)).astype(np.float32),
+                            rng.uniform(-1, 1, (40, cfg.act_dim)).astype(np.float32), True, "cpu"))
+    agent.working_dir = str(tmp_path)
+    mk = lambda: {"observation": torch.randn(4, cfg.obs_seq_len, cfg.obs_dim),         # noqa: E731
+                  "goal_observation": torch.randn(4, cfg.goal_seq_len, cfg.obs_dim),
+                  "action": torch.rand(4, cfg.obs_seq_len, cfg.act_dim) * 2 - 1}
+    train, test = [mk() for _ in range(5)], [mk() for _ in range(2)]
+    seen = []
+    agent.evaluate = lambda b: (seen.append(len(seen)), 0.5 + len(seen))[1]       # (sampling is GPU-only: stub the test MSE)
+    stops = []
+    real_stop = agent.early_stopping
+    agent.early_stopping = lambda best, mse, patience, epochs: (stops.append(mse), real_stop(best, mse, patience, epochs))[1]
+    sched_steps = []
+    real_sched = agent.lr_scheduler.step
+    agent.lr_scheduler.step = lambda *a, **k: (sched_steps.append(agent.steps), real_sched(*a, **k))[1]
+    agent.train_agent_on_epochs(train, test, 1)
+    assert agent.steps == 10 and agent.ema_helper.num_updates == 5          # two counts per batch, one EMA update per train_step
+    # 5 scheduler steps from train_step (at steps 1, 3, 5, 7, 9) + extra ones when the doubled counter hits 4 and 8
+    assert sched_steps == [1, 3, 4, 5, 7, 8, 9]
+    assert len(seen) == 2 and stops == [2.5]                                # the LAST test batch's value
+    assert (tmp_path / "model_state_dict.pth").exists()
 
 
 def test_fused_optimizer_is_not_used_on_cpu():
@@ -385,9 +417,9 @@ def test_device_prefetcher_passthrough_and_order():
 
 
 def test_hip_training_step_is_gpu_only_and_shape_gated():
-    """The HIP training step binds to HIP parameters only: on CPU GCDenoiser.loss stays on the autograd evaluation
-    (no library call); both action heads and all three dropouts are covered, an embedding width that is not a multiple
-    of 8 is not."""
+    """The HIP training step binds to HIP parameters only and there is nothing behind it: on CPU GCDenoiser.loss raises
+    (no torch-op evaluation of the network in the product), as does a direct forward under autograd; both action heads
+    and all three dropouts are covered by the kernels, an embedding width that is not a multiple of 8 is not."""
     from beso_amd.training import HipTrainStep
     cfg = O.TINY
     from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
@@ -405,10 +437,16 @@ def test_hip_training_step_is_gpu_only_and_shape_gated():
     state, action = torch.randn(B, cfg.obs_seq_len, cfg.obs_dim), torch.randn(B, cfg.obs_seq_len, cfg.act_dim)
     goal, noise, sigma = torch.randn(B, cfg.goal_seq_len, cfg.obs_dim), torch.randn(B, cfg.obs_seq_len, cfg.act_dim), torch.rand(B) + 0.1
     assert den.hip_train_step(state, action, goal, noise, sigma) is None
-    loss = den.loss(state, action, goal, noise, sigma)
-    assert "ScoreMatchingLoss" not in type(loss.grad_fn).__name__
-    loss.backward()
-    assert all(p.grad is not None for p in den.parameters())
+    with pytest.raises(ValueError, match="not on the GPU"):
+        den.loss(state, action, goal, noise, sigma)
+    with pytest.raises(ValueError, match="unsupported keyword"):
+        den.loss(state, action, goal, noise, sigma, some_future_flag=True)
+    den36 = GCDenoiser(DiffusionGPT(embed_pdrob=0.0, linear_output=True, **kw12), sigma_data=0.5).train()
+    with pytest.raises(ValueError, match="multiple of 8"):
+        den36.loss(state, action, goal, noise, sigma)
+    with pytest.raises(RuntimeError, match="no_grad"):
+        den.inner_model(state, action, goal, sigma)          # a differentiable forward does not exist
+    assert all(p.grad is None for p in den.parameters())
 
 
 def test_synthetic_workload_recipe_matches_the_oracles():
@@ -461,8 +499,8 @@ def replay_train_trace(agent, fx, device="cpu"):
     return loss_err, p_err, e_err
 
 
-def test_train_steps_match_the_reference_agent_trace():
-    """BesoAgent.train_step x 4 on CPU (autograd evaluation, torch AdamW, StepLR, the EMA helper with its warm-up rule)
+def test_train_steps_match_the_reference_agent_trace(autograd_training):
+    """BesoAgent.train_step x 4 on CPU (the loss through the autograd comparator, torch AdamW, StepLR, the EMA helper with its warm-up rule)
     against the trace the reference's own agent produced."""
     fx = load_golden("tiny_train_trace.npz")
     cfg = O.TINY

@@ -48,7 +48,7 @@ def test_param_count_matches_survey():
 
 @pytest.mark.parametrize("fixture,cfg_name", [
     ("kitchen_samplers.npz", "kitchen"), ("block_push_heun_cfg.npz", "block_push"),
-    ("long_horizon_euler.npz", "long_horizon")])
+    ("long_horizon_euler.npz", "long_horizon"), ("long_horizon_euler100.npz", "long_horizon")])
 def test_samplers_match_reference(fixture, cfg_name):
     fx = load_golden(fixture)
     cfg = O.CONFIGS[cfg_name]

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE config 3 on one GPU's share: kitchen train_step (score-matching loss, backward, AdamW, EMA) at
 1024 samples per step, through BesoAgent.train_step: HIP forward + backward (beso_loss_grad) and the fused
-Adam(W) + EMA launch; BESO_AMD_HIP_TRAIN=0 times the torch-autograd evaluation of the same step beside it.
-    python tools/bench_train.py [batch] [kitchen|block_push]"""
+Adam(W) + EMA launch; `--autograd` times the tests' torch-autograd comparator of the same step beside it.
+    python tools/bench_train.py [batch] [kitchen|block_push] [--autograd]"""
 import json
 import os
 import sys
@@ -22,6 +22,11 @@ from beso_amd.networks.scaler.scaler_class import Scaler  # noqa: E402
 
 
 def main():
+    if "--autograd" in sys.argv:
+        sys.argv.remove("--autograd")
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from autograd_reference import install_autograd_training
+        install_autograd_training()
     # one process per GPU under torchrun (python -m torch.distributed.run --nproc-per-node N tools/bench_train.py B):
     # every rank trains on its own B samples per step, gradients all-reduced (C1); single process otherwise
     from beso_amd import distributed as bdist

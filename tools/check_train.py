@@ -30,6 +30,10 @@ def gemm_case(lib, prec, aks, bks, M, N, K, splits):
     return err
 
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from autograd_reference import loss_autograd  # noqa: E402   (the comparator lives with the tests)
+
+
 def main():
     lib = _lib.load()
     worst = 0.0
@@ -57,13 +61,11 @@ def main():
             goal = torch.randn(B, kw["goal_seq_len"], kw["state_dim"], device="cuda")
             noise = torch.randn_like(action)
             sigma = torch.rand(B, device="cuda") * 0.9 + 0.05
-            os.environ["BESO_AMD_HIP_TRAIN"] = "0"
-            loss_ref = model.loss(state, action, goal, noise.clone(), sigma)
+            loss_ref = loss_autograd(model, state, action, goal, noise.clone(), sigma)     # tests/autograd_reference.py
             loss_ref.backward()
             ref = [p.grad.clone() for p in inner.parameters()]
             for p in inner.parameters():
                 p.grad = None
-            os.environ["BESO_AMD_HIP_TRAIN"] = "1"
             loss = model.loss(state, action, goal, noise.clone(), sigma)
             assert loss.grad_fn is not None and "ScoreMatchingLoss" in type(loss.grad_fn).__name__, type(loss.grad_fn)
             loss.backward()

@@ -14,6 +14,10 @@ from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
 from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser  # noqa: E402
 
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from autograd_reference import loss_autograd  # noqa: E402   (the comparator lives with the tests)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -39,13 +43,11 @@ def main():
         state, action = torch.randn(B, t, obs, device="cuda"), torch.randn(B, t, act, device="cuda")
         goal = torch.randn(B, G, obs, device="cuda") if G > 0 else None
         noise, sigma = torch.randn_like(action), torch.rand(B, device="cuda") * 0.9 + 0.05
-        os.environ["BESO_AMD_HIP_TRAIN"] = "0"
-        ref_loss = model.loss(state, action, goal, noise.clone(), sigma)
+        ref_loss = loss_autograd(model, state, action, goal, noise.clone(), sigma)     # tests/autograd_reference.py
         ref_loss.backward()
         ref = [p.grad.clone() for p in inner.parameters()]
         for p in inner.parameters():
             p.grad = None
-        os.environ["BESO_AMD_HIP_TRAIN"] = "1"
         loss = model.loss(state, action, goal, noise.clone(), sigma)
         assert "ScoreMatchingLoss" in type(loss.grad_fn).__name__, (D, H, W, G, obs, act, L, B, t)
         loss.backward()

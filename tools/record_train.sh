@@ -4,7 +4,7 @@
 REPO=$(pwd); O=$REPO/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 python tools/bench_train.py 1024 > $O/train_hip.txt 2>&1
 python tools/bench_train.py 8192 > $O/train_hip8k.txt 2>&1
-BESO_AMD_HIP_TRAIN=0 python tools/bench_train.py 1024 > $O/train_eager.txt 2>&1
+python tools/bench_train.py 1024 kitchen --autograd > $O/train_eager.txt 2>&1
 cd /tmp
 rm -rf $O/prof_train_stats $O/pmc_train_a $O/pmc_train_b $O/pmc_train_c
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train_stats -o tr -- python $REPO/tools/bench_train.py 1024 > /dev/null 2>&1
