@@ -10,16 +10,31 @@ MFMA, inputs resident in HBM).  Samples are independent, so N GPUs run N shards 
 collective in the loop (weak scaling: 4096 samples per GPU per step); value = all steps of all
 ranks / max-over-ranks time.
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches this script under
+`torch.distributed.run` (one process per GPU, RCCL); the ranks verify the group with an all-reduce of their rank
+numbers before anything is timed.  A world size that disagrees with --gpus, or fewer visible GPUs than N, is an error.
+
 Rank 0 prints ONE JSON line with the driver's fields plus
   "roofline":     the dominant kernel's achieved TFLOP/s (algorithmic FLOPs / HIP-event time on the
-                  launch stream) against the dense bf16 MFMA peak;
-  "cpu_baseline": the CPU oracle (numpy port of the reference) timed on this box's host cores on a
-                  bounded sample of the same workload.
+                  launch stream) against the dense bf16 MFMA peak; `traffic` = HBM bytes per launch from two
+                  rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this very script, run as child processes;
+  "parity_mode":  the same forward in the split-bf16 (BF16X3) instance of the same kernel -- the mode that meets the
+                  north-star 1e-4 tolerance -- timed beside the bf16 headline;
+  "cpu_baseline": the reference's CPU path (ATen restatement in oracle/beso_oracle_torch.py) timed on this box's
+                  host cores on a bounded sample of the same workload.
+
+`--workload train` times BASELINE configs[2]'s per-GPU share instead: BesoAgent.train_step (score-matching loss,
+backward, AdamW, EMA; kitchen dropouts and cond_mask_prob = 0.1) at 1024 samples per GPU, gradients all-reduced over
+the ranks (C1, `--c1-overlap 0|1`).
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with `hipIpcGetMemHandle: invalid argument`
@@ -32,85 +47,213 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}       # dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}       # dense MFMA peaks (MI355X_MICROARCH.md)
 
 
-def build_model(cfg, w, precision, dev):
+def build_model(cfg, w, precision, dev, attn_pdrop=0.0, resid_pdrop=0.0, goal_drop=0.0, train=False):
     from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
     from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser
     inner = DiffusionGPT(state_dim=cfg.obs_dim, device=dev, goal_conditioned=cfg.goal_conditioned,
-                         action_dim=cfg.act_dim, embed_dim=cfg.embed_dim, embed_pdrob=0, attn_pdrop=0,
-                         resid_pdrop=0, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=cfg.goal_seq_len,
-                         obs_seq_len=cfg.obs_seq_len, sigma_vocab_size=3, time_embedding_fn=None,
+                         action_dim=cfg.act_dim, embed_dim=cfg.embed_dim, embed_pdrob=0, attn_pdrop=attn_pdrop,
+                         resid_pdrop=resid_pdrop, n_layers=cfg.n_layers, n_heads=cfg.n_heads, goal_seq_len=cfg.goal_seq_len,
+                         obs_seq_len=cfg.obs_seq_len, sigma_vocab_size=3, time_embedding_fn=None, goal_drop=goal_drop,
                          linear_output=cfg.linear_output, precision=precision)
     m = GCDenoiser(inner, sigma_data=cfg.sigma_data)
     sd = m.state_dict()
     sd.update({k: torch.from_numpy(v.copy()) for k, v in w.items()})
     m.load_state_dict(sd)
-    return m.to(dev).eval()
+    m = m.to(dev)
+    return m.train() if train else m.eval()
 
 
-def cpu_baseline(cfg, w, batch, budget_s=15.0):
-    """The oracle (numpy fp32 port of the reference path) on the host cores, bounded to ~budget_s.  The ONLY place
-    where bench.py touches oracle/: it is the thing timed here, on the same synthetic workload."""
-    from oracle import beso_oracle as O
-    from beso_amd import synthetic as S
-    sample_b = 256
-    s, g, a = S.make_inputs(cfg, sample_b, seed=0)
-    cfg = O.ScoreGPTConfig(**cfg.as_dict())
-    sig = np.full(sample_b, 0.3, np.float32)
-    O.denoise(w, cfg, s[:8], a[:8], g[:8], sig[:8])           # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        O.denoise(w, cfg, s, a, g, sig)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 50:
-            break
-    samples_per_s = n * sample_b / el
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": samples_per_s / batch, "unit": f"denoise-steps/s (B={batch} per step)", "cores": int(cores),
-            "kind": "port",
-            "sample": f"{n} forwards of B={sample_b} kitchen samples, sigma=0.3 ({el:.1f} s of numpy fp32 on "
-                      f"{os.cpu_count()} host cores), scaled to B={batch}",
-            "samples_per_s": samples_per_s}
+# ------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a process group around us -> one rank per GPU under torch.distributed.run
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=4096, help="samples per GPU per denoising step")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--config", default="kitchen", choices=["kitchen", "block_push", "long_horizon"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--site", default=None, help="launch site timed for the roofline object")
-    args = ap.parse_args()
+def maybe_relaunch(args):
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch one rank per GPU "
+                     f"(torch.distributed.run --nproc-per-node {args.gpus}) or drop WORLD_SIZE")
+        return
+    if args.gpus <= 1:
+        return
+    if args.dry_run_backend is None:
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} requested but {n_dev} GPU(s) are visible to this process: "
+                     f"refusing to run fewer ranks than asked for")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.exit(subprocess.call(cmd))
 
+
+def init_ranks(args):
+    """-> (world, rank, local_rank, ranks_verified).  The process group is proven by an all-reduce of the rank numbers."""
     from beso_amd import distributed as bdist
-    from beso_amd import synthetic as S           # shipped shapes, seeded weights and inputs
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    verified = 1
     if world > 1:
-        bdist.init_from_env("nccl")
-    dev = f"cuda:{local_rank}"
-    torch.cuda.set_device(dev)
+        backend = args.dry_run_backend or "nccl"
+        bdist.init_from_env(backend)
+        import torch.distributed as dist
+        assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus, world)
+        dev = "cpu" if backend == "gloo" else f"cuda:{local_rank}"
+        t = torch.tensor([float(rank), 1.0], device=dev)
+        dist.all_reduce(t)
+        if t[0].item() != world * (world - 1) / 2 or t[1].item() != world:
+            raise SystemExit(f"bench.py: the {backend} group does not contain {world} distinct ranks (sum {t.tolist()})")
+        verified = int(t[1].item())
+    return world, rank, local_rank, verified
 
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's CPU path (ATen ops, fp32) on this box's host cores, bounded
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(cfg, w, batch, budget_s=12.0):
+    """oracle/beso_oracle_torch.py -- the ATen restatement of GCDenoiser.forward / sample_ddim that the CPU suite pins to
+    the reference's vectors -- timed on the host cores.  The ONLY place where bench.py touches oracle/: it is the thing
+    timed here, on the same synthetic workload, never a part of the GPU path."""
+    from oracle import beso_oracle as O
+    from oracle import beso_oracle_torch as OT
+    from beso_amd import synthetic as S
+    ocfg = O.ScoreGPTConfig(**cfg.as_dict())
+    W = OT.to_torch(w)
+    cores = os.cpu_count() or 1
+    # ATen's intra-op pool stops scaling on these [B*11, 360] x [360, 1440] problems early: measured on the GPU box's
+    # host (2 x EPYC 9575F, 256 hardware threads; tools/cpu_scan.py) 8 / 16 / 32 / 64 / 128 threads give 1465 / 1709 /
+    # 1734 / 973 / 430 samples/s at B = 4096 and 2408 / 3629 / 2071 / 908 / 205 at B = 64 -- 16 is the best setting
+    threads = min(cores, 16)
+    torch.set_num_threads(threads)
+    s, g, a = (torch.from_numpy(v) for v in S.make_inputs(cfg, batch, seed=0))
+    sig = torch.full((batch,), 0.3)
+    OT.denoise(W, ocfg, s[:64], a[:64], g[:64], sig[:64])                     # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        OT.denoise(W, ocfg, s, a, g, sig)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 20:
+            break
+    steps_per_s = n / el
+    # BASELINE configs[0]: kitchen, B = 64, 10 DDIM steps, reference on CPU
+    s64, g64, x64 = (torch.from_numpy(v) for v in S.make_inputs(cfg, 64, seed=1))
+    sigmas = torch.from_numpy(O.get_sigmas_exponential(10, 0.005, 1.0))
+    OT.sample_ddim(W, ocfg, s64, x64, g64, sigmas[-3:])
+    t1 = time.perf_counter()
+    reps = 0
+    while True:
+        OT.sample_ddim(W, ocfg, s64, x64, g64, sigmas)
+        reps += 1
+        el1 = time.perf_counter() - t1
+        if el1 > 5.0 or reps >= 10:
+            break
+    cfg1_ms = 1e3 * el1 / reps
+    return {"value": steps_per_s, "unit": f"denoise-steps/s (B={batch} per step)", "cores": int(threads),
+            "kind": "port",
+            "sample": f"{n} GCDenoiser.forward calls over B={batch} kitchen samples, sigma=0.3 ({el:.1f} s of ATen fp32 "
+                      f"with {threads} threads on a {cores}-core host)",
+            "samples_per_s": steps_per_s * batch,
+            "host_cores": cores,
+            "config0_b64_ddim10": {"ms": cfg1_ms, "denoise_steps_per_s": 10.0 / (cfg1_ms * 1e-3),
+                                   "sample_steps_per_s": 640.0 / (cfg1_ms * 1e-3), "threads": int(threads),
+                                   "what": "BASELINE configs[0]: kitchen, B=64, 10 DDIM steps, fp32 on CPU"}}
+
+
+# ------------------------------------------------------------------------------------------------
+# HBM traffic of the dominant kernel: two rocprofv3 PMC passes over a short child run of this script
+# ------------------------------------------------------------------------------------------------
+def measure_traffic(args, kernel_substr="layers_kernel"):
+    """FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots: MI355X_MICROARCH.md, rocprofv3 PMC slots), so each gets
+    its own run with --kernel-trace only.  Both are reported in KiB; the read side is doubled (gfx950: FETCH_SIZE counts
+    128-B requests as 64 B).  Returns (bytes per launch or None, detail dict)."""
+    if os.environ.get("BESO_BENCH_TRAFFIC", "1") == "0" or shutil.which("rocprofv3") is None:
+        return None, {"source": "not measured (rocprofv3 unavailable or BESO_BENCH_TRAFFIC=0)"}
+    import csv
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="beso_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", BESO_BENCH_TRAFFIC="0")
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", str(args.batch),
+             "--precision", args.precision, "--config", args.config, "--no-cpu-baseline", "--no-parity-line", "--settle-ms", "0"]
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "t", "--", *child]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return None, {"source": f"rocprofv3 pass {counter} failed (rc {r.returncode})"}
+            tot, cnt = 0.0, 0
+            for dp, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        for row in csv.DictReader(open(os.path.join(dp, f))):
+                            if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                                tot += float(row["Counter_Value"])
+                                cnt += 1
+            if cnt == 0:
+                return None, {"source": f"no {kernel_substr} rows in the {counter} pass"}
+            vals[counter] = (tot / cnt, cnt)
+    except Exception as e:        # noqa: BLE001   (a profiler hiccup must not cost the bench line)
+        return None, {"source": f"traffic measurement failed: {type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch_kib, write_kib = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    total = (2.0 * fetch_kib + write_kib) * 1024.0
+    return total, {"source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) "
+                             "over child runs of bench.py, averaged over the launches of " + kernel_substr,
+                   "FETCH_SIZE_KiB_avg": fetch_kib, "WRITE_SIZE_KiB_avg": write_kib, "launches_sampled": vals["FETCH_SIZE"][1],
+                   "formula": "2 * FETCH_SIZE (gfx950 correction) + WRITE_SIZE"}
+
+
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def settle(step, ms):
+    """Untimed: run the step until the clocks have left their idle state (a cold MI355X takes ~100 ms of load to reach
+    its sustained clock; with 5 warm-up steps of 0.9 ms the first timed steps run ~4 % slow)."""
+    if ms <= 0:
+        return 0
+    n = 0
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        n += 20
+    return n
+
+
+def timed(step, steps, world):
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    return time.perf_counter() - t0, out
+
+
+def run_forward(args, world, rank, dev):
+    from beso_amd import synthetic as S
     cfg = S.SHAPES[args.config]
     w = S.make_weights(cfg, seed=0, std=0.02)
     model = build_model(cfg, w, args.precision, dev)
     inner = model.inner_model
     B = args.batch
-    # every rank owns its own shard of the job: different samples per rank, seeded
-    s_np, g_np, a_np = S.make_inputs(cfg, B, seed=1000 + rank)
+    s_np, g_np, a_np = S.make_inputs(cfg, B, seed=1000 + rank)          # every rank its own shard of the job
     state, goal, action = (torch.from_numpy(v).to(dev) for v in (s_np, g_np, a_np))
     sigma = torch.full((B,), 0.3, device=dev)
     rt = inner.runtime(cfg.sigma_data)
@@ -123,8 +266,7 @@ def main():
         for _ in range(args.warmup):
             out = step()
         torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
+        settled = settle(step, args.settle_ms)
         # which launch site dominates?  time each once, then instrument the dominant one
         sites = ["fused_layer", "gemm_fc1", "gemm_fc2", "gemm_qkv", "gemm_proj", "attention", "layernorm"]
         site_ms = {}
@@ -138,82 +280,196 @@ def main():
         rt.profile_enable("off")
         dominant = args.site or max(site_ms, key=lambda k: site_ms[k][0])
         rt.profile_enable(dominant)
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed, out = timed(step, args.steps, world)
         kern_ms, kern_n = rt.profile_read()
         rt.profile_enable("off")
-    assert torch.isfinite(out).all()
+        assert torch.isfinite(out).all()
+        # the parity mode of the same kernel, timed beside the headline (rank 0, N = 1: it is not part of `value`)
+        parity = None
+        if world == 1 and not args.no_parity_line and args.precision == "bf16" and args.config in ("kitchen", "block_push"):
+            mx = build_model(cfg, w, "bf16x3", dev)
+            ix = mx.inner_model
+            rtx, px = ix.runtime(cfg.sigma_data), ix.packed_weights()
+            stepx = lambda: rtx.denoise(px, state, action, goal, sigma, precondition=True)      # noqa: E731
+            for _ in range(3):
+                outx = stepx()
+            rtx.profile_enable("fused_layer")
+            nx = max(3, min(args.steps, 10))
+            elx, outx = timed(stepx, nx, 1)
+            kx_ms, kx_n = rtx.profile_read()
+            rtx.profile_enable("off")
+            dev_rel = float((outx - out).abs().max() / out.abs().max())
+            parity = {"dtype": "bf16x3", "ms_per_step": 1e3 * elx / nx, "kernel_avg_launch_ms": kx_ms / max(kx_n, 1),
+                      "launches": kx_n, "max_rel_dev_of_bf16_from_this_mode": dev_rel,
+                      "what": "same GCDenoiser.forward through the split-bf16 instance of layers_kernel (3 MFMAs per operand "
+                              "pair, exact GELU, fp32 attention core): 1e-4-class parity with the fp32 reference "
+                              "(tests/test_gpu_parity.py: 7e-6 .. 3e-5)"}
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    if rank != 0:
+        return None
+    F = cfg.flops_per_sample()
+    D, T, t = cfg.embed_dim, cfg.block_size, cfg.obs_seq_len
+    M = B * T
+    # algorithmic FLOPs of ONE launch of each launch site: the REFERENCE's work
+    layers_flops = (24.0 * T * D * D + 4.0 * T * T * D) * B * cfg.n_layers
+    site_flops = {"gemm_qkv": 2.0 * M * 3 * D * D, "gemm_proj": 2.0 * M * D * D, "gemm_fc1": 2.0 * M * 4 * D * D,
+                  "gemm_fc2": 2.0 * M * 4 * D * D, "attention": 4.0 * B * T * T * D,
+                  "fused_layer": layers_flops, "forward": float(F) * B}
+    executed = dict(site_flops)
+    if "fused_layer" in site_ms and site_ms["fused_layer"][1] > 1:
+        # shapes without the fused attention phase launch the fused MLP block once per layer
+        site_flops["fused_layer"] = executed["fused_layer"] = 16.0 * T * D * D * B
+        kernel_symbol = "beso::mlp_block_kernel (LN2+FC1+GELU+FC2+residual, one launch per layer)"
+    else:
+        # the fused kernel runs ALL layers in one launch; in the LAST layer only the action tokens go through the
+        # out-projection and the MLP (nothing else reaches the head): 18 D^2 per skipped token
+        executed["fused_layer"] = layers_flops - 18.0 * (T - t) * D * D * B
+        kernel_symbol = "beso::layers_kernel<3,12> (all transformer layers, one launch)"
+    steps_per_s = world * args.steps / elapsed
+    fwd_tflops = B * F * args.steps / elapsed / 1e12          # per GPU
+    avg_ms = kern_ms / max(kern_n, 1)
+    ach = site_flops.get(dominant, 0.0) / (avg_ms * 1e-3) / 1e12 if kern_n else 0.0
+    ach_x = executed.get(dominant, 0.0) / (avg_ms * 1e-3) / 1e12 if kern_n else 0.0
+    peak = PEAK_TFLOPS[args.precision]
+    traffic, traffic_detail = (None, {"source": "not measured (N > 1 or --no-traffic)"})
+    if world == 1 and not args.no_traffic and dominant == "fused_layer":
+        traffic, traffic_detail = measure_traffic(args)
+    if parity is not None:
+        parity["forward_frac_of_bf16_mfma_peak"] = B * F / (parity["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"]
+        parity["executed_mfma_flops_over_algorithmic"] = 3.0
+    result = {
+        "metric": "denoising-steps/sec (score-GPT fwd) at kitchen obs-dim",
+        "value": steps_per_s, "unit": f"denoise-steps/s (one step = GCDenoiser.forward over B={B} samples per GPU)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[1]: Franka {args.config} score-GPT fwd "
+                               f"(GCDenoiser.forward), batch={B} synthetic obs/goal per GPU, 1 NFE per step",
+                   "obs_dim": cfg.obs_dim, "act_dim": cfg.act_dim, "window": cfg.obs_seq_len,
+                   "goal_seq_len": cfg.goal_seq_len, "embed_dim": D, "n_layers": cfg.n_layers,
+                   "n_heads": cfg.n_heads, "tokens_per_sample": T, "batch_per_gpu": B,
+                   "parallelism": f"batch-sharded x{world}, no collective in the loop",
+                   "weights": "seeded N(0,0.02) recipe (no trained checkpoints shipped)", "sigma": 0.3},
+        "untimed_settle_steps": settled,
+        "sample_nfe_per_s": steps_per_s * B,
+        "flops_per_sample_forward": F,
+        "forward_tflops_per_gpu": fwd_tflops,
+        "forward_frac_of_mfma_peak": fwd_tflops / peak,
+        "roofline": {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                     "frac": ach / peak, "traffic": traffic,
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)", "traffic_detail": traffic_detail,
+                     "kernel_symbol": kernel_symbol if dominant == "fused_layer" else dominant, "launches": kern_n,
+                     "avg_launch_ms": avg_ms, "flops_per_launch": site_flops.get(dominant, 0.0),
+                     "executed_flops_per_launch": executed.get(dominant, 0.0), "achieved_executed": ach_x,
+                     "frac_executed": ach_x / peak,
+                     "site_ms_one_forward": {k: v[0] for k, v in site_ms.items()}},
+    }
+    if parity is not None:
+        result["parity_mode"] = parity
+    if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only (the other ranks would idle at the barrier)
+        result["cpu_baseline"] = cpu_baseline(cfg, w, B)
+    return result
 
+
+def run_train(args, world, rank, dev):
+    """BASELINE configs[2] per-GPU share: kitchen train_step, 1024 samples per GPU, shipped dropouts, cond_mask_prob 0.1."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from _agent import build_agent
+    from beso_amd import distributed as bdist
+    from beso_amd import synthetic as S
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    os.environ["BESO_AMD_C1_OVERLAP"] = str(args.c1_overlap)
+    cfg = S.SHAPES[args.config]
+    w = S.make_weights(cfg, seed=0, std=0.02)
+    B = args.batch
+    attn_p, resid_p = {"kitchen": (0.3, 0.0), "block_push": (0.05, 0.05)}.get(args.config, (0.0, 0.0))
+    agent = build_agent(cfg, lambda: build_model(cfg, w, args.precision, dev, attn_p, resid_p, 0.1, train=True), device=dev)
+    rng = np.random.default_rng(0)
+    agent.get_scaler(Scaler(rng.standard_normal((256, cfg.obs_dim)).astype(np.float32),
+                            rng.standard_normal((256, cfg.act_dim)).astype(np.float32), True, dev))
+    agent.set_bounds(agent.scaler)
+    agent._sync_replicas()                                  # C2: replicas start identical, EMA re-seeded
+    torch.manual_seed(1234 + rank)                          # every rank its own samples, noise, sigma and masks
+    batch = {"observation": torch.randn(B, cfg.obs_seq_len, cfg.obs_dim, device=dev),
+             "action": torch.randn(B, cfg.obs_seq_len, cfg.act_dim, device=dev),
+             "goal_observation": torch.randn(B, cfg.goal_seq_len, cfg.obs_dim, device=dev)}
+    step = lambda: agent.train_step(batch)                  # noqa: E731
+    for _ in range(max(args.warmup, 2)):
+        loss = step()
+    settle(step, args.settle_ms)
+    elapsed, loss = timed(step, args.steps, world)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank != 0:
+        return None
+    assert np.isfinite(loss) and getattr(agent, "_hip_step", None) is not None
+    flops = 3.0 * cfg.flops_per_sample() * B                # forward + data gradients + weight gradients, per GPU
+    ms = 1e3 * elapsed / args.steps
+    ach = flops / (ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.precision]
+    return {
+        "metric": "train-steps/sec (score-matching train_step) at kitchen obs-dim",
+        "value": args.steps / elapsed, "unit": f"train_steps/s of the whole job (global batch {B * world}: {B} samples per GPU per step)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[2] per-GPU share: Franka {args.config} BesoAgent.train_step "
+                               f"(GCDenoiser.loss fwd+bwd, AdamW, EMA), {B} samples per GPU, global batch {B * world}",
+                   "attn_pdrop": attn_p, "resid_pdrop": resid_p, "cond_mask_prob": 0.1,
+                   "parallelism": f"dp{world}: all-reduce of {9381249 if args.config == 'kitchen' else 'all'} fp32 gradients "
+                                  f"(C1, overlap={'on' if args.c1_overlap else 'off'})",
+                   "optimizer": type(agent.optimizer).__name__ + " + EMA in one launch"},
+        "samples_per_s": B * world * args.steps / elapsed,
+        "loss": loss,
+        "roofline": {"bound": "mfma", "kernel": "train_step (all launches of one step)", "achieved": ach, "peak": peak,
+                     "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                     "flops_per_launch": flops, "avg_launch_ms": ms,
+                     "note": "3 x forward FLOPs x samples per GPU over the whole step time (optimizer, EMA, C1 included)"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU per step (forward: 4096, train: 1024)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--config", default="kitchen", choices=["kitchen", "block_push", "long_horizon"])
+    ap.add_argument("--workload", default="forward", choices=["forward", "train"])
+    ap.add_argument("--c1-overlap", type=int, default=1, choices=[0, 1], help="train workload, N > 1: overlapped gradient all-reduce")
+    ap.add_argument("--settle-ms", type=float, default=300.0, help="untimed load before the timed region (clock ramp)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-line", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true")
+    ap.add_argument("--site", default=None, help="launch site timed for the roofline object")
+    ap.add_argument("--dry-run-backend", default=None, choices=["gloo"],
+                    help="launcher self-test without GPUs: spawn the ranks, verify the group over this backend, print n_gpus")
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 4096 if args.workload == "forward" else 1024
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    maybe_relaunch(args)
+    world, rank, local_rank, verified = init_ranks(args)
+    if args.dry_run_backend is not None:
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "backend": args.dry_run_backend, "n_gpus": world, "ranks_verified": verified}))
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible (the score-denoising path has no CPU implementation to time)")
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(dev)
+    result = run_forward(args, world, rank, dev) if args.workload == "forward" else run_train(args, world, rank, dev)
     if rank == 0:
-        F = cfg.flops_per_sample()
-        D, T = cfg.embed_dim, cfg.block_size
-        M = B * T
-        # algorithmic FLOPs of ONE launch of each launch site: the REFERENCE's work; the fused kernel
-        # skips the part of the last layer that cannot reach the output, which is not subtracted here
-        site_flops = {"gemm_qkv": 2.0 * M * 3 * D * D, "gemm_proj": 2.0 * M * D * D, "gemm_fc1": 2.0 * M * 4 * D * D,
-                      "gemm_fc2": 2.0 * M * 4 * D * D, "attention": 4.0 * B * T * T * D,
-                      # the fused kernel runs ALL layers in one launch
-                      "fused_layer": (24.0 * T * D * D + 4.0 * T * T * D) * B * cfg.n_layers, "forward": float(F) * B}
-        if "fused_layer" in site_ms and site_ms["fused_layer"][1] > 1:
-            # shapes without the fused attention phase launch the fused MLP block once per layer
-            site_flops["fused_layer"] = 16.0 * T * D * D * B
-            kernel_symbol = "beso::mlp_block_kernel (LN2+FC1+GELU+FC2+residual, one launch per layer)"
-        else:
-            kernel_symbol = "beso::layers_kernel<3,12> (all transformer layers, one launch)"
-        steps_per_s = world * args.steps / elapsed
-        fwd_tflops = B * F * args.steps / elapsed / 1e12          # per GPU
-        avg_ms = kern_ms / max(kern_n, 1)
-        ach = site_flops.get(dominant, 0.0) / (avg_ms * 1e-3) / 1e12 if kern_n else 0.0
-        peak = PEAK_TFLOPS[args.precision]
-        # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
-        # runs, gfx950 2x read correction) that bench.py cannot make itself; the committed summary is quoted.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("kernel") == dominant and tj.get("batch") == B and tj.get("config") == args.config:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        kernel_names = {"fused_layer": kernel_symbol}
-        result = {
-            "metric": "denoising-steps/sec (score-GPT fwd) at kitchen obs-dim",
-            "value": steps_per_s, "unit": f"denoise-steps/s (one step = GCDenoiser.forward over B={B} samples per GPU)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: Franka {args.config} score-GPT fwd "
-                                   f"(GCDenoiser.forward), batch={B} synthetic obs/goal per GPU, 1 NFE per step",
-                       "obs_dim": cfg.obs_dim, "act_dim": cfg.act_dim, "window": cfg.obs_seq_len,
-                       "goal_seq_len": cfg.goal_seq_len, "embed_dim": D, "n_layers": cfg.n_layers,
-                       "n_heads": cfg.n_heads, "tokens_per_sample": T, "batch_per_gpu": B,
-                       "parallelism": f"batch-sharded x{world}, no collective in the loop",
-                       "weights": "seeded N(0,0.02) recipe (no trained checkpoints shipped)", "sigma": 0.3},
-            "sample_nfe_per_s": steps_per_s * B,
-            "flops_per_sample_forward": F,
-            "forward_tflops_per_gpu": fwd_tflops,
-            "forward_frac_of_mfma_peak": fwd_tflops / peak,
-            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)",
-                         "kernel_symbol": kernel_names.get(dominant, dominant), "launches": kern_n, "avg_launch_ms": avg_ms,
-                         "flops_per_launch": site_flops.get(dominant, 0.0),
-                         "site_ms_one_forward": {k: v[0] for k, v in site_ms.items()}},
-        }
-        if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only (the other ranks would idle at the barrier)
-            result["cpu_baseline"] = cpu_baseline(cfg, w, B)
+        result["ranks_verified"] = verified
         print(json.dumps(result))
     if world > 1:
         torch.distributed.barrier()

@@ -37,6 +37,39 @@ def test_forward_matches_reference(fixture, cfg_name):
         assert rel_err(O.denoise(w, cfg, s, a, g, sig, dtype=np.float64), fx[p + "denoised"]) < TOL
 
 
+@pytest.mark.parametrize("fixture,cfg_name", [
+    ("tiny_forward.npz", "tiny"), ("tiny_mlp_head_forward.npz", "tiny_mlp_head"),
+    ("tiny_nogoal_forward.npz", "tiny_nogoal"), ("kitchen_forward_std002.npz", "kitchen"),
+    ("block_push_forward.npz", "block_push"), ("long_horizon_forward.npz", "long_horizon")])
+def test_aten_backend_of_the_oracle_matches_reference(fixture, cfg_name):
+    """oracle/beso_oracle_torch.py (the ATen restatement that bench.py times as the CPU baseline) against the same
+    reference vectors, forward and a DDIM loop."""
+    import torch
+    from oracle import beso_oracle_torch as OT
+    fx = load_golden(fixture)
+    cfg = O.CONFIGS[cfg_name]
+    W = OT.to_torch(_weights(fx, cfg))
+    T = lambda v: torch.from_numpy(np.ascontiguousarray(v))      # noqa: E731
+    for t in fx["ts"]:
+        p = f"t{int(t)}::"
+        s, g, a, sig = (T(fx[p + k]) for k in ("state", "goal", "action", "sigma"))
+        assert rel_err(OT.score_gpt_forward(W, cfg, s, a, g, sig).numpy(), fx[p + "inner"]) < TOL
+        assert rel_err(OT.denoise(W, cfg, s, a, g, sig).numpy(), fx[p + "denoised"]) < TOL
+        assert rel_err(OT.denoise(W, cfg, s, a, g, sig, uncond=True).numpy(), fx[p + "denoised_uncond"]) < TOL
+
+
+def test_aten_backend_ddim_matches_reference():
+    import torch
+    from oracle import beso_oracle_torch as OT
+    fx = load_golden("kitchen_samplers.npz")
+    cfg = O.KITCHEN
+    W = OT.to_torch(_weights(fx, cfg))
+    T = lambda v: torch.from_numpy(np.ascontiguousarray(v))      # noqa: E731
+    for key in ("ddim_3_exponential", "ddim_10_exponential"):
+        out = OT.sample_ddim(W, cfg, T(fx["state"]), T(fx["x_t"]), T(fx["goal"]), T(fx[key + "::sigmas"]))
+        assert rel_err(out.numpy(), fx[key + "::out"]) < TOL, key
+
+
 def test_param_count_matches_survey():
     assert O.n_params(O.KITCHEN) == 9_381_249
     assert O.n_params(O.BLOCK_PUSH) == 2_783_762

@@ -18,9 +18,11 @@ def main():
            "-o", os.path.join(tmp, "fused.o"), *sys.argv[1:]]
     subprocess.run(cmd, cwd=tmp, check=True, stderr=subprocess.DEVNULL)
     text = open(os.path.join(tmp, "fused-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
-    start = next(i for i, l in enumerate(text) if l.startswith("_ZN4beso12_GLOBAL__N_113layers_kernel"))
+    # the throughput instance of the kitchen shape: layers_kernel<3, 12, 1, 2, 8, 6, 0>
+    sym = os.environ.get("BESO_VALU_SYMBOL", "_ZN4beso12_GLOBAL__N_113layers_kernelILi3ELi12ELi1ELi2ELi8ELi6ELi0EE")
+    start = next(i for i, l in enumerate(text) if l.startswith(sym) and ": ;" in l)
     ends = [i for i, l in enumerate(text) if "s_endpgm" in l and i > start]
-    lines = text[start:ends[1] + 1] if len(ends) > 1 else text[start:ends[0] + 1]
+    lines = text[start:ends[0] + 1]
     bars = [i for i, l in enumerate(lines) if "s_barrier" in l]
     prev = 0
     tot_v = tot_m = 0
