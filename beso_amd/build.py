@@ -6,6 +6,7 @@ hipcc cross-compiles without a GPU; the resulting .so travels to the GPU box wit
 from __future__ import annotations
 
 import concurrent.futures as cf
+import hashlib
 import os
 import subprocess
 import sys
@@ -15,6 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "build")
 LIB = os.path.join(LIBDIR, "libbeso_hip.so")
+STAMP = os.path.join(LIBDIR, "libbeso_hip.sha256")        # source hash the .so was built from (travels with it)
 UNITS = ["api", "elementwise", "attention", "gemm", "fused", "optim", "train", "feed"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -27,10 +29,18 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _deps_mtime() -> float:
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+def _source_hash() -> str:
+    """sha256 over every file the library is built from (csrc/*, include/beso_hip.h), the flags and the compiler path:
+    the key that decides whether the prebuilt .so is current.  (Modification times are not: the .so is git-ignored but
+    travels with the tree, and a checkout or copy can make a stale binary look newer than its sources.)"""
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC))
     files.append(os.path.join(os.path.dirname(PKG), "include", "beso_hip.h"))
-    return max(os.path.getmtime(f) for f in files)
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    h.update(" ".join(FLAGS + os.environ.get("BESO_EXTRA_HIPCC_FLAGS", "").split() + UNITS).encode())
+    return h.hexdigest()
 
 
 def _compile(unit: str) -> str:
@@ -49,17 +59,41 @@ def _compile(unit: str) -> str:
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
+    want = _source_hash()
+    try:
+        have = open(STAMP).read().strip()
+    except OSError:
+        have = ""
+    if not force and os.path.exists(LIB) and have == want:
         return LIB
+    try:
+        _hipcc()
+    except RuntimeError:
+        # no compiler on this box (e.g. a runtime-only image): the shipped binary is all there is; say what it is
+        if os.path.exists(LIB) and have:
+            sys.stderr.write(f"beso_amd.build: hipcc not found; using the prebuilt library (source hash {have[:12]}, "
+                             f"tree is {want[:12]})\n")
+            return LIB
+        raise
     with cf.ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
         objs = list(ex.map(_compile, UNITS))
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    with open(STAMP, "w") as f:
+        f.write(want + "\n")
     if verbose:
-        print(f"built {LIB} ({os.path.getsize(LIB) / 1024:.0f} KiB)")
+        print(f"built {LIB} ({os.path.getsize(LIB) / 1024:.0f} KiB, sources {want[:12]})")
     return LIB
+
+
+def is_current() -> bool:
+    """True when the library in lib/ was built from exactly the sources in the tree."""
+    try:
+        return os.path.exists(LIB) and open(STAMP).read().strip() == _source_hash()
+    except OSError:
+        return False
 
 
 if __name__ == "__main__":

@@ -1105,6 +1105,9 @@ __device__ __forceinline__ void gelu_pair(const f32x4 (&h)[RC][NT], float (&gq)[
 // VALU instruction directly behind its own MFMA issues in that MFMA's shadow, a run of them does not
 // (measured, tools/microbench/issue_rate.hip), and alternating two independent chains keeps the packed-fp32
 // pipe (8 cycles dependent, 5.5 independent) from waiting on itself.
+#ifndef BESO_GELU_SCALAR
+#define BESO_GELU_SCALAR 0           // 1: GELU chain as v_fma_f32 pairs instead of v_pk_fma_f32 (A/B experiment)
+#endif
 struct GeluChain { f32x2 v, vc, s, p; };
 template <int RC, int NT, int SIGMA>
 __device__ __forceinline__ void gelu_slot(const f32x4 (&h)[RC][NT], GeluChain& c0, GeluChain& c1, float (&gq)[8],
@@ -1119,6 +1122,20 @@ __device__ __forceinline__ void gelu_slot(const f32x4 (&h)[RC][NT], GeluChain& c
             g.v = f32x2{h[2 * j2 + (j >> 2)][t][j & 3], h[2 * j2 + (j >> 2)][t][(j & 3) + 1]};
             g.vc.x = __builtin_amdgcn_fmed3f(g.v.x, -4.0f, 4.0f);
         } else if constexpr (step == 1) g.vc.y = __builtin_amdgcn_fmed3f(g.v.y, -4.0f, 4.0f);
+#if BESO_GELU_SCALAR
+        // experiment: the same chain as single-lane-width ops (two per slot), kept apart so that they are not re-packed
+#define BESO_G2(dst, ex, ey) do { dst.x = (ex); asm volatile("" : "+v"(dst.x)); dst.y = (ey); asm volatile("" : "+v"(dst.y)); } while (0)
+        else if constexpr (step == 2) BESO_G2(g.s, g.vc.x * g.vc.x, g.vc.y * g.vc.y);
+        else if constexpr (step == 3) BESO_G2(g.p, __builtin_fmaf(g.s.x, 2.277972093e-08f, -1.598515742e-06f), __builtin_fmaf(g.s.y, 2.277972093e-08f, -1.598515742e-06f));
+        else if constexpr (step == 4) BESO_G2(g.p, __builtin_fmaf(g.p.x, g.s.x, 4.795382804e-05f), __builtin_fmaf(g.p.y, g.s.y, 4.795382804e-05f));
+        else if constexpr (step == 5) BESO_G2(g.p, __builtin_fmaf(g.p.x, g.s.x, -0.0008139993719f), __builtin_fmaf(g.p.y, g.s.y, -0.0008139993719f));
+        else if constexpr (step == 6) BESO_G2(g.p, __builtin_fmaf(g.p.x, g.s.x, 0.00877231165f), __builtin_fmaf(g.p.y, g.s.y, 0.00877231165f));
+        else if constexpr (step == 7) BESO_G2(g.p, __builtin_fmaf(g.p.x, g.s.x, -0.06457294506f), __builtin_fmaf(g.p.y, g.s.y, -0.06457294506f));
+        else if constexpr (step == 8) BESO_G2(g.p, __builtin_fmaf(g.p.x, g.s.x, 0.3978832308f), __builtin_fmaf(g.p.y, g.s.y, 0.3978832308f));
+        else if constexpr (step == 9) BESO_G2(g.p, __builtin_fmaf(g.vc.x, g.p.x, 0.5f), __builtin_fmaf(g.vc.y, g.p.y, 0.5f));
+        else if constexpr (step == 10) { gq[j] = g.v.x * g.p.x; asm volatile("" : "+v"(gq[j])); gq[j + 1] = g.v.y * g.p.y; }
+#undef BESO_G2
+#else
         else if constexpr (step == 2) g.s = g.vc * g.vc;
         else if constexpr (step == 3) g.p = __builtin_elementwise_fma(g.s, (f32x2)(2.277972093e-08f), (f32x2)(-1.598515742e-06f));
         else if constexpr (step == 4) g.p = __builtin_elementwise_fma(g.p, g.s, (f32x2)(4.795382804e-05f));
@@ -1128,6 +1145,7 @@ __device__ __forceinline__ void gelu_slot(const f32x4 (&h)[RC][NT], GeluChain& c
         else if constexpr (step == 8) g.p = __builtin_elementwise_fma(g.p, g.s, (f32x2)(0.3978832308f));
         else if constexpr (step == 9) g.p = __builtin_elementwise_fma(g.vc, g.p, (f32x2)(0.5f));
         else if constexpr (step == 10) { const f32x2 r = g.v * g.p; gq[j] = r.x; gq[j + 1] = r.y; }
+#endif
         // every slot is pinned where it is issued (otherwise the whole chain sinks to its use)
         if constexpr (step <= 1) asm volatile("" : "+v"(g.vc));
         else if constexpr (step == 2) asm volatile("" : "+v"(g.s));

@@ -19,6 +19,21 @@ def lib():
     return _lib.load()
 
 
+def test_library_is_built_from_the_sources_in_the_tree(lib):
+    """build() keys on a content hash of csrc/ + the header (not on modification times): after it, the shipped .so is
+    the one these sources produce; touching a source makes it stale."""
+    from beso_amd import build as B
+    assert B.is_current()
+    src = os.path.join(B.CSRC, "feed.hip")
+    text = open(src).read()
+    try:
+        open(src, "a").write("\n// probe\n")
+        assert not B.is_current()
+    finally:
+        open(src, "w").write(text)
+    assert B.is_current()
+
+
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "beso_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)

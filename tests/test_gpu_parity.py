@@ -74,6 +74,8 @@ def test_native_library_is_what_runs():
     from beso_amd import _lib
     lib = _lib.load()
     assert b"gfx950" in lib.beso_version()
+    from beso_amd import build as B
+    assert B.is_current(), "libbeso_hip.so was not built from the sources in this tree (stale binary)"
     maps = open("/proc/self/maps").read()
     assert "libbeso_hip.so" in maps
     m = make_module(O.TINY, O.make_weights(O.TINY))
@@ -386,6 +388,38 @@ def test_sampler_properties_block_push_2048():
         stepwise = ks.sample_heun(model, s, x, g, sig, disable=True, callback=lambda info: None)   # generic loop
         assert rel_err(fused.cpu().numpy(), stepwise.cpu().numpy()) < 1e-5
         assert torch.isfinite(fused).all()
+
+
+def test_block_push_2048_heun50_cfg_bf16():
+    """BASELINE configs[3] at full size: block-push, B = 2048, 50-step Heun, classifier-free guidance lambda = 2 (198
+    score-net forwards per sample, all enqueued by one beso_sample call) in the bf16 throughput mode.  Checked against
+    the same run in the split-bf16 parity mode (itself held to the oracle on spot samples), sample slices against the
+    same samples run alone (bit for bit: samples are independent), and for finiteness."""
+    from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+    from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
+    cfg = O.BLOCK_PUSH
+    w = O.make_weights(cfg, seed=7, std=0.05)
+    B = 2048
+    s_np, g_np, x_np = O.make_inputs(cfg, B, seed=3)
+    s, g, x = G(s_np), G(g_np), G(x_np)
+    sig = ks.get_sigmas_exponential(50, 0.05, 1.0)
+    outs = {}
+    with torch.no_grad():
+        for prec in ("bf16", "bf16x3"):
+            model = ClassifierFreeSampleModel(make_module(cfg, w, prec), 2.0)
+            n = count_fused_launches(lambda: outs.__setitem__(prec, ks.sample_heun(model, s, x, g, sig, disable=True)))
+            assert n == 99, n                                              # 2 * 50 - 1 evaluations, each ONE launch (cond + uncond inside)
+            assert torch.isfinite(outs[prec]).all()
+            if prec == "bf16":
+                part = ks.sample_heun(model, s[512:640], x[512:640], g[512:640], sig, disable=True)
+                assert torch.equal(outs[prec][512:640], part)
+    e_modes = rel_err(outs["bf16"].cpu().numpy(), outs["bf16x3"].cpu().numpy())
+    idx = [0, 1, 1023, 2047]
+    ref = O.sample_heun(O.make_model(w, cfg, cond_lambda=2.0), s_np[idx], x_np[idx], g_np[idx], sig.numpy())
+    e_x3 = rel_err(outs["bf16x3"][idx].cpu().numpy(), ref)
+    e_bf = rel_err(outs["bf16"][idx].cpu().numpy(), ref)
+    print(f"[parity] block-push B=2048 Heun-50 x CFG: bf16 vs bf16x3 {e_modes:.3e}; vs oracle (4 samples): bf16x3 {e_x3:.3e}, bf16 {e_bf:.3e}")
+    assert e_x3 < 3e-4 and e_modes < 2e-2 and e_bf < 2e-2
 
 
 def test_ragged_and_edge_shapes():

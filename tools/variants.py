@@ -62,7 +62,7 @@ def build(specs):
         print("built", lib)
 
 
-def time_one(batch, steps=30):
+def time_one(batch, steps=300):
     import torch
     from bench import build_model
     from beso_amd import synthetic as O
@@ -74,7 +74,7 @@ def time_one(batch, steps=30):
     inner = model.inner_model
     rt, packed = inner.runtime(cfg.sigma_data), inner.packed_weights()
     with torch.no_grad():
-        for _ in range(5):
+        for _ in range(300):                  # a cold chip needs ~100 ms of load to reach its sustained clock
             rt.denoise(packed, s, a, g, sig, precondition=True)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
