@@ -92,6 +92,8 @@ class BesoAgent(BaseAgent):
         self._ema_packed = None
         self._ema_packed_key = None
         self._grad_bucket = None
+        self._sharded_ex = None          # buffers of the sharded gradient exchange (BESO_AMD_C1=sharded)
+        self._ema_partial = False        # sharded exchange: the EMA shadow is current for the owned range only
         self._train_graphs = {}          # batch shape -> captured forward+backward (train_step)
         self._train_graph_ok = True
 
@@ -121,6 +123,7 @@ class BesoAgent(BaseAgent):
         if not self.use_ema:
             yield
             return
+        self._complete_ema()
         den = self._hip_denoiser()
         first = next(iter(self.model.parameters()), None)        # (listing all 113 parameters costs 0.3 ms per call)
         if den is not None and first is not None and first.is_cuda:
@@ -155,6 +158,30 @@ class BesoAgent(BaseAgent):
             self.ema_helper.load_shadow_params(self.model.get_params())
             self._ema_packed_key = None
             self._replicas_synced = True
+
+    def _c1_mode(self) -> str:
+        """How the data-parallel gradient exchange (C1) runs: 'overlap' (default: all-reduce in three ranges, the first
+        under the backward of the lower layers), 'flat' (one all-reduce after the backward), 'sharded' (reduce-scatter,
+        Adam(W) + EMA on the owned 1/world of the parameters, all-gather of the updated parameters: SURVEY.md 2.2)."""
+        mode = os.environ.get("BESO_AMD_C1", "overlap")
+        if os.environ.get("BESO_AMD_C1_OVERLAP", "1") == "0" and mode == "overlap":
+            mode = "flat"
+        if mode not in ("overlap", "flat", "sharded"):
+            raise ValueError(f"BESO_AMD_C1={mode!r}: choose overlap, flat or sharded")
+        return mode
+
+    def _sharded(self):
+        if getattr(self, "_sharded_ex", None) is None:
+            self._sharded_ex = bdist.ShardedExchange(self.model.get_params())
+        return self._sharded_ex
+
+    def _complete_ema(self):
+        """Sharded C1 updates the EMA shadow of the owned parameter range only; before the shadow is read (evaluation,
+        checkpoint) the ranges are gathered -- a collective: every rank gets here at the same step."""
+        if getattr(self, "_ema_partial", False) and bdist.is_distributed():
+            self._sharded().all_gather_flat_state(self.ema_helper._flat)
+            self.ema_helper.version += 1
+        self._ema_partial = False
 
     def train_agent(self, train_loader, test_loader):
         self._sync_replicas()
@@ -238,7 +265,9 @@ class BesoAgent(BaseAgent):
             # ones: the call orders self._c1_stream behind the completion of that range (BESO_AMD_C1_OVERLAP=0: one flat
             # all-reduce after the backward)
             early = None
-            if bdist.is_distributed() and state.is_cuda and os.environ.get("BESO_AMD_C1_OVERLAP", "1") == "1" \
+            if bdist.is_distributed() and self._c1_mode() == "sharded":
+                step.pad_to = self._sharded().padded
+            if bdist.is_distributed() and state.is_cuda and self._c1_mode() == "overlap" \
                     and not torch.cuda.is_current_stream_capturing():
                 if getattr(self, "_c1_stream", None) is None:
                     self._c1_stream = torch.cuda.Stream(state.device)
@@ -317,21 +346,32 @@ class BesoAgent(BaseAgent):
             loss = self._graphed_loss_backward(state, action, goal)
         else:
             loss = self._loss_backward(state, action, goal)
+        shard = None
         if bdist.is_distributed():
             flat = self._hip_step.flat_grads() if getattr(self, "_hip_step", None) is not None else None
-            if flat is not None and getattr(self, "_c1_early", None) is not None:
+            sharded = self._c1_mode() == "sharded"
+            if flat is not None and sharded and isinstance(self.optimizer, FusedAdam):
+                # reduce-scatter: this rank ends up with the summed gradient of the parameter range it owns
+                ex = self._sharded()
+                ex.reduce_scatter_grads(self._hip_step.flat_grads_padded())
+                shard = (ex.lo, ex.hi)
+            elif flat is not None and getattr(self, "_c1_early", None) is not None:
                 bdist.all_reduce_sum_overlapped(flat, self._hip_step.early_range(), self._c1_early)
             elif flat is not None:
                 bdist.all_reduce_sum(flat)                    # C1 on the flat buffer the kernels wrote (pre-scaled)
             else:
                 if self._grad_bucket is None:
                     self._grad_bucket = bdist.GradientBucket(self.model.get_params())
-                self._grad_bucket.sync()
+                self._grad_bucket.sync(decomposed=sharded)   # (eager optimizer: the same exchange as its two halves)
         self.steps += 1
         do_ema = self.steps % self.update_ema_every_n_steps == 0
         if isinstance(self.optimizer, FusedAdam):
-            # Adam(W) over all tensors and the EMA of the updated parameters in ONE HIP launch
-            self.optimizer.step(ema=self.ema_helper if do_ema else None)
+            # Adam(W) over all tensors and the EMA of the updated parameters in ONE HIP launch -- over the owned range
+            # only in the sharded exchange, followed by the all-gather of the updated parameters
+            self.optimizer.step(ema=self.ema_helper if do_ema else None, shard=shard)
+            if shard is not None:
+                self._sharded().all_gather_params()
+                self._ema_partial = getattr(self, "_ema_partial", False) or do_ema
             self.lr_scheduler.step()
         else:
             self.optimizer.step()
@@ -456,6 +496,7 @@ class BesoAgent(BaseAgent):
     def store_model_weights(self, store_path: str) -> None:
         """EMA weights -> model_state_dict.pth, raw weights -> non_ema_model_state_dict.pth
         (beso_agent.py:466-476)."""
+        self._complete_ema()
         if bdist.rank() != 0:
             return
         raw = {k: v.detach().clone() for k, v in self.model.state_dict().items()}

@@ -83,11 +83,24 @@ class GradientBucket:
                 p.grad.copy_(self.flat[off:off + n].view_as(p))
             off += n
 
-    def sync(self, async_op: bool = False):
+    def sync(self, async_op: bool = False, decomposed: bool = False):
+        """``decomposed``: the same sum as reduce-scatter + all-gather (the two halves of the sharded exchange, for
+        optimizers that step on all parameters)."""
         if not is_distributed():
             return None
         self._pack()
         self.flat.div_(world_size())            # mean over the GLOBAL batch (score_wrappers.py:79)
+        if decomposed:
+            n, w = self.flat.numel(), world_size()
+            s = shard_size(n, w)
+            padded = torch.zeros(s * w, dtype=self.flat.dtype, device=self.flat.device)
+            padded[:n].copy_(self.flat)
+            shard = torch.empty(s, dtype=self.flat.dtype, device=self.flat.device)
+            reduce_scatter_flat(padded, shard)
+            all_gather_flat(padded, shard)
+            self.flat.copy_(padded[:n])
+            self._unpack()
+            return None
         self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         if not async_op:
             self._unpack()
@@ -129,6 +142,85 @@ def all_reduce_sum_overlapped(flat: torch.Tensor, early_range, early_stream=None
         dist.all_reduce(flat[end:], op=dist.ReduceOp.SUM)
     if work is not None:
         work.wait()                                   # the current stream waits for the early collective
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C1 as reduce-scatter + all-gather (SURVEY.md 2.2), with the optimizer step on the owned shard in between (ZeRO-1):
+#   grads (flat, pre-scaled by 1/world)  --reduce-scatter-->  this rank's 1/world of the summed gradient
+#   Adam(W) (+EMA) on that range of parameters only (1/world of the optimizer work and of the moment traffic)
+#   updated parameter shards  --all-gather-->  every replica holds the new weights
+# On the fully connected xGMI mesh both halves are direct exchanges that keep all seven links busy; the volume on the
+# wire equals one all-reduce.  The EMA shadow is updated for the owned range only and gathered when it is next read.
+# ---------------------------------------------------------------------------------------------------------------------
+def shard_size(n: int, world: int) -> int:
+    return (n + world - 1) // world
+
+
+def shard_range_flat(n: int, world: int, rank_: int):
+    """[lo, hi) of the flat parameter / gradient order owned by ``rank_`` (equal shards of ceil(n / world), the last
+    one short)."""
+    s = shard_size(n, world)
+    return min(n, rank_ * s), min(n, (rank_ + 1) * s)
+
+
+def reduce_scatter_flat(flat_padded: torch.Tensor, out_shard: torch.Tensor) -> None:
+    """flat_padded: world * S floats (gradients, zero tail); out_shard (S floats) <- sum over ranks of this rank's shard."""
+    dist.reduce_scatter_tensor(out_shard, flat_padded, op=dist.ReduceOp.SUM)
+
+
+def all_gather_flat(full_padded: torch.Tensor, shard: torch.Tensor) -> None:
+    """full_padded (world * S floats) <- the shards of all ranks, in rank order."""
+    dist.all_gather_into_tensor(full_padded, shard)
+
+
+class ShardedExchange:
+    """Buffers and the two collectives of the sharded step for a parameter list of ``n`` floats in total."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = list(params)
+        self.n = sum(p.numel() for p in self.params)
+        self.world, self.rank = world_size(), rank()
+        self.S = shard_size(self.n, self.world)
+        self.lo, self.hi = shard_range_flat(self.n, self.world, self.rank)
+        dev = self.params[0].device
+        self.padded = self.S * self.world
+        self.g_shard = torch.zeros(self.S, dtype=torch.float32, device=dev)
+        self.p_shard = torch.zeros(self.S, dtype=torch.float32, device=dev)
+        self.full = torch.zeros(self.padded, dtype=torch.float32, device=dev)
+        self._offs = []
+        off = 0
+        for p in self.params:
+            self._offs.append(off)
+            off += p.numel()
+
+    def _pieces(self, lo, hi):
+        """(parameter index, start in the tensor, stop in the tensor, start in [lo, hi)) of the tensors that intersect."""
+        for i, (p, off) in enumerate(zip(self.params, self._offs)):
+            a, b = max(lo, off), min(hi, off + p.numel())
+            if a < b:
+                yield i, a - off, b - off, a - lo
+
+    def reduce_scatter_grads(self, flat_padded: torch.Tensor) -> None:
+        """flat_padded[lo:hi] <- this rank's shard of the summed gradients (the rest of the buffer is left as it was)."""
+        assert flat_padded.numel() == self.padded
+        reduce_scatter_flat(flat_padded, self.g_shard)
+        flat_padded[self.lo:self.hi].copy_(self.g_shard[: self.hi - self.lo])
+
+    def all_gather_params(self) -> None:
+        """Every replica's parameters <- the owners' updated shards."""
+        with torch.no_grad():
+            for i, a, b, at in self._pieces(self.lo, self.hi):
+                self.p_shard[at:at + (b - a)].copy_(self.params[i].detach().reshape(-1)[a:b])
+            all_gather_flat(self.full, self.p_shard)
+            for p, off in zip(self.params, self._offs):
+                p.copy_(self.full[off:off + p.numel()].view_as(p))
+
+    def all_gather_flat_state(self, flat_state: torch.Tensor) -> None:
+        """A flat per-parameter state (the EMA shadow) of which every rank holds its own range up to date: make it whole."""
+        send = torch.zeros(self.S, dtype=torch.float32, device=flat_state.device)
+        send[: self.hi - self.lo].copy_(flat_state[self.lo:self.hi])
+        all_gather_flat(self.full, send)
+        flat_state.copy_(self.full[: self.n])
 
 
 def all_reduce_mean(x: torch.Tensor) -> torch.Tensor:

@@ -36,9 +36,9 @@ class FusedAdam(torch.optim.Optimizer):
                        decoupled_weight_decay=decoupled) for g in opt.param_groups]
         return cls(groups)
 
-    def _prepare(self, gi: int, group: dict):
+    def _prepare(self, gi: int, group: dict, shard=None):
         params = [p for p in group["params"] if p.grad is not None]
-        sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
+        sig = (shard,) + tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
         st = self._groups[gi]
         if st is not None and st["sig"] == sig:
             return st
@@ -59,8 +59,11 @@ class FusedAdam(torch.optim.Optimizer):
             if g.dtype != torch.float32 or not g.is_contiguous():
                 raise ValueError("FusedAdam needs contiguous fp32 gradients")
             n, off = p.numel(), offs[id(p)]
-            for s in range(0, n, CHUNK):
-                c = min(CHUNK, n - s)
+            # shard = [lo, hi) of the flat parameter order (ZeRO-1 style data parallelism: this rank owns and updates
+            # only that range; the moments of the rest are never touched here)
+            s0, s1 = (0, n) if shard is None else (max(0, shard[0] - off), min(n, shard[1] - off))
+            for s in range(s0, s1, CHUNK):
+                c = min(CHUNK, s1 - s)
                 rows.append((p.data_ptr() + 4 * s, g.data_ptr() + 4 * s, off + s, c))
         st["table"] = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None      # 32-byte beso_optim_chunk rows
         st["n_chunks"] = len(rows)
@@ -69,14 +72,19 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
-    def step(self, closure=None, ema=None):
+    def step(self, closure=None, ema=None, shard=None):
         """One step.  ``ema``: an ``ExponentialMovingAverage`` over exactly this optimizer's parameters (in
-        order) whose shadow is updated in the same launch, with its own warm-up rule."""
+        order) whose shadow is updated in the same launch, with its own warm-up rule.  ``shard = (lo, hi)``: update
+        only the elements [lo, hi) of the flat parameter order (one parameter group) -- the sharded data-parallel
+        step, where this rank holds the reduced gradients of that range only."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        prepared = [self._prepare(gi, group) for gi, group in enumerate(self.param_groups)]   # validates devices/dtypes
+        if shard is not None and len(self.param_groups) != 1:
+            raise ValueError("a sharded step needs one parameter group")
+        shard = None if shard is None else (int(shard[0]), int(shard[1]))
+        prepared = [self._prepare(gi, group, shard) for gi, group in enumerate(self.param_groups)]   # validates devices/dtypes
         lib = _lib.load()
         ema_decay, ema_ptr = 0.0, None
         if ema is not None:

@@ -36,6 +36,8 @@ class HipTrainStep:
         self.n_params = self.lib.beso_num_params(C.byref(self.cfg))
         self.n_grad = int(self.lib.beso_grad_floats(C.byref(self.cfg)))
         self._flat: Optional[torch.Tensor] = None
+        self._flat_full: Optional[torch.Tensor] = None      # _flat plus the zero tail of the sharded exchange
+        self.pad_to = 0
         self._views: Optional[List[torch.Tensor]] = None
         self._ws: Optional[torch.Tensor] = None
 
@@ -62,8 +64,11 @@ class HipTrainStep:
         if fresh:
             flat = torch.empty(self.n_grad, dtype=torch.float32, device=dev)
         else:
-            if self._flat is None or self._flat.device != dev:
-                self._flat = torch.empty(self.n_grad, dtype=torch.float32, device=dev)
+            if self._flat is None or self._flat.device != dev or self._flat_full.numel() != max(self.n_grad, self.pad_to):
+                # (pad_to: the sharded data-parallel exchange reduce-scatters a buffer of world * ceil(n / world) floats;
+                # the kernels write the first n_grad, the tail stays zero)
+                self._flat_full = torch.zeros(max(self.n_grad, self.pad_to), dtype=torch.float32, device=dev)
+                self._flat = self._flat_full[: self.n_grad]
                 self._views = None
             flat = self._flat
         views, off = [], 0
@@ -169,6 +174,10 @@ class HipTrainStep:
             else:
                 p.grad.add_(v)
         return loss
+
+    def flat_grads_padded(self) -> Optional[torch.Tensor]:
+        """flat_grads() with its zero tail (``pad_to`` floats in all), for the reduce-scatter of the sharded exchange."""
+        return None if self.flat_grads() is None else self._flat_full
 
     def flat_grads(self) -> Optional[torch.Tensor]:
         """The flat buffer if every ``p.grad`` currently is its view of it (then one all-reduce covers them)."""

@@ -70,6 +70,41 @@ def _worker(rank, world, port, out):
         flat_g = torch.arange(7, dtype=torch.float32) * (rank + 1) / world
         bdist.all_reduce_sum_overlapped(flat_g, rng, None)
         assert torch.allclose(flat_g, torch.arange(7, dtype=torch.float32) * 1.5), rng
+    # --- the two halves of the sharded exchange: reduce-scatter + all-gather == all-reduce, for n not a multiple of world
+    for n in (7, 8, 1):
+        g0 = torch.arange(n, dtype=torch.float32) * (rank + 1) / world
+        s = bdist.shard_size(n, world)
+        padded = torch.zeros(s * world)
+        padded[:n] = g0
+        shard = torch.empty(s)
+        bdist.reduce_scatter_flat(padded, shard)
+        lo, hi = bdist.shard_range_flat(n, world, rank)
+        assert torch.allclose(shard[: hi - lo], (torch.arange(n, dtype=torch.float32) * 1.5)[lo:hi]), (n, shard)
+        full = torch.empty(s * world)
+        bdist.all_gather_flat(full, shard)
+        assert torch.allclose(full[:n], torch.arange(n, dtype=torch.float32) * 1.5), n
+    # ShardedExchange on a ragged parameter list: gradients reduced into the owned range, parameters / a flat state gathered
+    torch.manual_seed(5)
+    ps = [torch.nn.Parameter(torch.randn(3, 2)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 1))]
+    ex = bdist.ShardedExchange(ps)
+    assert ex.n == 13 and ex.S == 7 and (ex.lo, ex.hi) == ((0, 7) if rank == 0 else (7, 13))
+    gpad = torch.zeros(ex.padded)
+    gpad[:13] = torch.arange(13, dtype=torch.float32) * (rank + 1) / world
+    ex.reduce_scatter_grads(gpad)
+    assert torch.allclose(gpad[ex.lo:ex.hi], (torch.arange(13, dtype=torch.float32) * 1.5)[ex.lo:ex.hi])
+    flat_p = torch.cat([q.detach().reshape(-1) for q in ps])                  # same seed: replicas agree to start with
+    with torch.no_grad():                                                     # every rank "updates" only what it owns
+        for i, a, b, at in ex._pieces(ex.lo, ex.hi):
+            ps[i].reshape(-1)[a:b] += 100.0 * (rank + 1)
+    ex.all_gather_params()
+    want = flat_p.clone()
+    want[:7] += 100.0
+    want[7:] += 200.0
+    assert torch.allclose(torch.cat([q.detach().reshape(-1) for q in ps]), want)
+    state = torch.full((13,), -1.0)
+    state[ex.lo:ex.hi] = float(rank + 1)
+    ex.all_gather_flat_state(state)
+    assert torch.equal(state, torch.cat([torch.full((7,), 1.0), torch.full((6,), 2.0)]))
     # --- C2: broadcast makes replicas identical
     cfg, agent = _make_agent(seed=100 + rank)           # different init per rank on purpose
     bdist.broadcast_parameters(agent.model.get_params(), src=0)
@@ -88,6 +123,7 @@ def _worker(rank, world, port, out):
     real_randn_like, real_density = torch.randn_like, agent.make_sample_density
     torch.randn_like = lambda t: noise[lo:hi].clone()   # ... sliced like the batch
     agent.make_sample_density = lambda: (lambda shape, device: sigma[lo:hi].clone())
+    os.environ["BESO_AMD_C1"] = os.environ.get("TEST_C1_MODE", "overlap")
     try:
         loss = agent.train_step(shard)
     finally:
@@ -104,9 +140,11 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_training_step_matches_single_process(tmp_path, autograd_training):
+@pytest.mark.parametrize("c1_mode", ["overlap", "sharded"])
+def test_two_rank_gloo_training_step_matches_single_process(tmp_path, autograd_training, c1_mode, monkeypatch):
     out = str(tmp_path / "dp.pt")
     port = _free_port()
+    monkeypatch.setenv("TEST_C1_MODE", c1_mode)          # (inherited by the spawned ranks)
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     dp = torch.load(out)
     # single process, whole batch, same init (rank 0's) and the same noise / sigma

@@ -511,6 +511,47 @@ def test_fused_adam_matches_torch(kind):
 
 
 @pytest.mark.gpu
+def test_fused_adam_sharded_steps_equal_the_full_step():
+    """FusedAdam.step(shard=(lo, hi)) updates exactly the elements [lo, hi) of the flat parameter order (the owned range
+    of the sharded data-parallel exchange): stepping the shards of a 3-way split one after the other is the full step,
+    bit for bit (parameters and EMA shadow), and leaves everything outside a shard untouched."""
+    from beso_amd.optim import FusedAdam
+    from beso_amd.networks.ema_helper.ema import ExponentialMovingAverage
+    torch.manual_seed(0)
+    shapes = [(7, 5), (4100,), (3, 9000), (1,), (64, 33)]
+
+    def make():
+        torch.manual_seed(1)
+        ps = [torch.nn.Parameter(torch.randn(*sh, device=DEV)) for sh in shapes]
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        return ps, FusedAdam(ps, lr=1e-2, weight_decay=0.01, decoupled_weight_decay=True), ExponentialMovingAverage(ps, 0.999, DEV)
+
+    pf, of, ef = make()
+    ps, os_, es = make()
+    n = sum(p.numel() for p in pf)
+    cuts = [0, 4099, 4099 + 13001, n]
+    for it in range(3):
+        of.step(ema=ef)
+        decay_counted = False
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            before = torch.cat([p.detach().reshape(-1) for p in ps]).clone()
+            if decay_counted:                       # one EMA update per step: the warm-up counter advances once
+                es.num_updates -= 1
+            for st in os_._groups:                  # (the step counter too: three launches, one Adam step)
+                if st is not None:
+                    st["step"] = it
+            os_.step(ema=es, shard=(lo, hi))
+            decay_counted = True
+            after = torch.cat([p.detach().reshape(-1) for p in ps])
+            assert torch.equal(after[:lo], before[:lo]) and torch.equal(after[hi:], before[hi:])
+            assert not torch.equal(after[lo:hi], before[lo:hi])
+        for a, b in zip(pf, ps):
+            assert torch.equal(a, b)
+        assert torch.equal(ef._flat, es._flat)
+
+
+@pytest.mark.gpu
 def test_train_step_with_fused_optimizer_matches_eager(monkeypatch):
     """BesoAgent.train_step: fused Adam(W)+EMA launch == eager torch optimizer + EMA helper on the same batches."""
     from test_host_logic import build_agent
@@ -1439,8 +1480,9 @@ def test_overlapped_all_reduce_on_a_one_rank_group():
                  "action": torch.randn(32, cfg.obs_seq_len, cfg.act_dim, device=DEV),
                  "goal_observation": torch.randn(32, cfg.goal_seq_len, cfg.obs_dim, device=DEV)}
         params = {}
-        for overlap in ("1", "0"):
-            os.environ["BESO_AMD_C1_OVERLAP"] = overlap
+        for overlap in ("1", "0", "sharded"):
+            os.environ["BESO_AMD_C1_OVERLAP"] = "1" if overlap == "sharded" else overlap
+            os.environ["BESO_AMD_C1"] = "sharded" if overlap == "sharded" else "overlap"
             bdist.is_distributed = lambda: True                         # one rank, but take the data-parallel branch
             real_sum = bdist.all_reduce_sum_overlapped
             calls = []
@@ -1453,6 +1495,12 @@ def test_overlapped_all_reduce_on_a_one_rank_group():
             losses = [agent.train_step(batch) for _ in range(3)]
             bdist.all_reduce_sum_overlapped = real_sum
             assert (len(calls) == 3) == (overlap == "1") and all(np.isfinite(v) for v in losses)
+            if overlap == "sharded":
+                # reduce-scatter -> Adam(W) + EMA on the owned range (here: everything) -> all-gather, through RCCL
+                assert agent._sharded_ex is not None and (agent._sharded_ex.lo, agent._sharded_ex.hi) == (0, agent._sharded_ex.n)
+                assert agent._ema_partial
+                agent.evaluate(batch)                                   # reads the EMA: completes it first (a collective)
+                assert not agent._ema_partial
             params[overlap] = (torch.cat([q.detach().reshape(-1) for q in agent.model.get_params()]), losses)
         # same trajectory: equal losses; equal parameters except where the true gradient is zero (key biases: Adam turns
         # the atomics' rounding noise into +-lr there)
@@ -1460,9 +1508,13 @@ def test_overlapped_all_reduce_on_a_one_rank_group():
         diff = (params["1"][0] - params["0"][0]).abs()
         print(f"[overlap] losses {params['1'][1]} vs {params['0'][1]}; parameters differing by > 1e-6: {float((diff > 1e-6).float().mean()):.4f}")
         assert float((diff > 1e-6).float().mean()) < 0.03 and float(diff.max()) < 1e-3
+        assert np.allclose(params["sharded"][1], params["0"][1], rtol=1e-4)
+        diff = (params["sharded"][0] - params["0"][0]).abs()
+        assert float((diff > 1e-6).float().mean()) < 0.03 and float(diff.max()) < 1e-3
     finally:
         bdist.is_distributed = real
         os.environ.pop("BESO_AMD_C1_OVERLAP", None)
+        os.environ.pop("BESO_AMD_C1", None)
         dist.destroy_process_group()
 
 
