@@ -188,7 +188,7 @@ def measure_traffic(args, kernel_substr="layers_kernel"):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "t", "--", *child]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             if r.returncode != 0:
                 return None, {"source": f"rocprofv3 pass {counter} failed (rc {r.returncode})"}
             tot, cnt = 0.0, 0

@@ -215,11 +215,12 @@ __global__ void pack_qkv_kernel(const float* __restrict__ wq, const float* __res
 }
 
 // out[(h*3 + part)*64 + d] = b_part[h*hd + d] + sum_c W_part[h*hd + d][c] * beta[c]   (0 for d >= hd)
+// One wave per output: lanes stride over the row of W (coalesced), butterfly sum.
 __global__ void fold_qkv_bias_kernel(const float* __restrict__ wq, const float* __restrict__ wk,
                                      const float* __restrict__ wv, const float* __restrict__ bq,
                                      const float* __restrict__ bk, const float* __restrict__ bv,
                                      const float* __restrict__ beta, float* __restrict__ out, int D, int H, int hd) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= H * 3 * kHDP) return;
     int d = i % kHDP, part = (i / kHDP) % 3, h = i / (3 * kHDP);
     float acc = 0.f;
@@ -227,10 +228,10 @@ __global__ void fold_qkv_bias_kernel(const float* __restrict__ wq, const float* 
         const float* w = part == 0 ? wq : (part == 1 ? wk : wv);
         const float* b = part == 0 ? bq : (part == 1 ? bk : bv);
         const int r = h * hd + d;
-        acc = b[r];
-        for (int c = 0; c < D; ++c) acc = fmaf(w[(size_t)r * D + c], beta[c], acc);
+        for (int c = lane; c < D; c += 64) acc = fmaf(w[(size_t)r * D + c], beta[c], acc);
+        acc = wave_sum(acc) + b[r];
     }
-    out[i] = acc;
+    if (lane == 0) out[i] = acc;
 }
 
 // out-projection: k-step (2h + kk) covers head h, head dims 32kk .. 32kk+31 (zero for d >= hd)
@@ -278,17 +279,17 @@ __global__ void pack_head_kernel(const float* __restrict__ W, const float* __res
     }
 }
 
-// out[r] = b[r] + sum_c W[r][c] * beta[c]   (LayerNorm beta folded into the following Linear's bias)
+// out[r] = b[r] + sum_c W[r][c] * beta[c]   (LayerNorm beta folded into the following Linear's bias); one wave per row
 __global__ void fold_bias_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ beta,
                                  float* __restrict__ out, int rows, int cols, int rows_p) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (r >= rows_p) return;
     float acc = 0.f;
     if (r < rows) {
-        acc = b[r];
-        for (int c = 0; c < cols; ++c) acc = fmaf(W[(size_t)r * cols + c], beta[c], acc);
+        for (int c = lane; c < cols; c += 64) acc = fmaf(W[(size_t)r * cols + c], beta[c], acc);
+        acc = wave_sum(acc) + b[r];
     }
-    out[r] = acc;
+    if (lane == 0) out[r] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1551,8 +1552,15 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
 // exact GELU (erff) and the attention core on the exact-fp32 MFMA.  No software pipelining across phases: this
 // mode exists for parity (north-star 1e-4), its speed is set by three MFMAs per fragment pair and two weight images.
 // ---------------------------------------------------------------------------------------------
+#ifndef BESO_X3_FASTGELU
+#define BESO_X3_FASTGELU 0           // timing experiment only: the bf16 mode's polynomial in the parity mode
+#endif
 __device__ __forceinline__ float gelu_exact(float v) {            // nn.GELU(): v * Phi(v), erf form (score_gpts.py:107)
+#if BESO_X3_FASTGELU
+    return gelu_poly(v);
+#else
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+#endif
 }
 
 // MLP phase: per hidden chunk  FC1 -> GELU -> [barrier] -> hT (hi | lo) -> [barrier] -> FC2 into the residual.
@@ -2126,13 +2134,13 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
         }
         FTRY(hipGetLastError());
         if (half) continue;                      // the low image holds weight fragments only
-        hipLaunchKernelGGL(fold_bias_kernel, dim3((rt1 * 16 + 255) / 256), dim3(256), 0, s, f1w, f1b, ln2b,
+        hipLaunchKernelGGL(fold_bias_kernel, dim3((rt1 * 16 + 3) / 4), dim3(256), 0, s, f1w, f1b, ln2b,
                            (float*)(base + d.o_b1), 4 * D, D, rt1 * 16);
         FTRY(hipGetLastError());
         FTRY(launch_pack_matrix(f2b, 1, D, base + d.o_b2, 1, rt2 * 16, -1, s));
         if (d.attn) {
             (void)hipGetLastError();
-            hipLaunchKernelGGL(fold_qkv_bias_kernel, dim3((d.Hv * 3 * kHDP + 255) / 256), dim3(256), 0, s, qw, kw, vw,
+            hipLaunchKernelGGL(fold_qkv_bias_kernel, dim3((d.Hv * 3 * kHDP + 3) / 4), dim3(256), 0, s, qw, kw, vw,
                                qb, kb, vb, ln1b, (float*)(base + d.o_bqkv), D, d.Hv, d.hdv);
             FTRY(hipGetLastError());
             FTRY(launch_pack_matrix(pb, 1, D, base + d.o_bproj, 1, rt2 * 16, -1, s));
@@ -2144,7 +2152,7 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
             for (int part = 0; part < 3; ++part) {      // q / k / v
                 hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, ws3[part], D, D, ln1w,
                                    (uint16_t*)(base + d.o_wqkv_lin + (size_t)part * d.part_bytes), rt2, d.KS, rt2, 0);
-                hipLaunchKernelGGL(fold_bias_kernel, dim3((rt2 * 16 + 255) / 256), dim3(256), 0, s, ws3[part], bs3[part], ln1b,
+                hipLaunchKernelGGL(fold_bias_kernel, dim3((rt2 * 16 + 3) / 4), dim3(256), 0, s, ws3[part], bs3[part], ln1b,
                                    (float*)(base + d.o_bqkv_lin) + (size_t)part * rt2 * 16, D, D, rt2 * 16);
             }
             hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, pw, D, D, (const float*)nullptr,

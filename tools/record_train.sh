@@ -12,4 +12,4 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIV
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM --output-format csv -d $O/pmc_train_b -o tr -- python $REPO/tools/bench_train.py 1024 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $O/pmc_train_c -o tr -- python $REPO/tools/bench_train.py 1024 > /dev/null 2>&1
 cd $REPO
-python tools/pmc_train.py $O/pmc_train_a $O/pmc_train_b $O/pmc_train_c > $O/r01_train_step_pmc.json
+python tools/pmc_train.py $O/pmc_train_a $O/pmc_train_b $O/pmc_train_c > $O/r02_train_step_pmc.json

@@ -68,7 +68,7 @@ def time_one(batch, steps=300):
     from beso_amd import synthetic as O
     dev = "cuda:0"
     cfg = O.SHAPES["kitchen"]
-    model = build_model(cfg, O.make_weights(cfg, seed=0, std=0.02), "bf16", dev)
+    model = build_model(cfg, O.make_weights(cfg, seed=0, std=0.02), os.environ.get("BESO_VARIANT_PRECISION", "bf16"), dev)
     s, g, a = (torch.from_numpy(v).to(dev) for v in O.make_inputs(cfg, batch, seed=1))
     sig = torch.full((batch,), 0.3, device=dev)
     inner = model.inner_model
