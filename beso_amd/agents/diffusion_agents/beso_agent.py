@@ -157,6 +157,10 @@ class BesoAgent(BaseAgent):
                 den.inner_model.mark_weights_dirty()
             self.ema_helper.load_shadow_params(self.model.get_params())
             self._ema_packed_key = None
+            # every rank must draw its OWN noise, sigma, dropout and goal masks: scripts seed all ranks with
+            # the same cfg.seed (scripts/training.py:27), so the per-process generators are moved apart by the rank
+            seed = (torch.initial_seed() + 7919 * (bdist.rank() + 1)) % (2 ** 63 - 1)
+            torch.manual_seed(seed)
             self._replicas_synced = True
 
     def _c1_mode(self) -> str:

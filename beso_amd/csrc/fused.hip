@@ -1170,7 +1170,10 @@ __device__ __forceinline__ void gelu_slot(const f32x4 (&h)[RC][NT], GeluChain& c
 //     FC1(0)
 //     for c:  [FC2(c-1) || GELU(c)]  barrier  hT <- GELU(c)  FC1(c+1)  barrier
 //     FC2(n-1)
-constexpr int kFc1PF = 2;                // k-steps of FC1 weight fragments in flight per wave
+#ifndef BESO_FC1_PF
+#define BESO_FC1_PF 2
+#endif
+constexpr int kFc1PF = BESO_FC1_PF;      // k-steps of FC1 weight fragments in flight per wave
 #ifndef BESO_LAT_PF1
 #define BESO_LAT_PF1 4                   // ... in the latency instances (KS % BESO_LAT_PF1 == 0)
 #endif

@@ -113,6 +113,19 @@ def _worker(rank, world, port, out):
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     assert torch.equal(gathered[0], gathered[1])
+    # --- _sync_replicas (train_agent's first act): same weights everywhere, EMA re-seeded, per-rank random streams
+    cfg2, agent2 = _make_agent(seed=200 + rank)
+    torch.manual_seed(4242)                              # the scripts seed every rank alike
+    agent2._sync_replicas()
+    flat2 = torch.cat([q.detach().reshape(-1) for q in agent2.model.get_params()])
+    g2 = [torch.zeros_like(flat2) for _ in range(world)]
+    dist.all_gather(g2, flat2)
+    assert torch.equal(g2[0], g2[1])
+    assert torch.equal(torch.cat([q.reshape(-1) for q in agent2.ema_helper.shadow_params]), flat2)
+    draw = torch.randn(4)
+    draws = [torch.zeros(4) for _ in range(world)]
+    dist.all_gather(draws, draw)
+    assert not torch.equal(draws[0], draws[1]), "ranks would draw identical noise / sigma / masks"
     # --- one data-parallel training step: each rank sees its shard of the global batch
     full = _batch(cfg, 8, seed=7)
     lo, hi = bdist.shard_range(8, world, rank)
