@@ -161,18 +161,23 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
     for (int l = 0; l < (fused == 2 ? 0 : lay.L); ++l) {
         const LayerOff& o = lay.layer[l];
         if (lin_blocks) {
-            // LN1 + q/k/v and proj + residual as MLP-block style kernels (long sequences: no fused attention phase)
-            profile_begin(BESO_SITE_GEMM_QKV, s);
-            int st = fused_lin_block(lay, packed, l, 0, x, qkv, 3 * lay.D, M, s);
-            profile_end(BESO_SITE_GEMM_QKV, s);
-            if (st != BESO_OK) return st;
+            // long sequences (no fused attention phase): two launches per layer --
+            //   attention(q/k/v of this layer)  ->  [proj + residual -> LN2 -> MLP -> LN1 + q/k/v of the NEXT layer]
+            // with the residual tile in registers through the second one; layer 0's q/k/v come from their own block
+            if (l == 0) {
+                profile_begin(BESO_SITE_GEMM_QKV, s);
+                int st0 = fused_lin_block(lay, packed, 0, 0, x, qkv, 3 * lay.D, M, s);
+                profile_end(BESO_SITE_GEMM_QKV, s);
+                if (st0 != BESO_OK) return st0;
+            }
             profile_begin(BESO_SITE_ATTENTION, s);
             HIP_TRY(launch_attention(qkv, y, a.vbatch, a.T, lay.D, lay.H, lay.Kd, precision, s));
             profile_end(BESO_SITE_ATTENTION, s);
-            profile_begin(BESO_SITE_GEMM_PROJ, s);
-            st = fused_lin_block(lay, packed, l, 1, x, y, lay.Kd, M, s);
-            profile_end(BESO_SITE_GEMM_PROJ, s);
+            profile_begin(BESO_SITE_FUSED_LAYER, s);
+            int st = fused_lin_tail(lay, packed, l, x, y, lay.Kd, qkv, M, s);
+            profile_end(BESO_SITE_FUSED_LAYER, s);
             if (st != BESO_OK) return st;
+            continue;
         } else {
             profile_begin(BESO_SITE_LAYERNORM, s);
             HIP_TRY(launch_layernorm(x, F(o.ln1_w), F(o.ln1_b), xn, M, lay.D, lay.Kd, precision, s));

@@ -15,6 +15,8 @@ int    fused_mlp_block(const Layout& lay, const char* packed, int layer, float* 
 bool   fused_has_lin_blocks(const Layout& lay, int precision);
 int    fused_lin_block(const Layout& lay, const char* packed, int layer, int which, float* x, void* buf, int ld, int M,
                        hipStream_t s);
+int    fused_lin_tail(const Layout& lay, const char* packed, int layer, float* x, const void* y, int ld_y, void* qkv_next,
+                      int M, hipStream_t s);
 void   fused_set_stamps(void* buf, int cap);
 void   fused_set_small_batch_max(int n);
 void   fused_set_level_max(int n);

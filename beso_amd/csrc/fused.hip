@@ -1864,6 +1864,110 @@ __global__ __launch_bounds__(512, 2) void proj_block_kernel(float* __restrict__ 
     store_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
 }
 
+// Everything of a layer BEHIND its attention, plus the front of the next layer, for the long-sequence shapes, on one
+// 96-token tile whose residual stays in registers throughout:
+//     x += proj(y) + b_proj                      (score_gpts.py:79, :113)
+//     x += fc2(GELU(fc1(LN2 x)))                 (:105-114)
+//     qkv_next = [q | k | v](LN1' x)             (:58-66 of layer + 1; skipped behind the last layer)
+// i.e. proj_block_kernel, mlp_block_kernel and the next layer's qkv_block_kernel without the two store / reload round
+// trips of the fp32 residual between them (105 MB per layer at 17 k tokens) and two launches fewer per layer.
+template <int RPW, int KS>
+__global__ __launch_bounds__(512, 2) void tail_block_kernel(float* __restrict__ x, const char* __restrict__ lw,
+                                                            const char* __restrict__ lw_next, FusedDims d, int M,
+                                                            const uint16_t* __restrict__ y, int ld_y,
+                                                            uint16_t* __restrict__ qkv, unsigned long long* stamps, int cap) {
+    Stamps st{stamps, cap, 0};
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr LdsMap L = lds_map(KS, true);
+    int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.x * kMT;
+    Tile<RPW> T;
+    {
+        // ---- out-projection + residual (as proj_block_kernel)
+        const int n = lane & 15, g = lane >> 4;
+        u32x4* yT = (u32x4*)(lds + L.xnT);
+        for (int f = w; f < kNTT * KS; f += kWaves) {
+            const int t = f / KS, kk = f - t * KS;
+            const int tok = m0 + 16 * t + n;
+            uint2 lo = make_uint2(0u, 0u), hi = lo;
+            if (tok < M) {
+                const uint16_t* row = y + (size_t)tok * ld_y + 32 * kk + 4 * g;
+                lo = *(const uint2*)row;
+                hi = *(const uint2*)(row + 16);
+            }
+            yT[(size_t)f * 64 + lane] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+        load_x_tile<RPW>(T, x, d.D, m0, M, w, n, g);
+        u32x4 aE[RPW], aO[RPW];
+        const WPtr a = wptr((const u32x4*)(lw + d.o_wproj_lin) + (size_t)(w * RPW) * 64, lane);
+        prefetch_a<RPW>(aE, aO, a, kWaves * RPW);
+        __syncthreads();
+        gemm_phase<RPW, kNTT, kt16(KS)>(T.acc, aE, aO, a, kWaves * RPW, (const u32x4*)yT + lane, KS * 64, 64, KS);
+        const float* bp = (const float*)(lw + d.o_bproj_lin);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const f32x4 bv = *(const f32x4*)(bp + 16 * (w * RPW + i) + 4 * g);
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) T.acc[i][t] += bv;
+        }
+    }
+    {
+        // ---- LN2 + MLP (as mlp_block_kernel); the barrier inside the LayerNorm statistics is what orders the writes
+        // of xnT behind every wave's reads of yT above (same LDS region)
+        u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
+        mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)lw, w, lane);
+        layernorm_to_lds<RPW, KS, kWaves>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+                                          (const float*)(lw + d.o_b2), st);
+        mlp_phase<RPW, KS, kWaves>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
+                                   (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
+    }
+    if (lw_next != nullptr) {
+        // ---- the next layer's LN1 from the registers, then the residual leaves (its accumulators are free for q/k/v)
+        layernorm_to_lds<RPW, KS, kWaves, false>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane, nullptr, st);
+    }
+    {
+        asm volatile("" : "+v"(lane));
+        store_x_tile<RPW>(T, x, d.D, m0, M, w, lane & 15, lane >> 4);
+    }
+    if (lw_next == nullptr) return;
+    const u32x4* xnT = (const u32x4*)(lds + L.xnT);
+    const size_t ldq = (size_t)3 * d.D;
+#pragma unroll 1
+    for (int part = 0; part < 3; ++part) {
+        asm volatile("" : "+v"(lane));
+        const int gg = lane >> 4, nn = lane & 15;
+        f32x4 qa[RPW][kNTT];
+        const float* bq = (const float*)(lw_next + d.o_bqkv_lin) + (size_t)part * (kWaves * RPW * 16);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const f32x4 bv = *(const f32x4*)(bq + 16 * (w * RPW + i) + 4 * gg);
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) qa[i][t] = bv;
+        }
+        u32x4 aE[RPW], aO[RPW];
+        const WPtr a = wptr((const u32x4*)(lw_next + d.o_wqkv_lin + (size_t)part * d.part_bytes) + (size_t)(w * RPW) * 64, lane);
+        prefetch_a<RPW>(aE, aO, a, kWaves * RPW);
+        gemm_phase<RPW, kNTT, kt16(KS)>(qa, aE, aO, a, kWaves * RPW, xnT + lane, KS * 64, 64, KS);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int f0 = 16 * (w * RPW + i) + 4 * gg;
+            if (f0 < d.D) {
+#pragma unroll
+                for (int t = 0; t < kNTT; ++t) {
+                    const int tok = m0 + 16 * t + nn;
+                    if (tok < M) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(qa[i][t][0], qa[i][t][1]);
+                        pk.y = pack_bf16x2(qa[i][t][2], qa[i][t][3]);
+                        *(uint2*)(qkv + (size_t)tok * ldq + (size_t)part * d.D + f0) = pk;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Whole transformer layers [l0, l1) over the tile's 8 samples; x stays in registers in between.
 // NTL: token tiles that hold the action tokens of a full tile (8 samples x window, rounded up to an even count):
 // in the LAST layer only those go through the out-projection, LayerNorm-2 and the MLP -- nothing else reaches
@@ -2037,6 +2141,19 @@ hipError_t launch_lin_blocks(int which, float* x, const char* lw, const FusedDim
     else
         hipLaunchKernelGGL((proj_block_kernel<RPW, KS>), grid, block, L.total, s, x, lw, d, M, (const uint16_t*)buf, ld,
                            g_stamps, g_stamps_cap);
+    return hipGetLastError();
+}
+
+template <int RPW, int KS>
+hipError_t launch_tail_block(float* x, const char* lw, const char* lw_next, const FusedDims& d, int M, const void* y, int ld_y,
+                             void* qkv, hipStream_t s) {
+    constexpr LdsMap L = lds_map(KS, true);
+    static bool attr = false;
+    hipError_t e = ensure_lds(tail_block_kernel<RPW, KS>, L.total, &attr);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((tail_block_kernel<RPW, KS>), dim3((M + kMT - 1) / kMT), dim3(512), L.total, s, x, lw, lw_next, d, M,
+                       (const uint16_t*)y, ld_y, (uint16_t*)qkv, g_stamps, g_stamps_cap);
     return hipGetLastError();
 }
 
@@ -2252,6 +2369,20 @@ int fused_lin_block(const Layout& lay, const char* packed, int layer, int which,
     const char* base = packed + lay.fused + (size_t)layer * d.layer_bytes;
     hipError_t e;
     if (d.RPW == 4 && d.KS == 16) e = launch_lin_blocks<4, 16>(which, x, base, d, M, buf, ld, s);
+    else return BESO_ERR_UNSUPPORTED;
+    return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+// proj + residual + LN2 + MLP of `layer`, and -- unless it is the last -- LN1 + q/k/v of layer + 1 (qkv_next [M][3D] bf16),
+// as one launch (shapes with the lin blocks).
+int fused_lin_tail(const Layout& lay, const char* packed, int layer, float* x, const void* y, int ld_y, void* qkv_next, int M,
+                   hipStream_t s) {
+    FusedDims d;
+    if (!fused_dims(lay, &d) || !d.lin) return BESO_ERR_UNSUPPORTED;
+    const char* base = packed + lay.fused + (size_t)layer * d.layer_bytes;
+    const char* next = layer + 1 < lay.L ? base + d.layer_bytes : nullptr;
+    hipError_t e;
+    if (d.RPW == 4 && d.KS == 16) e = launch_tail_block<4, 16>(x, base, next, d, M, y, ld_y, qkv_next, s);
     else return BESO_ERR_UNSUPPORTED;
     return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
