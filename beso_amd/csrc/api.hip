@@ -486,6 +486,7 @@ int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precis
 void beso_debug_set_stamps(void* device_buf, int capacity_u64) { fused_set_stamps(device_buf, capacity_u64); }
 void beso_debug_set_small_batch_max(int n) { fused_set_small_batch_max(n); }
 void beso_debug_set_fused_level_max(int n) { fused_set_level_max(n); }
+void beso_debug_set_train_tail(int on) { train_set_tail_forward(on); }
 
 int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg, float* exp_avg_sq, float* ema,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,

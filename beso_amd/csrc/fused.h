@@ -17,6 +17,13 @@ int    fused_lin_block(const Layout& lay, const char* packed, int layer, int whi
                        hipStream_t s);
 int    fused_lin_tail(const Layout& lay, const char* packed, int layer, float* x, const void* y, int ld_y, void* qkv_next,
                       int M, hipStream_t s);
+// training forward through the tail block (train.hip): per-step fragment image of the weights + one launch per layer
+bool   fused_train_supported(const Layout& lay);
+size_t fused_train_image_bytes(const Layout& lay);
+int    fused_train_pack(const Layout& lay, const float* const* params, char* img, hipStream_t s);
+int    fused_train_tail(const Layout& lay, const char* img, int layer, int M, const float* x_in, const void* y, int ld_y,
+                        float* x_mid, float* x_out, float* st2, void* xn2, void* h, void* g, float* st1n, void* xn1n,
+                        void* qkvn, hipStream_t s);
 void   fused_set_stamps(void* buf, int cap);
 void   fused_set_small_batch_max(int n);
 void   fused_set_level_max(int n);

@@ -669,6 +669,25 @@ __device__ __forceinline__ void stamp(Stamps& st, int id) {
     }
 }
 
+// Hooks of the training-forward instance of the block kernels (train_tail_kernel): the phases below can apply the
+// LayerNorm affine themselves (training weights are not gamma-folded) and store what the backward pass keeps -- LayerNorm
+// statistics and output, the FC1 pre-activation h and GELU(h) -- row-major [token][feature] as the per-op training kernels
+// do.  The default types switch all of it off at compile time: the inference instances are unchanged.
+struct LnPlain { static constexpr bool on = false; };
+struct LnTrain {
+    static constexpr bool on = true;
+    const float* gamma; const float* beta;    // fp32, zero padded to the tile's feature count
+    float* stats;                             // [M][2] (mean, rstd)
+    uint16_t* xn;                             // [M][D] bf16, LayerNorm output with the affine applied
+    int m0, M, D;
+};
+struct MlpPlain { static constexpr bool on = false; };
+struct MlpTrain {
+    static constexpr bool on = true;
+    uint16_t* h; uint16_t* g;                 // [M][ld] bf16: FC1 pre-activation (with bias), GELU of it
+    int m0, M, ld;                            // ld = 4 D = number of real hidden features
+};
+
 template <int RPW>
 struct Tile {
     f32x4 acc[RPW][kNTT];
@@ -762,9 +781,10 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
 // NOTE: the red[] buffer is re-used by the next LayerNorm; the barrier at the end of this function (and
 // the phases in between) orders the reads above against those writes.
 // PX = 1 (BF16X3): the normalised values go out as split-bf16 pairs, the low fragment `lo_off` u32x4 behind the high one.
-template <int RPW, int KS, int NW, bool ADD_BIAS = true, int NT = kNTT, int PX = 0>
+template <int RPW, int KS, int NW, bool ADD_BIAS = true, int NT = kNTT, int PX = 0, class LX = LnPlain>
 __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float* red, int D, int w, int lane,
-                                                 const float* __restrict__ bias, Stamps& st, int lo_off = 0) {
+                                                 const float* __restrict__ bias, Stamps& st, int lo_off = 0,
+                                                 const LX lx = LX{}) {
     // `lane` is made opaque at the top of every phase: otherwise the per-lane address arithmetic of ALL
     // phases is hoisted out of the layer loop and kept live across it (46 spilled VGPRs).
     asm volatile("" : "+v"(lane));
@@ -776,11 +796,36 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
     } else ln_stats<RPW, NW, NT>(T, red, D, w, lane, mean, rstd, st);
     // Padding features (>= D) are NOT masked here: their xnT entries only ever meet the zero-padded
     // contraction columns of the packed QKV / FC1 weights, and (0 - mean) * rstd is finite.
+    f32x4 gam[LX::on ? RPW : 1], bet[LX::on ? RPW : 1];
+    if constexpr (LX::on) {
+        const int n = lane & 15;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            gam[i] = *(const f32x4*)(lx.gamma + 16 * (w * RPW + i) + 4 * g);
+            bet[i] = *(const f32x4*)(lx.beta + 16 * (w * RPW + i) + 4 * g);
+        }
+        if (w == 0 && g == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tok = lx.m0 + 16 * t + n;
+                if (tok < lx.M) *(float2*)(lx.stats + 2 * (size_t)tok) = make_float2(mean[t], rstd[t]);
+            }
+        }
+    }
     auto half = [&](int i, int t) {
         const float a = rstd[t], b = -mean[t] * rstd[t];
         uint2 pk;
-        pk.x = pack_bf16x2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
-        pk.y = pack_bf16x2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
+        if constexpr (LX::on) {
+            // gamma / beta applied here (zero for padding features: their xnT entries are exact zeros), and the
+            // operand-typed copy for the weight gradients goes out row-major
+            pk.x = pack_bf16x2(fmaf(fmaf(T.acc[i][t][0], a, b), gam[i][0], bet[i][0]), fmaf(fmaf(T.acc[i][t][1], a, b), gam[i][1], bet[i][1]));
+            pk.y = pack_bf16x2(fmaf(fmaf(T.acc[i][t][2], a, b), gam[i][2], bet[i][2]), fmaf(fmaf(T.acc[i][t][3], a, b), gam[i][3], bet[i][3]));
+            const int tok = lx.m0 + 16 * t + (lane & 15), f0 = 16 * (w * RPW + i) + 4 * g;
+            if (tok < lx.M && f0 < lx.D) *(uint2*)(lx.xn + (size_t)tok * lx.D + f0) = pk;
+        } else {
+            pk.x = pack_bf16x2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
+            pk.y = pack_bf16x2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
+        }
         return pk;
     };
     auto half_x3 = [&](int i, int t, uint2& hi, uint2& lo) {
@@ -1186,12 +1231,12 @@ __device__ __forceinline__ void mlp_prefetch(u32x4 (&a1r)[PF1][kChunkTiles / NW]
     prefetch_ring<RC, PF1>(a1r, wptr(w1p + (size_t)(RC * w) * 64, lane), kChunkTiles);
 }
 
-template <int RPW, int KS, int NW, int NT = kNTT, int PF1 = kFc1PF>   // NT: the first NT token tiles only (last layer);
-                                                                      // PF1: k-steps of FC1 weights in flight per wave
+template <int RPW, int KS, int NW, int NT = kNTT, int PF1 = kFc1PF, class MX = MlpPlain>   // NT: the first NT token tiles only
+                                                                      // (last layer); PF1: k-steps of FC1 weights in flight per wave
 __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
                                           const float* __restrict__ b1f, const u32x4* __restrict__ w2p, int HT,
                                           int KS2p, int w, int lane, u32x4 (&a1r)[PF1][kChunkTiles / NW],
-                                          Stamps& st) {
+                                          Stamps& st, const MX mx = MX{}) {
     asm volatile("" : "+v"(lane));
     const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
     constexpr int RC = kChunkTiles / NW, KW = RC / 2;       // row tiles / FC2 k-steps of a chunk per wave
@@ -1222,6 +1267,41 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 #pragma unroll
             for (int t = 0; t < NT; ++t) hT[((size_t)t * kKC + KW * w + j2) * 64 + lane] = hb[j2][t];
     };
+    // training instance: the pre-activation and GELU(h) of chunk c, row-major, for the backward pass (the fragment
+    // hb[j2][t] is {row tile 2 j2: features 4g..4g+3 | row tile 2 j2 + 1: the same}, i.e. two 8-byte row pieces)
+    auto keep_h = [&](int c, const f32x4 (&hv)[RC][NT]) {
+        if constexpr (MX::on) {
+            const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int r = 0; r < RC; ++r) {
+                const int f0 = 16 * (c * kChunkTiles + RC * w + r) + 4 * g;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int tok = mx.m0 + 16 * t + n;
+                    if (tok < mx.M && f0 < mx.ld)
+                        *(uint2*)(mx.h + (size_t)tok * mx.ld + f0) = make_uint2(pack_bf16x2(hv[r][t][0], hv[r][t][1]),
+                                                                                 pack_bf16x2(hv[r][t][2], hv[r][t][3]));
+                }
+            }
+        }
+    };
+    auto keep_g = [&](int c, const u32x4 (&hb)[KW][NT]) {
+        if constexpr (MX::on) {
+            const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int j2 = 0; j2 < KW; ++j2)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int f0 = 16 * (c * kChunkTiles + RC * w + 2 * j2 + q) + 4 * g;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int tok = mx.m0 + 16 * t + n;
+                        if (tok < mx.M && f0 < mx.ld)
+                            *(uint2*)(mx.g + (size_t)tok * mx.ld + f0) = make_uint2(hb[j2][t][2 * q], hb[j2][t][2 * q + 1]);
+                    }
+                }
+        }
+    };
 
     f32x4 h[RC][NT];
     u32x4 hb[KW][NT];
@@ -1237,12 +1317,14 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     // it under yet), hT(0), FC1(1).  Every later weight request is issued one phase ahead of its use.
     static_assert(KS % PF1 == 0, "FC1 weight ring");
     fc1(0, h, a1r);                 // rows beyond HT are zero weights + zero bias: harmless for every wave
+    keep_h(0, h);
     if (n_chunks > 1) prefetch_ring<RC, PF1>(a1r, fc1_a(1), kChunkTiles);
     fc2_prefetch(0);
 #pragma unroll
     for (int pi = 0; pi < PAIRS; ++pi) gelu_pair<RC, NT>(h, gq, hb, pi);
     write_hT(hb);
-    if (n_chunks > 1) fc1(1, h, a1r);
+    keep_g(0, hb);
+    if (n_chunks > 1) { fc1(1, h, a1r); keep_h(1, h); }
     stamp(st, 20);
     __syncthreads();                     // hT(0) complete
 #pragma unroll 1
@@ -1301,8 +1383,8 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
         stamp(st, 21);
         if (!(BESO_ABL_MASK & 2)) __syncthreads();                 // every wave is done reading hT(c-1)
         stamp(st, 22);
-        if (fc1_active) write_hT(hb);
-        if (c + 1 < n_chunks && next_active) fc1(c + 1, h, a1r);
+        if (fc1_active) { write_hT(hb); keep_g(pc(c), hb); }
+        if (c + 1 < n_chunks && next_active) { fc1(c + 1, h, a1r); keep_h(pc(c + 1), h); }
         stamp(st, 23);
         if (!(BESO_ABL_MASK & 2)) __syncthreads();                 // hT(c) complete
         stamp(st, 24);
@@ -1968,6 +2050,171 @@ __global__ __launch_bounds__(512, 2) void tail_block_kernel(float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Training forward: the tail block with everything the backward pass keeps (train.hip, loss_grad_e).  One launch replaces
+// out-projection (+ residual), LN2, FC1 (+ GELU), FC2 (+ residual) of a layer and LN1 + the q/k/v projection of the next
+// one -- six launches of the per-op training forward -- on a 96-token tile whose residual stays in registers; outputs
+// are the per-op kernels' buffers in their formats: x_mid, x_out fp32 [M][D]; LayerNorm statistics [M][2]; LayerNorm
+// outputs, h, GELU(h), q|k|v as bf16 row-major.  Weights come from the per-step training image (fragment order, LayerNorm
+// affine NOT folded: the kernel applies gamma / beta).  bf16 operands, no dropout on the proj / MLP outputs (resid_pdrop
+// = 0; with it the residual adds are no longer plain accumulations), any sequence length (there is no attention in here).
+// ---------------------------------------------------------------------------------------------
+struct TrainImg {            // byte offsets inside one layer's training image
+    uint32_t o_w1, o_b1, o_w2, o_b2, o_wqkv, o_bqkv, o_wproj, o_bproj, o_ln1w, o_ln1b, o_ln2w, o_ln2b, part_bytes, layer_bytes;
+};
+static TrainImg train_img(const FusedDims& d) {
+    TrainImg t;
+    const uint32_t rt2 = (uint32_t)d.RPW * kWaves, vec = (uint32_t)round_up_sz((size_t)rt2 * 16 * sizeof(float), 256);
+    uint32_t cur = 0;
+    auto carve = [&](uint32_t bytes) { uint32_t o = cur; cur = (uint32_t)round_up_sz((size_t)cur + bytes, 256); return o; };
+    t.part_bytes = rt2 * d.KS * 1024;
+    t.o_w1 = carve(d.w1_bytes); t.o_b1 = carve(d.b1_bytes);
+    t.o_w2 = carve(d.w2_bytes); t.o_b2 = carve(vec);
+    t.o_wqkv = carve(3 * t.part_bytes); t.o_bqkv = carve(3 * vec);
+    t.o_wproj = carve(t.part_bytes); t.o_bproj = carve(vec);
+    t.o_ln1w = carve(vec); t.o_ln1b = carve(vec); t.o_ln2w = carve(vec); t.o_ln2b = carve(vec);
+    t.layer_bytes = cur;
+    return t;
+}
+
+struct TrainTailArgs {
+    const float* x_in; const uint16_t* y; int ld_y;
+    float* x_mid; float* x_out; float* st2; uint16_t* xn2; uint16_t* h; uint16_t* g;
+    float* st1n; uint16_t* xn1n; uint16_t* qkvn;       // next layer (all null: nothing follows)
+};
+
+template <int RPW, int KS>
+__global__ __launch_bounds__(512, 2) void train_tail_kernel(const char* __restrict__ lw, const char* __restrict__ lw_next,
+                                                            FusedDims d, TrainImg ti, int M, TrainTailArgs a) {
+    Stamps st{nullptr, 0, 0};
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr LdsMap L = lds_map(KS, true);
+    int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.x * kMT;
+    Tile<RPW> T;
+    {
+        // ---- x_mid = x_in + proj(y) + b_proj
+        const int n = lane & 15, g = lane >> 4;
+        u32x4* yT = (u32x4*)(lds + L.xnT);
+        for (int f = w; f < kNTT * KS; f += kWaves) {
+            const int t = f / KS, kk = f - t * KS;
+            const int tok = m0 + 16 * t + n;
+            uint2 lo = make_uint2(0u, 0u), hi = lo;
+            if (tok < M) {
+                // (row pieces beyond D are zero: the padded contraction columns of the weights are zeros too, but the
+                // operand must be finite)
+                const int c0 = 32 * kk + 4 * g;
+                const uint16_t* row = a.y + (size_t)tok * a.ld_y + c0;
+                if (c0 < d.D) lo = *(const uint2*)row;
+                if (c0 + 16 < d.D) hi = *(const uint2*)(row + 16);
+            }
+            yT[(size_t)f * 64 + lane] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+        load_x_tile<RPW>(T, a.x_in, d.D, m0, M, w, n, g);
+        u32x4 aE[RPW], aO[RPW];
+        const WPtr wp = wptr((const u32x4*)(lw + ti.o_wproj) + (size_t)(w * RPW) * 64, lane);
+        prefetch_a<RPW>(aE, aO, wp, kWaves * RPW);
+        __syncthreads();
+        gemm_phase<RPW, kNTT, kt16(KS)>(T.acc, aE, aO, wp, kWaves * RPW, (const u32x4*)yT + lane, KS * 64, 64, KS);
+        const float* bp = (const float*)(lw + ti.o_bproj);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const f32x4 bv = *(const f32x4*)(bp + 16 * (w * RPW + i) + 4 * g);
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) T.acc[i][t] += bv;
+        }
+        store_x_tile<RPW>(T, a.x_mid, d.D, m0, M, w, n, g);
+    }
+    {
+        // ---- LN2 (statistics and affine output kept), MLP (h and GELU(h) kept), x_out
+        u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
+        mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)(lw + ti.o_w1), w, lane);
+        const LnTrain lx{(const float*)(lw + ti.o_ln2w), (const float*)(lw + ti.o_ln2b), a.st2, a.xn2, m0, M, d.D};
+        layernorm_to_lds<RPW, KS, kWaves, true, kNTT, 0, LnTrain>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+                                                                   (const float*)(lw + ti.o_b2), st, 0, lx);
+        const MlpTrain mx{a.h, a.g, m0, M, 4 * d.D};
+        mlp_phase<RPW, KS, kWaves, kNTT, kFc1PF, MlpTrain>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u),
+                                                            (const u32x4*)(lw + ti.o_w1), (const float*)(lw + ti.o_b1),
+                                                            (const u32x4*)(lw + ti.o_w2), d.HT, d.KS2p, w, lane, a1r, st, mx);
+    }
+    if (lw_next != nullptr) {
+        const LnTrain lx{(const float*)(lw_next + ti.o_ln1w), (const float*)(lw_next + ti.o_ln1b), a.st1n, a.xn1n, m0, M, d.D};
+        layernorm_to_lds<RPW, KS, kWaves, false, kNTT, 0, LnTrain>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
+                                                                    nullptr, st, 0, lx);
+    }
+    {
+        asm volatile("" : "+v"(lane));
+        store_x_tile<RPW>(T, a.x_out, d.D, m0, M, w, lane & 15, lane >> 4);
+    }
+    if (lw_next == nullptr) return;
+    const u32x4* xnT = (const u32x4*)(lds + L.xnT);
+    const size_t ldq = (size_t)3 * d.D;
+#pragma unroll 1
+    for (int part = 0; part < 3; ++part) {
+        asm volatile("" : "+v"(lane));
+        const int gg = lane >> 4, nn = lane & 15;
+        f32x4 qa[RPW][kNTT];
+        const float* bq = (const float*)(lw_next + ti.o_bqkv) + (size_t)part * (kWaves * RPW * 16);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const f32x4 bv = *(const f32x4*)(bq + 16 * (w * RPW + i) + 4 * gg);
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) qa[i][t] = bv;
+        }
+        u32x4 aE[RPW], aO[RPW];
+        const WPtr wq = wptr((const u32x4*)(lw_next + ti.o_wqkv + (size_t)part * ti.part_bytes) + (size_t)(w * RPW) * 64, lane);
+        prefetch_a<RPW>(aE, aO, wq, kWaves * RPW);
+        gemm_phase<RPW, kNTT, kt16(KS)>(qa, aE, aO, wq, kWaves * RPW, xnT + lane, KS * 64, 64, KS);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int f0 = 16 * (w * RPW + i) + 4 * gg;
+            if (f0 < d.D) {
+#pragma unroll
+                for (int t = 0; t < kNTT; ++t) {
+                    const int tok = m0 + 16 * t + nn;
+                    if (tok < M)
+                        *(uint2*)(a.qkvn + (size_t)tok * ldq + (size_t)part * d.D + f0) =
+                            make_uint2(pack_bf16x2(qa[i][t][0], qa[i][t][1]), pack_bf16x2(qa[i][t][2], qa[i][t][3]));
+                }
+            }
+        }
+    }
+}
+
+// The per-step training image of ALL layers in one launch: every segment is either a matrix in A-fragment order
+// (pack_mfma_a_kernel's layout) or a zero-padded fp32 vector; a workgroup serves one segment (table in the kernel argument).
+struct TrainPackSeg { const float* src; uint32_t dst; int rows, cols, rt, kt, grp, first_block; };   // rt = 0: vector of `rows` floats padded to `cols`
+constexpr int kTrainPackSegs = 96;                       // 13 per layer; the table travels as a kernel argument (< 4 KiB)
+struct TrainPackTable { TrainPackSeg seg[kTrainPackSegs]; int n, blocks; };
+__global__ void train_pack_kernel(TrainPackTable t, char* __restrict__ img) {
+    __shared__ int which;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = t.n - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.seg[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+        which = lo;
+    }
+    __syncthreads();
+    const TrainPackSeg& g = t.seg[which];
+    const int nb = (which + 1 < t.n ? t.seg[which + 1].first_block : t.blocks) - g.first_block;
+    const size_t start = (size_t)(blockIdx.x - g.first_block) * blockDim.x + threadIdx.x, stride = (size_t)nb * blockDim.x;
+    if (g.rt == 0) {
+        float* dst = (float*)(img + g.dst);
+        for (size_t i = start; i < (size_t)g.cols; i += stride) dst[i] = i < (size_t)g.rows ? g.src[i] : 0.f;
+        return;
+    }
+    uint16_t* dst = (uint16_t*)(img + g.dst);
+    const size_t total = (size_t)g.rt * g.kt * 512;
+    for (size_t i = start; i < total; i += stride) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const size_t tile = i >> 9;
+        const int rin = (int)(tile % g.grp), kk = (int)((tile / g.grp) % g.kt);
+        const int R = (int)(tile / ((size_t)g.grp * g.kt)) * g.grp + rin;
+        const int r = 16 * R + (lane & 15), c = 32 * kk + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+        dst[i] = f2bf((r < g.rows && c < g.cols) ? g.src[(size_t)r * g.cols + c] : 0.f);
+    }
+}
+
 // Whole transformer layers [l0, l1) over the tile's 8 samples; x stays in registers in between.
 // NTL: token tiles that hold the action tokens of a full tile (8 samples x window, rounded up to an even count):
 // in the LAST layer only those go through the out-projection, LayerNorm-2 and the MLP -- nothing else reaches
@@ -2385,6 +2632,95 @@ int fused_lin_tail(const Layout& lay, const char* packed, int layer, float* x, c
     if (d.RPW == 4 && d.KS == 16) e = launch_tail_block<4, 16>(x, base, next, d, M, y, ld_y, qkv_next, s);
     else return BESO_ERR_UNSUPPORTED;
     return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+// ---- training forward through the tail block (train.hip) -----------------------------------------------------------
+static bool train_tail_dims(const Layout& lay, FusedDims* d) {
+    if (!fused_dims(lay, d) || !shape_has_kernel(*d)) return false;
+    return (d->RPW == 3 && d->KS == 12) || (d->RPW == 2 && d->KS == 8);
+}
+
+bool fused_train_supported(const Layout& lay) { FusedDims d; return train_tail_dims(lay, &d); }
+
+size_t fused_train_image_bytes(const Layout& lay) {
+    FusedDims d;
+    if (!train_tail_dims(lay, &d)) return 0;
+    return (size_t)train_img(d).layer_bytes * lay.L;
+}
+
+// params: the parameter list of beso_pack_weights.  Packs layers [0, L) (fragment-ordered bf16 weights, padded fp32 biases
+// and LayerNorm affine parameters) into img.
+int fused_train_pack(const Layout& lay, const float* const* p, char* img, hipStream_t s) {
+    FusedDims d;
+    if (!train_tail_dims(lay, &d)) return BESO_ERR_UNSUPPORTED;
+    const TrainImg ti = train_img(d);
+    if (lay.L * 13 > kTrainPackSegs) return BESO_ERR_UNSUPPORTED;
+    TrainPackTable t;
+    t.n = 0;
+    int blocks = 0;
+    const int D = lay.D, rt1 = d.NCH * kChunkTiles, rt2 = d.RPW * kWaves;
+    auto mat = [&](const float* src, uint32_t dst, int rows, int cols, int rt, int kt, int grp) {
+        t.seg[t.n] = TrainPackSeg{src, dst, rows, cols, rt, kt, grp, blocks};
+        blocks += (rt * kt * 512 + 256 * 16 - 1) / (256 * 16);
+        ++t.n;
+    };
+    auto vec = [&](const float* src, uint32_t dst, int n, int n_pad) {
+        t.seg[t.n] = TrainPackSeg{src, dst, n, n_pad, 0, 0, 0, blocks};
+        blocks += 1;
+        ++t.n;
+    };
+    for (int l = 0; l < lay.L; ++l) {
+        const float* const* q = p + 3 + 16 * l;        // ln1.w ln1.b ln2.w ln2.b key.w key.b query.w query.b value.w value.b proj.w proj.b fc1.w fc1.b fc2.w fc2.b
+        const uint32_t base = (uint32_t)l * ti.layer_bytes;
+        mat(q[12], base + ti.o_w1, 4 * D, D, rt1, d.KS, kChunkTiles);
+        vec(q[13], base + ti.o_b1, 4 * D, rt1 * 16);
+        mat(q[14], base + ti.o_w2, D, 4 * D, rt2, d.KS2p, rt2);
+        vec(q[15], base + ti.o_b2, D, rt2 * 16);
+        const float* w3[3] = {q[6], q[4], q[8]};       // query, key, value: the [q | k | v] row order of the training buffers
+        const float* b3[3] = {q[7], q[5], q[9]};
+        for (int part = 0; part < 3; ++part) {
+            mat(w3[part], base + ti.o_wqkv + (uint32_t)part * ti.part_bytes, D, D, rt2, d.KS, rt2);
+            vec(b3[part], base + ti.o_bqkv + (uint32_t)part * rt2 * 16 * (uint32_t)sizeof(float), D, rt2 * 16);
+        }
+        mat(q[10], base + ti.o_wproj, D, D, rt2, d.KS, rt2);
+        vec(q[11], base + ti.o_bproj, D, rt2 * 16);
+        vec(q[0], base + ti.o_ln1w, D, rt2 * 16); vec(q[1], base + ti.o_ln1b, D, rt2 * 16);
+        vec(q[2], base + ti.o_ln2w, D, rt2 * 16); vec(q[3], base + ti.o_ln2b, D, rt2 * 16);
+    }
+    t.blocks = blocks;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(train_pack_kernel, dim3(blocks), dim3(256), 0, s, t, img);
+    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+// The tail block of `layer` (and LN1 + q/k/v of layer + 1 when next buffers are given) on M token rows.
+int fused_train_tail(const Layout& lay, const char* img, int layer, int M, const float* x_in, const void* y, int ld_y,
+                     float* x_mid, float* x_out, float* st2, void* xn2, void* h, void* g, float* st1n, void* xn1n, void* qkvn,
+                     hipStream_t s) {
+    FusedDims d;
+    if (!train_tail_dims(lay, &d)) return BESO_ERR_UNSUPPORTED;
+    const TrainImg ti = train_img(d);
+    const char* lw = img + (size_t)layer * ti.layer_bytes;
+    const char* lw_next = qkvn != nullptr ? lw + ti.layer_bytes : nullptr;
+    TrainTailArgs a{x_in, (const uint16_t*)y, ld_y, x_mid, x_out, st2, (uint16_t*)xn2, (uint16_t*)h, (uint16_t*)g,
+                    st1n, (uint16_t*)xn1n, (uint16_t*)qkvn};
+    const dim3 grid((M + kMT - 1) / kMT), block(512);
+    hipError_t e;
+    (void)hipGetLastError();
+    if (d.RPW == 3) {
+        constexpr LdsMap L = lds_map(12, true);
+        static bool attr = false;
+        e = ensure_lds(train_tail_kernel<3, 12>, L.total, &attr);
+        if (e != hipSuccess) return BESO_ERR_HIP;
+        hipLaunchKernelGGL((train_tail_kernel<3, 12>), grid, block, L.total, s, lw, lw_next, d, ti, M, a);
+    } else {
+        constexpr LdsMap L = lds_map(8, true);
+        static bool attr = false;
+        e = ensure_lds(train_tail_kernel<2, 8>, L.total, &attr);
+        if (e != hipSuccess) return BESO_ERR_HIP;
+        hipLaunchKernelGGL((train_tail_kernel<2, 8>), grid, block, L.total, s, lw, lw_next, d, ti, M, a);
+    }
+    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
 // Whole network (embed -> all layers -> head) or layers only.  Returns in *fused_edges whether the token

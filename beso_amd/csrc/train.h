@@ -13,6 +13,7 @@ int    train_loss_grad(const beso_config* c, const float* const* params, int n_p
                        float goal_drop, uint32_t seed, float grad_scale, void* workspace, size_t workspace_bytes, hipStream_t s, hipStream_t early_stream,
                        hipError_t* err, int* err_line);
 int    train_goal_mask(float* mask, size_t n, float goal_drop, uint32_t seed, hipStream_t s, hipError_t* err, int* err_line);
+void   train_set_tail_forward(int on);
 int    train_early_layer(const beso_config* c);
 void   train_early_range(const beso_config* c, size_t* begin, size_t* end);
 int    train_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,

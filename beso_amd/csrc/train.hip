@@ -21,6 +21,7 @@
 // Dropout masks come from a counter-based hash of (seed, site, element index): the backward recomputes them.
 #include <string.h>
 #include "common.h"
+#include "fused.h"
 #include "train.h"
 
 namespace beso {
@@ -1194,6 +1195,7 @@ struct TrainWs {
     size_t w_hid, b_hid, hz, ha, hdz, dw_hid, db_hid;
     size_t dx, dx0b, dxn, dy, ln_part;
     size_t ya, xa, dxa, dya;                                        // compact action rows of the last layer
+    size_t fimg;                                                    // per-step fragment image of the weights (tail-block forward)
     TrainLayerWs layer[kMaxLayers];
     size_t total;
 };
@@ -1232,6 +1234,10 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
         w->dxa = carve_t(cur, f * Ma * D); w->dya = carve_t(cur, e * Ma * D);
     }
     w->ln_part = carve_t(cur, f * (size_t)(2 * c->n_layers + 1) * ((M + 15) / 16) * 3 * D);     // LayerNorm backward block partials
+    {
+        Layout lay;
+        w->fimg = carve_t(cur, (precision == BESO_PREC_BF16 && make_layout(c, BESO_PREC_BF16, &lay)) ? fused_train_image_bytes(lay) : 0);
+    }
     for (int l = 0; l < c->n_layers; ++l) {
         TrainLayerWs& y = w->layer[l];
         y.w_qkv = carve_t(cur, e * (size_t)3 * D * D); y.b_qkv = carve_t(cur, f * (size_t)3 * D);
@@ -1302,6 +1308,14 @@ size_t train_grad_floats(const beso_config* c) {
                           : (size_t)kHeadHidden * D + kHeadHidden + (size_t)c->act_dim * kHeadHidden + c->act_dim;
     return n;
 }
+
+// The tail-block forward pays off once its 96-token tiles are several rounds of workgroups (measured on MI355X, kitchen:
+// 8192 samples = 939 tiles 16.57 vs 17.41 ms per step; 1024 samples = 118 tiles 3.43 vs 3.39 ms -- at under one round both
+// forms are bound by a lone workgroup's latency).  0: never, 1: from kTailMinRows token rows on, 2: always (tests).
+static int g_tail_forward = 1;
+constexpr int kTailMinRows = 40000;
+static bool tail_forward_enabled(int rows) { return g_tail_forward == 2 || (g_tail_forward == 1 && rows >= kTailMinRows); }
+void train_set_tail_forward(int on) { g_tail_forward = on; }
 
 #define TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { *err = _e; *err_line = __LINE__; return BESO_ERR_HIP; } } while (0)
 
@@ -1409,13 +1423,26 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     if (lds_b > 64 * 1024) {
         TRY(hipFuncSetAttribute((const void*)attn_bwd_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     }
+    // bf16, no dropout on the proj / MLP outputs, a shape with a fused tile kernel: everything of a layer behind its
+    // attention and the LN1 + q/k/v of the next layer run as ONE launch (fused.hip: train_tail_kernel) on 96-token tiles
+    // with the residual in registers -- six launches of the per-op forward below -- writing the same kept activations in
+    // the same formats.  The last layer stays per-op (it continues on the compact action rows).
+    Layout flay;
+    const bool use_tail = sizeof(E) == 2 && resid_p == 0.f && L >= 2 && L * 13 <= 96 && make_layout(c, BESO_PREC_BF16, &flay) &&
+                          fused_train_supported(flay) && fused_train_image_bytes(flay) > 0 && tail_forward_enabled(M);
+    if (use_tail) {
+        const int pst = fused_train_pack(flay, p, ws + w.fimg, s);
+        if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
+    }
     for (int l = 0; l < L; ++l) {
         const TrainLayerWs& y = w.layer[l];
         const float* x_in = l == 0 ? F(w.x0) : F(w.layer[l - 1].x_out);
         const bool last = l == L - 1;
-        TRY(ln_fwd(x_in, lp[l].ln1w.p, lp[l].ln1b.p, P(y.xn1), F(y.st1), M));
-        TRY((tgemm<E, false, false>(P(y.xn1), D, P(y.w_qkv), D, M, D3, D, 1,
-                                    EpiStore<E>{nullptr, P(y.qkv), F(y.b_qkv), D3}, s)));
+        if (!(use_tail && l > 0)) {           // (behind a tail block these arrive from the previous layer's launch)
+            TRY(ln_fwd(x_in, lp[l].ln1w.p, lp[l].ln1b.p, P(y.xn1), F(y.st1), M));
+            TRY((tgemm<E, false, false>(P(y.xn1), D, P(y.w_qkv), D, M, D3, D, 1,
+                                        EpiStore<E>{nullptr, P(y.qkv), F(y.b_qkv), D3}, s)));
+        }
         if (attn_small) {
 #define ATT(TT) hipLaunchKernelGGL((attn_small_kernel<E, false, TT>), dim3(batch * H), dim3(64), 0, s, (const E*)P(y.qkv), \
                                    (const E*)nullptr, P(y.y), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l))
@@ -1425,6 +1452,13 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
             hipLaunchKernelGGL(attn_fwd_kernel<E>, dim3(batch * H), dim3(64), lds_f, s, (const E*)P(y.qkv), P(y.y), T, D, H,
                                hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
         TRY(hipGetLastError());
+        if (use_tail && !last) {
+            const TrainLayerWs& nx = w.layer[l + 1];
+            const int tst = fused_train_tail(flay, ws + w.fimg, l, M, x_in, P(y.y), D, F(y.x_mid), F(y.x_out), F(y.st2), P(y.xn2),
+                                             P(y.h), P(y.g), F(nx.st1), P(nx.xn1), P(nx.qkv), s);
+            if (tst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return tst; }
+            continue;
+        }
         // the last layer continues on the compact action rows only (its buffers hold Ma rows from here on)
         const int rows = last ? Ma : M;
         const E* y_in = P(y.y);

@@ -274,6 +274,10 @@ void beso_debug_set_small_batch_max(int n);
  * where the shape has such a kernel; 1: LN2 + MLP blocks only; 0: the per-op kernels (LayerNorm, GEMMs, attention) only.
  * The comparison "fused kernel against per-op kernels in the same arithmetic" is a test of the former.               */
 void beso_debug_set_fused_level_max(int n);
+/* Development aid (tests, A/B timing): how the bf16 beso_loss_grad runs its forward -- 0: per-op kernels for every layer;
+ * 1 (default): each layer's out-projection .. next layer's q/k/v as one tile kernel once there are enough token rows for
+ * several rounds of workgroups (>= 40,000: that is where it measures faster), per-op below; 2: the tile kernel always. */
+void beso_debug_set_train_tail(int on);
 int  beso_profile_read(double* total_ms, int* launches);
 
 #ifdef __cplusplus

@@ -1021,6 +1021,38 @@ def test_hip_training_goal_masking(cfg_name, B, precision):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name,B,t", [("kitchen", 200, None), ("kitchen", 37, 2), ("block_push", 96, None)])
+def test_training_forward_tail_block_equals_the_per_op_forward(cfg_name, B, t):
+    """bf16 training step: the forward runs each layer's out-projection .. next layer's q/k/v as one tile kernel
+    (train_tail_kernel, fused.hip) instead of six per-op launches.  Same kept activations in the same formats, same
+    arithmetic type; only the accumulation order inside the GEMMs differs -- so loss and gradients of the two forms of
+    the forward must agree far inside the bf16 bound that holds them to autograd (1e-1): here 2e-2 per tensor (measured
+    ~5e-3), loss 1e-3; ragged token counts (M not a multiple of the 96-token tile) and a short window included."""
+    from beso_amd import _lib
+    lib = _lib.load()
+    cfg = O.CONFIGS[cfg_name]
+    m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), "bf16", attn_pdrop=0.3)
+    state, action, goal, noise, sigma = _train_inputs(cfg, B, seed=5)
+    if t is not None:
+        state, action, noise = state[:, :t].contiguous(), action[:, :t].contiguous(), noise[:, :t].contiguous()
+    step = m.hip_train_step(state, action, goal, noise, sigma)
+    out = {}
+    try:
+        for on in (2, 0):                                    # 2: the tile kernel whatever the size; 0: per-op kernels
+            lib.beso_debug_set_train_tail(on)
+            loss, flat, views = step.run(state, action, goal, noise, sigma, seed=77, fresh_grads=True)
+            out[1 if on else 0] = (loss.item(), [v.clone() for v in views])
+    finally:
+        lib.beso_debug_set_train_tail(1)
+    errs = _grad_errors(out[1][1], out[0][1], 2e-3)
+    worst = max(range(len(errs)), key=lambda i: errs[i])
+    print(f"[parity] tail-block vs per-op training forward {cfg_name} B={B}: loss {abs(out[1][0] - out[0][0]) / abs(out[0][0]):.2e}, "
+          f"worst gradient {errs[worst]:.2e} ({list(dict(m.named_parameters()))[worst]})")
+    assert abs(out[1][0] - out[0][0]) < 1e-3 * abs(out[0][0])
+    assert errs[worst] < 2e-2
+
+
+@pytest.mark.gpu
 def test_agent_train_step_with_goal_drop_runs_the_hip_step():
     """BesoAgent.train_step on a model built with goal_drop = 0.1 and the kitchen dropouts (configs[2] / [3]): the HIP step
     serves it (no host-side masking, no torch-op network), losses are finite and decrease over a few steps."""

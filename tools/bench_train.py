@@ -22,6 +22,14 @@ from beso_amd.networks.scaler.scaler_class import Scaler  # noqa: E402
 
 
 def main():
+    if "--per-op-forward" in sys.argv:          # A/B: every layer of the training forward through the per-op kernels
+        sys.argv.remove("--per-op-forward")
+        from beso_amd import _lib
+        _lib.load().beso_debug_set_train_tail(0)
+    if "--tail-forward" in sys.argv:            # ... or through the tile kernel whatever the batch size
+        sys.argv.remove("--tail-forward")
+        from beso_amd import _lib
+        _lib.load().beso_debug_set_train_tail(2)
     if "--autograd" in sys.argv:
         sys.argv.remove("--autograd")
         sys.path.insert(0, os.path.join(ROOT, "tests"))
