@@ -64,7 +64,8 @@ class HipTrainStep:
         if fresh:
             flat = torch.empty(self.n_grad, dtype=torch.float32, device=dev)
         else:
-            if self._flat is None or self._flat.device != dev or self._flat_full.numel() != max(self.n_grad, self.pad_to):
+            if (self._flat is None or self._flat_full is None or self._flat.device != dev
+                    or self._flat_full.numel() != max(self.n_grad, self.pad_to)):
                 # (pad_to: the sharded data-parallel exchange reduce-scatters a buffer of world * ceil(n / world) floats;
                 # the kernels write the first n_grad, the tail stays zero)
                 self._flat_full = torch.zeros(max(self.n_grad, self.pad_to), dtype=torch.float32, device=dev)

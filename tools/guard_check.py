@@ -103,6 +103,7 @@ def main():
                 step._ws = torch.empty(wtotal, dtype=torch.uint8, device=dev)[wtotal - need:]
                 gtotal = ((step.n_grad * 4 + PAGE - 1) // PAGE) * PAGE // 4
                 step._flat, step._views = torch.empty(gtotal, dtype=torch.float32, device=dev)[gtotal - step.n_grad:], None
+                step._flat_full = step._flat
                 loss = step.loss_backward(s, a, g, nz, sg, seed=3)
                 torch.cuda.synchronize()
                 assert torch.isfinite(loss) and all(torch.isfinite(prm.grad).all() for prm in inner.parameters())
