@@ -1058,15 +1058,17 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
 // K7 fused: ln_f on the action tokens, action_pred (ln_f folded into it), c_out / c_skip and the
 // classifier-free combination (score_gpts.py:341-354, score_wrappers.py:96, classifier_free_sampler.py:49).
 // Every wave reduces its 48 features of every action token to `act` partial sums; LDS sums the waves.
-template <int RPW>
+// NT: token tiles that can hold action tokens -- with the action tokens first in the tile (layers_kernel's peeled last
+// layer) those are the first NTL tiles and the statistics / partial sums of the other tiles are never read.
+template <int RPW, int NT = kNTT>
 __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw,
                                           float* red, float* part, int s0, int n_samples, int Tn, int w, int lane,
                                           const SlotTabs* tb, Stamps& st) {
     asm volatile("" : "+v"(lane));
     const int n = lane & 15, g = lane >> 4;
     const int act = d.act, Dp = d.Dp;
-    float mean[kNTT], rstd[kNTT];
-    ln_stats<RPW, kWaves>(T, red, d.D, w, lane, mean, rstd, st);
+    float mean[NT], rstd[NT];
+    ln_stats<RPW, kWaves, NT>(T, red, d.D, w, lane, mean, rstd, st);
     const float* Wh = (const float*)(gw + d.g_headw);
     // part[(w*kMT + tokl)*16 + a]
     for (int a = 0; a < act; ++a) {
@@ -1074,7 +1076,7 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
 #pragma unroll
         for (int i = 0; i < RPW; ++i) wv[i] = *(const f32x4*)(Wh + (size_t)a * Dp + 16 * (w * RPW + i) + 4 * g);
 #pragma unroll
-        for (int t = 0; t < kNTT; ++t) {
+        for (int t = 0; t < NT; ++t) {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
@@ -2345,7 +2347,11 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     }
     }
     stamp(st, 4);
-    if (e.fuse_head) head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
+    if (e.fuse_head) {
+        // (peel: the action tokens are the first n_samples * t slots, i.e. inside the first NTLa token tiles)
+        if (peel && NTLa < kNTT) head_tile<RPW, NTLa>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
+        else head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
+    }
     else store_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 5);
     stamp(st, 101);
