@@ -1402,6 +1402,27 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     __syncthreads();
 }
 
+// A operand of Y^T = V^T P^T (v_mfma_f32_16x16x16_bf16: lane (d = 16 dt + n, key group g) holds V[row0 + 4g + r][d], r = 0..3)
+// with gfx950's transpose read: the 16 lanes of a group address the [4 keys][16 dims] block row by row (lane i: key
+// 4g + i/4, dims 4(i%4)..+3, 8 bytes) and each receives column i of it -- four ds_read_b64_tr_b16 per sample and head
+// instead of sixteen 16-bit reads and their shifts (V stays row-major in LDS: 144-byte rows).
+#ifndef BESO_V_TR
+#define BESO_V_TR 1                  // 0: the 16-bit gather (A/B)
+#endif
+__device__ __forceinline__ uint2 v_frag(const uint16_t* qkv, int row0, int dt, int n, int g) {
+#if BESO_V_TR
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    const uint16_t* p = qkv + ((size_t)2 * kQKVRows + row0 + 4 * g + (n >> 2)) * kQKVRow + 16 * dt + 4 * (n & 3);
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p)));
+#else
+    const uint16_t* vb = qkv + ((size_t)2 * kQKVRows + row0 + 4 * g) * kQKVRow + n + 16 * dt;
+    uint2 va;
+    va.x = (uint32_t)vb[0] | ((uint32_t)vb[kQKVRow] << 16);
+    va.y = (uint32_t)vb[2 * kQKVRow] | ((uint32_t)vb[3 * kQKVRow] << 16);
+    return va;
+#endif
+}
+
 // First two k-steps of the first head pair's QKV weights of a layer (issued before the LayerNorm that precedes
 // the phase): even / odd fragments of gemm_phase.
 template <int KS>
@@ -1473,16 +1494,12 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         if (w < n_samples && !(BESO_ABL_MASK & 16)) {
             const uint16_t* qb = qkv + ((size_t)0 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
             const uint16_t* kb = qkv + ((size_t)1 * kQKVRows + w * Tn + n) * kQKVRow + 8 * g;
-            const uint16_t* vb = qkv + ((size_t)2 * kQKVRows + w * Tn + 4 * g) * kQKVRow + n;
             u32x4 qf[2], kf[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) { qf[kk] = *(const u32x4*)(qb + 32 * kk); kf[kk] = *(const u32x4*)(kb + 32 * kk); }
             uint2 va[4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                va[dt].x = (uint32_t)vb[16 * dt] | ((uint32_t)vb[kQKVRow + 16 * dt] << 16);
-                va[dt].y = (uint32_t)vb[2 * kQKVRow + 16 * dt] | ((uint32_t)vb[3 * kQKVRow + 16 * dt] << 16);
-            }
+            for (int dt = 0; dt < 4; ++dt) va[dt] = v_frag(qkv, w * Tn, dt, n, g);
             f32x4 y[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) y[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1564,13 +1581,10 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         sum += __shfl_xor(sum, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(sum);
         uint2 pb = make_uint2(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]));
-        const uint16_t* vb = qkv + ((size_t)2 * kQKVRows + w * Tn + 4 * g) * kQKVRow + n;
         f32x4 y[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            uint2 va;
-            va.x = (uint32_t)vb[16 * dt] | ((uint32_t)vb[kQKVRow + 16 * dt] << 16);
-            va.y = (uint32_t)vb[2 * kQKVRow + 16 * dt] | ((uint32_t)vb[3 * kQKVRow + 16 * dt] << 16);
+            const uint2 va = v_frag(qkv, w * Tn, dt, n, g);
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             y[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, va),
                                                               __builtin_bit_cast(s16x4, pb), z, 0, 0, 0);
