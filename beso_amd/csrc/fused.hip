@@ -73,6 +73,7 @@ struct FusedDims {
     // per-model image behind the L per-layer images (fp32): embeddings transposed to [in][Dp], head with ln_f folded
     int Dp, obs, act, seq, G, L, head_fused;
     uint32_t g_tokT, g_tokb, g_actT, g_actb, g_sigw, g_sigb, g_pos, g_headw, g_headb, global_bytes;
+    uint32_t g_tokA, g_actA;      // tok_emb / action_emb weights as split-bf16 A fragments: [hi: 8*RPW KiB | lo: 8*RPW KiB]
     // BF16X3 image: a second copy of the L per-layer images holding the LOW halves of the split-bf16 weight fragments,
     // x3_delta bytes behind the first (= L * layer_bytes + global_bytes); same offsets inside, biases not repeated
     uint32_t x3_delta;
@@ -140,6 +141,7 @@ bool fused_dims(const Layout& lay, FusedDims* d) {
     d->g_sigw = carve(d->Dp); d->g_sigb = carve(d->Dp);
     d->g_pos = carve((size_t)lay.seq_size * d->Dp);
     d->g_headw = carve((size_t)16 * d->Dp); d->g_headb = carve(16);
+    d->g_tokA = carve((size_t)2 * d->RPW * kWaves * 256); d->g_actA = carve((size_t)2 * d->RPW * kWaves * 256);
     d->global_bytes = cur;
     d->x3_delta = (uint32_t)((size_t)lay.L * d->layer_bytes + d->global_bytes);
     return true;
@@ -953,7 +955,11 @@ __device__ __forceinline__ void sample_of(const EdgeArgs& e, int vb, int& b, boo
 // Written WITHOUT divergent control flow around loads: every load is unconditional from a clamped
 // (always valid) address and its value is selected afterwards -- a load inside a per-lane `if` is waited
 // for at the end of its block, which serialised ~120 cache-cold round trips (70 kcycles per workgroup).
-template <int RPW>
+// PX = 0 (bf16 instances): the two embedding GEMMs run as split-bf16 products on the bf16 MFMA (operands (hi, lo) pairs, three
+// MFMAs per pair: 2^-16 relative, three orders below the bf16 rounding of the layers that follow) -- one k-step of
+// 32 inputs for tok_emb and a half k-step for action_emb instead of eleven k-steps of the 1/16-rate fp32 MFMA: the
+// embedding's matrix-pipe time drops from 6.3 k to 1.3 k cycles per wave.  PX = 1 (BF16X3) keeps the exact-fp32 form.
+template <int RPW, int PX = 1>
 __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw, int s0,
                                            int n_samples, int Tn, int w, int lane, const SlotTabs* tb, Stamps& st) {
     asm volatile("" : "+v"(lane));
@@ -990,6 +996,87 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
     // gathered from the inputs, zero for tokens of another kind).  Every operand of both GEMMs is requested
     // up front; kEmbObsK / kEmbActK bound obs / act (fused_level).
     stamp(st, 40);
+    if constexpr (PX == 0) {
+        // A: weight fragments (rows = output features) of this wave's row tiles, hi and lo images
+        const u32x4* tokA = (const u32x4*)(gw + d.g_tokA);
+        const u32x4* actA = (const u32x4*)(gw + d.g_actA);
+        constexpr int RT = RPW * kWaves;
+        u32x4 ath[RPW], atl[RPW], aah[RPW], aal[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            ath[i] = tokA[(size_t)(w * RPW + i) * 64 + lane]; atl[i] = tokA[(size_t)(RT + w * RPW + i) * 64 + lane];
+            aah[i] = actA[(size_t)(w * RPW + i) * 64 + lane]; aal[i] = actA[(size_t)(RT + w * RPW + i) * 64 + lane];
+        }
+        // B: the lane's eight (tok_emb) / four (action_emb) inputs of every token tile -- contraction slot j of lane group g
+        // is input 16 (j >> 2) + 4 g + (j & 3), as everywhere; clamped addresses, values selected afterwards
+        float vt[kNTT][8], va[kNTT][4];
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) {
+            const float* pt = kind[t] == 1 ? src[t] : tokT;
+            const float* pa = kind[t] == 2 ? src[t] : tokT;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vt[t][j] = pt[min(16 * (j >> 2) + 4 * g + (j & 3), d.obs - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) va[t][j] = pa[min(4 * g + j, d.act - 1)];
+        }
+        stamp(st, 41);
+        float lsig[kNTT];
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) lsig[t] = logf(sg[t]) / 4.0f;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int f0 = 16 * (w * RPW + i) + 4 * g;
+            T.fvalid[i] = f0 < d.D;
+            const f32x4 bt = *(const f32x4*)((const float*)(gw + d.g_tokb) + f0);
+            const f32x4 ba = *(const f32x4*)((const float*)(gw + d.g_actb) + f0);
+            const f32x4 sw = *(const f32x4*)((const float*)(gw + d.g_sigw) + f0);
+            const f32x4 sb = *(const f32x4*)((const float*)(gw + d.g_sigb) + f0);
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) {
+                const int k = kind[t];
+                const f32x4 pos = *(const f32x4*)((const float*)(gw + d.g_pos) + (size_t)prow[t] * Dp + f0);
+                const f32x4 sig = sw * lsig[t] + sb;
+                const f32x4 lin = (k == 2 ? ba : bt) + pos;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                T.acc[i][t] = k == 0 ? zero : k == 3 ? sig : lin;
+            }
+        }
+        stamp(st, 42);
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) {
+            u32x4 bh, bl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 16 * (q >> 1) + 4 * g + 2 * (q & 1);
+                const float x0 = (kind[t] == 1 && c0 < d.obs) ? vt[t][2 * q] : 0.f;
+                const float x1 = (kind[t] == 1 && c0 + 1 < d.obs) ? vt[t][2 * q + 1] : 0.f;
+                const SplitPair p = split_bf16x2(x0, x1);
+                bh[q] = p.hi; bl[q] = p.lo;
+            }
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                T.acc[i][t] = mfma_bf16(atl[i], bh, T.acc[i][t]);
+                T.acc[i][t] = mfma_bf16(ath[i], bl, T.acc[i][t]);
+                T.acc[i][t] = mfma_bf16(ath[i], bh, T.acc[i][t]);
+            }
+            u32x4 ch = {0, 0, 0, 0}, cl = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c0 = 4 * g + 2 * q;
+                const float x0 = (kind[t] == 2 && c0 < d.act) ? va[t][2 * q] * scale[t] : 0.f;
+                const float x1 = (kind[t] == 2 && c0 + 1 < d.act) ? va[t][2 * q + 1] * scale[t] : 0.f;
+                const SplitPair p = split_bf16x2(x0, x1);
+                ch[q] = p.hi; cl[q] = p.lo;
+            }
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                T.acc[i][t] = mfma_bf16_half(aal[i], ch, T.acc[i][t]);
+                T.acc[i][t] = mfma_bf16_half(aah[i], cl, T.acc[i][t]);
+                T.acc[i][t] = mfma_bf16_half(aah[i], ch, T.acc[i][t]);
+            }
+        }
+        return;
+    }
     float aT[kEmbObsK][RPW], bT[kEmbObsK][kNTT], aA[kEmbActK][RPW], bA[kEmbActK][kNTT];
     // A token's source row has obs (state / goal) or act (action) elements: a row is only ever read by the
     // pass it belongs to -- every other token reads the (always long enough) weight table instead.
@@ -2285,7 +2372,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.1f * n, 0.2f, 0.3f * g, 0.4f};
         }
-    } else if (e.fuse_embed) embed_tile<RPW>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, st);
+    } else if (e.fuse_embed) embed_tile<RPW, PX>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, st);
     else load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 43);
     // The last layer (when this launch contains it and the action tokens of the tile fit NTL token tiles) runs its
@@ -2560,6 +2647,16 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
                            (float*)(gw + d.g_tokT), d.Dp);
         hipLaunchKernelGGL(transpose_pad_kernel, dim3((lay.act * d.Dp + 255) / 256), dim3(256), 0, s, actw, D, lay.act,
                            (float*)(gw + d.g_actT), d.Dp);
+        {
+            // split-bf16 A fragments of the two embedding matrices ([D][obs], [D][act]: one k-step each)
+            const int rt2 = d.RPW * kWaves;
+            for (int half = 0; half < 2; ++half) {
+                hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(32), dim3(256), 0, s, tokw, D, lay.obs, (const float*)nullptr,
+                                   (uint16_t*)(gw + d.g_tokA + (size_t)half * rt2 * 1024), rt2, 1, rt2, half);
+                hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(32), dim3(256), 0, s, actw, D, lay.act, (const float*)nullptr,
+                                   (uint16_t*)(gw + d.g_actA + (size_t)half * rt2 * 1024), rt2, 1, rt2, half);
+            }
+        }
         FTRY(hipGetLastError());
         FTRY(launch_pack_matrix(tokb, 1, D, gw + d.g_tokb, 1, d.Dp, -1, s));
         FTRY(launch_pack_matrix(actb, 1, D, gw + d.g_actb, 1, d.Dp, -1, s));
