@@ -301,6 +301,18 @@ __global__ void fold_bias_kernel(const float* __restrict__ W, const float* __res
 #define BESO_ABL_MASK 0              // timing experiments only (results are wrong): 1 GELU = identity, 2 no MLP-loop
 #endif                               // barriers, 4 no embedding, 8 LayerNorm statistics skipped, 16 no attention core,
                                      // 32 no LDS refills of the activation fragments
+// All-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) on gfx950's lane-swap instructions: two
+// VALU swaps instead of the two ds_bpermute_b32 that __shfl_xor(., 16) / (., 32) compile to -- those go through the LDS
+// pipe and sit on the serial chain of the attention core (max -> exp -> sum -> 1/sum).  Same pairing as the shuffles:
+// (r0 op r1) op (r2 op r3), bit-identical results.
+template <bool IS_MAX>
+__device__ __forceinline__ float rows_allreduce(float v) {
+    const u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float r = IS_MAX ? fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])) : __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r), __float_as_uint(r), false, false);
+    return IS_MAX ? fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1])) : __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     f32x2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
@@ -1172,8 +1184,7 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
                     for (int r = 0; r < 4; ++r) s = fmaf((T.acc[i][t][r] - mean[t]) * rstd[t], wv[i][r], s);
                 }
             }
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
+            s = rows_allreduce<false>(s);
             if (g == 0) part[((size_t)w * kMT + t * 16 + n) * 16 + a] = s;
         }
     }
@@ -1610,13 +1621,11 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                     e[r] = (4 * g + r <= n) ? sT[r] * scale_log2e : -INFINITY;
                     mx = fmaxf(mx, e[r]);
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = rows_allreduce<true>(mx);
                 float sum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - mx); sum += e[r]; }
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
+                sum = rows_allreduce<false>(sum);
                 const float inv = __builtin_amdgcn_rcpf(sum);
                 const uint2 pb = make_uint2(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]));
 #pragma unroll
@@ -1659,13 +1668,11 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
             e[r] = (4 * g + r <= n) ? sT[r] * scale_log2e : -INFINITY;     // (q k^T)/sqrt(hd), in log2 units
             m = fmaxf(m, e[r]);
         }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows_allreduce<true>(m);
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - m); sum += e[r]; }   // exp2(-inf) = 0
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows_allreduce<false>(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
         uint2 pb = make_uint2(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]));
         f32x4 y[4];
@@ -1869,13 +1876,11 @@ __device__ __forceinline__ void attn_phase_x3(Tile<RPW>& T, const u32x4* xnT, in
                 e[r] = (4 * g + r <= n) ? sT[r] * scale_log2e : -INFINITY;       // (q k^T)/sqrt(hd), causal, log2 units
                 mx = fmaxf(mx, e[r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = rows_allreduce<true>(mx);
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - mx); sum += e[r]; }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = rows_allreduce<false>(sum);
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
