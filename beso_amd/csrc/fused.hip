@@ -1583,6 +1583,9 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     //   operand (k = 4g..4g+3) of v_mfma_f32_16x16x16_bf16 for
     //   Y^T[d][i] = sum_j V[j][d] P[i][j]          4 x (A = V^T gathered with 16-bit LDS reads)
     //   whose D layout is the B fragment of the out-projection (same k permutation as the weights).
+    // token slot of (sample w, position lane & 15): looked up ONCE (it was an LDS round trip at the tail of every core's
+    // serial chain); clamped index, used only where position < Tn
+    const int my_tok = tb->slot_of_row[min(w, n_samples - 1) * Tn + min(lane & 15, Tn - 1)];
     auto core = [&]() {
     const int n = ln & 15, g = ln >> 4;
     if constexpr (HG > 1) {
@@ -1642,7 +1645,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                 }
             }
             if (n < Tn) {
-                const int tok = tb->slot_of_row[w * Tn + n];          // token slot of (sample w, position n)
+                const int tok = my_tok;                               // token slot of (sample w, position n)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     u32x4 yb;
@@ -1684,7 +1687,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                                                               __builtin_bit_cast(s16x4, pb), z, 0, 0, 0);
         }
         if (n < Tn) {
-            const int tok = tb->slot_of_row[w * Tn + n];          // token slot of (sample w, position n)
+            const int tok = my_tok;                               // token slot of (sample w, position n)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 u32x4 yb;
