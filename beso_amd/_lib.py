@@ -25,7 +25,8 @@ EXPORTS = ["beso_version", "beso_status_string", "beso_last_error", "beso_num_pa
            "beso_profile_enable", "beso_profile_read", "beso_debug_set_stamps", "beso_adam_step",
            "beso_train_workspace_bytes", "beso_grad_floats", "beso_loss_grad", "beso_debug_gemm", "beso_gather_windows",
            "beso_loss_grad_overlap", "beso_grad_early_range", "beso_debug_set_small_batch_max",
-           "beso_sample_ancestral", "beso_debug_set_fused_level_max", "beso_goal_mask", "beso_debug_set_train_tail"]
+           "beso_sample_ancestral", "beso_debug_set_fused_level_max", "beso_goal_mask", "beso_debug_set_train_tail",
+           "beso_debug_set_train_option"]
 
 
 class BesoConfig(C.Structure):
@@ -98,6 +99,9 @@ def load() -> C.CDLL:
         if hasattr(lib, "beso_debug_set_train_tail") or not os.environ.get("BESO_HIP_LIB"):
             lib.beso_debug_set_train_tail.restype = None
             lib.beso_debug_set_train_tail.argtypes = [i32]
+        if hasattr(lib, "beso_debug_set_train_option") or not os.environ.get("BESO_HIP_LIB"):
+            lib.beso_debug_set_train_option.restype = None
+            lib.beso_debug_set_train_option.argtypes = [i32, i32]
         if hasattr(lib, "beso_debug_set_fused_level_max") or not os.environ.get("BESO_HIP_LIB"):
             lib.beso_debug_set_fused_level_max.restype = None
             lib.beso_debug_set_fused_level_max.argtypes = [i32]

@@ -148,6 +148,11 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
     if (fused == 2) {
         // embed -> all transformer layers -> head as ONE launch: the residual tile of 8 samples never leaves
         // the CU's registers (shapes whose head cannot be fused store x and run the head kernel)
+        if (!(fused_layer_edges(lay) & 1)) {              // (long sequences: the layers are one launch, the edges their own)
+            profile_begin(BESO_SITE_EMBED, s);
+            HIP_TRY(launch_embed(lay, packed, a, x, s));
+            profile_end(BESO_SITE_EMBED, s);
+        }
         profile_begin(BESO_SITE_FUSED_LAYER, s);
         int st = fused_layers(lay, packed, a, x, &fused_edges, precision, s);
         profile_end(BESO_SITE_FUSED_LAYER, s);
@@ -487,6 +492,11 @@ void beso_debug_set_stamps(void* device_buf, int capacity_u64) { fused_set_stamp
 void beso_debug_set_small_batch_max(int n) { fused_set_small_batch_max(n); }
 void beso_debug_set_fused_level_max(int n) { fused_set_level_max(n); }
 void beso_debug_set_train_tail(int on) { train_set_tail_forward(on); }
+void beso_debug_set_train_option(int what, int value) {
+    if (what == 0) train_set_tail_forward(value);
+    else if (what == 1) train_set_tail_backward(value);
+    else if (what == 2) train_set_wgrad_side(value);
+}
 
 int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg, float* exp_avg_sq, float* ema,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,

@@ -9,6 +9,7 @@ size_t fused_workspace_bytes(const Layout& lay, int vbatch, int T, int precision
 int    fused_pack(const Layout& lay, const float* const* params, char* packed, int precision, hipStream_t s);
 bool   fused_supported(const Layout& lay, const FwdArgs& a, int precision);
 int    fused_level(const Layout& lay, const FwdArgs& a, int precision);   // 0 none, 1 MLP block, 2 whole layers
+int    fused_layer_edges(const Layout& lay);        // bit 0: fused_layers embeds, bit 1: it runs the head
 int    fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, int precision,
                     hipStream_t s);
 int    fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, int M, hipStream_t s);
@@ -24,6 +25,13 @@ int    fused_train_pack(const Layout& lay, const float* const* params, char* img
 int    fused_train_tail(const Layout& lay, const char* img, int layer, int M, const float* x_in, const void* y, int ld_y,
                         float* x_mid, float* x_out, float* st2, void* xn2, void* h, void* g, float* st1n, void* xn1n,
                         void* qkvn, hipStream_t s);
+// training backward through the mirrored tail block: transposed-weight image + one launch per layer boundary
+size_t fused_train_bwd_image_bytes(const Layout& lay);
+int    fused_train_bwd_pack(const Layout& lay, const float* const* params, char* img, hipStream_t s);
+int    fused_train_bwd_tiles(int M);
+int    fused_train_bwd_tail(const Layout& lay, const char* img, int layer, int M, const void* dqkv, const float* x_in,
+                            const float* st1, float* gres, void* dyo, const void* h, void* dh, float* db1, const float* x_mid,
+                            const float* st2, void* dym, void* dy, float* part1, float* part2, hipStream_t s);
 void   fused_set_stamps(void* buf, int cap);
 void   fused_set_small_batch_max(int n);
 void   fused_set_level_max(int n);

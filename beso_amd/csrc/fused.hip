@@ -53,6 +53,7 @@ constexpr int kChunkTiles = 2 * kWaves;   // hidden row tiles per MLP chunk: 2 p
 constexpr int kNTT = 6;                   // token tiles (16 tokens) per workgroup
 constexpr int kMT = kNTT * 16;            // 96 token slots
 constexpr int kSPW = 8;                   // samples per workgroup in layers_kernel
+constexpr int kLongNT = 5;                // token tiles of the one-sample-per-workgroup instance (sequences up to 80 tokens)
 constexpr int kHDP = 64;                  // padded head dim of the attention phase
 constexpr int kQKVRow = kHDP + 8;         // bf16 elements per q/k/v row in LDS: 144 B, 16-B aligned, conflict-free b128 reads
 constexpr int kQKVRows = kMT + 8;         // rows per part: a sample's 16-row MFMA window may run 8 rows past the last slot
@@ -61,7 +62,9 @@ constexpr int kQKVBytes = 3 * kQKVRows * kQKVRow * 2;   // 44928
 struct FusedDims {
     int D, FT, RPW, KS, HT, NCH, KS2p, H, hd;
     int HG, Hv, hdv;                      // HG real heads form one 'virtual head' of hdv = HG*hd <= 64 dims; Hv = H / HG
-    bool attn;                            // attention phase available (hd <= 64, 8*block_size <= 96, even Hv)
+    bool attn;                            // attention phase available (hd <= 64, even Hv, and 8*block_size <= 96 or seq1)
+    int seq1;                             // long sequences (8 samples do not fit a tile, one does in 5 token tiles): one sample per
+                                          // workgroup, the attention core runs a query tile per wave (layers_kernel CORE = 1)
     // per-layer image: [w1 | b1 | w2 | b2 | wqkv | bqkv | wproj | bproj]
     // (32-bit: the struct is a kernel argument and every field the kernel touches costs SGPRs)
     uint32_t w1_bytes, b1_bytes, w2_bytes, b2_bytes, wqkv_bytes, bqkv_bytes, wproj_bytes, bproj_bytes, layer_bytes;
@@ -102,7 +105,9 @@ bool fused_dims(const Layout& lay, FusedDims* d) {
         if (lay.hd * g <= kHDP && lay.H % (2 * g) == 0) { d->HG = g; break; }
     d->Hv = lay.H / d->HG;
     d->hdv = lay.hd * d->HG;
-    d->attn = d->hdv <= kHDP && lay.hd % 4 == 0 && kSPW * T <= kMT && d->Hv % 2 == 0;
+    const bool heads_ok = d->hdv <= kHDP && lay.hd % 4 == 0 && d->Hv % 2 == 0;
+    d->seq1 = (heads_ok && d->HG == 1 && kSPW * T > kMT && T <= 16 * kLongNT && d->RPW == 4 && d->KS == 16 && lay.D == 16 * kWaves * d->RPW) ? 1 : 0;
+    d->attn = heads_ok && (kSPW * T <= kMT || d->seq1);
     const size_t rt2 = (size_t)d->RPW * kWaves;
     d->w1_bytes = (size_t)d->NCH * kChunkTiles * d->KS * 1024;
     d->b1_bytes = round_up_sz((size_t)d->NCH * kChunkTiles * 16 * sizeof(float), 256);
@@ -120,7 +125,7 @@ bool fused_dims(const Layout& lay, FusedDims* d) {
     d->o_wproj = d->o_bqkv + d->bqkv_bytes;
     d->o_bproj = d->o_wproj + d->wproj_bytes;
     d->layer_bytes = d->o_bproj + d->bproj_bytes;
-    d->lin = d->attn ? 0 : 1;
+    d->lin = (d->attn && !d->seq1) ? 0 : 1;      // (the long shapes keep both forms: whole layers, and the block kernels)
     d->part_bytes = (uint32_t)(rt2 * d->KS * 1024);
     if (d->lin) {
         d->o_wqkv_lin = d->layer_bytes;
@@ -623,12 +628,12 @@ constexpr int kKCc = kChunkTiles / 2;      // FC2 k-steps per hidden chunk (= kK
 struct LdsMap {            // byte offsets inside the dynamic LDS block
     int xnT, u, red, tab, total;
 };
-__host__ __device__ constexpr LdsMap lds_map(int KS, bool mlp_only = false) {
+__host__ __device__ constexpr LdsMap lds_map(int KS, bool mlp_only = false, int NT = kNTT) {
     // u is the phase-local region: attention (q/k/v 3*104*72*2 = 44928 | yT 12288) or MLP (hT 6*8 KiB = 49152);
     // the MLP-block kernel needs only the latter (which lets D = 512, KS = 16: 96 KiB of xnT, fit in 160 KiB)
     LdsMap m{};
     m.xnT = 0;
-    m.u = kNTT * KS * 1024;
+    m.u = NT * KS * 1024;                  // (NT < kNTT: instances that only ever touch the first NT token tiles)
     m.red = m.u + (mlp_only ? kNTT * kKCc * 1024 : 59648);
     m.tab = m.red + 2 * kWaves * kMT * 4;
     m.total = m.tab + 512;
@@ -747,31 +752,32 @@ __device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restri
 template <int RPW, int NW, int NT = kNTT>         // NT: the first NT token tiles only
 __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, int w, int lane, float (&mean)[NT],
                                          float (&rstd)[NT], Stamps& st) {
-    static_assert(NT % 2 == 0, "token tiles are reduced in pairs");
-    const int n = lane & 15, row = lane >> 4;
+    const int n = lane & 15, row = lane >> 4;            // (token tiles are reduced in pairs; an odd last one pairs with zeros)
     const float invD = 1.0f / (float)D;
     // Cross-lane part of the reduction (over the four 16-lane rows g) on gfx950's lane-swap instructions:
     //   v_permlane32_swap(s, q) + add : rows {0,1} = s(g) + s(g+2), rows {2,3} = q(g) + q(g+2)
     //   v_permlane16_swap(r_t, r_t+1) + add : row 0 = S_t, row 1 = S_t+1, row 2 = Q_t, row 3 = Q_t+1
     // so every lane ends up with one finished (token, statistic) and writes it: red[token][wave][stat].
 #pragma unroll
-    for (int tp = 0; tp < NT / 2; ++tp) {
+    for (int tp = 0; tp < (NT + 1) / 2; ++tp) {
         float r[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int t = 2 * tp + h;
+            const int t = 2 * tp + h < NT ? 2 * tp + h : NT - 1;
             float s = 0.f, q = 0.f;
+            if (2 * tp + h < NT) {
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { const float v = T.acc[i][t][k]; s += v; q = fmaf(v, v, q); }
+            }
             }
             const u32x2 x = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(q), false, false);
             r[h] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
         }
         const u32x2 y = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[0]), __float_as_uint(r[1]), false, false);
         const float v = __uint_as_float(y[0]) + __uint_as_float(y[1]);
-        const int tok = (2 * tp + (row & 1)) * 16 + n;
+        const int tok = (2 * tp + (row & 1)) * 16 + n;      // (odd NT: the last pair's second token tile is tile NT < kNTT, unused)
         red[(tok * NW + w) * 2 + (row >> 1)] = v;
     }
     stamp(st, 30);
@@ -1542,7 +1548,9 @@ __device__ __forceinline__ void attn_prefetch(u32x4 (&qE)[3], u32x4 (&qO)[3], co
 // the next pair before core(B); each head's projection weights (two k-steps: all of them) are requested
 // before the barrier that precedes its core.
 // HG > 1: a virtual head is HG real heads of `hd` dims side by side (FusedDims); H counts virtual heads.
-template <int RPW, int KS, int HG, int NTP = kNTT, int NTQ = kNTT>   // NTP: token tiles that receive the out-projection (last layer:
+// CORE = 1 (one sample of up to 16 NTQ tokens per workgroup): the core of a head runs on waves 0 .. NTQ-1, wave qt owning
+// query tile qt against key tiles 0 .. qt (causal), softmax over all of its keys in registers.
+template <int RPW, int KS, int HG, int NTP = kNTT, int NTQ = kNTT, int CORE = 0>   // NTP: token tiles that receive the out-projection (last layer:
                                                                      // action tokens only); NTQ: token tiles that hold tokens at all
 __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsigned char* u,
                                            const u32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
@@ -1588,7 +1596,70 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     const int my_tok = tb->slot_of_row[min(w, n_samples - 1) * Tn + min(lane & 15, Tn - 1)];
     auto core = [&]() {
     const int n = ln & 15, g = ln >> 4;
-    if constexpr (HG > 1) {
+    if constexpr (CORE == 1) {
+        // ---- long sequence, one sample: S^T tiles [key tile kt][query tile w] for kt <= w, same operand roles and D
+        // layout as below (lane (i, g) holds keys 16 kt + 4 g + r of query 16 w + i), one softmax over the wave's
+        // 4 (w + 1) scores per lane, Y^T accumulated over the key tiles
+        static_assert(HG == 1, "grouped heads are a short-sequence layout");
+        if (w < NTQ && !(BESO_ABL_MASK & 16)) {
+            const uint16_t* qb = qkv + ((size_t)0 * kQKVRows + 16 * w + n) * kQKVRow + 8 * g;
+            const u32x4 q0 = *(const u32x4*)qb, q1 = *(const u32x4*)(qb + 32);
+            float e[NTQ][4];
+            float m = -INFINITY;
+            const int query = 16 * w + n;
+#pragma unroll
+            for (int kt = 0; kt < NTQ; ++kt) {
+                if (kt <= w) {                                             // wave-uniform
+                    const uint16_t* kb = qkv + ((size_t)1 * kQKVRows + 16 * kt + n) * kQKVRow + 8 * g;
+                    f32x4 sT = {0.f, 0.f, 0.f, 0.f};
+                    sT = mfma_bf16(*(const u32x4*)kb, q0, sT);
+                    sT = mfma_bf16(*(const u32x4*)(kb + 32), q1, sT);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = 16 * kt + 4 * g + r;
+                        e[kt][r] = (key <= query && key < Tn) ? sT[r] * scale_log2e : -INFINITY;
+                        m = fmaxf(m, e[kt][r]);
+                    }
+                }
+            }
+            m = rows_allreduce<true>(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NTQ; ++kt) {
+                if (kt <= w) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { e[kt][r] = __builtin_amdgcn_exp2f(e[kt][r] - m); sum += e[kt][r]; }
+                }
+            }
+            sum = rows_allreduce<false>(sum);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+            f32x4 y[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) y[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NTQ; ++kt) {
+                if (kt <= w) {
+                    const uint2 pb = make_uint2(pack_bf16x2(e[kt][0], e[kt][1]), pack_bf16x2(e[kt][2], e[kt][3]));
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const uint2 va = v_frag(qkv, 16 * kt, dt, n, g);
+                        y[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, va),
+                                                                          __builtin_bit_cast(s16x4, pb), y[dt], 0, 0, 0);
+                    }
+                }
+            }
+            // (tokens in natural order: query 16 w + n sits in slot 16 w + n)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 yb;
+                yb[0] = pack_bf16x2(y[2 * kk][0] * inv, y[2 * kk][1] * inv);
+                yb[1] = pack_bf16x2(y[2 * kk][2] * inv, y[2 * kk][3] * inv);
+                yb[2] = pack_bf16x2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
+                yb[3] = pack_bf16x2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
+                yT[((size_t)w * 2 + kk) * 64 + ln] = yb;
+            }
+        }
+    } else if constexpr (HG > 1) {
         // Grouped heads: the same fragments, but head h only sees its own dims.  S_h: the Q fragment with the
         // other heads' dims zeroed (dword granular: hd is a multiple of 4); Y rows are taken from the head they
         // belong to (lane-group granular for the same reason), already normalised by that head's 1/sum.
@@ -2295,7 +2366,7 @@ __global__ __launch_bounds__(512, 2) void train_tail_kernel(const char* __restri
 
 // The per-step training image of ALL layers in one launch: every segment is either a matrix in A-fragment order
 // (pack_mfma_a_kernel's layout) or a zero-padded fp32 vector; a workgroup serves one segment (table in the kernel argument).
-struct TrainPackSeg { const float* src; uint32_t dst; int rows, cols, rt, kt, grp, first_block; };   // rt = 0: vector of `rows` floats padded to `cols`
+struct TrainPackSeg { const float* src; uint32_t dst; int rows, cols, rt, kt, grp, first_block, tr; };   // rt = 0: vector of `rows` floats padded to `cols`; tr: the matrix is src^T (src is [cols][rows])
 constexpr int kTrainPackSegs = 96;                       // 13 per layer; the table travels as a kernel argument (< 4 KiB)
 struct TrainPackTable { TrainPackSeg seg[kTrainPackSegs]; int n, blocks; };
 __global__ void train_pack_kernel(TrainPackTable t, char* __restrict__ img) {
@@ -2322,7 +2393,427 @@ __global__ void train_pack_kernel(TrainPackTable t, char* __restrict__ img) {
         const int rin = (int)(tile % g.grp), kk = (int)((tile / g.grp) % g.kt);
         const int R = (int)(tile / ((size_t)g.grp * g.kt)) * g.grp + rin;
         const int r = 16 * R + (lane & 15), c = 32 * kk + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
-        dst[i] = f2bf((r < g.rows && c < g.cols) ? g.src[(size_t)r * g.cols + c] : 0.f);
+        dst[i] = f2bf((r < g.rows && c < g.cols) ? (g.tr ? g.src[(size_t)c * g.rows + r] : g.src[(size_t)r * g.cols + c]) : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Training backward: the mirror image of train_tail_kernel.  Between two attention backward launches the chain of data
+// gradients of a 96-token tile runs as ONE launch with the residual gradient in registers:
+//     dxn1  = dqkv(l) Wqkv(l)                               (front half of layer l)
+//     G_out(l-1) = G_mid(l) + LN1'(dxn1)                     LayerNorm backward, + gamma / beta / FC2-bias partial sums
+//     dh    = (bf16(G_out) W2(l-1)) * GELU'(h)               (back half of layer l-1; dh kept for the FC1 weight gradient)
+//     dxn2  = dh W1(l-1)
+//     G_mid(l-1) = G_out + LN2'(dxn2)                        + gamma / beta / proj-bias partial sums
+//     dy    = bf16(G_mid) Wproj(l-1)                         -> attention backward of layer l-1
+// i.e. eight launches of the per-op backward (q/k/v, FC2 (+GELU'), FC1, proj data gradients, two LayerNorm backwards)
+// without the fp32 round trips of dxn between them.  Data gradients are X^T-side products: the A operands are the
+// TRANSPOSED weights in fragment order (per-step image, train_bwd_img).  Outputs in the per-op kernels' buffers and formats.
+// ---------------------------------------------------------------------------------------------
+struct TrainBwdImg { uint32_t o_wqkvT, o_w2T, o_w1T, o_wprojT, o_ln1w, o_ln2w, part_bytes, layer_bytes; };
+static TrainBwdImg train_bwd_img(const FusedDims& d) {
+    TrainBwdImg t;
+    const uint32_t rt2 = (uint32_t)d.RPW * kWaves, vec = (uint32_t)round_up_sz((size_t)rt2 * 16 * sizeof(float), 256);
+    uint32_t cur = 0;
+    auto carve = [&](uint32_t bytes) { uint32_t o = cur; cur = (uint32_t)round_up_sz((size_t)cur + bytes, 256); return o; };
+    t.part_bytes = rt2 * d.KS * 1024;
+    t.o_wqkvT = carve(3 * t.part_bytes);
+    t.o_w2T = carve(d.w1_bytes);            // W2^T [4D][D] in the FC1 image layout
+    t.o_w1T = carve(d.w2_bytes);            // W1^T [D][4D] in the FC2 image layout
+    t.o_wprojT = carve(t.part_bytes);
+    t.o_ln1w = carve(vec); t.o_ln2w = carve(vec);
+    t.layer_bytes = cur;
+    return t;
+}
+
+struct TrainBwdArgs {
+    const uint16_t* dqkv;     // [M][3D] layer l
+    const float* x_in;        // [M][D]  input of LN1(l)
+    const float* st1;         // [M][2]
+    float* gres;              // [M][D]  fp32 residual gradient: G_mid(l) on entry, G_mid(l-1) on exit
+    uint16_t* dyo;            // [M][D]  bf16(G_out(l-1))                 (FC2 weight-gradient operand)
+    const uint16_t* h;        // [M][4D] FC1 pre-activation of layer l-1
+    uint16_t* dh;             // [M][4D]
+    float* db1;               // [4D]    FC1 bias gradient (atomics)
+    const float* x_mid;       // [M][D]  input of LN2(l-1)
+    const float* st2;         // [M][2]
+    uint16_t* dym;            // [M][D]  bf16(G_mid(l-1))                 (proj weight-gradient operand)
+    uint16_t* dy;             // [M][D]  gradient of the attention output of layer l-1
+    float* part1; float* part2;   // [tiles][3][D] partial sums of the two LayerNorm backwards
+};
+
+// sum over the 16 lanes of a row (DPP: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror); every lane gets it
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// B fragment (token tile t, k-step kk) of a row-major bf16 matrix [tok][ld] (columns [0, ncols) real): lane (n, g) holds
+// columns 32 kk + 4 g .. +3 and 32 kk + 16 + 4 g .. +3 of token m0 + 16 t + n; zeros outside.
+__device__ __forceinline__ u32x4 load_b_frag(const uint16_t* __restrict__ src, size_t ld, int ncols, int m0, int M, int t, int kk,
+                                             int n, int g) {
+    const int tok = m0 + 16 * t + n, c0 = 32 * kk + 4 * g;
+    uint2 lo = make_uint2(0u, 0u), hi = lo;
+    if (tok < M) {
+        const uint16_t* row = src + (size_t)tok * ld + c0;
+        if (c0 < ncols) lo = *(const uint2*)row;
+        if (c0 + 16 < ncols) hi = *(const uint2*)(row + 16);
+    }
+    return u32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
+// Accumulator-layout values -> bf16 B fragments in LDS: fn(i, t) = the four features 16 (w RPW + i) + 4 g .. +3 of token
+// 16 t + n as two packed pairs (the write pattern of layernorm_to_lds).
+template <int RPW, int KS, class F>
+__device__ __forceinline__ void put_b_frags(u32x4* xnT, int w, int lane, F fn) {
+    auto pair = [&](int i) {
+        const int ks = (w * RPW + i) >> 1;
+        if (ks < KS) {
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) {
+                const uint2 lo = fn(i, t), hi = fn(i + 1, t);
+                xnT[((size_t)t * KS + ks) * 64 + lane] = u32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+        }
+    };
+    auto single = [&](int i) {
+        const int Rf = w * RPW + i;
+        if ((Rf >> 1) < KS) {
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) *((uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane) + (Rf & 1)) = fn(i, t);
+        }
+    };
+    if constexpr (RPW % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < RPW; i += 2) pair(i);
+    } else {
+        static_assert(RPW == 3, "row tiles per wave");
+        if (w & 1) { single(0); pair(1); }
+        else { pair(0); single(2); }
+    }
+}
+
+// LayerNorm backward on the tile (ln_bwd_kernel of train.hip on the accumulator layout).  T.acc holds dxn (gradient of
+// the LayerNorm output, before gamma) on entry and the new residual gradient G = gprev + dLN on exit, which also goes out
+// as fp32 (gout), as bf16 row-major (gb) and as B fragments (xnT).  part: this workgroup's [3][D] slab of partial sums
+// (gamma gradient, beta gradient, column sums of G = bias gradient of the Linear in front).  x is read twice (the second
+// time from L2) instead of being held in 72 registers.  Contains two barriers: one inside the token sums -- which also
+// orders the xnT writes behind every wave's reads of the previous phase -- and one at the end.
+template <int RPW, int KS>
+__device__ __forceinline__ void ln_bwd_tile(Tile<RPW>& T, const float* __restrict__ x, const float* __restrict__ stats,
+                                            const float* __restrict__ gamma, const float* gprev, float* gout,
+                                            uint16_t* __restrict__ gb, u32x4* xnT, float* red, float* __restrict__ part, int D,
+                                            int m0, int M, int w, int lane, Stamps& st) {
+    asm volatile("" : "+v"(lane));
+    stamp(st, 54);
+    const int n = lane & 15, g = lane >> 4, row = g;
+    constexpr int NT = kNTT, NW = kWaves;
+    float mean[NT], rstd[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tok = m0 + 16 * t + n;
+        float2 ms = make_float2(0.f, 0.f);
+        if (tok < M) ms = *(const float2*)(stats + 2 * (size_t)tok);
+        mean[t] = ms.x; rstd[t] = ms.y;
+    }
+    f32x4 gam[RPW], ag[RPW], ab[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        gam[i] = *(const f32x4*)(gamma + 16 * (w * RPW + i) + 4 * g);
+        ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i];
+    }
+    auto load_xh = [&](int i, int t) {
+        const int tok = m0 + 16 * t + n, f0 = 16 * (w * RPW + i) + 4 * g;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (T.fvalid[i] && tok < M) v = (*(const f32x4*)(x + (size_t)tok * D + f0) - mean[t]) * rstd[t];
+        return v;
+    };
+    // ---- pass 1: per-token sums of dy = dxn * gamma and dy * xhat; per-feature sums of dxn * xhat and dxn
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const f32x4 xh = load_xh(i, t), go = T.acc[i][t], dy = go * gam[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a1 += dy[k]; a2 = fmaf(dy[k], xh[k], a2); }
+            ag[i] += go * xh;
+            ab[i] += go;
+        }
+        s1[t] = a1; s2[t] = a2;
+    }
+    // token sums over all features: lane rows, then the waves through LDS (the exchange of ln_stats)
+    const float invD = 1.0f / (float)D;
+#pragma unroll
+    for (int tp = 0; tp < NT / 2; ++tp) {
+        float r[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const u32x2 xx = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1[2 * tp + hh]), __float_as_uint(s2[2 * tp + hh]), false, false);
+            r[hh] = __uint_as_float(xx[0]) + __uint_as_float(xx[1]);
+        }
+        const u32x2 y = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[0]), __float_as_uint(r[1]), false, false);
+        const float v = __uint_as_float(y[0]) + __uint_as_float(y[1]);
+        const int tok = (2 * tp + (row & 1)) * 16 + n;
+        red[(tok * NW + w) * 2 + (row >> 1)] = v;
+    }
+    stamp(st, 55);
+    __syncthreads();
+    stamp(st, 56);
+    float c1[NT], c2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4* pr = (const f32x4*)(red + (size_t)(t * 16 + n) * NW * 2);
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW / 2; ++k) { const f32x4 v = pr[k]; s += v[0] + v[2]; q += v[1] + v[3]; }
+        c1[t] = s * invD; c2[t] = q * invD;
+    }
+    // ---- pass 2: G = gprev + (dy - c1 - xhat c2) rstd
+    f32x4 ac[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        ac[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int f0 = 16 * (w * RPW + i) + 4 * g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int tok = m0 + 16 * t + n;
+            const bool ok = T.fvalid[i] && tok < M;
+            const f32x4 xh = load_xh(i, t);
+            f32x4 tot = (T.acc[i][t] * gam[i] - c1[t] - xh * c2[t]) * rstd[t];
+            if (ok) {
+                if (gprev) tot += *(const f32x4*)(gprev + (size_t)tok * D + f0);
+                *(f32x4*)(gout + (size_t)tok * D + f0) = tot;
+                *(uint2*)(gb + (size_t)tok * D + f0) = make_uint2(pack_bf16x2(tot[0], tot[1]), pack_bf16x2(tot[2], tot[3]));
+            } else tot = f32x4{0.f, 0.f, 0.f, 0.f};
+            T.acc[i][t] = tot;
+            ac[i] += tot;
+        }
+    }
+    stamp(st, 57);
+    put_b_frags<RPW, KS>(xnT, w, lane, [&](int i, int t) {
+        return make_uint2(pack_bf16x2(T.acc[i][t][0], T.acc[i][t][1]), pack_bf16x2(T.acc[i][t][2], T.acc[i][t][3]));
+    });
+    // ---- per-feature partial sums of the tile (over its 96 tokens: the 16 lanes of a row)
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int f0 = 16 * (w * RPW + i) + 4 * g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = row16_sum(ag[i][k]), b = row16_sum(ab[i][k]), c = row16_sum(ac[i][k]);
+            if (n == 0 && f0 + k < D) { part[f0 + k] = a; part[D + f0 + k] = b; part[2 * D + f0 + k] = c; }
+        }
+    }
+    stamp(st, 58);
+    __syncthreads();
+    stamp(st, 59);
+}
+
+// MLP backward of the tile: xnT holds bf16(G_out) fragments; per hidden chunk  dg = W2^T-side product -> dh = dg *
+// GELU'(h) (h from the forward pass) -> kept (row-major bf16) and, as B fragments in hT, contracted with W1^T into
+// T.acc (= dxn2, zeroed here).  The FC1 bias gradient (column sums of dh as stored) goes out with one atomic per
+// feature and tile.  Plain chunk loop (two barriers per chunk): the phase is bound by the h / dh traffic of the tile.
+template <int RPW, int KS, int NW>
+__device__ __forceinline__ void mlp_bwd_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
+                                              const u32x4* __restrict__ w2p, int HT, int w, int lane,
+                                              const uint16_t* __restrict__ hs, uint16_t* __restrict__ dh, float* db1, int m0,
+                                              int M, int ld, Stamps& st) {
+    asm volatile("" : "+v"(lane));
+    constexpr int NT = kNTT, RC = kChunkTiles / NW, KW = RC / 2, A2KS = NW * RPW, PF1 = kFc1PF;
+    static_assert(KS % PF1 == 0, "FC1 weight ring");
+    const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
+    auto fc1_a = [&](int c) { return wptr(w1p + (size_t)(RC * w) * 64, lane).adv((size_t)c * KS * kChunkTiles); };
+    auto fc2_a = [&](int c) { return wptr(w2p + (size_t)(w * RPW) * 64, lane).adv((size_t)(c * kKC) * (NW * RPW)); };
+    u32x4 a1r[PF1][RC];
+    prefetch_ring<RC, PF1>(a1r, fc1_a(0), kChunkTiles);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) T.acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < n_chunks; ++c) {
+        asm volatile("" : "+v"(lane));
+        const int n = lane & 15, g = lane >> 4;
+        // the forward pass's pre-activations of this wave's rows of the chunk (in flight across the product)
+        uint2 hv[RC][NT];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            const int f0 = 16 * (c * kChunkTiles + RC * w + r) + 4 * g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tok = m0 + 16 * t + n;
+                hv[r][t] = make_uint2(0u, 0u);
+                if (tok < M && f0 < ld) hv[r][t] = *(const uint2*)(hs + (size_t)tok * ld + f0);
+            }
+        }
+        f32x4 h[RC][NT];
+#pragma unroll
+        for (int r = 0; r < RC; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) h[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stamp(st, 60);
+        gemm_phase_ring<RC, NT, PF1, kt16(KS)>(h, a1r, fc1_a(c), kChunkTiles, xnT + lane, KS * 64, 64, KS);
+        stamp(st, 61);
+        if (c + 1 < n_chunks) prefetch_ring<RC, PF1>(a1r, fc1_a(c + 1), kChunkTiles);
+        u32x4 af2[2][RPW];
+        {
+            const WPtr a2 = fc2_a(c);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) { af2[0][r] = a2.at(r); af2[1][r] = a2.at(r + A2KS); }
+        }
+        u32x4 hb[KW][NT];
+        float cs[RC][4];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            const int f0 = 16 * (c * kChunkTiles + RC * w + r) + 4 * g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cs[r][k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tok = m0 + 16 * t + n;
+                const float v0 = __uint_as_float(hv[r][t].x << 16), v1 = __uint_as_float(hv[r][t].x & 0xffff0000u);
+                const float v2 = __uint_as_float(hv[r][t].y << 16), v3 = __uint_as_float(hv[r][t].y & 0xffff0000u);
+                uint2 pk;
+                pk.x = pack_bf16x2(h[r][t][0] * gelu_grad_poly(v0), h[r][t][1] * gelu_grad_poly(v1));
+                pk.y = pack_bf16x2(h[r][t][2] * gelu_grad_poly(v2), h[r][t][3] * gelu_grad_poly(v3));
+                if (tok < M && f0 < ld) *(uint2*)(dh + (size_t)tok * ld + f0) = pk;
+                cs[r][0] += __uint_as_float(pk.x << 16); cs[r][1] += __uint_as_float(pk.x & 0xffff0000u);
+                cs[r][2] += __uint_as_float(pk.y << 16); cs[r][3] += __uint_as_float(pk.y & 0xffff0000u);
+                hb[r >> 1][t][2 * (r & 1)] = pk.x;
+                hb[r >> 1][t][2 * (r & 1) + 1] = pk.y;
+            }
+        }
+        stamp(st, 62);
+        __syncthreads();                     // every wave is done reading hT(c-1)
+        stamp(st, 63);
+#pragma unroll
+        for (int j2 = 0; j2 < KW; ++j2)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) hT[((size_t)t * kKC + KW * w + j2) * 64 + lane] = hb[j2][t];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            const int f0 = 16 * (c * kChunkTiles + RC * w + r) + 4 * g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float sum = row16_sum(cs[r][k]);
+                if (n == 0 && f0 + k < ld) unsafeAtomicAdd(db1 + f0 + k, sum);
+            }
+        }
+        stamp(st, 64);
+        __syncthreads();                     // hT(c) complete
+        stamp(st, 65);
+        const int tiles_here = min(kChunkTiles, HT - c * kChunkTiles);
+        gemm_phase<RPW, NT, false, kNTT>(T.acc, af2[0], af2[1], fc2_a(c), A2KS, hT + lane, kKC * 64, 64,
+                                         tiles_here == kChunkTiles ? kKC : (((tiles_here >> 1) + 1) & ~1));
+        stamp(st, 66);
+    }
+    __syncthreads();
+    stamp(st, 67);
+}
+
+template <int RPW, int KS>
+__global__ __launch_bounds__(512, 2) void train_bwd_tail_kernel(const char* __restrict__ lw, const char* __restrict__ lw_prev,
+                                                                FusedDims d, TrainBwdImg bi, int M, TrainBwdArgs a,
+                                                                unsigned long long* stamps, int cap) {
+    Stamps st{stamps, cap, 0};
+    stamp(st, 100);
+    stamp(st, 1);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int kBuf = kNTT * KS * 1024;                    // one set of B fragments of the tile: 96 tokens x 32 KS columns
+    static_assert(kBuf >= kNTT * kKC * 1024, "hT fits the second buffer");
+    u32x4* buf0 = (u32x4*)lds;
+    u32x4* buf1 = (u32x4*)(lds + kBuf);
+    float* red = (float*)(lds + 2 * kBuf);
+    int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.x * kMT;
+    Tile<RPW> T;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        T.fvalid[i] = 16 * (w * RPW + i) + 4 * (lane >> 4) < d.D;
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+        // ---- dxn1 = dqkv Wqkv: three contractions over the q, k, v columns; the column blocks alternate between two
+        // LDS buffers, the third one travels through registers under the first product
+        constexpr int NF = kNTT * KS / kWaves;
+        static_assert(kNTT * KS % kWaves == 0, "fragments per wave");
+        const int n = lane & 15, g = lane >> 4;
+        const size_t ldq = (size_t)3 * d.D;
+        u32x4 sr[NF];
+        auto fetch = [&](int part) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int f = w + j * kWaves, t = f / KS, kk = f - t * KS;
+                sr[j] = load_b_frag(a.dqkv + (size_t)part * d.D, ldq, d.D, m0, M, t, kk, n, g);
+            }
+        };
+        auto put = [&](u32x4* buf) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) buf[(size_t)(w + j * kWaves) * 64 + lane] = sr[j];
+        };
+        auto wq = [&](int part) {
+            return wptr((const u32x4*)(lw + bi.o_wqkvT + (size_t)part * bi.part_bytes) + (size_t)(w * RPW) * 64, lane);
+        };
+        u32x4 aE[RPW], aO[RPW];
+        fetch(0); put(buf0);
+        fetch(1); put(buf1);
+        prefetch_a<RPW>(aE, aO, wq(0), kWaves * RPW);
+        stamp(st, 50);
+        __syncthreads();
+        stamp(st, 51);
+        fetch(2);
+        gemm_phase<RPW, kNTT, kt16(KS)>(T.acc, aE, aO, wq(0), kWaves * RPW, (const u32x4*)buf0 + lane, KS * 64, 64, KS);
+        prefetch_a<RPW>(aE, aO, wq(1), kWaves * RPW);
+        stamp(st, 52);
+        __syncthreads();                     // every wave is done with the q block
+        put(buf0);
+        gemm_phase<RPW, kNTT, kt16(KS)>(T.acc, aE, aO, wq(1), kWaves * RPW, (const u32x4*)buf1 + lane, KS * 64, 64, KS);
+        prefetch_a<RPW>(aE, aO, wq(2), kWaves * RPW);
+        __syncthreads();                     // the v block is complete
+        stamp(st, 53);
+        gemm_phase<RPW, kNTT, kt16(KS)>(T.acc, aE, aO, wq(2), kWaves * RPW, (const u32x4*)buf0 + lane, KS * 64, 64, KS);
+    }
+    // ---- LayerNorm-1 backward of layer l: G_out(l-1), kept as fp32 (re-read by the second LayerNorm backward below:
+    // the MLP phase needs its registers), bf16 (FC2 weight gradient) and B fragments
+    ln_bwd_tile<RPW, KS>(T, a.x_in, a.st1, (const float*)(lw + bi.o_ln1w), a.gres, a.gres, a.dyo, buf0, red,
+                         a.part1 + (size_t)blockIdx.x * 3 * d.D, d.D, m0, M, w, lane, st);
+    mlp_bwd_phase<RPW, KS, kWaves>(T, buf0, buf1, (const u32x4*)(lw_prev + bi.o_w2T), (const u32x4*)(lw_prev + bi.o_w1T), d.HT,
+                                   w, lane, a.h, a.dh, a.db1, m0, M, 4 * d.D, st);
+    ln_bwd_tile<RPW, KS>(T, a.x_mid, a.st2, (const float*)(lw_prev + bi.o_ln2w), a.gres, a.gres, a.dym, buf0, red,
+                         a.part2 + (size_t)blockIdx.x * 3 * d.D, d.D, m0, M, w, lane, st);
+    {
+        // ---- dy = bf16(G_mid) Wproj
+        asm volatile("" : "+v"(lane));
+        const int gg = lane >> 4, nn = lane & 15;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 aE[RPW], aO[RPW];
+        const WPtr wp = wptr((const u32x4*)(lw_prev + bi.o_wprojT) + (size_t)(w * RPW) * 64, lane);
+        prefetch_a<RPW>(aE, aO, wp, kWaves * RPW);
+        gemm_phase<RPW, kNTT, kt16(KS)>(T.acc, aE, aO, wp, kWaves * RPW, (const u32x4*)buf0 + lane, KS * 64, 64, KS);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int f0 = 16 * (w * RPW + i) + 4 * gg;
+            if (f0 < d.D) {
+#pragma unroll
+                for (int t = 0; t < kNTT; ++t) {
+                    const int tok = m0 + 16 * t + nn;
+                    if (tok < M)
+                        *(uint2*)(a.dy + (size_t)tok * d.D + f0) =
+                            make_uint2(pack_bf16x2(T.acc[i][t][0], T.acc[i][t][1]), pack_bf16x2(T.acc[i][t][2], T.acc[i][t][3]));
+                }
+            }
+        }
+        stamp(st, 68);
+        stamp(st, 101);
     }
 }
 
@@ -2335,13 +2826,15 @@ __global__ void train_pack_kernel(TrainPackTable t, char* __restrict__ img) {
 // spreads over B/2 CUs and every phase runs a third of the MFMA / LDS / VALU work -- what is left is the L2 -> CU
 // stream of the weights.  Same phases, same per-sample arithmetic (results are bit-identical between the instances).
 // PX = 1: the BF16X3 instance (split-bf16 GEMMs, exact GELU, fp32 attention core): the parity mode of this kernel.
-template <int RPW, int KS, int HG, int NTL, int SPW = kSPW, int NTA = kNTT, int PX = 0>
+// CORE = 1: the long-sequence instance (SPW = 1: a sample of up to 16 NTA tokens per workgroup; edges outside the kernel).
+template <int RPW, int KS, int HG, int NTL, int SPW = kSPW, int NTA = kNTT, int PX = 0, int CORE = 0>
 __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, const char* __restrict__ lw0,
                                                         FusedDims d, int l0, int l1, int n_samples_total, int Tn,
                                                         EdgeArgs e, unsigned long long* stamps, int cap) {
     Stamps st{stamps, cap, 0};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr LdsMap Lb = lds_map(KS);
+    static_assert(CORE == 0 || (SPW == 1 && PX == 0), "long-sequence instance");
+    constexpr LdsMap Lb = lds_map(KS, false, CORE == 1 ? NTA : kNTT);
     constexpr LdsMapX3 X = lds_map_x3(KS, NTA);
     constexpr LdsMap L = PX ? LdsMap{0, X.u, X.red, X.tab, X.total} : Lb;
     const int lane = threadIdx.x & 63;
@@ -2349,7 +2842,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     const int n = lane & 15, g = lane >> 4;
     constexpr int NTLa = NTL < NTA ? NTL : NTA;
     // the latency instances are bound by the L2 -> CU weight stream: more FC1 weight fragments in flight per wave
-    constexpr int PF1 = NTA < kNTT ? BESO_LAT_PF1 : kFc1PF;
+    constexpr int PF1 = (NTA < kNTT && CORE == 0) ? BESO_LAT_PF1 : kFc1PF;
     const int s0 = blockIdx.x * SPW;
     const int n_samples = min(SPW, n_samples_total - s0);
     const int m0 = s0 * Tn, m_end = m0 + n_samples * Tn;
@@ -2380,7 +2873,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.1f * n, 0.2f, 0.3f * g, 0.4f};
         }
-    } else if (e.fuse_embed) embed_tile<RPW, PX>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, st);
+    } else if (CORE == 0 && e.fuse_embed) embed_tile<RPW, PX>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, st);
     else load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 43);
     // The last layer (when this launch contains it and the action tokens of the tile fit NTL token tiles) runs its
@@ -2422,7 +2915,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         layernorm_to_lds<RPW, KS, kWaves, true, NTA>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                           (const float*)(lw + d.o_bproj), st);
         stamp(st, 7);
-        attn_phase<RPW, KS, HG, NTA, NTA>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
+        attn_phase<RPW, KS, HG, NTA, NTA, CORE>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
                                 (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
                                 lane, tb, qE, qO, st);
         stamp(st, 3);
@@ -2442,7 +2935,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         layernorm_to_lds<RPW, KS, kWaves, true, NTA>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                           (const float*)(lw + d.o_bproj), st);
         stamp(st, 7);
-        attn_phase<RPW, KS, HG, NTLa, NTA>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
+        attn_phase<RPW, KS, HG, NTLa, NTA, CORE>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
                                      (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
                                      lane, tb, qE, qO, st);
         stamp(st, 3);
@@ -2456,7 +2949,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     }
     }
     stamp(st, 4);
-    if (e.fuse_head) {
+    if (CORE == 0 && e.fuse_head) {
         // (peel: the action tokens are the first n_samples * t slots, i.e. inside the first NTLa token tiles)
         if (peel && NTLa < kNTT) head_tile<RPW, NTLa>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
         else head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
@@ -2568,12 +3061,27 @@ hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, 
     return hipGetLastError();
 }
 
+// The long-sequence instance: one sample (Tn <= 16 NT tokens) per workgroup, layers only (x in, x out).
+template <int RPW, int KS, int NT>
+hipError_t launch_layers_long(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
+                              const EdgeArgs& edge, hipStream_t s) {
+    constexpr LdsMap L = lds_map(KS, false, NT);
+    static_assert(L.total <= 160 * 1024, "LDS of the long-sequence instance");
+    static bool attr = false;
+    hipError_t e = ensure_lds(layers_kernel<RPW, KS, 1, NT, 1, NT, 0, 1>, L.total, &attr);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((layers_kernel<RPW, KS, 1, NT, 1, NT, 0, 1>), dim3(n_samples), dim3(512), L.total, s, x, lw0, d, l0, l1,
+                       n_samples, Tn, edge, g_stamps, g_stamps_cap);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
 static bool x3_shape(const FusedDims& d) {
     // BF16X3 exists as an instance of layers_kernel only (the shipped shapes with the fused attention phase)
-    return d.attn && ((d.RPW == 3 && d.KS == 12 && d.HG == 1) || (d.RPW == 2 && d.KS == 8 && d.HG == 3));
+    return d.attn && !d.seq1 && ((d.RPW == 3 && d.KS == 12 && d.HG == 1) || (d.RPW == 2 && d.KS == 8 && d.HG == 3));
 }
 
 size_t fused_packed_bytes(const Layout& lay, int precision) {
@@ -2706,7 +3214,9 @@ int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     if (precision == BESO_PREC_BF16X3) return whole ? 2 : 0;     // BF16X3 is an instance of layers_kernel and nothing else
     if (g_level_max < 0) g_level_max = getenv("BESO_FUSED_LEVEL_MAX") ? atoi(getenv("BESO_FUSED_LEVEL_MAX")) : 2;   // kernel experiments
     if (g_level_max < 2) return g_level_max;
-    return whole ? 2 : 1;
+    // long sequences: all layers in one launch, a sample per workgroup (the edges stay outside: no classifier-free pairs)
+    const bool whole_long = d.seq1 && a.T <= 16 * kLongNT && a.vbatch == a.batch;
+    return (whole || whole_long) ? 2 : 1;
 }
 
 void fused_set_level_max(int n) { g_level_max = n < 0 ? 2 : n; }
@@ -2785,12 +3295,12 @@ int fused_train_pack(const Layout& lay, const float* const* p, char* img, hipStr
     int blocks = 0;
     const int D = lay.D, rt1 = d.NCH * kChunkTiles, rt2 = d.RPW * kWaves;
     auto mat = [&](const float* src, uint32_t dst, int rows, int cols, int rt, int kt, int grp) {
-        t.seg[t.n] = TrainPackSeg{src, dst, rows, cols, rt, kt, grp, blocks};
+        t.seg[t.n] = TrainPackSeg{src, dst, rows, cols, rt, kt, grp, blocks, 0};
         blocks += (rt * kt * 512 + 256 * 16 - 1) / (256 * 16);
         ++t.n;
     };
     auto vec = [&](const float* src, uint32_t dst, int n, int n_pad) {
-        t.seg[t.n] = TrainPackSeg{src, dst, n, n_pad, 0, 0, 0, blocks};
+        t.seg[t.n] = TrainPackSeg{src, dst, n, n_pad, 0, 0, 0, blocks, 0};
         blocks += 1;
         ++t.n;
     };
@@ -2848,8 +3358,91 @@ int fused_train_tail(const Layout& lay, const char* img, int layer, int M, const
     return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
+// ---- training backward through the mirrored tail block -------------------------------------------------------------
+size_t fused_train_bwd_image_bytes(const Layout& lay) {
+    FusedDims d;
+    if (!train_tail_dims(lay, &d)) return 0;
+    return (size_t)train_bwd_img(d).layer_bytes * lay.L;
+}
+
+// Transposed weights of layers [0, L) in fragment order + LayerNorm gammas into img (one launch).
+int fused_train_bwd_pack(const Layout& lay, const float* const* p, char* img, hipStream_t s) {
+    FusedDims d;
+    if (!train_tail_dims(lay, &d)) return BESO_ERR_UNSUPPORTED;
+    const TrainBwdImg bi = train_bwd_img(d);
+    if (lay.L * 8 > kTrainPackSegs) return BESO_ERR_UNSUPPORTED;
+    TrainPackTable t;
+    t.n = 0;
+    int blocks = 0;
+    const int D = lay.D, rt1 = d.NCH * kChunkTiles, rt2 = d.RPW * kWaves;
+    auto matT = [&](const float* src, uint32_t dst, int rows, int cols, int rt, int kt, int grp) {   // the matrix is src^T: [rows][cols]
+        t.seg[t.n] = TrainPackSeg{src, dst, rows, cols, rt, kt, grp, blocks, 1};
+        blocks += (rt * kt * 512 + 256 * 16 - 1) / (256 * 16);
+        ++t.n;
+    };
+    auto vec = [&](const float* src, uint32_t dst, int n, int n_pad) {
+        t.seg[t.n] = TrainPackSeg{src, dst, n, n_pad, 0, 0, 0, blocks, 0};
+        blocks += 1;
+        ++t.n;
+    };
+    for (int l = 0; l < lay.L; ++l) {
+        const float* const* q = p + 3 + 16 * l;        // (order as in fused_train_pack)
+        const uint32_t base = (uint32_t)l * bi.layer_bytes;
+        const float* w3[3] = {q[6], q[4], q[8]};       // query, key, value
+        for (int part = 0; part < 3; ++part) matT(w3[part], base + bi.o_wqkvT + (uint32_t)part * bi.part_bytes, D, D, rt2, d.KS, rt2);
+        matT(q[14], base + bi.o_w2T, 4 * D, D, rt1, d.KS, kChunkTiles);      // fc2.weight [D][4D] -> W2^T [4D][D]
+        matT(q[12], base + bi.o_w1T, D, 4 * D, rt2, d.KS2p, rt2);            // fc1.weight [4D][D] -> W1^T [D][4D]
+        matT(q[10], base + bi.o_wprojT, D, D, rt2, d.KS, rt2);
+        vec(q[0], base + bi.o_ln1w, D, rt2 * 16);
+        vec(q[2], base + bi.o_ln2w, D, rt2 * 16);
+    }
+    t.blocks = blocks;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(train_pack_kernel, dim3(blocks), dim3(256), 0, s, t, img);
+    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+int fused_train_bwd_tiles(int M) { return (M + kMT - 1) / kMT; }
+
+// Front half of `layer` (>= 1) and back half of layer - 1 on M token rows (see train_bwd_tail_kernel).
+int fused_train_bwd_tail(const Layout& lay, const char* img, int layer, int M, const void* dqkv, const float* x_in,
+                         const float* st1, float* gres, void* dyo, const void* h, void* dh, float* db1, const float* x_mid,
+                         const float* st2, void* dym, void* dy, float* part1, float* part2, hipStream_t s) {
+    FusedDims d;
+    if (!train_tail_dims(lay, &d) || layer < 1) return BESO_ERR_UNSUPPORTED;
+    const TrainBwdImg bi = train_bwd_img(d);
+    const char* lw = img + (size_t)layer * bi.layer_bytes;
+    const char* lw_prev = lw - bi.layer_bytes;
+    TrainBwdArgs a{(const uint16_t*)dqkv, x_in, st1, gres, (uint16_t*)dyo, (const uint16_t*)h, (uint16_t*)dh, db1, x_mid, st2,
+                   (uint16_t*)dym, (uint16_t*)dy, part1, part2};
+    const dim3 grid((M + kMT - 1) / kMT), block(512);
+    hipError_t e;
+    (void)hipGetLastError();
+    if (d.RPW == 3) {
+        constexpr int lds_bytes = 2 * kNTT * 12 * 1024 + 2 * kWaves * kMT * 4;
+        static bool attr = false;
+        e = ensure_lds(train_bwd_tail_kernel<3, 12>, lds_bytes, &attr);
+        if (e != hipSuccess) return BESO_ERR_HIP;
+        hipLaunchKernelGGL((train_bwd_tail_kernel<3, 12>), grid, block, lds_bytes, s, lw, lw_prev, d, bi, M, a, g_stamps, g_stamps_cap);
+    } else {
+        constexpr int lds_bytes = 2 * kNTT * 8 * 1024 + 2 * kWaves * kMT * 4;
+        static bool attr = false;
+        e = ensure_lds(train_bwd_tail_kernel<2, 8>, lds_bytes, &attr);
+        if (e != hipSuccess) return BESO_ERR_HIP;
+        hipLaunchKernelGGL((train_bwd_tail_kernel<2, 8>), grid, block, lds_bytes, s, lw, lw_prev, d, bi, M, a, g_stamps, g_stamps_cap);
+    }
+    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
 // Whole network (embed -> all layers -> head) or layers only.  Returns in *fused_edges whether the token
 // embedding / action head ran inside the kernel (bit 0 / bit 1).
+// which network edges fused_layers runs inside the kernel (bit 0: embedding, bit 1: head); the caller runs the others
+int fused_layer_edges(const Layout& lay) {
+    FusedDims d;
+    if (!fused_dims(lay, &d) || !d.attn || d.seq1) return 0;
+    return 1 | (d.head_fused ? 2 : 0);
+}
+
 int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, int precision,
                  hipStream_t s) {
     FusedDims d;
@@ -2861,8 +3454,8 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     e.two = a.vbatch > a.batch ? 1 : 0;
     e.uncond_all = (!e.two && a.uncond_from == 0) ? 1 : 0;
     e.cond_lambda = a.cond_lambda; e.sigma_data = a.sigma_data;
-    e.fuse_embed = 1;
-    e.fuse_head = d.head_fused;
+    e.fuse_embed = d.seq1 ? 0 : 1;
+    e.fuse_head = d.seq1 ? 0 : d.head_fused;
     // with a classifier-free pair the virtual samples are interleaved (2b, 2b+1) so that both halves of a
     // pair live in one workgroup; that ordering only exists inside the kernel, so the head must be fused too
     if (e.two && !e.fuse_head) return BESO_ERR_UNSUPPORTED;
@@ -2870,6 +3463,7 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     hipError_t err;
     if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1, 2>(x, base, d, 0, lay.L, a.vbatch, a.T, e, precision, s);    // kitchen: 8 x 4 action tokens
     else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3, 4>(x, base, d, 0, lay.L, a.vbatch, a.T, e, precision, s);   // block-push: 8 x 5
+    else if (d.seq1 && precision == BESO_PREC_BF16) err = launch_layers_long<4, 16, kLongNT>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);   // long horizon: 1 x 67 tokens
     else return BESO_ERR_UNSUPPORTED;
     return err == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }

@@ -14,6 +14,8 @@ int    train_loss_grad(const beso_config* c, const float* const* params, int n_p
                        hipError_t* err, int* err_line);
 int    train_goal_mask(float* mask, size_t n, float goal_drop, uint32_t seed, hipStream_t s, hipError_t* err, int* err_line);
 void   train_set_tail_forward(int on);
+void   train_set_tail_backward(int on);
+void   train_set_wgrad_side(int on);
 int    train_early_layer(const beso_config* c);
 void   train_early_range(const beso_config* c, size_t* begin, size_t* end);
 int    train_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,

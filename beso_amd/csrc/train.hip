@@ -752,13 +752,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // sums the block partials of every LayerNorm backward of the step: call z -> gamma / beta gradient and the bias
 // gradient of the linear layer that consumed its output (assigned: each destination has exactly one source)
 struct LnRedCall { float* dgamma; float* dbeta; float* dbias; };
-struct LnRedTable { LnRedCall c[2 * kMaxLayers + 1]; };
+struct LnRedTable { LnRedCall c[2 * kMaxLayers + 1]; int nb[2 * kMaxLayers + 1]; };    // nb: block partials call z wrote (<= nblk, the slab stride)
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, LnRedTable t, int nblk, int D,
                                                         int call0) {
     __shared__ float red[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, which = blockIdx.y, call = blockIdx.z + call0;
     const int c = blockIdx.x * 64 + cx;
     const float* src = part + ((size_t)call * nblk * 3 + which) * D;
+    nblk = t.nb[call];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;          // four loads in flight per thread
     if (c < D) {
         int b = ry;
@@ -1196,6 +1197,7 @@ struct TrainWs {
     size_t dx, dx0b, dxn, dy, ln_part;
     size_t ya, xa, dxa, dya;                                        // compact action rows of the last layer
     size_t fimg;                                                    // per-step fragment image of the weights (tail-block forward)
+    size_t bimg;                                                    // ... of the transposed weights (tail-block backward)
     TrainLayerWs layer[kMaxLayers];
     size_t total;
 };
@@ -1236,7 +1238,9 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
     w->ln_part = carve_t(cur, f * (size_t)(2 * c->n_layers + 1) * ((M + 15) / 16) * 3 * D);     // LayerNorm backward block partials
     {
         Layout lay;
-        w->fimg = carve_t(cur, (precision == BESO_PREC_BF16 && make_layout(c, BESO_PREC_BF16, &lay)) ? fused_train_image_bytes(lay) : 0);
+        const bool img = precision == BESO_PREC_BF16 && make_layout(c, BESO_PREC_BF16, &lay);
+        w->fimg = carve_t(cur, img ? fused_train_image_bytes(lay) : 0);
+        w->bimg = carve_t(cur, img ? fused_train_bwd_image_bytes(lay) : 0);
     }
     for (int l = 0; l < c->n_layers; ++l) {
         TrainLayerWs& y = w->layer[l];
@@ -1316,6 +1320,17 @@ static int g_tail_forward = 1;
 constexpr int kTailMinRows = 40000;
 static bool tail_forward_enabled(int rows) { return g_tail_forward == 2 || (g_tail_forward == 1 && rows >= kTailMinRows); }
 void train_set_tail_forward(int on) { g_tail_forward = on; }
+// The same for the chain of data gradients (fused.hip: train_bwd_tail_kernel): 0 (default) never, 1 where the shape has the
+// kernel.  Measured SLOWER than the eight per-op launches it replaces (209 us vs 164 us + launch gaps per layer at 1024
+// kitchen samples): off unless asked for.
+static int g_tail_backward = 0;
+void train_set_tail_backward(int on) { g_tail_backward = on; }
+// Weight gradients on a side stream: the grouped weight-gradient launch of a layer is independent of the chain of data
+// gradients of the layers in front of it and can run under it on a second stream.  0 (default): one grouped launch behind
+// the chain on the main stream -- the concurrent form measures SLOWER (3.63 vs 3.39 ms per 1024-sample kitchen step,
+// 16.9 vs 16.5 ms per 8192: the two streams evict each other's operands from L2 / MALL).
+static int g_wgrad_side = 0;
+void train_set_wgrad_side(int on) { g_wgrad_side = on; }
 
 #define TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { *err = _e; *err_line = __LINE__; return BESO_ERR_HIP; } } while (0)
 
@@ -1512,6 +1527,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     auto ln_bwd = [&](const float* x, size_t st, const float* gamma, const float* dres_in, float* dres_out, E* dxb, int rows,
                       float* dgam, float* dbet, float* dbias, float p_site, uint32_t site, int skip_mod = 0) -> hipError_t {
         float* part = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
+        lrt.nb[ln_calls] = lnb_grid;
         lrt.c[ln_calls++] = LnRedCall{dgam, dbet, dbias};
 #define LNB(NV)                                                                                                     \
         hipLaunchKernelGGL((ln_bwd_kernel<E, NV>), dim3(lnb_grid), dim3(256), 0, s, (const float*)F(w.dxn), x,                \
@@ -1526,11 +1542,36 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     GTable gt;
     gt.n = 0;
     int g_tiles = 0;
+    static thread_local hipStream_t side = nullptr;
+    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    const bool use_side = g_wgrad_side != 0;
+    if (use_side && !side) {
+        TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    bool side_busy = false;
+    // launches the collected weight gradients: behind everything issued on `s` so far, on the side stream (or on `s`)
     auto flush_group = [&]() -> hipError_t {
         if (gt.n == 0) return hipSuccess;
-        hipLaunchKernelGGL(tgemm_wgrad_group_kernel<E>, dim3(g_tiles), dim3(kGT), 0, s, gt);
+        hipStream_t ws_s = s;
+        if (use_side) {
+            hipError_t e = hipEventRecord(ev_fork, s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
+            if (e != hipSuccess) return e;
+            ws_s = side;
+            side_busy = true;
+        }
+        hipLaunchKernelGGL(tgemm_wgrad_group_kernel<E>, dim3(g_tiles), dim3(kGT), 0, ws_s, gt);
         gt.n = 0; g_tiles = 0;
         return hipGetLastError();
+    };
+    // orders `to` behind the weight gradients issued so far
+    auto join_side = [&](hipStream_t to) -> hipError_t {
+        if (!side_busy) return hipSuccess;
+        hipError_t e = hipEventRecord(ev_join, side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(to, ev_join, 0);
+        return e;
     };
     auto wgrad = [&](const E* A, int lda, int Mo, const E* B, int ldb, int No, int rows, float* out) -> hipError_t {
         if (gt.n == kMaxGroup) { hipError_t e = flush_group(); if (e != hipSuccess) return e; }
@@ -1554,24 +1595,40 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     }
     TRY(ln_bwd(x_last, w.stf, lnfw.p, nullptr, F(w.dxa), P(w.layer[L - 1].dyo), Ma, lnfw.g, lnfb.g, lp[L - 1].f2b.g, resid_p,
                (uint32_t)(4 * (L - 1) + 2)));
+    // bf16, no dropout on the proj / MLP outputs, a shape with the tile kernels: between two attention backwards the whole
+    // chain of data gradients (q/k/v of layer l, LayerNorm-1, FC2 (+GELU'), FC1, LayerNorm-2, proj of layer l-1) is ONE
+    // launch (fused.hip: train_bwd_tail_kernel) writing the same kept gradients in the same formats.  The last layer's
+    // back half (compact action rows) and layer 0's front half (embedding dropout) stay per-op.
+    const bool use_btail = sizeof(E) == 2 && resid_p == 0.f && L >= 2 && L * 8 <= 96 && g_tail_backward != 0 &&
+                           make_layout(c, BESO_PREC_BF16, &flay) && fused_train_supported(flay) &&
+                           fused_train_bwd_image_bytes(flay) > 0 && fused_train_bwd_tiles(M) <= lnb_grid;
+    if (use_btail) {
+        const int pst = fused_train_bwd_pack(flay, p, ws + w.bimg, s);
+        if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
+    }
     for (int l = L - 1; l >= 0; --l) {
         const TrainLayerWs& y = w.layer[l];
         const float* x_in = l == 0 ? F(w.x0) : F(w.layer[l - 1].x_out);
         const bool last = l == L - 1;
         const int rows = last ? Ma : M;
         float* dres = last ? F(w.dxa) : F(w.dx);          // residual gradient of this layer's second half
+        const bool back_fused = use_btail && !last;       // (done by the launch of layer l + 1)
         // FC2: dW2 = dyo^T g, dh = (dyo W2) * GELU'(h)
         TRY(wgrad(P(y.dyo), D, D, P(y.g), D4, D4, rows, lp[l].f2w.g));
-        TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), lp[l].f1b.g, D4}, s)));
+        if (!back_fused)
+            TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), lp[l].f1b.g, D4}, s)));
         // FC1: dW1 = dh^T xn2, db1, dxn2 = dh W1
         TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, rows, lp[l].f1w.g));
-        TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, rows, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
-        TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, dres, dres, P(y.dym), rows, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
-                   (uint32_t)(4 * l + 1)));
+        if (!back_fused) {
+            TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, rows, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+            TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, dres, dres, P(y.dym), rows, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
+                       (uint32_t)(4 * l + 1)));
+        }
         // proj: dWp = dym^T y, dy = dym Wp
         TRY(wgrad(P(y.dym), D, D, last ? P(w.ya) : P(y.y), D, D, rows, lp[l].pw.g));
-        TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, rows, D, D, 1,
-                                   EpiStore<E>{nullptr, last ? P(w.dya) : P(w.dy), nullptr, D}, s)));
+        if (!back_fused)
+            TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, rows, D, D, 1,
+                                       EpiStore<E>{nullptr, last ? P(w.dya) : P(w.dy), nullptr, D}, s)));
         if (last) {
             // back to all token rows: dy and the residual gradient are zero off the action rows
             const size_t n4 = (size_t)M * (D / 4);
@@ -1594,16 +1651,32 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(wgrad(P(y.dqkv) + D, D3, D, P(y.xn1), D, D, M, lp[l].kw.g));
         TRY(wgrad(P(y.dqkv) + 2 * D, D3, D, P(y.xn1), D, D, M, lp[l].vw.g));
         TRY(colsum(P(y.dqkv), D3, D3, M, lp[l].qb.g, lp[l].kb.g, lp[l].vb.g, D));
-        TRY((tgemm<E, false, true>(P(y.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
         const bool first = l == 0;
-        TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, F(w.dx), F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo), M, lp[l].ln1w.g,
-                   lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? embed_p : resid_p,
-                   first ? kEmbedSite : (uint32_t)(4 * (l - 1) + 2), first ? T : 0));
+        if (use_btail && !first) {
+            const TrainLayerWs& pv = w.layer[l - 1];
+            const int nt = fused_train_bwd_tiles(M);
+            float* part1 = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
+            lrt.nb[ln_calls] = nt;
+            lrt.c[ln_calls++] = LnRedCall{lp[l].ln1w.g, lp[l].ln1b.g, lp[l - 1].f2b.g};
+            float* part2 = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
+            lrt.nb[ln_calls] = nt;
+            lrt.c[ln_calls++] = LnRedCall{lp[l - 1].ln2w.g, lp[l - 1].ln2b.g, lp[l - 1].pb.g};
+            const int bst = fused_train_bwd_tail(flay, ws + w.bimg, l, M, P(y.dqkv), x_in, F(y.st1), F(w.dx), P(pv.dyo), P(pv.h),
+                                                 P(pv.dh), lp[l - 1].f1b.g, F(pv.x_mid), F(pv.st2), P(pv.dym), P(w.dy), part1, part2, s);
+            if (bst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return bst; }
+        } else {
+            TRY((tgemm<E, false, true>(P(y.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+            TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, F(w.dx), F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo), M, lp[l].ln1w.g,
+                       lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? embed_p : resid_p,
+                       first ? kEmbedSite : (uint32_t)(4 * (l - 1) + 2), first ? T : 0));
+        }
+        if (use_side) TRY(flush_group());     // this layer's weight gradients run under the data gradients of the layers in front
         if (early_stream && l == train_early_layer(c) && l > 0) {
             // the gradients of layers l .. L-1 and ln_f are complete once their weight gradients and LayerNorm sums
             // have run: do those now and order `early_stream` behind this point (the C1 exchange of that range can
             // start under the backward of layers l-1 .. 0)
             TRY(flush_group());
+            TRY(join_side(early_stream));
             hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls), dim3(256), 0, s, (const float*)F(w.ln_part),
                                lrt, lnb_grid, D, 0);
             TRY(hipGetLastError());
@@ -1617,6 +1690,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // embeddings: dWcat[Ke][D] = Xemb^T dx0, routed to pos_emb / tok_emb / action_emb / sigma_emb after the launch
     TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dx0b), D, D, M, F(w.dw_cat)));
     TRY(flush_group());
+    TRY(join_side(s));
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls - ln_reduced), dim3(256), 0, s,
                        (const float*)F(w.ln_part), lrt, lnb_grid, D, ln_reduced);
     TRY(hipGetLastError());

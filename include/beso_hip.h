@@ -278,6 +278,12 @@ void beso_debug_set_fused_level_max(int n);
  * 1 (default): each layer's out-projection .. next layer's q/k/v as one tile kernel once there are enough token rows for
  * several rounds of workgroups (>= 40,000: that is where it measures faster), per-op below; 2: the tile kernel always. */
 void beso_debug_set_train_tail(int on);
+/* Development aid (tests, A/B timing), bf16 beso_loss_grad.  what = 0: as beso_debug_set_train_tail.  what = 1: the chain
+ * of data gradients between two attention backwards (q/k/v of a layer, both LayerNorm backwards, FC2 (+GELU'), FC1 and
+ * out-projection of the layer in front) as one tile kernel where the shape has it -- 0 (default) off: it measures slower
+ * than the per-op kernels; 1 on.  what = 2: the grouped weight-gradient launches -- 0 (default): one launch behind the
+ * chain on the caller's stream; 1: per layer on a side stream under the data gradients of the layers in front (slower). */
+void beso_debug_set_train_option(int what, int value);
 int  beso_profile_read(double* total_ms, int* launches);
 
 #ifdef __cplusplus

@@ -1053,6 +1053,39 @@ def test_training_forward_tail_block_equals_the_per_op_forward(cfg_name, B, t):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name,B,t", [("kitchen", 200, None), ("kitchen", 37, 2), ("block_push", 96, None)])
+def test_training_backward_tail_block_equals_the_per_op_backward(cfg_name, B, t):
+    """bf16 training step: between two attention backwards the chain of data gradients (q/k/v of a layer, LayerNorm-1
+    backward, FC2 (+GELU'), FC1, LayerNorm-2 backward and out-projection of the layer in front) runs as one tile kernel
+    (train_bwd_tail_kernel, fused.hip) instead of eight per-op launches.  Same kept gradients in the same formats, the
+    same GELU' and LayerNorm formulae; only the accumulation order inside the GEMMs / partial sums differs -- the loss is
+    the same (the forward is untouched) and every gradient tensor agrees to 2e-2 (norm-wise); ragged token counts
+    and a short window included."""
+    from beso_amd import _lib
+    lib = _lib.load()
+    cfg = O.CONFIGS[cfg_name]
+    m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), "bf16", attn_pdrop=0.3)
+    state, action, goal, noise, sigma = _train_inputs(cfg, B, seed=5)
+    if t is not None:
+        state, action, noise = state[:, :t].contiguous(), action[:, :t].contiguous(), noise[:, :t].contiguous()
+    step = m.hip_train_step(state, action, goal, noise, sigma)
+    out = {}
+    try:
+        for on in (1, 0):
+            lib.beso_debug_set_train_option(1, on)
+            loss, flat, views = step.run(state, action, goal, noise, sigma, seed=77, fresh_grads=True)
+            out[on] = (loss.item(), [v.clone() for v in views])
+    finally:
+        lib.beso_debug_set_train_option(1, 0)
+    errs = _grad_errors(out[1][1], out[0][1], 2e-3)
+    worst = max(range(len(errs)), key=lambda i: errs[i])
+    names = list(dict(m.named_parameters()))
+    print(f"[parity] tail-block vs per-op training backward {cfg_name} B={B}: worst gradient {errs[worst]:.2e} ({names[worst]})")
+    assert abs(out[1][0] - out[0][0]) < 1e-6 * abs(out[0][0])      # (the loss sum is atomics: its order is not fixed)
+    assert errs[worst] < 2e-2, [(names[i], round(float(e), 4)) for i, e in enumerate(errs) if e > 2e-2]
+
+
+@pytest.mark.gpu
 def test_agent_train_step_with_goal_drop_runs_the_hip_step():
     """BesoAgent.train_step on a model built with goal_drop = 0.1 and the kitchen dropouts (configs[2] / [3]): the HIP step
     serves it (no host-side masking, no torch-op network), losses are finite and decrease over a few steps."""

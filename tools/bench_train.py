@@ -26,6 +26,14 @@ def main():
         sys.argv.remove("--per-op-forward")
         from beso_amd import _lib
         _lib.load().beso_debug_set_train_tail(0)
+    if "--tail-backward" in sys.argv:           # A/B: the chain of data gradients through the tile kernel (default: per-op)
+        sys.argv.remove("--tail-backward")
+        from beso_amd import _lib
+        _lib.load().beso_debug_set_train_option(1, 1)
+    if "--wgrad-side-stream" in sys.argv:       # A/B: the weight gradients per layer on a side stream (default: one launch behind the chain)
+        sys.argv.remove("--wgrad-side-stream")
+        from beso_amd import _lib
+        _lib.load().beso_debug_set_train_option(2, 1)
     if "--tail-forward" in sys.argv:            # ... or through the tile kernel whatever the batch size
         sys.argv.remove("--tail-forward")
         from beso_amd import _lib
