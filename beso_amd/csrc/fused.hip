@@ -2842,7 +2842,10 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     const int n = lane & 15, g = lane >> 4;
     constexpr int NTLa = NTL < NTA ? NTL : NTA;
     // the latency instances are bound by the L2 -> CU weight stream: more FC1 weight fragments in flight per wave
-    constexpr int PF1 = (NTA < kNTT && CORE == 0) ? BESO_LAT_PF1 : kFc1PF;
+#ifndef BESO_LONG_PF1
+#define BESO_LONG_PF1 BESO_FC1_PF        // ... in the long-sequence instance
+#endif
+    constexpr int PF1 = CORE == 1 ? BESO_LONG_PF1 : (NTA < kNTT ? BESO_LAT_PF1 : kFc1PF);
     const int s0 = blockIdx.x * SPW;
     const int n_samples = min(SPW, n_samples_total - s0);
     const int m0 = s0 * Tn, m_end = m0 + n_samples * Tn;

@@ -213,6 +213,59 @@ def test_fused_bf16_kernel_against_the_per_op_bf16_kernels(cfg_name):
         assert e_fp < 2.0 * max(e_f, e_p)
 
 
+@pytest.mark.parametrize("B,t", [(1, 32), (3, 32), (37, 16), (5, 1), (2, 31)])
+def test_long_sequence_layers_kernel_against_block_kernels_and_oracle(B, t):
+    """Long-horizon shape (D = 512, up to 67 tokens: BASELINE config 5), bf16: all layers as ONE launch -- a sample per
+    workgroup in five token tiles, attention core with one query tile per wave (layers_kernel, CORE = 1) -- against the
+    two-launches-per-layer form of the same library (attention kernel + tail block) and against the oracle, for full, short
+    and odd windows (T = 67, 35, 5, 65 tokens) and batch sizes that leave workgroups empty-handed nowhere (one sample
+    each).  Launch sites asserted: 1 fused launch at level 2, one tail block per layer at level 1.  Bounds as for the
+    kitchen / block-push kernels: no less accurate than the block form (x1.5), and within twice the larger error of it."""
+    from beso_amd import _lib
+    lib = _lib.load()
+    cfg = O.CONFIGS["long_horizon"]
+    wts = O.make_weights(cfg, seed=3, std=0.02)
+    m = make_module(cfg, wts, "bf16")
+    s_np, g_np, a_np = O.make_inputs(cfg, B, seed=9 + t, t=t)
+    sg_np = np.linspace(0.05, 1.0, B).astype(np.float32)
+    s, a, g, sg = G(s_np), G(a_np), G(g_np), G(sg_np)
+    ref = O.denoise(wts, cfg, s_np, a_np, g_np, sg_np)
+    outs = {}
+    try:
+        with torch.no_grad():
+            for lvl in (2, 1):
+                lib.beso_debug_set_fused_level_max(lvl)
+                n = count_fused_launches(lambda: outs.__setitem__(lvl, m(s, a, g, sg).cpu().numpy()))
+                assert n == (1 if lvl == 2 else cfg.n_layers), (lvl, n)
+    finally:
+        lib.beso_debug_set_fused_level_max(2)
+    e_f, e_p, e_fp = rel_err(outs[2], ref), rel_err(outs[1], ref), rel_err(outs[2], outs[1])
+    print(f"[parity] long_horizon B={B} t={t}: one-launch-vs-oracle {e_f:.3e} block-kernels-vs-oracle {e_p:.3e} one-launch-vs-blocks {e_fp:.3e}")
+    assert e_f < 4e-3 and e_f < 1.5 * e_p + 1e-4
+    assert e_fp < 2.0 * max(e_f, e_p)
+
+
+def test_long_sequence_classifier_free_pairs_take_the_block_kernels():
+    """The one-launch long-sequence instance carries no classifier-free pairs (its edges are outside the kernel): a
+    conditional-lambda forward of that shape runs the block kernels (one tail block per layer) and agrees with the oracle's
+    classifier-free combination (classifier_free_sampler.py:35-49)."""
+    from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
+    cfg = O.CONFIGS["long_horizon"]
+    wts = O.make_weights(cfg, seed=4, std=0.02)
+    m = make_module(cfg, wts, "bf16")
+    s_np, g_np, a_np = O.make_inputs(cfg, 3, seed=2)
+    sg_np = np.array([0.2, 0.5, 0.9], np.float32)
+    lam = 1.5
+    model = ClassifierFreeSampleModel(m, lam)
+    out = {}
+    with torch.no_grad():
+        n = count_fused_launches(lambda: out.__setitem__(0, model(G(s_np), G(a_np), G(g_np), G(sg_np)).cpu().numpy()))
+    assert n == cfg.n_layers
+    err = rel_err(out[0], O.denoise_cfg(wts, cfg, s_np, a_np, g_np, sg_np, lam))
+    print(f"[parity] long_horizon classifier-free lambda={lam}: {err:.3e}")
+    assert err < 1e-2
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_fused_sampler_loops_vs_reference_vectors(precision):
     """beso_sample (ddim / euler / heun as one enqueue) against the reference's sampler outputs."""

@@ -22,7 +22,7 @@ NAMES = {40: "emb_prologue", 41: "emb_loads_issued", 42: "emb_bias", 43: "emb_mf
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     dev = "cuda:0"
-    cfg = O.SHAPES["kitchen"]
+    cfg = O.SHAPES[sys.argv[2] if len(sys.argv) > 2 else "kitchen"]
     model = build_model(cfg, O.make_weights(cfg, seed=0, std=0.02), "bf16", dev)
     s, g, a = (torch.from_numpy(v).to(dev) for v in O.make_inputs(cfg, B, seed=1))
     sig = torch.full((B,), 0.3, device=dev)
