@@ -916,11 +916,13 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
 // score_gpts.py:344-354) -- can run them on the first two token tiles only.  q/k/v rows in LDS stay in natural
 // order (sample-major, position order) for the attention core; the tables translate.
 struct SlotTabs {
-    unsigned char sp_of_slot[kMT];    // (sample << 4) | position of the token in a slot; 0xFF = empty slot
+    unsigned char sp_of_slot[kMT];    // (sample << PS) | position of the token in a slot; 0xFF = empty slot  (PS = 4; 7 in the
+                                      // one-sample-per-workgroup instance, whose positions run to 79)
     unsigned char row_of_slot[kMT];   // natural row (sample*Tn + position) of a slot; empty slots map to themselves
     unsigned char slot_of_row[kMT];   // inverse
 };
-__device__ __forceinline__ void build_slot_tabs(SlotTabs* tb, int n_samples, int Tn, int t_win, int G, bool actions_first) {
+__device__ __forceinline__ void build_slot_tabs(SlotTabs* tb, int n_samples, int Tn, int t_win, int G, bool actions_first,
+                                                int pshift = 4) {
     const int slot = threadIdx.x;
     if (slot < kMT) {
         const int nv = n_samples * Tn;
@@ -938,7 +940,7 @@ __device__ __forceinline__ void build_slot_tabs(SlotTabs* tb, int n_samples, int
                     p = r <= G ? r : G + 1 + 2 * (r - G - 1);
                 }
             } else { sl = slot / Tn; p = slot - sl * Tn; }
-            sp = (unsigned char)((sl << 4) | p);
+            sp = (unsigned char)((sl << pshift) | p);
             row = sl * Tn + p;
         }
         tb->sp_of_slot[slot] = sp;
@@ -977,7 +979,7 @@ __device__ __forceinline__ void sample_of(const EdgeArgs& e, int vb, int& b, boo
 // MFMAs per pair: 2^-16 relative, three orders below the bf16 rounding of the layers that follow) -- one k-step of
 // 32 inputs for tok_emb and a half k-step for action_emb instead of eleven k-steps of the 1/16-rate fp32 MFMA: the
 // embedding's matrix-pipe time drops from 6.3 k to 1.3 k cycles per wave.  PX = 1 (BF16X3) keeps the exact-fp32 form.
-template <int RPW, int PX = 1>
+template <int RPW, int PX = 1, int PS = 4>
 __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw, int s0,
                                            int n_samples, int Tn, int w, int lane, const SlotTabs* tb, Stamps& st) {
     asm volatile("" : "+v"(lane));
@@ -993,7 +995,7 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
     for (int t = 0; t < kNTT; ++t) {
         const int sp = tb->sp_of_slot[t * 16 + n];
         const bool live = sp != 0xFF;
-        const int sl = live ? sp >> 4 : 0, p = live ? sp & 15 : 0;
+        const int sl = live ? sp >> PS : 0, p = live ? sp & ((1 << PS) - 1) : 0;
         int b; bool un;
         sample_of(e, min(s0 + sl, last), b, un);
         sg[t] = e.sigma[b];
@@ -2826,7 +2828,7 @@ __global__ __launch_bounds__(512, 2) void train_bwd_tail_kernel(const char* __re
 // spreads over B/2 CUs and every phase runs a third of the MFMA / LDS / VALU work -- what is left is the L2 -> CU
 // stream of the weights.  Same phases, same per-sample arithmetic (results are bit-identical between the instances).
 // PX = 1: the BF16X3 instance (split-bf16 GEMMs, exact GELU, fp32 attention core): the parity mode of this kernel.
-// CORE = 1: the long-sequence instance (SPW = 1: a sample of up to 16 NTA tokens per workgroup; edges outside the kernel).
+// CORE = 1: the long-sequence instance (SPW = 1: a sample of up to 16 NTA tokens per workgroup, tokens in natural order).
 template <int RPW, int KS, int HG, int NTL, int SPW = kSPW, int NTA = kNTT, int PX = 0, int CORE = 0>
 __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, const char* __restrict__ lw0,
                                                         FusedDims d, int l0, int l1, int n_samples_total, int Tn,
@@ -2862,8 +2864,9 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     }
     // action tokens first whenever both network edges are inside the kernel (otherwise x travels in natural order)
     SlotTabs* tb = (SlotTabs*)(lds + L.tab);
-    const bool actions_first = e.fuse_embed && e.fuse_head;
-    build_slot_tabs(tb, n_samples, Tn, e.t, d.G, actions_first);
+    // (CORE = 1: natural order -- the long-sequence core addresses slots by position, and five tiles leave nothing to peel)
+    const bool actions_first = CORE == 0 && e.fuse_embed && e.fuse_head;
+    build_slot_tabs(tb, n_samples, Tn, e.t, d.G, actions_first, CORE == 1 ? 7 : 4);
     __syncthreads();
     Tile<RPW> T;
     stamp(st, 100);
@@ -2876,7 +2879,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.1f * n, 0.2f, 0.3f * g, 0.4f};
         }
-    } else if (CORE == 0 && e.fuse_embed) embed_tile<RPW, PX>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, st);
+    } else if (e.fuse_embed) embed_tile<RPW, PX, CORE == 1 ? 7 : 4>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, st);
     else load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 43);
     // The last layer (when this launch contains it and the action tokens of the tile fit NTL token tiles) runs its
@@ -2952,9 +2955,10 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     }
     }
     stamp(st, 4);
-    if (CORE == 0 && e.fuse_head) {
+    if (e.fuse_head) {
         // (peel: the action tokens are the first n_samples * t slots, i.e. inside the first NTLa token tiles)
-        if (peel && NTLa < kNTT) head_tile<RPW, NTLa>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
+        if constexpr (CORE == 1) head_tile<RPW, NTA>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
+        else if (peel && NTLa < kNTT) head_tile<RPW, NTLa>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
         else head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
     }
     else store_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
@@ -3064,7 +3068,7 @@ hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, 
     return hipGetLastError();
 }
 
-// The long-sequence instance: one sample (Tn <= 16 NT tokens) per workgroup, layers only (x in, x out).
+// The long-sequence instance: one sample (Tn <= 16 NT tokens) per workgroup.
 template <int RPW, int KS, int NT>
 hipError_t launch_layers_long(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
                               const EdgeArgs& edge, hipStream_t s) {
@@ -3217,8 +3221,8 @@ int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     if (precision == BESO_PREC_BF16X3) return whole ? 2 : 0;     // BF16X3 is an instance of layers_kernel and nothing else
     if (g_level_max < 0) g_level_max = getenv("BESO_FUSED_LEVEL_MAX") ? atoi(getenv("BESO_FUSED_LEVEL_MAX")) : 2;   // kernel experiments
     if (g_level_max < 2) return g_level_max;
-    // long sequences: all layers in one launch, a sample per workgroup (the edges stay outside: no classifier-free pairs)
-    const bool whole_long = d.seq1 && a.T <= 16 * kLongNT && a.vbatch == a.batch;
+    // long sequences: the whole network in one launch, a sample per workgroup (so no classifier-free pairs, whose halves share one)
+    const bool whole_long = d.seq1 && a.T <= 16 * kLongNT && a.vbatch == a.batch && d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK;
     return (whole || whole_long) ? 2 : 1;
 }
 
@@ -3442,7 +3446,7 @@ int fused_train_bwd_tail(const Layout& lay, const char* img, int layer, int M, c
 // which network edges fused_layers runs inside the kernel (bit 0: embedding, bit 1: head); the caller runs the others
 int fused_layer_edges(const Layout& lay) {
     FusedDims d;
-    if (!fused_dims(lay, &d) || !d.attn || d.seq1) return 0;
+    if (!fused_dims(lay, &d) || !d.attn) return 0;
     return 1 | (d.head_fused ? 2 : 0);
 }
 
@@ -3457,8 +3461,8 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     e.two = a.vbatch > a.batch ? 1 : 0;
     e.uncond_all = (!e.two && a.uncond_from == 0) ? 1 : 0;
     e.cond_lambda = a.cond_lambda; e.sigma_data = a.sigma_data;
-    e.fuse_embed = d.seq1 ? 0 : 1;
-    e.fuse_head = d.seq1 ? 0 : d.head_fused;
+    e.fuse_embed = 1;
+    e.fuse_head = d.head_fused;
     // with a classifier-free pair the virtual samples are interleaved (2b, 2b+1) so that both halves of a
     // pair live in one workgroup; that ordering only exists inside the kernel, so the head must be fused too
     if (e.two && !e.fuse_head) return BESO_ERR_UNSUPPORTED;

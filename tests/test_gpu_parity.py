@@ -215,8 +215,8 @@ def test_fused_bf16_kernel_against_the_per_op_bf16_kernels(cfg_name):
 
 @pytest.mark.parametrize("B,t", [(1, 32), (3, 32), (37, 16), (5, 1), (2, 31)])
 def test_long_sequence_layers_kernel_against_block_kernels_and_oracle(B, t):
-    """Long-horizon shape (D = 512, up to 67 tokens: BASELINE config 5), bf16: all layers as ONE launch -- a sample per
-    workgroup in five token tiles, attention core with one query tile per wave (layers_kernel, CORE = 1) -- against the
+    """Long-horizon shape (D = 512, up to 67 tokens: BASELINE config 5), bf16: the whole network as ONE launch -- a sample
+    per workgroup in five token tiles, attention core with one query tile per wave (layers_kernel, CORE = 1) -- against the
     two-launches-per-layer form of the same library (attention kernel + tail block) and against the oracle, for full, short
     and odd windows (T = 67, 35, 5, 65 tokens) and batch sizes that leave workgroups empty-handed nowhere (one sample
     each).  Launch sites asserted: 1 fused launch at level 2, one tail block per layer at level 1.  Bounds as for the
@@ -246,7 +246,7 @@ def test_long_sequence_layers_kernel_against_block_kernels_and_oracle(B, t):
 
 
 def test_long_sequence_classifier_free_pairs_take_the_block_kernels():
-    """The one-launch long-sequence instance carries no classifier-free pairs (its edges are outside the kernel): a
+    """The one-launch long-sequence instance carries no classifier-free pairs (a pair would have to share a workgroup): a
     conditional-lambda forward of that shape runs the block kernels (one tail block per layer) and agrees with the oracle's
     classifier-free combination (classifier_free_sampler.py:35-49)."""
     from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
