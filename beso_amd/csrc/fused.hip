@@ -634,7 +634,8 @@ __host__ __device__ constexpr LdsMap lds_map(int KS, bool mlp_only = false, int 
     LdsMap m{};
     m.xnT = 0;
     m.u = NT * KS * 1024;                  // (NT < kNTT: instances that only ever touch the first NT token tiles)
-    m.red = m.u + (mlp_only ? kNTT * kKCc * 1024 : 59648);
+    // phase-local region; the long-sequence instance (NT = kLongNT) keeps q/k/v of two heads: 2 x 3 x 16 NT rows of 144 B
+    m.red = m.u + (mlp_only ? kNTT * kKCc * 1024 : (NT == kLongNT ? 2 * 3 * 16 * kLongNT * kQKVRow * 2 : 59648));
     m.tab = m.red + 2 * kWaves * kMT * 4;
     m.total = m.tab + 512;
     return m;
@@ -1817,6 +1818,140 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     __syncthreads();
 }
 
+// Attention phase of the long-sequence instance (one sample of up to 16 NT tokens per workgroup, tokens in natural
+// order; layers_kernel CORE = 1).  q/k/v of BOTH heads of a pair sit in LDS ([head][q | k | v][16 NT rows][kQKVRow]), so the
+// pair costs three barriers and its ten (head, query tile) cores run at once:
+//     QKV(A, B)  write(A, B) | bar | cores(A, B) | bar | proj(A), proj(B) | bar
+// wave (head = w & 1, query tile qt): S^T tiles [key tile kt][query tile qt] for kt <= qt on v_mfma_f32_16x16x32_bf16 (the
+// short core's operand roles and D layout: lane (i, g) holds keys 16 kt + 4 g + r of query 16 qt + i), ONE softmax over the
+// 4 (qt + 1) scores of a lane, Y^T accumulated over the key tiles on v_mfma_f32_16x16x16_bf16.  Work is 1 .. NT key tiles
+// per query tile; the eight waves take {4}, {4}, {3}, {3}, {2, 0}, {2, 0}, {1}, {1} (NT = 5: at most five tile units each).
+// The normalised Y^T of query tile qt goes out as the out-projection's B fragments INTO the q rows of that tile -- read by
+// this wave only, and already in its registers -- which is what lets two heads fit: 2 x 34.5 KiB + nothing for y.
+template <int RPW, int KS, int NT>
+__device__ __forceinline__ void attn_phase_long(Tile<RPW>& T, const u32x4* xnT, unsigned char* u, const u32x4* __restrict__ wqkv,
+                                                const float* __restrict__ bqkv, const u32x4* __restrict__ wproj, int H, int hd,
+                                                int Tn, int w, int lane, u32x4 (&qE)[3], u32x4 (&qO)[3], Stamps& st) {
+    static_assert(NT == 5, "the wave -> query tile table below");
+    asm volatile("" : "+v"(lane));
+    constexpr int kRows = 16 * NT, kHead = 3 * kRows * kQKVRow;        // bf16 elements of one head's q | k | v
+    constexpr int kYT = 16 * kQKVRow * 2 / 16;                        // u32x4 between the y fragments of two token tiles (= 16 q rows)
+    uint16_t* qkv = (uint16_t*)u;
+    const int wa = w & 3, hsel = w >> 2;                  // this wave's q/k/v rows: tiles 3wa..3wa+2 of head 2*pair + hsel
+    const float scale_log2e = 1.4426950408889634f * __builtin_amdgcn_rsqf((float)hd);
+    auto qkv_a = [&](int pair) { return wptr(wqkv + (size_t)(3 * w) * 64, lane).adv((size_t)pair * KS * 24); };
+    auto proj_a = [&](int h) { return wptr(wproj + (size_t)(w * RPW) * 64, lane).adv((size_t)(2 * h) * (kWaves * RPW)); };
+    int ln = lane;
+    auto core = [&](int head, int qt) {
+        const int n = ln & 15, g = ln >> 4;
+        uint16_t* hq = qkv + (size_t)head * kHead;
+        const uint16_t* qb = hq + ((size_t)16 * qt + n) * kQKVRow + 8 * g;
+        const u32x4 q0 = *(const u32x4*)qb, q1 = *(const u32x4*)(qb + 32);
+        float e[NT][4];
+        float m = -INFINITY;
+        const int query = 16 * qt + n;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt <= qt) {                                            // wave-uniform
+                const uint16_t* kb = hq + ((size_t)kRows + 16 * kt + n) * kQKVRow + 8 * g;
+                f32x4 sT = {0.f, 0.f, 0.f, 0.f};
+                sT = mfma_bf16(*(const u32x4*)kb, q0, sT);
+                sT = mfma_bf16(*(const u32x4*)(kb + 32), q1, sT);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * kt + 4 * g + r;
+                    e[kt][r] = (key <= query && key < Tn) ? sT[r] * scale_log2e : -INFINITY;
+                    m = fmaxf(m, e[kt][r]);
+                }
+            }
+        }
+        m = rows_allreduce<true>(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt <= qt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { e[kt][r] = __builtin_amdgcn_exp2f(e[kt][r] - m); sum += e[kt][r]; }
+            }
+        }
+        sum = rows_allreduce<false>(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        f32x4 y[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) y[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt <= qt) {
+                const uint2 pb = make_uint2(pack_bf16x2(e[kt][0], e[kt][1]), pack_bf16x2(e[kt][2], e[kt][3]));
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    // V^T fragment through the transpose read (v_frag's addressing on this phase's row count)
+                    const uint16_t* pv = hq + ((size_t)2 * kRows + 16 * kt + 4 * g + (n >> 2)) * kQKVRow + 16 * dt + 4 * (n & 3);
+                    const uint2 va = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pv)));
+                    y[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, va),
+                                                                      __builtin_bit_cast(s16x4, pb), y[dt], 0, 0, 0);
+                }
+            }
+        }
+        u32x4* yT = (u32x4*)(hq + (size_t)16 * qt * kQKVRow);          // the q rows of this query tile
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 yb;
+            yb[0] = pack_bf16x2(y[2 * kk][0] * inv, y[2 * kk][1] * inv);
+            yb[1] = pack_bf16x2(y[2 * kk][2] * inv, y[2 * kk][3] * inv);
+            yb[2] = pack_bf16x2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
+            yb[3] = pack_bf16x2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
+            yT[kk * 64 + ln] = yb;
+        }
+    };
+#pragma unroll 1
+    for (int pair = 0; pair < H / 2; ++pair) {
+        const int hA = 2 * pair, hB = hA + 1;
+        asm volatile("" : "+v"(ln));
+        const int n = ln & 15, g = ln >> 4;
+        stamp(st, 10);
+        u32x4 aE[RPW], aO[RPW];
+        f32x4 qa[3][NT];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x4 bv = *(const f32x4*)(bqkv + ((hA + hsel) * 12 + 3 * wa + i) * 16 + 4 * g);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) qa[i][t] = bv;
+        }
+        gemm_phase<3, NT, kt16(KS)>(qa, qE, qO, qkv_a(pair), 24, xnT + lane, KS * 64, 64, KS);
+        prefetch_a<RPW>(aE, aO, proj_a(hA), kWaves * RPW);
+        // q/k/v of this wave's head: row = token slot (natural order)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int rt = 3 * wa + i, part = rt >> 2, d0 = (rt & 3) * 16 + 4 * g;
+            uint16_t* dst = qkv + (size_t)hsel * kHead + (size_t)part * kRows * kQKVRow + d0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                *(uint2*)(dst + (size_t)(16 * t + n) * kQKVRow) =
+                    make_uint2(pack_bf16x2(qa[i][t][0], qa[i][t][1]), pack_bf16x2(qa[i][t][2], qa[i][t][3]));
+        }
+        stamp(st, 11);
+        __syncthreads();
+        stamp(st, 12);
+        if (!(BESO_ABL_MASK & 16)) {
+            const int head = w & 1, slot = w >> 1;                    // slot 0: tile 4; 1: tile 3; 2: tiles 2 and 0; 3: tile 1
+            core(head, slot == 0 ? 4 : slot == 1 ? 3 : slot == 2 ? 2 : 1);
+            if (slot == 2) core(head, 0);
+        }
+        if (pair + 1 < H / 2) prefetch_a<3>(qE, qO, qkv_a(pair + 1), 24);
+        stamp(st, 16);
+        __syncthreads();
+        stamp(st, 17);
+        gemm_phase<RPW, NT, false, kNTT>(T.acc, aE, aO, proj_a(hA), kWaves * RPW, (const u32x4*)qkv + lane, kYT, 64, 2);
+        prefetch_a<RPW>(aE, aO, proj_a(hB), kWaves * RPW);
+        gemm_phase<RPW, NT, false, kNTT>(T.acc, aE, aO, proj_a(hB), kWaves * RPW, (const u32x4*)(qkv + kHead) + lane, kYT, 64, 2);
+        stamp(st, 13);
+        __syncthreads();                     // the y fragments live in the q rows the next pair overwrites
+        stamp(st, 14);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BF16X3 instances of the two phases: same decomposition (wave = feature slice of the residual tile, weights as A
 // fragments from L2, activations as B fragments through LDS, accumulator -> operand chaining), split-bf16 GEMMs,
@@ -2844,6 +2979,9 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     const int n = lane & 15, g = lane >> 4;
     constexpr int NTLa = NTL < NTA ? NTL : NTA;
     // the latency instances are bound by the L2 -> CU weight stream: more FC1 weight fragments in flight per wave
+#ifndef BESO_LONG_PAIRED
+#define BESO_LONG_PAIRED 1               // long-sequence instance: both heads of a pair in LDS, their cores at once (0: A/B)
+#endif
 #ifndef BESO_LONG_PF1
 #define BESO_LONG_PF1 BESO_FC1_PF        // ... in the long-sequence instance
 #endif
@@ -2921,6 +3059,11 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         layernorm_to_lds<RPW, KS, kWaves, true, NTA>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                           (const float*)(lw + d.o_bproj), st);
         stamp(st, 7);
+        if constexpr (CORE == 1 && BESO_LONG_PAIRED)
+            attn_phase_long<RPW, KS, NTA>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
+                                          (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, w, lane,
+                                          qE, qO, st);
+        else
         attn_phase<RPW, KS, HG, NTA, NTA, CORE>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
                                 (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,
                                 lane, tb, qE, qO, st);
