@@ -475,6 +475,43 @@ def test_block_push_2048_heun50_cfg_bf16():
     assert e_x3 < 3e-4 and e_modes < 2e-2 and e_bf < 2e-2
 
 
+def test_long_horizon_256_euler100_bf16():
+    """BASELINE configs[4] at one GPU's share: long-horizon (D = 512, 67 tokens), B = 256, 100 Euler steps, bf16 -- every
+    one of the 100 forwards ONE launch of the long-sequence instance (a sample per workgroup), all enqueued by one
+    beso_sample call.  Checked: the launch count; sample slices against the same samples run alone (bit for bit: a sample is
+    its own workgroup, whatever the batch); the same run with the block kernels (two launches per layer) to 2e-2; four
+    samples against the oracle's Euler loop; finiteness."""
+    from beso_amd import _lib
+    from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+    lib = _lib.load()
+    cfg = O.CONFIGS["long_horizon"]
+    w = O.make_weights(cfg, seed=7, std=0.03)
+    m = make_module(cfg, w, "bf16")
+    B = 256
+    s_np, g_np, x_np = O.make_inputs(cfg, B, seed=3)
+    s, g, x = G(s_np), G(g_np), G(x_np)
+    sig = ks.get_sigmas_exponential(100, 0.05, 1.0)
+    outs = {}
+    try:
+        with torch.no_grad():
+            for lvl in (2, 1):
+                lib.beso_debug_set_fused_level_max(lvl)
+                n = count_fused_launches(lambda: outs.__setitem__(lvl, ks.sample_euler(m, s, x, g, sig, disable=True)))
+                assert n == (100 if lvl == 2 else 100 * cfg.n_layers), (lvl, n)
+                assert torch.isfinite(outs[lvl]).all()
+            lib.beso_debug_set_fused_level_max(2)
+            part = ks.sample_euler(m, s[100:103], x[100:103], g[100:103], sig, disable=True)
+            assert torch.equal(outs[2][100:103], part)
+    finally:
+        lib.beso_debug_set_fused_level_max(2)
+    idx = [0, 1, 127, 255]
+    ref = O.sample_euler(O.make_model(w, cfg), s_np[idx], x_np[idx], g_np[idx], sig.numpy())
+    e_forms = rel_err(outs[2].cpu().numpy(), outs[1].cpu().numpy())
+    e_or = rel_err(outs[2][idx].cpu().numpy(), ref)
+    print(f"[parity] long-horizon B=256 Euler-100: one launch vs block kernels {e_forms:.3e}; vs oracle (4 samples) {e_or:.3e}")
+    assert e_forms < 2e-2 and e_or < 2e-2
+
+
 def test_ragged_and_edge_shapes():
     """B = 1 rollouts, t < W warm-up windows, a batch that is not a multiple of any tile, shared goal."""
     cfg = O.KITCHEN
