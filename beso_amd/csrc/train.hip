@@ -1317,7 +1317,7 @@ size_t train_grad_floats(const beso_config* c) {
 // 8192 samples = 939 tiles 16.57 vs 17.41 ms per step; 1024 samples = 118 tiles 3.43 vs 3.39 ms -- at under one round both
 // forms are bound by a lone workgroup's latency).  0: never, 1: from kTailMinRows token rows on, 2: always (tests).
 static int g_tail_forward = 1;
-constexpr int kTailMinRows = 40000;
+constexpr int kTailMinRows = 16000;       // kitchen: 3.39 = 3.40 ms at 1024 samples (11 k rows), 4.99 vs 5.37 at 2048, 8.61 vs 8.96 at 4096
 static bool tail_forward_enabled(int rows) { return g_tail_forward == 2 || (g_tail_forward == 1 && rows >= kTailMinRows); }
 void train_set_tail_forward(int on) { g_tail_forward = on; }
 // The same for the chain of data gradients (fused.hip: train_bwd_tail_kernel): 0 (default) never, 1 where the shape has the

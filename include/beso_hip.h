@@ -276,7 +276,7 @@ void beso_debug_set_small_batch_max(int n);
 void beso_debug_set_fused_level_max(int n);
 /* Development aid (tests, A/B timing): how the bf16 beso_loss_grad runs its forward -- 0: per-op kernels for every layer;
  * 1 (default): each layer's out-projection .. next layer's q/k/v as one tile kernel once there are enough token rows for
- * several rounds of workgroups (>= 40,000: that is where it measures faster), per-op below; 2: the tile kernel always. */
+ * a round of workgroups (>= 16,000: that is where it measures faster), per-op below; 2: the tile kernel always. */
 void beso_debug_set_train_tail(int on);
 /* Development aid (tests, A/B timing), bf16 beso_loss_grad.  what = 0: as beso_debug_set_train_tail.  what = 1: the chain
  * of data gradients between two attention backwards (q/k/v of a layer, both LayerNorm backwards, FC2 (+GELU'), FC1 and
