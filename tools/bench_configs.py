@@ -4,7 +4,10 @@ GPU through the public sampler API:  python tools/bench_configs.py [--out profil
 
   config 1  kitchen,      B = 64,   10-step DDIM            (the reference's own CPU-runnable case)
   config 4  block-push,   B = 2048, 50-step Heun (99 NFE), classifier-free guidance lambda = 2 (198 forwards / sample)
-  config 5  long-horizon, B = 256 per GPU, 100-step Euler   (window 32, D = 512, T = 67; generic path)
+  config 5  long-horizon, B = 256 per GPU, 100-step Euler   (obs window 32, D = 512, H = 8, L = 6, G = 2: T = 1 + G + 64 = 67 tokens;
+            the whole network is one launch per forward, a sample per workgroup.  The reference interleaves one action token
+            per observation -- it has no action window apart from the obs window (score_gpts.py:330-331) -- so BASELINE's
+            "action_window=8" is read as "of the 32 predicted actions keep the last 8": all 32 are computed and counted)
 
 Reports wall time per sampler call, denoise-steps/s, NFE/s, sample*NFE/s and the achieved TFLOP/s
 (algorithmic FLOPs per forward per sample x forwards).  Synthetic inputs, seeded weight recipe, bf16.
