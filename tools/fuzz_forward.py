@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Development aid (GPU box): random (shape, batch, window, lambda) forwards through the one-launch kernels against the
 per-op / block-kernel form of the same library (beso_debug_set_fused_level_max) -- bf16, both carry their own rounding, so
-the bound is the test suite's: relative difference < 2e-2 of the output's max -- and, for small batches, against the
-oracle.   python tools/fuzz_forward.py [cases] [seed]"""
+the bound is the test suite's: relative difference < 2e-2 of the output's max (4e-2 under classifier-free guidance) -- and,
+for small batches, against the oracle.  (A miss is examined with the BF16X3 / fp32 modes of the same kernels: 1e-5 / 2e-6
+there means rounding, not a defect.)   python tools/fuzz_forward.py [cases] [seed]"""
 import os
 import sys
 
@@ -38,7 +39,7 @@ def main():
         t = int(rng.integers(1, cfg.obs_seq_len + 1))
         lam = float(rng.choice([1.0, 1.0, 2.0, 0.0]))
         s_np, g_np, a_np = O.make_inputs(cfg, B, seed=case, t=t)
-        sg_np = rng.uniform(0.02, 3.0, B).astype(np.float32)
+        sg_np = np.exp(rng.uniform(np.log(0.02), np.log(1.0), B)).astype(np.float32)       # the shipped sigma range, log-uniform
         model = m if lam == 1.0 else ClassifierFreeSampleModel(m, lam)
         outs = {}
         try:
@@ -52,7 +53,9 @@ def main():
         eo = -1.0
         if B <= 9:
             eo = T.rel_err(outs[2], O.denoise_cfg(w, cfg, s_np, a_np, g_np, sg_np, lam))
-        ok = np.isfinite(outs[2]).all() and e < 2e-2 and eo < 2e-2
+        # classifier-free pairs amplify both members' rounding by (1 + 2 lambda); a handful of outputs (B = 1) has no averaging
+        bound = 2e-2 * (1.0 if lam in (0.0, 1.0) else 2.0)
+        ok = np.isfinite(outs[2]).all() and e < bound and eo < bound
         key = name
         worst[key] = max(worst.get(key, 0.0), e)
         print(f"{case:3d} {name:13s} B={B:4d} t={t:2d} lam={lam}: fused-vs-per-op {e:.2e} vs-oracle {eo:.2e} {'ok' if ok else 'FAIL'}", flush=True)
