@@ -183,7 +183,7 @@ def measure_traffic(args, kernel_substr="layers_kernel"):
     tmp = tempfile.mkdtemp(prefix="beso_traffic_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", BESO_BENCH_TRAFFIC="0")
     child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", str(args.batch),
-             "--precision", args.precision, "--config", args.config, "--no-cpu-baseline", "--no-parity-line", "--settle-ms", "0"]
+             "--precision", args.precision, "--config", args.config, "--no-cpu-baseline", "--no-parity-line", "--no-other-configs", "--settle-ms", "0"]
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
@@ -371,7 +371,56 @@ def run_forward(args, world, rank, dev):
         result["parity_mode"] = parity
     if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only (the other ranks would idle at the barrier)
         result["cpu_baseline"] = cpu_baseline(cfg, w, B)
+    if world == 1 and not args.no_other_configs and args.config == "kitchen" and args.precision == "bf16":
+        result["other_configs"] = other_configs(args, dev)
     return result
+
+
+def other_configs(args, dev):
+    """The other BASELINE.json configurations, measured in the same run (N = 1 only, after the timed region of the headline)
+    through the public sampler API / BesoAgent.train_step, a few calls each -- so that the record of this command also carries
+    configs 0, 2, 3 and 4.  tools/bench_configs.py / tools/bench_train.py are the longer stand-alone forms."""
+    import copy
+    from beso_amd import synthetic as S
+    from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+    from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
+    out = []
+
+    def sampler_run(name, shape, B, sampler, n_steps, smin, smax, lam, reps):
+        cfg = S.SHAPES[shape]
+        model = build_model(cfg, S.make_weights(cfg, seed=0, std=0.02), "bf16", dev)
+        call = model if lam is None else ClassifierFreeSampleModel(model, lam)
+        s, g, a = (torch.from_numpy(v).to(dev) for v in S.make_inputs(cfg, B, seed=1))
+        x_t = torch.randn_like(a) * smax
+        sigmas = ks.get_sigmas_exponential(n_steps, smin, smax)
+        fn = {"ddim": ks.sample_ddim, "euler": ks.sample_euler, "heun": ks.sample_heun}[sampler]
+        nfe = n_steps if sampler != "heun" else 2 * n_steps - 1
+        per_nfe = 2 if (lam is not None and lam not in (0.0, 1.0)) else 1
+        with torch.no_grad():
+            fn(call, s, x_t, g, sigmas, disable=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                res = fn(call, s, x_t, g, sigmas, disable=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+        assert torch.isfinite(res).all()
+        flops = cfg.flops_per_sample() * B * nfe * per_nfe
+        out.append({"config": name, "batch": B, "sampler": sampler, "steps": n_steps, "nfe": nfe, "cond_lambda": lam, "dtype": "bf16",
+                    "calls_timed": reps, "ms_per_call": 1e3 * dt, "denoise_steps_per_s": n_steps / dt,
+                    "sample_nfe_per_s": B * nfe / dt, "tflops": flops / dt / 1e12, "frac_of_bf16_mfma_peak": flops / dt / 1e12 / PEAK_TFLOPS["bf16"]})
+
+    sampler_run("configs[0]: kitchen B=64 DDIM-10", "kitchen", 64, "ddim", 10, 0.005, 1.0, None, 20)
+    sampler_run("configs[3]: block-push B=2048 Heun-50 x CFG lambda=2", "block_push", 2048, "heun", 50, 0.05, 1.0, 2.0, 3)
+    sampler_run("configs[4]: long-horizon (D=512, 67 tokens) B=256 per GPU Euler-100", "long_horizon", 256, "euler", 100, 0.005, 1.0, None, 3)
+    targs = copy.copy(args)
+    targs.workload, targs.batch, targs.steps, targs.warmup, targs.settle_ms, targs.config = "train", 1024, 20, 3, 100.0, "kitchen"
+    tr = run_train(targs, 1, 0, dev)
+    out.append({"config": "configs[2] per-GPU share: kitchen BesoAgent.train_step, 1024 samples", "dtype": "bf16",
+                "steps_timed": targs.steps, "ms_per_step": tr["ms_per_step"], "samples_per_s": tr["samples_per_s"],
+                "tflops": tr["roofline"]["achieved"], "frac_of_bf16_mfma_peak": tr["roofline"]["frac"], "loss": tr["loss"]})
+    return out
+
 
 
 def run_train(args, world, rank, dev):
@@ -446,6 +495,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-line", action="store_true")
     ap.add_argument("--no-traffic", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs 0, 2, 3, 4 behind the headline")
     ap.add_argument("--site", default=None, help="launch site timed for the roofline object")
     ap.add_argument("--dry-run-backend", default=None, choices=["gloo"],
                     help="launcher self-test without GPUs: spawn the ranks, verify the group over this backend, print n_gpus")

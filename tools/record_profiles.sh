@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic"       # (bench.py runs its own PMC passes otherwise)
+BENCH="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --no-other-configs"       # (bench.py runs its own PMC passes otherwise)
 BENCHP="$BENCH --no-parity-line"                                                         # counter passes: the bf16 instance only
 cd /tmp
 rm -rf $OUT/prof_${TAG}_stats $OUT/prof_${TAG}_fetch $OUT/prof_${TAG}_write $OUT/prof_${TAG}_sq
