@@ -421,9 +421,11 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
         uint32_t bits; memcpy(&bits, &v, 4);
         return hipMemsetD32Async((hipDeviceptr_t)sig, (int)bits, (size_t)batch, s);
     };
+    // the sigma vector of an evaluation is written by the update launch in front of it (the first one by a fill): two
+    // dependent launches per evaluation, not three
+    HIP_TRY(fill_sigma(sigmas[0]));
     for (int i = 0; i + 1 < n_sigmas; ++i) {
         const float si = sigmas[i], sn = sigmas[i + 1];
-        HIP_TRY(fill_sigma(si));
         st = beso_denoise_fwd(cfg, packed, precision, state, x, goal, sig, den, batch, t, 0, cond_lambda, workspace,
                               workspace_bytes, stream);
         if (st != BESO_OK) return st;
@@ -432,18 +434,17 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
             const float tt = -logf(si), tn = -logf(sn);      // sn == 0 -> tn = +inf -> x = den exactly
             const float h = tn - tt;
             const float c0 = expf(-tn) / expf(-tt), c1 = expm1f(-h);
-            HIP_TRY(launch_sampler_step(BESO_STEP_DDIM, x, nullptr, x, nullptr, den, c0, c1, n, s));
+            HIP_TRY(launch_sampler_step(BESO_STEP_DDIM, x, nullptr, x, nullptr, den, c0, c1, n, s, sig, sn, batch));
         } else if (sampler == BESO_SAMPLER_EULER || sn == 0.f) {
             // gamma = 0: sigma_hat = sigma_i; d = (x - den)/sigma_hat; x += d*(sigma_next - sigma_hat)  (:205-210, :301-303)
-            HIP_TRY(launch_sampler_step(BESO_STEP_EULER, x, nullptr, x, nullptr, den, si, sn - si, n, s));
+            HIP_TRY(launch_sampler_step(BESO_STEP_EULER, x, nullptr, x, nullptr, den, si, sn - si, n, s, sig, sn, batch));
         } else {
             // Heun: predictor, second evaluation at sigma_{i+1}, trapezoid corrector (:304-310)
-            HIP_TRY(launch_sampler_step(BESO_STEP_HEUN_PREDICT, x2, d1, x, nullptr, den, si, sn - si, n, s));
-            HIP_TRY(fill_sigma(sn));
+            HIP_TRY(launch_sampler_step(BESO_STEP_HEUN_PREDICT, x2, d1, x, nullptr, den, si, sn - si, n, s, sig, sn, batch));
             st = beso_denoise_fwd(cfg, packed, precision, state, x2, goal, sig, den, batch, t, 0, cond_lambda,
                                   workspace, workspace_bytes, stream);
             if (st != BESO_OK) return st;
-            HIP_TRY(launch_sampler_step(BESO_STEP_HEUN_CORRECT, x, d1, x, x2, den, sn, sn - si, n, s));
+            HIP_TRY(launch_sampler_step(BESO_STEP_HEUN_CORRECT, x, d1, x, x2, den, sn, sn - si, n, s));     // (sig already holds sigma_{i+1})
         }
     }
     return BESO_OK;

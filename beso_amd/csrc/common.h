@@ -147,7 +147,8 @@ hipError_t launch_gemm(int precision, int epi, const void* A, int lda, const voi
                        const float* bias, void* out, int ldo,
                        int n_store, int M, int Np, int Kp, hipStream_t s);
 hipError_t launch_sampler_step(int mode, float* out, float* aux, const float* x, const float* x2, const float* den,
-                               float c0, float c1, size_t n, hipStream_t s);
+                               float c0, float c1, size_t n, hipStream_t s, float* sig_next = nullptr, float sigma_next = 0.f,
+                               int n_sig = 0);
 
 // profile hooks (api.hip)
 void profile_begin(int site, hipStream_t s);

@@ -339,9 +339,14 @@ hipError_t launch_head(const Layout& lay, const char* packed, const FwdArgs& a, 
 // -----------------------------------------------------------------------------------------------
 // K8: sampler update, in the reference's operation order (gc_sampling.py:205-210,296-310,921-923)
 // -----------------------------------------------------------------------------------------------
+// sig_next != nullptr: the launch also writes the sigma vector of the NEXT network evaluation (sig_next[0 .. n_sig) = sigma_next;
+// it would be a launch of its own between two dependent ones otherwise).
 __global__ void sampler_step_kernel(int mode, float* __restrict__ out, float* __restrict__ aux,
                                     const float* __restrict__ x, const float* __restrict__ x2,
-                                    const float* __restrict__ den, float c0, float c1, size_t n) {
+                                    const float* __restrict__ den, float c0, float c1, size_t n, float* __restrict__ sig_next,
+                                    float sigma_next, int n_sig) {
+    if (sig_next)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sig; i += gridDim.x * blockDim.x) sig_next[i] = sigma_next;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float xv = x[i], dv = den[i], r;
         if (mode == BESO_STEP_DDIM) {
@@ -364,12 +369,13 @@ __global__ void sampler_step_kernel(int mode, float* __restrict__ out, float* __
 }
 
 hipError_t launch_sampler_step(int mode, float* out, float* aux, const float* x, const float* x2, const float* den,
-                               float c0, float c1, size_t n, hipStream_t s) {
+                               float c0, float c1, size_t n, hipStream_t s, float* sig_next, float sigma_next, int n_sig) {
     (void)hipGetLastError();   // clear any stale error left by other runtime users in this thread
     int grid = (int)((n + 255) / 256);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(sampler_step_kernel, dim3(grid), dim3(256), 0, s, mode, out, aux, x, x2, den, c0, c1, n);
+    hipLaunchKernelGGL(sampler_step_kernel, dim3(grid), dim3(256), 0, s, mode, out, aux, x, x2, den, c0, c1, n, sig_next, sigma_next,
+                       n_sig);
     return hipGetLastError();
 }
 
