@@ -625,6 +625,12 @@ __device__ __forceinline__ void gemm_x3(f32x4 (&acc)[R][NTA], WPtr a, int a_ks, 
 // shared pieces of the kernels
 // ---------------------------------------------------------------------------------------------
 constexpr int kKCc = kChunkTiles / 2;      // FC2 k-steps per hidden chunk (= kKC below)
+#ifndef BESO_RED_PAD
+#define BESO_RED_PAD 4               // floats of padding per token in the LayerNorm statistics exchange (0: A/B)
+#endif
+// LayerNorm statistics exchange: per token kWaves (sum, sum of squares) pairs + padding -- with 16 floats per token the 16
+// lanes of a row hit 4 banks groups four times over (reads of 16 B at a 64-B stride); 20 floats spread them over all 64 banks
+constexpr int kRedTok = 2 * kWaves + BESO_RED_PAD;
 struct LdsMap {            // byte offsets inside the dynamic LDS block
     int xnT, u, red, tab, total;
 };
@@ -636,7 +642,7 @@ __host__ __device__ constexpr LdsMap lds_map(int KS, bool mlp_only = false, int 
     m.u = NT * KS * 1024;                  // (NT < kNTT: instances that only ever touch the first NT token tiles)
     // phase-local region; the long-sequence instance (NT = kLongNT) keeps q/k/v of two heads: 2 x 3 x 16 NT rows of 144 B
     m.red = m.u + (mlp_only ? kNTT * kKCc * 1024 : (NT == kLongNT ? 2 * 3 * 16 * kLongNT * kQKVRow * 2 : 59648));
-    m.tab = m.red + 2 * kWaves * kMT * 4;
+    m.tab = m.red + kRedTok * kMT * 4;
     m.total = m.tab + 512;
     return m;
 }
@@ -662,7 +668,7 @@ __host__ __device__ constexpr LdsMapX3 lds_map_x3(int KS, int NT) {
     m.yT = (front + 1023) / 1024 * 1024;                          // relative to u
     const int need = m.yT + 2 * y_bytes, head = kWaves * kMT * 16 * 4;
     m.red = m.u + (need > head ? need : head);
-    m.tab = m.red + 2 * kWaves * kMT * 4;
+    m.tab = m.red + kRedTok * kMT * 4;
     m.total = m.tab + 512;
     return m;
 }
@@ -779,14 +785,14 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
         const u32x2 y = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[0]), __float_as_uint(r[1]), false, false);
         const float v = __uint_as_float(y[0]) + __uint_as_float(y[1]);
         const int tok = (2 * tp + (row & 1)) * 16 + n;      // (odd NT: the last pair's second token tile is tile NT < kNTT, unused)
-        red[(tok * NW + w) * 2 + (row >> 1)] = v;
+        red[tok * kRedTok + w * 2 + (row >> 1)] = v;
     }
     stamp(st, 30);
     __syncthreads();
     stamp(st, 31);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const f32x4* pr = (const f32x4*)(red + (size_t)(t * 16 + n) * NW * 2);
+        const f32x4* pr = (const f32x4*)(red + (size_t)(t * 16 + n) * kRedTok);
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int k = 0; k < NW / 2; ++k) { const f32x4 v = pr[k]; s += v[0] + v[2]; q += v[1] + v[3]; }
@@ -2696,7 +2702,7 @@ __device__ __forceinline__ void ln_bwd_tile(Tile<RPW>& T, const float* __restric
         const u32x2 y = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[0]), __float_as_uint(r[1]), false, false);
         const float v = __uint_as_float(y[0]) + __uint_as_float(y[1]);
         const int tok = (2 * tp + (row & 1)) * 16 + n;
-        red[(tok * NW + w) * 2 + (row >> 1)] = v;
+        red[tok * kRedTok + w * 2 + (row >> 1)] = v;
     }
     stamp(st, 55);
     __syncthreads();
@@ -2704,7 +2710,7 @@ __device__ __forceinline__ void ln_bwd_tile(Tile<RPW>& T, const float* __restric
     float c1[NT], c2[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const f32x4* pr = (const f32x4*)(red + (size_t)(t * 16 + n) * NW * 2);
+        const f32x4* pr = (const f32x4*)(red + (size_t)(t * 16 + n) * kRedTok);
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int k = 0; k < NW / 2; ++k) { const f32x4 v = pr[k]; s += v[0] + v[2]; q += v[1] + v[3]; }
@@ -3569,13 +3575,13 @@ int fused_train_bwd_tail(const Layout& lay, const char* img, int layer, int M, c
     hipError_t e;
     (void)hipGetLastError();
     if (d.RPW == 3) {
-        constexpr int lds_bytes = 2 * kNTT * 12 * 1024 + 2 * kWaves * kMT * 4;
+        constexpr int lds_bytes = 2 * kNTT * 12 * 1024 + kRedTok * kMT * 4;
         static bool attr = false;
         e = ensure_lds(train_bwd_tail_kernel<3, 12>, lds_bytes, &attr);
         if (e != hipSuccess) return BESO_ERR_HIP;
         hipLaunchKernelGGL((train_bwd_tail_kernel<3, 12>), grid, block, lds_bytes, s, lw, lw_prev, d, bi, M, a, g_stamps, g_stamps_cap);
     } else {
-        constexpr int lds_bytes = 2 * kNTT * 8 * 1024 + 2 * kWaves * kMT * 4;
+        constexpr int lds_bytes = 2 * kNTT * 8 * 1024 + kRedTok * kMT * 4;
         static bool attr = false;
         e = ensure_lds(train_bwd_tail_kernel<2, 8>, lds_bytes, &attr);
         if (e != hipSuccess) return BESO_ERR_HIP;
