@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("BESO_HIP_LIB") or os.path.join(_HERE, "lib", "libbeso
 PREC_BF16, PREC_FP32, PREC_BF16X3 = 0, 1, 2
 PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
 FLAG_UNCOND = 1
+SAMPLE_STEPWISE = 1
 SAMPLER_IDS = {"ddim": 0, "euler": 1, "heun": 2}
 GOAL_RANDOM, GOAL_TAIL, GOAL_SEQ_END = 0, 1, 2
 STEP_DDIM, STEP_EULER, STEP_HEUN_PREDICT, STEP_HEUN_CORRECT = 0, 1, 2, 3
@@ -85,7 +86,7 @@ def load() -> C.CDLL:
         lib.beso_sampler_step.restype = i32
         lib.beso_sampler_step.argtypes = [i32, vp, vp, vp, vp, vp, f32, f32, sz, vp]
         lib.beso_sample.restype = i32
-        lib.beso_sample.argtypes = [cfgp, vp, i32, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_float), i32, f32,
+        lib.beso_sample.argtypes = [cfgp, vp, i32, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_float), i32, f32, i32,
                                     vp, sz, vp]
         if hasattr(lib, "beso_sample_ancestral") or not os.environ.get("BESO_HIP_LIB"):
             lib.beso_sample_ancestral.restype = i32

@@ -107,7 +107,8 @@ class GCDenoiser(nn.Module):
             return False            # training-mode goal masking / dropout live in DiffusionGPT.forward
         return inner._hip_eligible(*tensors)
 
-    def fused_sampler(self, sampler: str, state, x_t, goal, sigmas, cond_lambda: float = 1.0, eta: float = 1.0, noise=None):
+    def fused_sampler(self, sampler: str, state, x_t, goal, sigmas, cond_lambda: float = 1.0, eta: float = 1.0, noise=None,
+                      stepwise: bool = False):
         """Whole ddim / euler / heun / euler_ancestral loop as one enqueue (``beso_sample``, ``beso_sample_ancestral``); None
         if not applicable."""
         inner = self.inner_model
@@ -117,4 +118,4 @@ class GCDenoiser(nn.Module):
             return inner.runtime(self.sigma_data).sample_ancestral(inner.packed_weights(), state, x_t, goal, sigmas,
                                                                    cond_lambda=cond_lambda, eta=eta, noise=noise)
         return inner.runtime(self.sigma_data).sample(inner.packed_weights(), sampler, state, x_t, goal, sigmas,
-                                                     cond_lambda=cond_lambda)
+                                                     cond_lambda=cond_lambda, stepwise=stepwise)

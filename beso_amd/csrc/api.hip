@@ -397,10 +397,10 @@ int beso_sampler_step(int mode, float* out, float* aux, const float* x, const fl
 
 int beso_sample(const beso_config* cfg, const void* packed, int precision, int sampler, const float* state,
                 const float* goal, float* x, int batch, int t, const float* sigmas, int n_sigmas,
-                float cond_lambda, void* workspace, size_t workspace_bytes, void* stream) {
+                float cond_lambda, int flags, void* workspace, size_t workspace_bytes, void* stream) {
     int st = validate_config(cfg);
     if (st != BESO_OK) return st;
-    if (sampler < BESO_SAMPLER_DDIM || sampler > BESO_SAMPLER_HEUN) return BESO_ERR_BAD_ARG;
+    if (sampler < BESO_SAMPLER_DDIM || sampler > BESO_SAMPLER_HEUN || (flags & ~BESO_SAMPLE_STEPWISE)) return BESO_ERR_BAD_ARG;
     if (!sigmas || n_sigmas < 2 || !x || !workspace) return BESO_ERR_BAD_ARG;
     if (batch < 1 || t < 1 || t > cfg->obs_seq_len) return BESO_ERR_BAD_SHAPE;
     Layout lay;
@@ -417,6 +417,57 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
     float* d1 = (float*)(wsp + ws.d1);
     float* sig = (float*)(wsp + ws.sig);
     const size_t n = (size_t)batch * t * lay.act;
+    // The evaluations of the loop and the update behind each (coefficients in fp32 on the host, as the reference's 0-d
+    // tensors: gc_sampling.py:921-923 DDIM, :205-210 Euler, :296-310 Heun with plain Euler on the last step :301-303).
+    std::vector<StepRec> recs;
+    std::vector<int> step_first;                  // index of the first evaluation of every sampler step
+    for (int i = 0; i + 1 < n_sigmas; ++i) {
+        const float si = sigmas[i], sn = sigmas[i + 1];
+        step_first.push_back((int)recs.size());
+        if (sampler == BESO_SAMPLER_DDIM) {
+            // t = -log(sigma); h = t_next - t; x = (sigma_fn(t_next)/sigma_fn(t))*x - expm1(-h)*den
+            const float tt = -logf(si), tn = -logf(sn);      // sn == 0 -> tn = +inf -> x = den exactly
+            const float h = tn - tt;
+            recs.push_back(StepRec{si, expf(-tn) / expf(-tt), expm1f(-h), BESO_STEP_DDIM});
+        } else if (sampler == BESO_SAMPLER_EULER || sn == 0.f) {
+            // gamma = 0: sigma_hat = sigma_i; d = (x - den)/sigma_hat; x += d*(sigma_next - sigma_hat)
+            recs.push_back(StepRec{si, si, sn - si, BESO_STEP_EULER});
+        } else {
+            // Heun: predictor, second evaluation at sigma_{i+1}, trapezoid corrector
+            recs.push_back(StepRec{si, si, sn - si, BESO_STEP_HEUN_PREDICT});
+            recs.push_back(StepRec{sn, sn, sn - si, BESO_STEP_HEUN_CORRECT});
+        }
+    }
+    step_first.push_back((int)recs.size());
+    {
+        // ONE launch for the whole loop where the shape has the one-launch kernel (K8 fused into K7: the workgroup that owns a
+        // sample from the embedding to the head also applies the update and feeds itself the next input); loops of more than
+        // kMaxLoopEvals evaluations are cut at step boundaries (x travels through `x`, the Heun state lives inside a step)
+        FwdArgs a;
+        a.state = state; a.action = x; a.goal = goal; a.sigma = sig; a.out = x; a.aux = d1;
+        a.batch = batch; a.vbatch = two ? 2 * batch : batch; a.t = t; a.T = 1 + lay.G + 2 * t;
+        a.precondition = 1;
+        a.uncond_from = two ? batch : (cond_lambda == 0.f ? 0 : a.vbatch);
+        a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
+        if (!packed || !state || (cfg->goal_seq_len > 0 && !goal)) return BESO_ERR_BAD_ARG;
+        if (!(flags & BESO_SAMPLE_STEPWISE) && fused_can_loop(lay, a, precision)) {
+            size_t i0 = 0;
+            const size_t n_steps = step_first.size() - 1;
+            while (i0 < n_steps) {
+                size_t i1 = i0 + 1;
+                while (i1 < n_steps && step_first[i1 + 1] - step_first[i0] <= kMaxLoopEvals) ++i1;
+                SampleSteps S{};
+                S.n = step_first[i1] - step_first[i0];
+                for (int k = 0; k < S.n; ++k) S.rec[k] = recs[step_first[i0] + k];
+                profile_begin(BESO_SITE_FUSED_LAYER, s);
+                st = fused_layers(lay, (const char*)packed, a, (float*)(wsp + ws.x), nullptr, precision, s, &S);
+                profile_end(BESO_SITE_FUSED_LAYER, s);
+                if (st != BESO_OK) return st;
+                i0 = i1;
+            }
+            return BESO_OK;
+        }
+    }
     auto fill_sigma = [&](float v) -> hipError_t {
         uint32_t bits; memcpy(&bits, &v, 4);
         return hipMemsetD32Async((hipDeviceptr_t)sig, (int)bits, (size_t)batch, s);

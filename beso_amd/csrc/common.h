@@ -69,6 +69,38 @@ __device__ __forceinline__ float gelu_grad_poly(float v) {
     return fmaf(vc, p, 0.5f) + v * phi;
 }
 
+// One sampler update on one element, in the reference's operation order (gc_sampling.py:921-923 DDIM, :205-210 Euler,
+// :296-310 Heun; torch evaluates every product, quotient and sum as its own rounded fp32 operation, so nothing here may
+// be contracted into an fma).  Shared by sampler_step_kernel (the step-by-step form) and the sampler loop inside
+// layers_kernel, which therefore agree bit for bit.
+//   DDIM          x <- c0*x - c1*den                                    next input: x
+//   EULER         d = (x - den)/c0;  x <- x + d*c1                      next input: x
+//   HEUN_PREDICT  d = (x - den)/c0;  aux <- d;  x2 <- x + d*c1          next input: x2   (x unchanged)
+//   HEUN_CORRECT  d2 = (x2 - den)/c0;  x <- x + ((aux + d2)/2)*c1       next input: x
+// Returns the value the mode writes to `out` (x for DDIM / EULER / HEUN_CORRECT, x2 for HEUN_PREDICT).
+__device__ __forceinline__ float sampler_update(int mode, float xv, float x2v, float dv, float& aux, float c0, float c1) {
+#pragma clang fp contract(off)
+    if (mode == BESO_STEP_DDIM) {
+        const float a = c0 * xv, b = c1 * dv;
+        return a - b;
+    }
+    if (mode == BESO_STEP_EULER) {
+        const float d = (xv - dv) / c0;
+        const float s = d * c1;
+        return xv + s;
+    }
+    if (mode == BESO_STEP_HEUN_PREDICT) {
+        const float d = (xv - dv) / c0;
+        aux = d;
+        const float s = d * c1;
+        return xv + s;
+    }
+    const float d2 = (x2v - dv) / c0;
+    const float dp = (aux + d2) / 2.0f;
+    const float s = dp * c1;
+    return xv + s;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -124,6 +156,7 @@ bool make_workspace(const beso_config* cfg, const Layout& lay, int batch, int t,
 struct FwdArgs {
     const float* state; const float* action; const float* goal; const float* sigma;
     float* out;
+    float* aux = nullptr;   // sampler loop only: [B][t][act] scratch (Heun's first slope between its two evaluations)
     int batch;        // real batch B
     int vbatch;       // virtual batch: B or 2B (classifier-free guidance)
     int t;            // observations in the window

@@ -348,21 +348,14 @@ __global__ void sampler_step_kernel(int mode, float* __restrict__ out, float* __
     if (sig_next)
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sig; i += gridDim.x * blockDim.x) sig_next[i] = sigma_next;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float xv = x[i], dv = den[i], r;
-        if (mode == BESO_STEP_DDIM) {
-            r = c0 * xv - c1 * dv;
-        } else if (mode == BESO_STEP_EULER) {
-            float d = (xv - dv) / c0;
-            r = xv + d * c1;
-        } else if (mode == BESO_STEP_HEUN_PREDICT) {
-            float d = (xv - dv) / c0;
-            aux[i] = d;
-            r = xv + d * c1;
-        } else if (mode == BESO_STEP_ADD_NOISE) {
+        const float xv = x[i], dv = den[i];
+        float r;
+        if (mode == BESO_STEP_ADD_NOISE) {
             r = xv + x2[i] * c0;
         } else {
-            float d2 = (x2[i] - dv) / c0;
-            r = xv + ((aux[i] + d2) / 2.0f) * c1;
+            float a = (mode == BESO_STEP_HEUN_CORRECT) ? aux[i] : 0.f;
+            r = sampler_update(mode, xv, mode == BESO_STEP_HEUN_CORRECT ? x2[i] : 0.f, dv, a, c0, c1);
+            if (mode == BESO_STEP_HEUN_PREDICT) aux[i] = a;
         }
         out[i] = r;
     }

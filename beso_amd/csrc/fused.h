@@ -4,6 +4,18 @@
 
 namespace beso {
 
+// The sampler loop inside layers_kernel (K8 fused into K7): one record per network evaluation of the launch -- the sigma it
+// is evaluated at (the same for every sample) and the update that follows it in the head (BESO_STEP_* with the coefficients
+// of beso_sampler_step).  Travels as a kernel argument: no table in device memory, nothing to copy, graph-capturable.
+constexpr int kMaxLoopEvals = 128;
+struct StepRec { float sigma, c0, c1; int mode; };
+struct SampleSteps {
+    int n;                         // evaluations of this launch; 0: one plain forward (per-sample sigma, out <- denoised)
+    int pad[3];
+    StepRec rec[kMaxLoopEvals];
+};
+constexpr int kLoopMaxElems = 512;   // action-window elements per workgroup the loop can carry (one per thread)
+
 size_t fused_packed_bytes(const Layout& lay, int precision);
 size_t fused_workspace_bytes(const Layout& lay, int vbatch, int T, int precision);
 int    fused_pack(const Layout& lay, const float* const* params, char* packed, int precision, hipStream_t s);
@@ -11,7 +23,8 @@ bool   fused_supported(const Layout& lay, const FwdArgs& a, int precision);
 int    fused_level(const Layout& lay, const FwdArgs& a, int precision);   // 0 none, 1 MLP block, 2 whole layers
 int    fused_layer_edges(const Layout& lay);        // bit 0: fused_layers embeds, bit 1: it runs the head
 int    fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, int precision,
-                    hipStream_t s);
+                    hipStream_t s, const SampleSteps* steps = nullptr);
+bool   fused_can_loop(const Layout& lay, const FwdArgs& a, int precision);   // the whole sampler loop can run inside one launch
 int    fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, int M, hipStream_t s);
 bool   fused_has_lin_blocks(const Layout& lay, int precision);
 int    fused_lin_block(const Layout& lay, const char* packed, int layer, int which, float* x, void* buf, int ld, int M,

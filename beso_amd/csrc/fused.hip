@@ -631,8 +631,9 @@ constexpr int kKCc = kChunkTiles / 2;      // FC2 k-steps per hidden chunk (= kK
 // LayerNorm statistics exchange: per token kWaves (sum, sum of squares) pairs + padding -- with 16 floats per token the 16
 // lanes of a row hit 4 banks groups four times over (reads of 16 B at a 64-B stride); 20 floats spread them over all 64 banks
 constexpr int kRedTok = 2 * kWaves + BESO_RED_PAD;
+constexpr int kXsBytes = 2048;        // the workgroup's action windows (n_real x t x act <= 512 floats): input of every evaluation
 struct LdsMap {            // byte offsets inside the dynamic LDS block
-    int xnT, u, red, tab, total;
+    int xnT, u, red, tab, xs, total;
 };
 __host__ __device__ constexpr LdsMap lds_map(int KS, bool mlp_only = false, int NT = kNTT) {
     // u is the phase-local region: attention (q/k/v 3*104*72*2 = 44928 | yT 12288) or MLP (hT 6*8 KiB = 49152);
@@ -643,7 +644,8 @@ __host__ __device__ constexpr LdsMap lds_map(int KS, bool mlp_only = false, int 
     // phase-local region; the long-sequence instance (NT = kLongNT) keeps q/k/v of two heads: 2 x 3 x 16 NT rows of 144 B
     m.red = m.u + (mlp_only ? kNTT * kKCc * 1024 : (NT == kLongNT ? 2 * 3 * 16 * kLongNT * kQKVRow * 2 : 59648));
     m.tab = m.red + kRedTok * kMT * 4;
-    m.total = m.tab + 512;
+    m.xs = m.tab + 512;
+    m.total = m.xs + kXsBytes;
     return m;
 }
 
@@ -653,7 +655,7 @@ __host__ __device__ constexpr LdsMap lds_map(int KS, bool mlp_only = false, int 
 // of finite bf16 values = finite fp32 values, and only ever meet zero probabilities.
 constexpr int kQKVRowF = kHDP + 4;         // fp32 elements per q/k/v row: 272 B, conflict-free b128 reads down a column of rows
 struct LdsMapX3 {
-    int xn_lo, u, qkv_rows, yT, y_lo, h_lo, red, tab, total;     // *_lo: distance hi -> lo fragment in u32x4 units; rest bytes
+    int xn_lo, u, qkv_rows, yT, y_lo, h_lo, red, tab, xs, total;     // *_lo: distance hi -> lo fragment in u32x4 units; rest bytes
 };
 __host__ __device__ constexpr LdsMapX3 lds_map_x3(int KS, int NT) {
     LdsMapX3 m{};
@@ -669,7 +671,8 @@ __host__ __device__ constexpr LdsMapX3 lds_map_x3(int KS, int NT) {
     const int need = m.yT + 2 * y_bytes, head = kWaves * kMT * 16 * 4;
     m.red = m.u + (need > head ? need : head);
     m.tab = m.red + kRedTok * kMT * 4;
-    m.total = m.tab + 512;
+    m.xs = m.tab + 512;
+    m.total = m.xs + kXsBytes;
     return m;
 }
 
@@ -759,6 +762,9 @@ __device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restri
 template <int RPW, int NW, int NT = kNTT>         // NT: the first NT token tiles only
 __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, int w, int lane, float (&mean)[NT],
                                          float (&rstd)[NT], Stamps& st) {
+    // (every multiply-add below is written out: which products the compiler contracts must not depend on the instance this is
+    // inlined into -- the instances of the kernel agree bit for bit)
+#pragma clang fp contract(off)
     const int n = lane & 15, row = lane >> 4;            // (token tiles are reduced in pairs; an odd last one pairs with zeros)
     const float invD = 1.0f / (float)D;
     // Cross-lane part of the reduction (over the four 16-lane rows g) on gfx950's lane-swap instructions:
@@ -797,7 +803,7 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
 #pragma unroll
         for (int k = 0; k < NW / 2; ++k) { const f32x4 v = pr[k]; s += v[0] + v[2]; q += v[1] + v[3]; }
         mean[t] = s * invD;
-        rstd[t] = __builtin_amdgcn_rsqf(fmaxf(q * invD - mean[t] * mean[t], 0.f) + 1e-5f);     // v_rsq_f32 (1 ulp); 1/sqrtf is ~35 VALU ops
+        rstd[t] = __builtin_amdgcn_rsqf(fmaxf(fmaf(-mean[t], mean[t], q * invD), 0.f) + 1e-5f);     // v_rsq_f32 (1 ulp); 1/sqrtf is ~35 VALU ops
     }
 }
 
@@ -957,12 +963,15 @@ __device__ __forceinline__ void build_slot_tabs(SlotTabs* tb, int n_samples, int
 }
 
 // Inputs / outputs of the network edges when they are fused into layers_kernel.
+// One forward: out = D(state, action, goal, sigma).  Sampler loop (SampleSteps::n > 0): `action` holds x_T, every
+// evaluation's sigma comes from its step record (`sigma` is not read), `out` receives the sample (it may alias `action`).
 struct EdgeArgs {
     const float* state;    // [B][t][obs]
     const float* action;   // [B][t][act]
     const float* goal;     // [B][G][obs]
     const float* sigma;    // [B]
     float* out;            // [B][t][act]
+    float* aux;            // [B][t][act] scratch of the sampler loop (Heun's first slope), or nullptr
     int B, t, precondition, uncond_all, two;   // two: classifier-free pair (cond, uncond) = virtual samples (2b, 2b+1)
     float cond_lambda, sigma_data;
     int fuse_embed, fuse_head;
@@ -986,9 +995,14 @@ __device__ __forceinline__ void sample_of(const EdgeArgs& e, int vb, int& b, boo
 // MFMAs per pair: 2^-16 relative, three orders below the bf16 rounding of the layers that follow) -- one k-step of
 // 32 inputs for tok_emb and a half k-step for action_emb instead of eleven k-steps of the 1/16-rate fp32 MFMA: the
 // embedding's matrix-pipe time drops from 6.3 k to 1.3 k cycles per wave.  PX = 1 (BF16X3) keeps the exact-fp32 form.
+// The noisy actions are read from `xs` (LDS: the action windows of the workgroup's real samples, [n_real][t][act], staged by
+// the kernel -- in the sampler loop the previous evaluation's update left the next input there); sigma_u > 0: the
+// evaluation's sigma, the same for every sample (sampler loop), else sigma[b].
 template <int RPW, int PX = 1, int PS = 4>
 __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw, int s0,
-                                           int n_samples, int Tn, int w, int lane, const SlotTabs* tb, Stamps& st) {
+                                           int n_samples, int Tn, int w, int lane, const SlotTabs* tb, const float* xs,
+                                           float sigma_u, Stamps& st) {
+#pragma clang fp contract(off)          // (explicit fmas only: the instances of the kernel agree bit for bit)
     asm volatile("" : "+v"(lane));
     const int n = lane & 15, g = lane >> 4;
     const int G = d.G, Dp = d.Dp;
@@ -997,7 +1011,10 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
     const float* src[kNTT];
     float scale[kNTT], sg[kNTT];
     int kind[kNTT], prow[kNTT];       // kind: 0 none, 1 tok_emb input (state / goal), 2 action, 3 sigma, 4 zeroed goal
+    int xoff[kNTT];                   // offset in xs of the action window row a slot's token belongs to (valid for every slot)
     const int last = s0 + n_samples - 1;
+    int b0; bool un0;
+    sample_of(e, s0, b0, un0);
 #pragma unroll
     for (int t = 0; t < kNTT; ++t) {
         const int sp = tb->sp_of_slot[t * 16 + n];
@@ -1005,17 +1022,17 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
         const int sl = live ? sp >> PS : 0, p = live ? sp & ((1 << PS) - 1) : 0;
         int b; bool un;
         sample_of(e, min(s0 + sl, last), b, un);
-        sg[t] = e.sigma[b];
+        sg[t] = sigma_u > 0.f ? sigma_u : e.sigma[b];
         const int idx = p - G - 1, i = max(idx, 0) >> 1;
+        xoff[t] = ((b - b0) * e.t + i) * d.act;
         const bool is_sig = p == 0, is_goal = p >= 1 && p <= G, is_act = idx >= 0 && (idx & 1);
         kind[t] = !live ? 0 : is_sig ? 3 : is_goal ? (un ? 4 : 1) : is_act ? 2 : 1;
         prow[t] = is_sig ? 0 : is_goal ? p - 1 : G + i;
         const float* ps = e.state + ((size_t)b * e.t + i) * d.obs;
         const float* pg = e.goal + ((size_t)b * G + max(p - 1, 0)) * d.obs;
-        const float* pa = e.action + ((size_t)b * e.t + i) * d.act;
-        src[t] = kind[t] == 1 ? (is_goal ? pg : ps) : kind[t] == 2 ? pa : tokT;      // tokT: any readable address
+        src[t] = kind[t] == 1 ? (is_goal ? pg : ps) : tokT;      // tokT: any readable address
         scale[t] = 1.f;
-        if (kind[t] == 2 && e.precondition) scale[t] = __builtin_amdgcn_rsqf(sg[t] * sg[t] + e.sigma_data * e.sigma_data);   // c_in
+        if (kind[t] == 2 && e.precondition) scale[t] = __builtin_amdgcn_rsqf(fmaf(sg[t], sg[t], e.sigma_data * e.sigma_data));   // c_in
     }
     // tok_emb over states / goals and action_emb over the (pre-conditioned) noisy actions, exact fp32 on the
     // matrix pipe: X^T[f][tok] += W^T[f][c] * in[tok][c], four input features per v_mfma_f32_16x16x4_f32
@@ -1039,12 +1056,11 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
         float vt[kNTT][8], va[kNTT][4];
 #pragma unroll
         for (int t = 0; t < kNTT; ++t) {
-            const float* pt = kind[t] == 1 ? src[t] : tokT;
-            const float* pa = kind[t] == 2 ? src[t] : tokT;
+            const float* pt = src[t];
 #pragma unroll
             for (int j = 0; j < 8; ++j) vt[t][j] = pt[min(16 * (j >> 2) + 4 * g + (j & 3), d.obs - 1)];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) va[t][j] = pa[min(4 * g + j, d.act - 1)];
+            for (int j = 0; j < 4; ++j) va[t][j] = xs[xoff[t] + min(4 * g + j, d.act - 1)];
         }
         stamp(st, 41);
         float lsig[kNTT];
@@ -1062,7 +1078,7 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
             for (int t = 0; t < kNTT; ++t) {
                 const int k = kind[t];
                 const f32x4 pos = *(const f32x4*)((const float*)(gw + d.g_pos) + (size_t)prow[t] * Dp + f0);
-                const f32x4 sig = sw * lsig[t] + sb;
+                const f32x4 sig = __builtin_elementwise_fma(sw, (f32x4)(lsig[t]), sb);
                 const f32x4 lin = (k == 2 ? ba : bt) + pos;
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 T.acc[i][t] = k == 0 ? zero : k == 3 ? sig : lin;
@@ -1112,7 +1128,7 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
 #pragma unroll
         for (int i = 0; i < RPW; ++i) a_[i] = wT[(size_t)cl * Dp + 16 * (w * RPW + i) + n];
 #pragma unroll
-        for (int t = 0; t < kNTT; ++t) b_[t] = (kind[t] == want ? src[t] : wT)[cl];
+        for (int t = 0; t < kNTT; ++t) b_[t] = want == 2 ? xs[xoff[t] + cl] : src[t][cl];
     };
     auto mask = [&](int n_in, int want, int kk, float (&a_)[RPW], float (&b_)[kNTT]) {
         const bool cv = 4 * kk + g < n_in;
@@ -1142,7 +1158,7 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
         for (int t = 0; t < kNTT; ++t) {
             const int k = kind[t];
             const f32x4 pos = *(const f32x4*)((const float*)(gw + d.g_pos) + (size_t)prow[t] * Dp + f0);
-            const f32x4 sig = sw * lsig[t] + sb;
+            const f32x4 sig = __builtin_elementwise_fma(sw, (f32x4)(lsig[t]), sb);
             const f32x4 lin = (k == 2 ? ba : bt) + pos;
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             T.acc[i][t] = k == 0 ? zero : k == 3 ? sig : lin;
@@ -1174,10 +1190,21 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
 // Every wave reduces its 48 features of every action token to `act` partial sums; LDS sums the waves.
 // NT: token tiles that can hold action tokens -- with the action tokens first in the tile (layers_kernel's peeled last
 // layer) those are the first NTL tiles and the statistics / partial sums of the other tiles are never read.
+// Sampler loop (ls.mode >= 0): the thread that owns an element of the action window applies the step's update to the denoised
+// value it has just computed (sampler_update: the step-by-step kernel's arithmetic, K8 of SURVEY 2.1) and leaves the input of
+// the next evaluation in xs.  DDIM / Euler carry x in xs alone; a Heun step parks x (in `out`) and its first slope (in
+// `aux`) in global memory between its two evaluations -- written and read back by the same thread.  The caller's barrier
+// behind this function orders the xs write against the next embed.
+struct LoopState {
+    int mode;              // -1: a single forward (out <- denoised); else the BESO_STEP_* update of this evaluation
+    float c0, c1, sigma;   // the step's coefficients; sigma of this evaluation (> 0: uniform over the batch)
+    bool last;             // the last evaluation of the launch: x goes out
+};
 template <int RPW, int NT = kNTT>
 __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw,
                                           float* red, float* part, int s0, int n_samples, int Tn, int w, int lane,
-                                          const SlotTabs* tb, Stamps& st) {
+                                          const SlotTabs* tb, float* xs, LoopState& ls, Stamps& st) {
+#pragma clang fp contract(off)          // (explicit fmas only: the instances of the kernel agree bit for bit)
     asm volatile("" : "+v"(lane));
     const int n = lane & 15, g = lane >> 4;
     const int act = d.act, Dp = d.Dp;
@@ -1204,11 +1231,15 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
         }
     }
     __syncthreads();
-    // one thread per (real sample slot, step i, action dim)
+    // one thread per (real sample slot, step i, action dim): element `it` of the workgroup's action windows
     const int G = d.G, per = e.two ? 2 : 1;
     const int n_real = n_samples / per;
     const float* bh = (const float*)(gw + d.g_headb);
-    for (int it = threadIdx.x; it < n_real * e.t * act; it += blockDim.x) {
+    int b0; bool un0;
+    sample_of(e, s0, b0, un0);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));            // (the sampler loop: nothing of this block may be hoisted out of it and kept live)
+    for (int it = tid; it < n_real * e.t * act; it += blockDim.x) {
         const int a = it % act, i = (it / act) % e.t, sr = it / (act * e.t);
         const int sl = sr * per;
         int b; bool un;
@@ -1223,21 +1254,32 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
 #pragma unroll
             for (int ww = 0; ww < kWaves; ++ww) fu += part[((size_t)ww * kMT + tok_u) * 16 + a];
         }
-        const float sg = e.sigma[b];
-        const float av = e.action[((size_t)b * e.t + i) * act + a];
+        const float sg = ls.sigma > 0.f ? ls.sigma : e.sigma[b];
+        const float av = xs[it];                       // the evaluation's input action (x, or Heun's x2)
         float c_skip = 0.f, c_out = 1.f;
         if (e.precondition) {
-            const float sd2 = e.sigma_data * e.sigma_data;
-            c_skip = sd2 / (sg * sg + sd2);
-            c_out = sg * e.sigma_data / sqrtf(sg * sg + sd2);
+            const float sd2 = e.sigma_data * e.sigma_data, s2 = fmaf(sg, sg, sd2);
+            c_skip = sd2 / s2;
+            c_out = sg * e.sigma_data / sqrtf(s2);
         }
-        const float oc = fc * c_out + av * c_skip;
+        const float skip = av * c_skip;
+        const float oc = fmaf(fc, c_out, skip);
         float r = oc;
         if (e.two) {
-            const float ou = fu * c_out + av * c_skip;
-            r = ou + e.cond_lambda * (oc - ou);
+            const float ou = fmaf(fu, c_out, skip);
+            r = fmaf(e.cond_lambda, oc - ou, ou);
         }
-        e.out[((size_t)b * e.t + i) * act + a] = r;
+        float* dst = e.out + (size_t)b0 * e.t * act + it;
+        if (ls.mode < 0) *dst = r;
+        else {
+            float* daux = e.aux + (size_t)b0 * e.t * act + it;
+            float xv = av, x2v = 0.f, d1 = 0.f;
+            if (ls.mode == BESO_STEP_HEUN_CORRECT) { xv = *dst; x2v = av; d1 = *daux; }      // (wave-uniform)
+            const float o = sampler_update(ls.mode, xv, x2v, r, d1, ls.c0, ls.c1);
+            xs[it] = o;
+            if (ls.mode == BESO_STEP_HEUN_PREDICT) { *dst = xv; *daux = d1; }
+            else if (ls.last) *dst = o;
+        }
     }
 }
 
@@ -1964,15 +2006,22 @@ __device__ __forceinline__ void attn_phase_long(Tile<RPW>& T, const u32x4* xnT, 
 // exact GELU (erff) and the attention core on the exact-fp32 MFMA.  No software pipelining across phases: this
 // mode exists for parity (north-star 1e-4), its speed is set by three MFMAs per fragment pair and two weight images.
 // ---------------------------------------------------------------------------------------------
-#ifndef BESO_X3_FASTGELU
-#define BESO_X3_FASTGELU 0           // timing experiment only: the bf16 mode's polynomial in the parity mode
-#endif
-__device__ __forceinline__ float gelu_exact(float v) {            // nn.GELU(): v * Phi(v), erf form (score_gpts.py:107)
-#if BESO_X3_FASTGELU
-    return gelu_poly(v);
-#else
-    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-#endif
+// nn.GELU(): v * Phi(v), erf form (score_gpts.py:107), to fp32-class accuracy in 14 VALU instructions (erff is ~40, and was
+// 16 % of this mode's time): erf(x) = sign(x) (1 - (a1 t + .. + a5 t^5) exp(-x^2)), t = 1/(1 + p |x|)  (Abramowitz & Stegun
+// 7.1.26, |error| <= 1.5e-7), with v_rcp_f32 / v_exp_f32; measured in fp32 arithmetic: max |GELU error| 4.7e-7 over
+// |v| <= 8 -- thirty times below the 2^-16 relative precision of the split-bf16 operand the result becomes next.
+__device__ __forceinline__ float gelu_exact(float v) {
+    const float ax = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float ex = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+    const float r = fmaf(-p, ex, 1.0f);                 // erf(|v| / sqrt 2)
+    const float hv = 0.5f * v;
+    return fmaf(fabsf(hv), r, hv);                     // v/2 (1 + sign(v) r)
 }
 
 // MLP phase: per hidden chunk  FC1 -> GELU -> [barrier] -> hT (hi | lo) -> [barrier] -> FC2 into the residual.
@@ -2970,16 +3019,18 @@ __global__ __launch_bounds__(512, 2) void train_bwd_tail_kernel(const char* __re
 // stream of the weights.  Same phases, same per-sample arithmetic (results are bit-identical between the instances).
 // PX = 1: the BF16X3 instance (split-bf16 GEMMs, exact GELU, fp32 attention core): the parity mode of this kernel.
 // CORE = 1: the long-sequence instance (SPW = 1: a sample of up to 16 NTA tokens per workgroup, tokens in natural order).
-template <int RPW, int KS, int HG, int NTL, int SPW = kSPW, int NTA = kNTT, int PX = 0, int CORE = 0>
+// LOOP = 1: the sampler-loop instance (S.n evaluations, each followed by its update in the head); LOOP = 0 is one forward and
+// compiles to the loop-free code (S is not read).
+template <int RPW, int KS, int HG, int NTL, int SPW = kSPW, int NTA = kNTT, int PX = 0, int CORE = 0, int LOOP = 0>
 __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, const char* __restrict__ lw0,
                                                         FusedDims d, int l0, int l1, int n_samples_total, int Tn,
-                                                        EdgeArgs e, unsigned long long* stamps, int cap) {
+                                                        EdgeArgs e, SampleSteps S, unsigned long long* stamps, int cap) {
     Stamps st{stamps, cap, 0};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     static_assert(CORE == 0 || (SPW == 1 && PX == 0), "long-sequence instance");
     constexpr LdsMap Lb = lds_map(KS, false, CORE == 1 ? NTA : kNTT);
     constexpr LdsMapX3 X = lds_map_x3(KS, NTA);
-    constexpr LdsMap L = PX ? LdsMap{0, X.u, X.red, X.tab, X.total} : Lb;
+    constexpr LdsMap L = PX ? LdsMap{0, X.u, X.red, X.tab, X.xs, X.total} : Lb;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
@@ -2995,27 +3046,45 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     const int s0 = blockIdx.x * SPW;
     const int n_samples = min(SPW, n_samples_total - s0);
     const int m0 = s0 * Tn, m_end = m0 + n_samples * Tn;
+    // action tokens first whenever both network edges are inside the kernel (otherwise x travels in natural order)
+    SlotTabs* tb = (SlotTabs*)(lds + L.tab);
+    float* xs = (float*)(lds + L.xs);
+    // (CORE = 1: natural order -- the long-sequence core addresses slots by position, and five tiles leave nothing to peel)
+    const bool actions_first = CORE == 0 && e.fuse_embed && e.fuse_head;
+    build_slot_tabs(tb, n_samples, Tn, e.t, d.G, actions_first, CORE == 1 ? 7 : 4);
+    // the action windows of the workgroup's real samples (contiguous in `action`): x_T of the sampler loop / the noisy action
+    LoopState ls{-1, 0.f, 0.f, 0.f, true};
+    if (e.fuse_embed) {
+        int b0; bool un0;
+        sample_of(e, s0, b0, un0);
+        const int n_el = (n_samples / (e.two ? 2 : 1)) * e.t * d.act;
+        for (int i = threadIdx.x; i < n_el; i += blockDim.x) xs[i] = e.action[(size_t)b0 * e.t * d.act + i];
+    }
+    Tile<RPW> T;
+    stamp(st, 100);
+    const char* gw = lw0 + (size_t)d.L * d.layer_bytes;          // per-model image (embeddings, head)
+    // Sampler loop (K8 fused): S.n > 0 evaluations of the network back to back, each followed by
+    // its step's update in the head; samples never interact, so the workgroup needs nothing from outside between them.
+    const int n_evals = LOOP ? S.n : 1;
+#pragma unroll 1
+    for (int ev = 0; ev < n_evals; ++ev) {
+    if constexpr (LOOP) ls.sigma = S.rec[ev].sigma;
+    int tid = threadIdx.x;
+    if constexpr (LOOP) asm volatile("" : "+v"(tid));      // (per evaluation: nothing thread-derived is kept live across the loop)
     // LDS that is read but never written by the phases must be finite: the attention-output fragments of
-    // padding tokens, and the 8 q/k/v rows past the last token slot (a sample's 16-row window reaches them)
+    // padding tokens, and the 8 q/k/v rows past the last token slot (a sample's 16-row window reaches them).
+    // (Per evaluation: the head's partial sums are laid over them.)
     if constexpr (PX) {
-        for (int i = threadIdx.x; i < (L.red - L.u) / 16; i += blockDim.x) ((u32x4*)(lds + L.u))[i] = u32x4{0, 0, 0, 0};
+        for (int i = tid; i < (L.red - L.u) / 16; i += blockDim.x) ((u32x4*)(lds + L.u))[i] = u32x4{0, 0, 0, 0};
     } else {
-    for (int i = threadIdx.x; i < kNTT * 2 * 64; i += blockDim.x) ((u32x4*)(lds + L.u + kQKVBytes))[i] = u32x4{0, 0, 0, 0};
-    for (int i = threadIdx.x; i < 3 * 8 * kQKVRow / 2; i += blockDim.x) {
+    for (int i = tid; i < kNTT * 2 * 64; i += blockDim.x) ((u32x4*)(lds + L.u + kQKVBytes))[i] = u32x4{0, 0, 0, 0};
+    for (int i = tid; i < 3 * 8 * kQKVRow / 2; i += blockDim.x) {
         const int part = i / (8 * kQKVRow / 2), rem = i % (8 * kQKVRow / 2);
         ((uint32_t*)(lds + L.u))[((size_t)part * kQKVRows + kMT) * kQKVRow / 2 + rem] = 0u;
     }
     }
-    // action tokens first whenever both network edges are inside the kernel (otherwise x travels in natural order)
-    SlotTabs* tb = (SlotTabs*)(lds + L.tab);
-    // (CORE = 1: natural order -- the long-sequence core addresses slots by position, and five tiles leave nothing to peel)
-    const bool actions_first = CORE == 0 && e.fuse_embed && e.fuse_head;
-    build_slot_tabs(tb, n_samples, Tn, e.t, d.G, actions_first, CORE == 1 ? 7 : 4);
     __syncthreads();
-    Tile<RPW> T;
-    stamp(st, 100);
     stamp(st, 1);
-    const char* gw = lw0 + (size_t)d.L * d.layer_bytes;          // per-model image (embeddings, head)
     if ((BESO_ABL_MASK & 4) && e.fuse_embed) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
@@ -3023,7 +3092,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.1f * n, 0.2f, 0.3f * g, 0.4f};
         }
-    } else if (e.fuse_embed) embed_tile<RPW, PX, CORE == 1 ? 7 : 4>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, st);
+    } else if (e.fuse_embed) embed_tile<RPW, PX, CORE == 1 ? 7 : 4>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, xs, ls.sigma, st);
     else load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 43);
     // The last layer (when this launch contains it and the action tokens of the tile fit NTL token tiles) runs its
@@ -3104,14 +3173,21 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     }
     }
     stamp(st, 4);
+    if constexpr (LOOP) {
+        const StepRec rec = S.rec[ev];
+        ls.mode = rec.mode; ls.c0 = rec.c0; ls.c1 = rec.c1;
+        ls.last = ev + 1 == n_evals;
+    }
     if (e.fuse_head) {
         // (peel: the action tokens are the first n_samples * t slots, i.e. inside the first NTLa token tiles)
-        if constexpr (CORE == 1) head_tile<RPW, NTA>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
-        else if (peel && NTLa < kNTT) head_tile<RPW, NTLa>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
-        else head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, st);
+        if constexpr (CORE == 1) head_tile<RPW, NTA>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, xs, ls, st);
+        else if (peel && NTLa < kNTT) head_tile<RPW, NTLa>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, xs, ls, st);
+        else head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, xs, ls, st);
     }
     else store_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 5);
+    if (LOOP && ev + 1 < n_evals) __syncthreads();      // the head's partial sums are read, the next input is in xs
+    }
     stamp(st, 101);
 }
 
@@ -3170,66 +3246,72 @@ hipError_t launch_tail_block(float* x, const char* lw, const char* lw_next, cons
 
 int g_small_batch_max = 512;           // batches up to this size take the latency instance (beso_debug_set_small_batch_max)
 
+// One instance of layers_kernel: LDS attribute once, then the launch (LOOP = 1: the sampler-loop form, steps.n evaluations).
+template <int RPW, int KS, int HG, int NTL, int SPW, int NTA, int PX, int CORE, int LOOP>
+hipError_t launch_instance(size_t lds_bytes, int grid, float* x, const char* lw0, const FusedDims& d, int l0, int l1,
+                           int n_samples, int Tn, const EdgeArgs& edge, const SampleSteps& steps, hipStream_t s) {
+    static bool attr = false;
+    hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL, SPW, NTA, PX, CORE, LOOP>, lds_bytes, &attr);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((layers_kernel<RPW, KS, HG, NTL, SPW, NTA, PX, CORE, LOOP>), dim3(grid), dim3(512), lds_bytes, s, x, lw0, d,
+                       l0, l1, n_samples, Tn, edge, steps, g_stamps, g_stamps_cap);
+    return hipGetLastError();
+}
+template <int RPW, int KS, int HG, int NTL, int SPW, int NTA, int PX, int CORE>
+hipError_t launch_either(size_t lds_bytes, float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
+                         const EdgeArgs& edge, const SampleSteps& steps, hipStream_t s) {
+    const int grid = (n_samples + SPW - 1) / SPW;
+    if (steps.n > 0)
+        return launch_instance<RPW, KS, HG, NTL, SPW, NTA, PX, CORE, 1>(lds_bytes, grid, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
+    return launch_instance<RPW, KS, HG, NTL, SPW, NTA, PX, CORE, 0>(lds_bytes, grid, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
+}
+
+// samples of Tn tokens in NT token tiles: the tokens, and the last sample's 16-row attention window, must fit
+// (the q/k/v rows in LDS run 8 rows past the last slot)
+constexpr bool tiles_hold(int spw, int Tn, int nt) { return spw * Tn <= 16 * nt && (spw - 1) * Tn + 16 <= 16 * nt + 8; }
+
 template <int RPW, int KS, int HG, int NTL>
 hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
-                         const EdgeArgs& edge, int precision, hipStream_t s) {
+                         const EdgeArgs& edge, const SampleSteps& steps, int precision, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS);
     constexpr int kSmallSPW = 2, kSmallNT = 2, kMidSPW = 4, kMidNT = 4;
     if (precision == BESO_PREC_BF16X3) {
-        // the split-bf16 instance: two samples in two token tiles per workgroup at every batch size (both halves of
-        // every activation fragment have to fit the 160 KiB of LDS)
+        // The split-bf16 instances keep both halves of every activation fragment in LDS, which bounds the token tiles per
+        // workgroup at three (145 KiB; four would need 182 KiB).  Every workgroup streams BOTH weight images (40 MB, kitchen):
+        // samples per weight byte is what sets this mode's speed, so batches beyond one workgroup of two samples per CU take
+        // FOUR samples in three token tiles (4 x 11 = 44 or 4 x 12 = 48 of 48 slots) -- half the workgroups and half the
+        // L2 -> CU weight stream of the two-sample instance (82 GB per B = 4096 forward), at 1.5x its MFMAs per workgroup.
+        // (NTL = all three tiles: the last layer is not trimmed to the action-token tiles in this instance -- with the trimmed
+        // copy of the layer code beside the full one this instance, and no other, produced run-to-run differences in whole
+        // workgroups on the MI355X, in every combination of trimmed phases (tools/.. round-3 notes in DESIGN.md); untrimmed it
+        // is bit-stable and bit-identical to the two-sample instance)
+        constexpr int kX3SPW = 4, kX3NT = 3;
+        if (n_samples > g_small_batch_max && tiles_hold(kX3SPW, Tn, kX3NT)) {
+            constexpr LdsMapX3 X = lds_map_x3(KS, kX3NT);
+            static_assert(X.total <= 160 * 1024, "LDS of the four-sample split-bf16 instance");
+            return launch_either<RPW, KS, HG, kX3NT, kX3SPW, kX3NT, 1, 0>(X.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
+        }
         if (!(kSmallSPW * Tn <= 16 * kSmallNT && (kSmallSPW - 1) * Tn + 16 <= 16 * kSmallNT)) return hipErrorInvalidValue;
         constexpr LdsMapX3 X = lds_map_x3(KS, kSmallNT);
-        static bool attr_x = false;
-        hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL, kSmallSPW, kSmallNT, 1>, X.total, &attr_x);
-        if (e != hipSuccess) return e;
-        (void)hipGetLastError();
-        hipLaunchKernelGGL((layers_kernel<RPW, KS, HG, NTL, kSmallSPW, kSmallNT, 1>), dim3((n_samples + kSmallSPW - 1) / kSmallSPW),
-                           dim3(512), X.total, s, x, lw0, d, l0, l1, n_samples, Tn, edge, g_stamps, g_stamps_cap);
-        return hipGetLastError();
+        return launch_either<RPW, KS, HG, NTL, kSmallSPW, kSmallNT, 1, 0>(X.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
     }
     // latency instances: the samples' tokens and the last sample's 16-row attention window must fit the token tiles
-    if (n_samples <= g_small_batch_max && kSmallSPW * Tn <= 16 * kSmallNT && (kSmallSPW - 1) * Tn + 16 <= 16 * kSmallNT) {
-        static bool attr_s = false;
-        hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL, kSmallSPW, kSmallNT>, L.total, &attr_s);
-        if (e != hipSuccess) return e;
-        (void)hipGetLastError();
-        hipLaunchKernelGGL((layers_kernel<RPW, KS, HG, NTL, kSmallSPW, kSmallNT>), dim3((n_samples + kSmallSPW - 1) / kSmallSPW),
-                           dim3(512), L.total, s, x, lw0, d, l0, l1, n_samples, Tn, edge, g_stamps, g_stamps_cap);
-        return hipGetLastError();
-    }
+    if (n_samples <= g_small_batch_max && kSmallSPW * Tn <= 16 * kSmallNT && (kSmallSPW - 1) * Tn + 16 <= 16 * kSmallNT)
+        return launch_either<RPW, KS, HG, NTL, kSmallSPW, kSmallNT, 0, 0>(L.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
     // up to one workgroup of four samples per CU: two thirds of the throughput instance's work per workgroup
-    if (n_samples <= 2 * g_small_batch_max && kMidSPW * Tn <= 16 * kMidNT && (kMidSPW - 1) * Tn + 16 <= 16 * kMidNT) {
-        static bool attr_m = false;
-        hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL, kMidSPW, kMidNT>, L.total, &attr_m);
-        if (e != hipSuccess) return e;
-        (void)hipGetLastError();
-        hipLaunchKernelGGL((layers_kernel<RPW, KS, HG, NTL, kMidSPW, kMidNT>), dim3((n_samples + kMidSPW - 1) / kMidSPW),
-                           dim3(512), L.total, s, x, lw0, d, l0, l1, n_samples, Tn, edge, g_stamps, g_stamps_cap);
-        return hipGetLastError();
-    }
-    static bool attr = false;
-    hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL>, L.total, &attr);
-    if (e != hipSuccess) return e;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((layers_kernel<RPW, KS, HG, NTL>), dim3((n_samples + kSPW - 1) / kSPW), dim3(512), L.total, s, x, lw0, d,
-                       l0, l1, n_samples, Tn, edge, g_stamps, g_stamps_cap);
-    return hipGetLastError();
+    if (n_samples <= 2 * g_small_batch_max && kMidSPW * Tn <= 16 * kMidNT && (kMidSPW - 1) * Tn + 16 <= 16 * kMidNT)
+        return launch_either<RPW, KS, HG, NTL, kMidSPW, kMidNT, 0, 0>(L.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
+    return launch_either<RPW, KS, HG, NTL, kSPW, kNTT, 0, 0>(L.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
 }
 
 // The long-sequence instance: one sample (Tn <= 16 NT tokens) per workgroup.
 template <int RPW, int KS, int NT>
 hipError_t launch_layers_long(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
-                              const EdgeArgs& edge, hipStream_t s) {
+                              const EdgeArgs& edge, const SampleSteps& steps, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS, false, NT);
     static_assert(L.total <= 160 * 1024, "LDS of the long-sequence instance");
-    static bool attr = false;
-    hipError_t e = ensure_lds(layers_kernel<RPW, KS, 1, NT, 1, NT, 0, 1>, L.total, &attr);
-    if (e != hipSuccess) return e;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((layers_kernel<RPW, KS, 1, NT, 1, NT, 0, 1>), dim3(n_samples), dim3(512), L.total, s, x, lw0, d, l0, l1,
-                       n_samples, Tn, edge, g_stamps, g_stamps_cap);
-    return hipGetLastError();
+    return launch_either<RPW, KS, 1, NT, 1, NT, 0, 1>(L.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
 }
 
 }  // namespace
@@ -3599,13 +3681,23 @@ int fused_layer_edges(const Layout& lay) {
     return 1 | (d.head_fused ? 2 : 0);
 }
 
+// The sampler loop needs both network edges inside the kernel and one action-window element per thread of a workgroup.
+bool fused_can_loop(const Layout& lay, const FwdArgs& a, int precision) {
+    FusedDims d;
+    if (fused_level(lay, a, precision) != 2 || !fused_dims(lay, &d) || !d.attn || !d.head_fused) return false;
+    return (d.seq1 ? 1 : kSPW) * a.t * lay.act <= kLoopMaxElems;
+}
+
 int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, int precision,
-                 hipStream_t s) {
+                 hipStream_t s, const SampleSteps* steps) {
     FusedDims d;
     if (!fused_dims(lay, &d) || !d.attn) return BESO_ERR_UNSUPPORTED;
+    static const SampleSteps no_steps{};
+    const SampleSteps& S = steps ? *steps : no_steps;
     const char* base = packed + lay.fused;
     EdgeArgs e;
     e.state = a.state; e.action = a.action; e.goal = a.goal; e.sigma = a.sigma; e.out = a.out;
+    e.aux = a.aux;
     e.B = a.batch; e.t = a.t; e.precondition = a.precondition;
     e.two = a.vbatch > a.batch ? 1 : 0;
     e.uncond_all = (!e.two && a.uncond_from == 0) ? 1 : 0;
@@ -3616,10 +3708,11 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     // pair live in one workgroup; that ordering only exists inside the kernel, so the head must be fused too
     if (e.two && !e.fuse_head) return BESO_ERR_UNSUPPORTED;
     if (fused_edges) *fused_edges = (e.fuse_embed ? 1 : 0) | (e.fuse_head ? 2 : 0);
+    if (S.n > 0 && !(e.fuse_embed && e.fuse_head)) return BESO_ERR_UNSUPPORTED;
     hipError_t err;
-    if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1, 2>(x, base, d, 0, lay.L, a.vbatch, a.T, e, precision, s);    // kitchen: 8 x 4 action tokens
-    else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3, 4>(x, base, d, 0, lay.L, a.vbatch, a.T, e, precision, s);   // block-push: 8 x 5
-    else if (d.seq1 && precision == BESO_PREC_BF16) err = launch_layers_long<4, 16, kLongNT>(x, base, d, 0, lay.L, a.vbatch, a.T, e, s);   // long horizon: 1 x 67 tokens
+    if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1, 2>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, precision, s);    // kitchen: 8 x 4 action tokens
+    else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3, 4>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, precision, s);   // block-push: 8 x 5
+    else if (d.seq1 && precision == BESO_PREC_BF16) err = launch_layers_long<4, 16, kLongNT>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, s);   // long horizon: 1 x 67 tokens
     else return BESO_ERR_UNSUPPORTED;
     return err == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }

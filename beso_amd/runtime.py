@@ -179,8 +179,10 @@ class ScoreNetRuntime:
         return out
 
     def sample(self, packed: PackedWeights, sampler: str, state, x_t, goal, sigmas, cond_lambda: float = 1.0,
-               inplace: bool = False) -> torch.Tensor:
-        """sample_ddim / sample_euler / sample_heun (s_churn = 0) as ONE enqueue of all steps."""
+               inplace: bool = False, stepwise: bool = False) -> torch.Tensor:
+        """sample_ddim / sample_euler / sample_heun (s_churn = 0) as ONE enqueue of all steps -- one launch for the whole
+        loop where the shape has the one-launch kernel; ``stepwise`` enqueues evaluation by evaluation instead (same
+        arithmetic, bit-identical results)."""
         if sampler not in _lib.SAMPLER_IDS:
             raise ValueError("desired sampler type not found!")
         dev, B, t, state, x, goal, _ = self._prep(state, x_t, goal, None)
@@ -194,7 +196,8 @@ class ScoreNetRuntime:
         with torch.cuda.device(dev):
             st = self.lib.beso_sample(C.byref(self.cfg), packed.buf.data_ptr(), packed.precision,
                                       _lib.SAMPLER_IDS[sampler], state.data_ptr(), gp, x.data_ptr(), B, t, arr,
-                                      len(sig), float(cond_lambda), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+                                      len(sig), float(cond_lambda), _lib.SAMPLE_STEPWISE if stepwise else 0,
+                                      ws.data_ptr(), ws.numel(), _stream_ptr(dev))
         _lib.check(st, f"sample[{sampler}]")
         return x
 

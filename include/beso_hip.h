@@ -146,10 +146,17 @@ int beso_sampler_step(int mode, float* out, float* aux, const float* x, const fl
 
 /* A whole sampling loop: x[batch,t,act] holds x_T on entry and the sample on return.
  * `sigmas` is a HOST array of n_sigmas values, the last one 0 (get_sigmas_*: gc_sampling.py:26-44).
- * No host synchronisation inside: all n_sigmas-1 steps are enqueued back to back.                */
+ * No host synchronisation inside.  Where the shape has the one-launch kernel (bf16 / bf16x3: kitchen, block-push,
+ * long-horizon without classifier-free pairs) the WHOLE loop is ONE launch: the workgroup that owns a sample from the
+ * embedding to the head also applies the step's update and feeds itself the next evaluation (up to 128 evaluations per
+ * launch; longer loops are cut at step boundaries).  Otherwise, and with BESO_SAMPLE_STEPWISE, every evaluation is
+ * enqueued as the forward launch(es) + one update launch.  Both forms run the same arithmetic (bit-identical results). */
+enum {
+    BESO_SAMPLE_STEPWISE = 1   /* beso_sample flags: enqueue evaluation by evaluation */
+};
 int beso_sample(const beso_config* cfg, const void* packed, int precision, int sampler,
                 const float* state, const float* goal, float* x, int batch, int t,
-                const float* sigmas, int n_sigmas, float cond_lambda,
+                const float* sigmas, int n_sigmas, float cond_lambda, int flags,
                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* sample_euler_ancestral (gc_sampling.py:216-256, scaler = None) as one enqueue: per step an Euler step to sigma_down and,

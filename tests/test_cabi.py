@@ -93,7 +93,8 @@ def test_null_and_shape_errors_do_not_touch_the_device(lib):
     assert lib.beso_denoise_fwd(C.byref(cfg), one, 7, one, one, one, one, one, 2, 2, 0, 1.0, one, 1 << 30, None) == -3
     assert lib.beso_denoise_fwd(C.byref(cfg), one, 0, one, one, one, one, one, 2, 2, 8, 1.0, one, 1 << 30, None) == -3
     sig = (C.c_float * 3)(1.0, 0.5, 0.0)
-    assert lib.beso_sample(C.byref(cfg), one, 0, 9, one, one, one, 2, 2, sig, 3, 1.0, one, 1 << 30, None) == -3
+    assert lib.beso_sample(C.byref(cfg), one, 0, 9, one, one, one, 2, 2, sig, 3, 1.0, 0, one, 1 << 30, None) == -3
+    assert lib.beso_sample(C.byref(cfg), one, 0, 0, one, one, one, 2, 2, sig, 3, 1.0, 8, one, 1 << 30, None) == -3     # unknown flag
     # workspace too small
     st = lib.beso_denoise_fwd(C.byref(cfg), one, 0, one, one, one, one, one, 2, 2, 0, 1.0, one, 16, None)
     assert st == -4

@@ -294,6 +294,40 @@ def test_fused_sampler_loops_vs_reference_vectors(precision):
             assert err < tol, key
 
 
+@pytest.mark.parametrize("cfg_name,precision,B,lam", [
+    ("kitchen", "bf16", 3, 1.0), ("kitchen", "bf16", 64, 1.0), ("kitchen", "bf16", 700, 1.0), ("kitchen", "bf16", 1100, 1.0),
+    ("kitchen", "bf16x3", 5, 1.0), ("kitchen", "bf16x3", 600, 1.0),
+    ("block_push", "bf16", 130, 2.0), ("block_push", "bf16", 1030, 2.0), ("block_push", "bf16x3", 258, 2.0),
+    ("block_push", "bf16", 9, 0.0), ("long_horizon", "bf16", 5, 1.0)])
+def test_sampler_loop_is_one_launch_and_equals_the_stepwise_loop(cfg_name, precision, B, lam):
+    """K8 fused into K7: beso_sample runs the whole DDIM / Euler / Heun loop inside ONE launch
+    of layers_kernel -- the workgroup that owns a sample applies the step's update in the head and feeds itself the next
+    evaluation -- and the result equals the step-by-step form (forward launch + update launch per evaluation:
+    BESO_SAMPLE_STEPWISE) BIT FOR BIT, in every instance of the kernel (2 / 4 / 8 samples per workgroup, the split-bf16
+    instances, classifier-free pairs, the long-sequence instance), for full and short windows.  Loops of more than 128
+    evaluations are cut at step boundaries."""
+    from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+    cfg = O.CONFIGS[cfg_name]
+    m = make_module(cfg, O.make_weights(cfg, seed=3, std=0.03), precision)
+    s_np, g_np, x_np = O.make_inputs(cfg, B, seed=11)
+    with torch.no_grad():
+        for t in sorted({cfg.obs_seq_len, max(1, cfg.obs_seq_len - 2)}):
+            s, g, x = G(s_np[:, :t]), G(g_np), G(x_np[:, :t])
+            for sampler, n_steps, n_evals in (("ddim", 3, 3), ("euler", 7, 7), ("heun", 4, 7), ("heun", 70, 139)):
+                if n_steps == 70 and (B > 200 or t != cfg.obs_seq_len):
+                    continue
+                sig = ks.get_sigmas_exponential(n_steps, 0.05, 1.0)
+                out = {}
+                n_loop = count_fused_launches(lambda: out.__setitem__(
+                    "loop", m.fused_sampler(sampler, s, x, g, sig, cond_lambda=lam)))
+                n_step = count_fused_launches(lambda: out.__setitem__(
+                    "step", m.fused_sampler(sampler, s, x, g, sig, cond_lambda=lam, stepwise=True)))
+                assert n_loop == (n_evals + 127) // 128, (sampler, n_steps, n_loop)
+                assert n_step == n_evals, (sampler, n_steps, n_step)
+                assert torch.isfinite(out["loop"]).all()
+                assert torch.equal(out["loop"], out["step"]), (cfg_name, precision, B, t, sampler, n_steps)
+
+
 def test_stochastic_and_adaptive_samplers_on_gpu():
     """lms, dpm_fast, dpm_adaptive (incl. rejected steps), dpmpp_2s_ancestral and dpmpp_sde with the HIP denoiser
     (fp32 mode) against the reference's outputs; the injected noise is drawn from the seeded CPU generator the
@@ -461,7 +495,7 @@ def test_block_push_2048_heun50_cfg_bf16():
         for prec in ("bf16", "bf16x3"):
             model = ClassifierFreeSampleModel(make_module(cfg, w, prec), 2.0)
             n = count_fused_launches(lambda: outs.__setitem__(prec, ks.sample_heun(model, s, x, g, sig, disable=True)))
-            assert n == 99, n                                              # 2 * 50 - 1 evaluations, each ONE launch (cond + uncond inside)
+            assert n == 1, n                                               # 2 * 50 - 1 evaluations (cond + uncond inside) in ONE launch
             assert torch.isfinite(outs[prec]).all()
             if prec == "bf16":
                 part = ks.sample_heun(model, s[512:640], x[512:640], g[512:640], sig, disable=True)
@@ -497,7 +531,7 @@ def test_long_horizon_256_euler100_bf16():
             for lvl in (2, 1):
                 lib.beso_debug_set_fused_level_max(lvl)
                 n = count_fused_launches(lambda: outs.__setitem__(lvl, ks.sample_euler(m, s, x, g, sig, disable=True)))
-                assert n == (100 if lvl == 2 else 100 * cfg.n_layers), (lvl, n)
+                assert n == (1 if lvl == 2 else 100 * cfg.n_layers), (lvl, n)       # the whole loop is one launch
                 assert torch.isfinite(outs[lvl]).all()
             lib.beso_debug_set_fused_level_max(2)
             part = ks.sample_euler(m, s[100:103], x[100:103], g[100:103], sig, disable=True)
@@ -802,6 +836,40 @@ def test_fused_instances_are_bit_identical(cfg_name):
         lib.beso_debug_set_small_batch_max(512)
 
 
+@pytest.mark.parametrize("cfg_name", ["kitchen", "block_push"])
+def test_bf16x3_instances_are_bit_identical_and_stable_from_run_to_run(cfg_name):
+    """The split-bf16 mode has two instances of the kernel: two samples in two token tiles per workgroup (batches up to
+    512) and four samples in three (larger batches: half the workgroups, half the L2 -> CU weight stream).  Same per-sample
+    arithmetic: equal bits for every batch size, window and conditioning mode, through a sampler loop, and from run to
+    run (eight repetitions at B = 4096 -- a variant of the four-sample instance once differed between runs)."""
+    from beso_amd import _lib
+    from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+    from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
+    lib = _lib.load()
+    cfg = O.CONFIGS[cfg_name]
+    m = make_module(cfg, O.make_weights(cfg, seed=5, std=0.04), "bf16x3")
+    cfgm = ClassifierFreeSampleModel(m, 1.5)
+    sig = ks.get_sigmas_exponential(3, 0.05, 1.0)
+    try:
+        with torch.no_grad():
+            for B, t in [(513, cfg.obs_seq_len), (771, 2), (1030, cfg.obs_seq_len - 1), (4096, cfg.obs_seq_len)]:
+                s, g, a = (G(v) for v in O.make_inputs(cfg, B, seed=B + t, t=t))
+                sg = G(np.linspace(0.05, 1.0, B).astype(np.float32))
+                outs = []
+                for limit in (1 << 20, 512):          # two samples per workgroup at every size / four above 512
+                    lib.beso_debug_set_small_batch_max(limit)
+                    outs.append((m(s, a, g, sg), m(s, a, g, sg, uncond=True), cfgm(s, a, g, sg),
+                                 ks.sample_heun(cfgm, s, a, g, sig, disable=True)))
+                for x2, x4 in zip(*outs):
+                    assert torch.isfinite(x4).all() and torch.equal(x2, x4), (B, t)
+                if B == 4096:
+                    for _ in range(8):
+                        assert torch.equal(m(s, a, g, sg), outs[1][0]) and torch.equal(cfgm(s, a, g, sg), outs[1][2])
+                        assert torch.equal(ks.sample_heun(cfgm, s, a, g, sig, disable=True), outs[1][3])
+    finally:
+        lib.beso_debug_set_small_batch_max(512)
+
+
 @pytest.mark.gpu
 def test_device_prefetcher_on_gpu():
     """Batches arrive on the device, complete and in order, while their staging buffers are being reused."""
@@ -863,9 +931,13 @@ def test_no_writes_outside_output_and_workspace(cfg_name, precision):
             _lib.check(st, "denoise_fwd")
             sig = (C.c_float * 4)(1.0, 0.3, 0.05, 0.0)
             st = lib.beso_sample(C.byref(rt.cfg), packed.buf.data_ptr(), packed.precision, _lib.SAMPLER_IDS["heun"],
-                                 s.data_ptr(), g.data_ptr(), xbig.data_ptr() + 4096, B, t, sig, 4, lam,
+                                 s.data_ptr(), g.data_ptr(), xbig.data_ptr() + 4096, B, t, sig, 4, lam, 0,
                                  wsbig.data_ptr() + PAD, ws_bytes, stream)
             _lib.check(st, "sample")
+            st = lib.beso_sample(C.byref(rt.cfg), packed.buf.data_ptr(), packed.precision, _lib.SAMPLER_IDS["heun"],
+                                 s.data_ptr(), g.data_ptr(), xbig.data_ptr() + 4096, B, t, sig, 4, lam, _lib.SAMPLE_STEPWISE,
+                                 wsbig.data_ptr() + PAD, ws_bytes, stream)
+            _lib.check(st, "sample (stepwise)")
             torch.cuda.synchronize()
             assert bool((wsbig[:PAD] == 0xAB).all()) and bool((wsbig[PAD + ws_bytes:] == 0xAB).all()), (B, t, lam, "workspace")
             for big in (outbig, xbig):
