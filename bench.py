@@ -20,6 +20,10 @@ Rank 0 prints ONE JSON line with the driver's fields plus
                   rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this very script, run as child processes;
   "parity_mode":  the same forward in the split-bf16 (BF16X3) instance of the same kernel -- the mode that meets the
                   north-star 1e-4 tolerance -- timed beside the bf16 headline;
+  "fp16_mode":    the same forward through the fp16-operand build of the same kernel (BESO_PREC_FP16), with the deviation
+                  of both 16-bit modes from the parity mode's output;
+  "cold_ms_per_step" / "long_run": the K steps timed straight behind the W warm-up steps (before the clock-settle loop),
+                  and >= 200 steps of the settled loop -- `value` itself is exactly K steps behind the settle loop;
   "cpu_baseline": the reference's CPU path (ATen restatement in oracle/beso_oracle_torch.py) timed on this box's
                   host cores on a bounded sample of the same workload.
 
@@ -47,7 +51,7 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}       # dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}       # dense MFMA peaks (MI355X_MICROARCH.md)
 
 
 def build_model(cfg, w, precision, dev, attn_pdrop=0.0, resid_pdrop=0.0, goal_drop=0.0, train=False):
@@ -158,15 +162,75 @@ def cpu_baseline(cfg, w, batch, budget_s=12.0):
         if el1 > 5.0 or reps >= 10:
             break
     cfg1_ms = 1e3 * el1 / reps
+    multi = cpu_baseline_multiprocess(cfg, batch, cores)
     return {"value": steps_per_s, "unit": f"denoise-steps/s (B={batch} per step)", "cores": int(threads),
             "kind": "port",
             "sample": f"{n} GCDenoiser.forward calls over B={batch} kitchen samples, sigma=0.3 ({el:.1f} s of ATen fp32 "
                       f"with {threads} threads on a {cores}-core host)",
             "samples_per_s": steps_per_s * batch,
             "host_cores": cores,
+            "all_cores": multi,
             "config0_b64_ddim10": {"ms": cfg1_ms, "denoise_steps_per_s": 10.0 / (cfg1_ms * 1e-3),
                                    "sample_steps_per_s": 640.0 / (cfg1_ms * 1e-3), "threads": int(threads),
                                    "what": "BASELINE configs[0]: kitchen, B=64, 10 DDIM steps, fp32 on CPU"}}
+
+
+def cpu_baseline_multiprocess(cfg, batch, cores, run_s=8.0):
+    """The same ATen forward on ALL host cores: samples are independent, so P processes x 16 threads each take a disjoint
+    shard of the batch (ATen's intra-op pool stops scaling at ~16 threads on these GEMMs; processes do not share it).
+    Every worker warms up, waits for a common start time, runs its shard repeatedly for `run_s` seconds and reports
+    (samples processed, elapsed); the figure is sum(samples) / max(elapsed)."""
+    threads = 16
+    procs = max(1, min(cores // threads, 16))
+    if procs == 1:
+        return None
+    shard = max(16, batch // procs)
+    t_start = time.time() + 12.0                        # (imports + warm-up of the workers)
+    from beso_amd import synthetic as S
+    name = next(k for k, v in S.SHAPES.items() if v == cfg)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", name,
+           str(shard), str(threads), repr(t_start), repr(run_s)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    kids = [subprocess.Popen(cmd + [str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(procs)]
+    res = []
+    for k in kids:
+        try:
+            out, _ = k.communicate(timeout=run_s + 60.0)
+            line = [ln for ln in out.splitlines() if ln.startswith("{")]
+            if line:
+                res.append(json.loads(line[-1]))
+        except Exception:      # noqa: BLE001
+            k.kill()
+    if len(res) != procs:
+        return {"error": f"{len(res)} of {procs} workers reported"}
+    samples = sum(r["samples"] for r in res)
+    el = max(r["elapsed"] for r in res)
+    return {"samples_per_s": samples / el, "denoise_steps_per_s_at_this_batch": samples / el / batch, "processes": procs,
+            "threads_per_process": threads, "cores": procs * threads, "shard": shard, "run_s": el,
+            "what": f"{procs} processes x {threads} ATen threads, each the fp32 forward over its own {shard}-sample shard, "
+                    f"common start, {run_s:.0f} s"}
+
+
+def cpu_worker(argv):
+    name, shard, threads, t_start, run_s, idx = argv[0], int(argv[1]), int(argv[2]), float(argv[3]), float(argv[4]), int(argv[5])
+    from oracle import beso_oracle as O
+    from oracle import beso_oracle_torch as OT
+    from beso_amd import synthetic as S
+    torch.set_num_threads(threads)
+    cfg = S.SHAPES[name]
+    ocfg = O.ScoreGPTConfig(**cfg.as_dict())
+    W = OT.to_torch(S.make_weights(cfg, seed=0, std=0.02))
+    s, g, a = (torch.from_numpy(v) for v in S.make_inputs(cfg, shard, seed=100 + idx))
+    sig = torch.full((shard,), 0.3)
+    OT.denoise(W, ocfg, s[:16], a[:16], g[:16], sig[:16])
+    while time.time() < t_start:
+        time.sleep(0.005)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < run_s:
+        OT.denoise(W, ocfg, s, a, g, sig)
+        n += 1
+    print(json.dumps({"samples": n * shard, "elapsed": time.perf_counter() - t0}))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -266,6 +330,8 @@ def run_forward(args, world, rank, dev):
         for _ in range(args.warmup):
             out = step()
         torch.cuda.synchronize()
+        # the driver's protocol taken literally: K steps straight behind the W warm-up steps (a cold MI355X is still ramping)
+        cold_elapsed, _ = timed(step, args.steps, world)
         settled = settle(step, args.settle_ms)
         # which launch site dominates?  time each once, then instrument the dominant one
         sites = ["fused_layer", "gemm_fc1", "gemm_fc2", "gemm_qkv", "gemm_proj", "attention", "layernorm"]
@@ -284,8 +350,11 @@ def run_forward(args, world, rank, dev):
         kern_ms, kern_n = rt.profile_read()
         rt.profile_enable("off")
         assert torch.isfinite(out).all()
+        # ... and a region long enough to carry a sub-percent margin (>= 200 steps of the same settled loop)
+        long_steps = max(200, args.steps)
+        long_elapsed, _ = timed(step, long_steps, world)
         # the parity mode of the same kernel, timed beside the headline (rank 0, N = 1: it is not part of `value`)
-        parity = None
+        parity = fp16 = None
         if world == 1 and not args.no_parity_line and args.precision == "bf16" and args.config in ("kitchen", "block_push"):
             mx = build_model(cfg, w, "bf16x3", dev)
             ix = mx.inner_model
@@ -302,12 +371,30 @@ def run_forward(args, world, rank, dev):
             parity = {"dtype": "bf16x3", "ms_per_step": 1e3 * elx / nx, "kernel_avg_launch_ms": kx_ms / max(kx_n, 1),
                       "launches": kx_n, "max_rel_dev_of_bf16_from_this_mode": dev_rel,
                       "what": "same GCDenoiser.forward through the split-bf16 instance of layers_kernel (3 MFMAs per operand "
-                              "pair, exact GELU, fp32 attention core): 1e-4-class parity with the fp32 reference "
-                              "(tests/test_gpu_parity.py: 7e-6 .. 3e-5)"}
+                              "pair, exact GELU, fp32 attention core; four samples in three token tiles per workgroup): "
+                              "1e-4-class parity with the fp32 reference (tests/test_gpu_parity.py: 5e-6 .. 3e-5)"}
+            # the fp16-operand build of the same kernel, the same way; its deviation from the parity mode beside bf16's
+            mh = build_model(cfg, w, "fp16", dev)
+            ih = mh.inner_model
+            rth, ph = ih.runtime(cfg.sigma_data), ih.packed_weights()
+            steph = lambda: rth.denoise(ph, state, action, goal, sigma, precondition=True)      # noqa: E731
+            for _ in range(20):
+                outh = steph()
+            rth.profile_enable("fused_layer")
+            nh = max(50, args.steps)
+            elh, outh = timed(steph, nh, 1)
+            kh_ms, kh_n = rth.profile_read()
+            rth.profile_enable("off")
+            fp16 = {"dtype": "fp16", "ms_per_step": 1e3 * elh / nh, "kernel_avg_launch_ms": kh_ms / max(kh_n, 1), "launches": kh_n,
+                    "max_rel_dev_from_parity_mode": float((outh - outx).abs().max() / outx.abs().max()),
+                    "bf16_max_rel_dev_from_parity_mode": dev_rel,
+                    "what": "same GCDenoiser.forward through the fp16-operand build of layers_kernel (BESO_PREC_FP16: "
+                            "v_mfma_f32_16x16x32_f16, the bf16 MFMA rate, 11-bit significands); vs the reference's vectors "
+                            "1.3e-3 .. 1.8e-3 where bf16 measures 7e-3 .. 1.2e-2 (tests/test_gpu_parity.py)"}
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed, cold_elapsed, long_elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, cold_elapsed, long_elapsed = (float(v) for v in tmax.tolist())
     if rank != 0:
         return None
     F = cfg.flops_per_sample()
@@ -354,6 +441,9 @@ def run_forward(args, world, rank, dev):
                    "parallelism": f"batch-sharded x{world}, no collective in the loop",
                    "weights": "seeded N(0,0.02) recipe (no trained checkpoints shipped)", "sigma": 0.3},
         "untimed_settle_steps": settled,
+        "cold_ms_per_step": 1e3 * cold_elapsed / args.steps,
+        "long_run": {"steps": long_steps, "ms_per_step": 1e3 * long_elapsed / long_steps,
+                     "frac_of_mfma_peak": B * F / (long_elapsed / long_steps) / 1e12 / peak},
         "sample_nfe_per_s": steps_per_s * B,
         "flops_per_sample_forward": F,
         "forward_tflops_per_gpu": fwd_tflops,
@@ -369,6 +459,9 @@ def run_forward(args, world, rank, dev):
     }
     if parity is not None:
         result["parity_mode"] = parity
+    if fp16 is not None:
+        fp16["forward_frac_of_fp16_mfma_peak"] = B * F / (fp16["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS["fp16"]
+        result["fp16_mode"] = fp16
     if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only (the other ranks would idle at the barrier)
         result["cpu_baseline"] = cpu_baseline(cfg, w, B)
     if world == 1 and not args.no_other_configs and args.config == "kitchen" and args.precision == "bf16":
@@ -413,6 +506,9 @@ def other_configs(args, dev):
     sampler_run("configs[0]: kitchen B=64 DDIM-10", "kitchen", 64, "ddim", 10, 0.005, 1.0, None, 20)
     sampler_run("configs[3]: block-push B=2048 Heun-50 x CFG lambda=2", "block_push", 2048, "heun", 50, 0.05, 1.0, 2.0, 3)
     sampler_run("configs[4]: long-horizon (D=512, 67 tokens) B=256 per GPU Euler-100", "long_horizon", 256, "euler", 100, 0.005, 1.0, None, 3)
+    # (a sample per workgroup: 256 is exactly one workgroup per CU; 384 = 1.5 rounds and 1024 = 4 rounds beside it)
+    sampler_run("configs[4] at B=384 per GPU", "long_horizon", 384, "euler", 100, 0.005, 1.0, None, 2)
+    sampler_run("configs[4] at B=1024 per GPU", "long_horizon", 1024, "euler", 100, 0.005, 1.0, None, 1)
     targs = copy.copy(args)
     targs.workload, targs.batch, targs.steps, targs.warmup, targs.settle_ms, targs.config = "train", 1024, 20, 3, 100.0, "kitchen"
     tr = run_train(targs, 1, 0, dev)
@@ -482,12 +578,14 @@ def run_train(args, world, rank, dev):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU per step (forward: 4096, train: 1024)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "bf16x3"])
     ap.add_argument("--config", default="kitchen", choices=["kitchen", "block_push", "long_horizon"])
     ap.add_argument("--workload", default="forward", choices=["forward", "train"])
     ap.add_argument("--c1-overlap", type=int, default=1, choices=[0, 1], help="train workload, N > 1: overlapped gradient all-reduce")

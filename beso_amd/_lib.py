@@ -10,10 +10,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BESO_HIP_LIB points the binding at another build of the same library (kernel experiments: tools/variants.py)
 LIB_PATH = os.environ.get("BESO_HIP_LIB") or os.path.join(_HERE, "lib", "libbeso_hip.so")
 
-PREC_BF16, PREC_FP32, PREC_BF16X3 = 0, 1, 2
-PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
+PREC_BF16, PREC_FP32, PREC_BF16X3, PREC_FP16 = 0, 1, 2, 3
+PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "fp16": PREC_FP16}
 FLAG_UNCOND = 1
-SAMPLE_STEPWISE = 1
+# execution-plan hints of the forward calls (include/beso_hip.h: which kernels run, never what they compute)
+PLAN_PER_OP, PLAN_BLOCKS = 0x10, 0x20
+PLAN_SPW2, PLAN_SPW4, PLAN_SPW8 = 0x100, 0x200, 0x300
+SAMPLE_STEPWISE = 0x1000
+TRAIN_LAST_ACTION_ONLY, TRAIN_PLAN_PER_OP, TRAIN_PLAN_TILES = 1, 2, 4
 SAMPLER_IDS = {"ddim": 0, "euler": 1, "heun": 2}
 GOAL_RANDOM, GOAL_TAIL, GOAL_SEQ_END = 0, 1, 2
 STEP_DDIM, STEP_EULER, STEP_HEUN_PREDICT, STEP_HEUN_CORRECT = 0, 1, 2, 3
@@ -23,11 +27,12 @@ SITES = {"off": 0, "gemm_qkv": 1, "gemm_proj": 2, "gemm_fc1": 3, "gemm_fc2": 4, 
 # every symbol include/beso_hip.h declares (tests check that the library exports all of them)
 EXPORTS = ["beso_version", "beso_status_string", "beso_last_error", "beso_num_params", "beso_packed_bytes", "beso_pack_weights",
            "beso_workspace_bytes", "beso_score_fwd", "beso_denoise_fwd", "beso_sampler_step", "beso_sample",
-           "beso_profile_enable", "beso_profile_read", "beso_debug_set_stamps", "beso_adam_step",
-           "beso_train_workspace_bytes", "beso_grad_floats", "beso_loss_grad", "beso_debug_gemm", "beso_gather_windows",
-           "beso_loss_grad_overlap", "beso_grad_early_range", "beso_debug_set_small_batch_max",
-           "beso_sample_ancestral", "beso_debug_set_fused_level_max", "beso_goal_mask", "beso_debug_set_train_tail",
-           "beso_debug_set_train_option"]
+           "beso_profile_enable", "beso_profile_read", "beso_adam_step",
+           "beso_train_workspace_bytes", "beso_grad_floats", "beso_loss_grad", "beso_gather_windows",
+           "beso_loss_grad_overlap", "beso_grad_early_range", "beso_sample_ancestral", "beso_goal_mask"]
+# include/beso_hip_debug.h: the development build only (libbeso_hip_dev.so); the product library exports none of them
+DEV_EXPORTS = ["beso_debug_set_stamps", "beso_debug_gemm"]
+DEV_LIB_PATH = os.path.join(_HERE, "lib", "libbeso_hip_dev.so")
 
 
 class BesoConfig(C.Structure):
@@ -91,23 +96,9 @@ def load() -> C.CDLL:
         if hasattr(lib, "beso_sample_ancestral") or not os.environ.get("BESO_HIP_LIB"):
             lib.beso_sample_ancestral.restype = i32
             lib.beso_sample_ancestral.argtypes = [cfgp, vp, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_float), i32, f32, f32, vp,
-                                                  vp, sz, vp]
+                                                  i32, vp, sz, vp]
         lib.beso_profile_enable.restype = None
         lib.beso_profile_enable.argtypes = [i32]
-        if hasattr(lib, "beso_debug_set_small_batch_max") or not os.environ.get("BESO_HIP_LIB"):
-            lib.beso_debug_set_small_batch_max.restype = None
-            lib.beso_debug_set_small_batch_max.argtypes = [i32]
-        if hasattr(lib, "beso_debug_set_train_tail") or not os.environ.get("BESO_HIP_LIB"):
-            lib.beso_debug_set_train_tail.restype = None
-            lib.beso_debug_set_train_tail.argtypes = [i32]
-        if hasattr(lib, "beso_debug_set_train_option") or not os.environ.get("BESO_HIP_LIB"):
-            lib.beso_debug_set_train_option.restype = None
-            lib.beso_debug_set_train_option.argtypes = [i32, i32]
-        if hasattr(lib, "beso_debug_set_fused_level_max") or not os.environ.get("BESO_HIP_LIB"):
-            lib.beso_debug_set_fused_level_max.restype = None
-            lib.beso_debug_set_fused_level_max.argtypes = [i32]
-        lib.beso_debug_set_stamps.restype = None
-        lib.beso_debug_set_stamps.argtypes = [vp, i32]
         if hasattr(lib, "beso_adam_step") or not os.environ.get("BESO_HIP_LIB"):   # (A/B builds of older revisions)
             lib.beso_adam_step.restype = i32
             lib.beso_adam_step.argtypes = [vp, i32, vp, vp, vp, f32, f32, f32, f32, f32, i32, i32, f32, vp]
@@ -126,8 +117,6 @@ def load() -> C.CDLL:
                 lib.beso_loss_grad_overlap.argtypes = lib.beso_loss_grad.argtypes + [vp]
                 lib.beso_grad_early_range.restype = i32
                 lib.beso_grad_early_range.argtypes = [cfgp, C.POINTER(sz), C.POINTER(sz)]
-            lib.beso_debug_gemm.restype = i32
-            lib.beso_debug_gemm.argtypes = [i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]
         if hasattr(lib, "beso_gather_windows") or not os.environ.get("BESO_HIP_LIB"):
             lib.beso_gather_windows.restype = i32
             lib.beso_gather_windows.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, C.c_longlong, vp, vp, i32, i32, i32,
@@ -136,6 +125,26 @@ def load() -> C.CDLL:
         lib.beso_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i32)]
         _lib = lib
     return _lib
+
+
+_dev = None
+
+
+def load_dev() -> C.CDLL:
+    """The development build (`python -m beso_amd.build --dev`, include/beso_hip_debug.h): phase stamps and the GEMM layout
+    probe.  A separate library image with its own state; nothing in the package uses it."""
+    global _dev
+    if _dev is None:
+        import torch  # noqa: F401      (the HIP runtime of the process: see load())
+        if not os.path.exists(DEV_LIB_PATH):
+            raise BesoHipError(f"{DEV_LIB_PATH} not found: build it with `python -m beso_amd.build --dev`")
+        lib = C.CDLL(DEV_LIB_PATH)
+        lib.beso_debug_set_stamps.restype = None
+        lib.beso_debug_set_stamps.argtypes = [C.c_void_p, C.c_int]
+        lib.beso_debug_gemm.restype = C.c_int
+        lib.beso_debug_gemm.argtypes = [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+        _dev = lib
+    return _dev
 
 
 def check(status: int, what: str = "") -> None:

@@ -129,7 +129,8 @@ class DiffusionGPT(nn.Module):
         return rt
 
     def set_precision(self, precision: str) -> None:
-        """'bf16' (throughput), 'bf16x3' (parity mode of the fused kernel: split-bf16, fp32-class), 'fp32' (exact-fp32
+        """'bf16' (throughput), 'fp16' (the one-launch kernel with fp16 operands: the bf16 rate, ~8x smaller operand rounding;
+        shapes with that kernel only), 'bf16x3' (parity mode of the fused kernel: split-bf16, fp32-class), 'fp32' (exact-fp32
         MFMA, per-op kernels, any shape)."""
         if precision != self.precision:
             self.precision = precision

@@ -17,7 +17,11 @@ LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "build")
 LIB = os.path.join(LIBDIR, "libbeso_hip.so")
 STAMP = os.path.join(LIBDIR, "libbeso_hip.sha256")        # source hash the .so was built from (travels with it)
-UNITS = ["api", "elementwise", "attention", "gemm", "fused", "optim", "train", "feed"]
+# the development build: the same sources with -DBESO_DEV_API=1 (include/beso_hip_debug.h: phase stamps, the GEMM layout
+# probe).  Nothing in the package loads it; tools/ and one operand-layout test do.
+DEV_LIB = os.path.join(LIBDIR, "libbeso_hip_dev.so")
+DEV_STAMP = os.path.join(LIBDIR, "libbeso_hip_dev.sha256")
+UNITS = ["api", "elementwise", "attention", "gemm", "fused", "fused_f16", "optim", "train", "feed"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -36,6 +40,7 @@ def _source_hash() -> str:
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC))
     files.append(os.path.join(os.path.dirname(PKG), "include", "beso_hip.h"))
+    files.append(os.path.join(os.path.dirname(PKG), "include", "beso_hip_debug.h"))
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
@@ -43,10 +48,10 @@ def _source_hash() -> str:
     return h.hexdigest()
 
 
-def _compile(unit: str) -> str:
+def _compile(unit: str, dev: bool = False) -> str:
     src = os.path.join(CSRC, unit + ".hip")
-    obj = os.path.join(OBJDIR, unit + ".o")
-    extra = os.environ.get("BESO_EXTRA_HIPCC_FLAGS", "").split()
+    obj = os.path.join(OBJDIR, unit + ("_dev.o" if dev else ".o"))
+    extra = os.environ.get("BESO_EXTRA_HIPCC_FLAGS", "").split() + (["-DBESO_DEV_API=1"] if dev else [])
     cmd = [_hipcc(), *FLAGS, *extra, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -56,7 +61,9 @@ def _compile(unit: str) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
+    """Build the product library (dev=False) or the development build (dev=True); returns its path."""
+    LIB, STAMP = (DEV_LIB, DEV_STAMP) if dev else (globals()["LIB"], globals()["STAMP"])
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     want = _source_hash()
@@ -76,7 +83,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             return LIB
         raise
     with cf.ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
-        objs = list(ex.map(_compile, UNITS))
+        objs = list(ex.map(lambda u: _compile(u, dev), UNITS))
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -97,4 +104,4 @@ def is_current() -> bool:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, dev="--dev" in sys.argv)

@@ -5,10 +5,12 @@
 #include <string.h>
 #include <stdio.h>
 #include <vector>
-#include <mutex>
 #include "common.h"
 #include "fused.h"
 #include "train.h"
+#if BESO_DEV_API
+#include "../../include/beso_hip_debug.h"
+#endif
 
 namespace beso {
 
@@ -33,7 +35,8 @@ static size_t carve(size_t& cur, size_t bytes) {
 
 bool make_layout(const beso_config* c, int precision, Layout* o) {
     if (validate_config(c) != BESO_OK) return false;
-    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32 && precision != BESO_PREC_BF16X3) return false;
+    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32 && precision != BESO_PREC_BF16X3 && precision != BESO_PREC_FP16)
+        return false;
     memset(o, 0, sizeof(*o));
     o->D = c->embed_dim; o->H = c->n_heads; o->hd = o->D / o->H; o->L = c->n_layers;
     o->G = c->goal_seq_len; o->W = c->obs_seq_len; o->obs = c->obs_dim; o->act = c->act_dim;
@@ -65,7 +68,7 @@ bool make_layout(const beso_config* c, int precision, Layout* o) {
         y.w_qkv = carve(cur, e * o->Nqkv * o->Kd); y.w_proj = carve(cur, e * o->Nd * o->Kd);
         y.w_fc1 = carve(cur, e * o->Nh * o->Kd); y.w_fc2 = carve(cur, e * o->Nd * o->Kh);
     }
-    o->fused = carve(cur, fused_packed_bytes(*o, precision));
+    o->fused = carve(cur, precision == BESO_PREC_FP16 ? fused_packed_bytes_f16(*o, BESO_PREC_BF16) : fused_packed_bytes(*o, precision));
     o->total = cur;
     return true;
 }
@@ -75,6 +78,7 @@ bool make_workspace(const beso_config* c, const Layout& lay, int batch, int t, i
     if (batch < 1 || t < 1 || t > c->obs_seq_len) return false;
     memset(w, 0, sizeof(*w));
     const size_t vb = (size_t)batch * (cfg_guidance ? 2 : 1);
+    (void)precision;
     const size_t T = 1 + lay.G + 2 * (size_t)t;
     const size_t M = round_up_sz(vb * T, kTileMN);        // rows padded so tile loads never need a clamp
     const size_t e = lay.elem_bytes, f = sizeof(float);
@@ -87,7 +91,7 @@ bool make_workspace(const beso_config* c, const Layout& lay, int batch, int t, i
     const size_t na = (size_t)batch * t * lay.act;
     w->den = carve(cur, f * na); w->x2 = carve(cur, f * na); w->d1 = carve(cur, f * na);
     w->sig = carve(cur, f * batch);
-    w->fused = carve(cur, fused_workspace_bytes(lay, (int)vb, (int)T, precision));
+    w->fused = carve(cur, 0);
     w->total = cur;
     return true;
 }
@@ -95,11 +99,11 @@ bool make_workspace(const beso_config* c, const Layout& lay, int batch, int t, i
 // ---------------------------------------------------------------------------------------------
 // profiling hooks
 // ---------------------------------------------------------------------------------------------
-static std::mutex g_prof_mu;
-static int g_prof_site = 0;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
-static std::vector<hipEvent_t> g_prof_free;
-static hipEvent_t g_prof_open = nullptr;
+// (state of the CALLING THREAD: a thread that times its launch sites does not see, and does not disturb, other callers)
+static thread_local int g_prof_site = 0;
+static thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static thread_local std::vector<hipEvent_t> g_prof_free;
+static thread_local hipEvent_t g_prof_open = nullptr;
 
 static hipEvent_t prof_get_event() {
     if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
@@ -110,7 +114,6 @@ static hipEvent_t prof_get_event() {
 
 void profile_begin(int site, hipStream_t s) {
     if (g_prof_site != site) return;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
     hipEvent_t e = prof_get_event();
     if (!e) return;
     (void)hipEventRecord(e, s);
@@ -119,7 +122,6 @@ void profile_begin(int site, hipStream_t s) {
 
 void profile_end(int site, hipStream_t s) {
     if (g_prof_site != site) return;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_open) return;
     hipEvent_t e = prof_get_event();
     if (!e) return;
@@ -148,13 +150,15 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
     if (fused == 2) {
         // embed -> all transformer layers -> head as ONE launch: the residual tile of 8 samples never leaves
         // the CU's registers (shapes whose head cannot be fused store x and run the head kernel)
-        if (!(fused_layer_edges(lay) & 1)) {              // (long sequences: the layers are one launch, the edges their own)
+        const bool f16 = precision == BESO_PREC_FP16;
+        if (!((f16 ? fused_layer_edges_f16(lay) : fused_layer_edges(lay)) & 1)) {
             profile_begin(BESO_SITE_EMBED, s);
             HIP_TRY(launch_embed(lay, packed, a, x, s));
             profile_end(BESO_SITE_EMBED, s);
         }
         profile_begin(BESO_SITE_FUSED_LAYER, s);
-        int st = fused_layers(lay, packed, a, x, &fused_edges, precision, s);
+        int st = f16 ? fused_layers_f16(lay, packed, a, x, &fused_edges, BESO_PREC_BF16, s)
+                     : fused_layers(lay, packed, a, x, &fused_edges, precision, s);
         profile_end(BESO_SITE_FUSED_LAYER, s);
         if (st != BESO_OK) return st;
     } else {
@@ -231,11 +235,12 @@ static int forward(const beso_config* cfg, const void* packed, int precision, co
                    hipStream_t s) {
     int st = validate_config(cfg);
     if (st != BESO_OK) return st;
-    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32 && precision != BESO_PREC_BF16X3) return BESO_ERR_BAD_ARG;
+    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32 && precision != BESO_PREC_BF16X3 && precision != BESO_PREC_FP16)
+        return BESO_ERR_BAD_ARG;
     if (batch < 1 || t < 1 || t > cfg->obs_seq_len) return BESO_ERR_BAD_SHAPE;
     if (!packed || !state || !action || !sigma || !out || !workspace) return BESO_ERR_BAD_ARG;
     if (cfg->goal_seq_len > 0 && !goal) return BESO_ERR_BAD_ARG;
-    if (flags & ~BESO_FLAG_UNCOND) return BESO_ERR_BAD_ARG;
+    if (flags & ~(BESO_FLAG_UNCOND | BESO_PLAN_MASK)) return BESO_ERR_BAD_ARG;
     Layout lay;
     if (!make_layout(cfg, precision, &lay)) return BESO_ERR_BAD_CONFIG;
     // ClassifierFreeSampleModel (classifier_free_sampler.py:35-49)
@@ -254,9 +259,10 @@ static int forward(const beso_config* cfg, const void* packed, int precision, co
     a.precondition = precondition;
     a.uncond_from = two ? batch : (uncond ? 0 : a.vbatch);
     a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
-    const int level = fused_level(lay, a, precision);
-    // BF16X3 is the split-bf16 instance of the fused kernel (layers_kernel) and has no per-op form
-    if (precision == BESO_PREC_BF16X3 && level != 2) return BESO_ERR_UNSUPPORTED;
+    a.plan = flags & BESO_PLAN_MASK;
+    const int level = precision == BESO_PREC_FP16 ? fused_level_f16(lay, a, BESO_PREC_BF16) : fused_level(lay, a, precision);
+    // BF16X3 / FP16 are instances of the one-launch kernel (layers_kernel) and have no per-op form
+    if ((precision == BESO_PREC_BF16X3 || precision == BESO_PREC_FP16) && level != 2) return BESO_ERR_UNSUPPORTED;
     profile_begin(BESO_SITE_FORWARD, s);
     int r = forward_generic(lay, ws, (const char*)packed, precision, a, (char*)workspace, s, level);
     profile_end(BESO_SITE_FORWARD, s);
@@ -303,7 +309,8 @@ int beso_pack_weights(const beso_config* cfg, const float* const* p, int n_param
     if (st != BESO_OK) return st;
     Layout lay;
     if (!make_layout(cfg, precision, &lay)) return BESO_ERR_BAD_ARG;
-    if (precision == BESO_PREC_BF16X3 && lay.fused == lay.total) return BESO_ERR_UNSUPPORTED;   // no fused instance for this shape
+    if ((precision == BESO_PREC_BF16X3 || precision == BESO_PREC_FP16) && lay.fused == lay.total)
+        return BESO_ERR_UNSUPPORTED;   // no fused instance for this shape
     if (!p || !packed_v) return BESO_ERR_BAD_ARG;
     if (n_params != beso_num_params(cfg)) return BESO_ERR_BAD_ARG;
     for (int i = 0; i < n_params; ++i) if (!p[i]) return BESO_ERR_BAD_ARG;
@@ -314,9 +321,10 @@ int beso_pack_weights(const beso_config* cfg, const float* const* p, int n_param
     int i = 0;
     // fp32 sections: precision -1
 #define PACK32(off, rows, cols, rp, cp) HIP_TRY(launch_pack_matrix(p[i++], rows, cols, pk + (off), rp, cp, -1, s))
-    // (the GEMM operands of the per-op path are not used by BF16X3: its weights live in the fused image only)
+    // (the GEMM operands of the per-op path are not used by BF16X3 / FP16: their weights live in the fused image only)
 #define PACKW(src, off, rows, cols, rp, cp) \
-    do { if (precision != BESO_PREC_BF16X3) HIP_TRY(launch_pack_matrix(src, rows, cols, pk + (off), rp, cp, precision, s)); } while (0)
+    do { if (precision != BESO_PREC_BF16X3 && precision != BESO_PREC_FP16) \
+             HIP_TRY(launch_pack_matrix(src, rows, cols, pk + (off), rp, cp, precision, s)); } while (0)
     PACK32(lay.pos_emb, lay.seq_size, D, lay.seq_size, D);
     PACK32(lay.tok_w, D, lay.obs, D, lay.obs);
     PACK32(lay.tok_b, 1, D, 1, D);
@@ -359,6 +367,7 @@ int beso_pack_weights(const beso_config* cfg, const float* const* p, int n_param
 #undef PACK32
 #undef PACKW
     if (i != n_params) return BESO_ERR_BAD_ARG;
+    if (precision == BESO_PREC_FP16) return fused_pack_f16(lay, p, pk, BESO_PREC_BF16, s);
     return fused_pack(lay, p, pk, precision, s);
 }
 
@@ -400,7 +409,9 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
                 float cond_lambda, int flags, void* workspace, size_t workspace_bytes, void* stream) {
     int st = validate_config(cfg);
     if (st != BESO_OK) return st;
-    if (sampler < BESO_SAMPLER_DDIM || sampler > BESO_SAMPLER_HEUN || (flags & ~BESO_SAMPLE_STEPWISE)) return BESO_ERR_BAD_ARG;
+    if (sampler < BESO_SAMPLER_DDIM || sampler > BESO_SAMPLER_HEUN || (flags & ~(BESO_SAMPLE_STEPWISE | BESO_PLAN_MASK)))
+        return BESO_ERR_BAD_ARG;
+    const int plan = flags & BESO_PLAN_MASK;
     if (!sigmas || n_sigmas < 2 || !x || !workspace) return BESO_ERR_BAD_ARG;
     if (batch < 1 || t < 1 || t > cfg->obs_seq_len) return BESO_ERR_BAD_SHAPE;
     Layout lay;
@@ -449,8 +460,10 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
         a.precondition = 1;
         a.uncond_from = two ? batch : (cond_lambda == 0.f ? 0 : a.vbatch);
         a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
+        a.plan = plan;
         if (!packed || !state || (cfg->goal_seq_len > 0 && !goal)) return BESO_ERR_BAD_ARG;
-        if (!(flags & BESO_SAMPLE_STEPWISE) && fused_can_loop(lay, a, precision)) {
+        const bool f16 = precision == BESO_PREC_FP16;
+        if (!(flags & BESO_SAMPLE_STEPWISE) && (f16 ? fused_can_loop_f16(lay, a, BESO_PREC_BF16) : fused_can_loop(lay, a, precision))) {
             size_t i0 = 0;
             const size_t n_steps = step_first.size() - 1;
             while (i0 < n_steps) {
@@ -460,7 +473,8 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
                 S.n = step_first[i1] - step_first[i0];
                 for (int k = 0; k < S.n; ++k) S.rec[k] = recs[step_first[i0] + k];
                 profile_begin(BESO_SITE_FUSED_LAYER, s);
-                st = fused_layers(lay, (const char*)packed, a, (float*)(wsp + ws.x), nullptr, precision, s, &S);
+                st = f16 ? fused_layers_f16(lay, (const char*)packed, a, (float*)(wsp + ws.x), nullptr, BESO_PREC_BF16, s, &S)
+                         : fused_layers(lay, (const char*)packed, a, (float*)(wsp + ws.x), nullptr, precision, s, &S);
                 profile_end(BESO_SITE_FUSED_LAYER, s);
                 if (st != BESO_OK) return st;
                 i0 = i1;
@@ -477,7 +491,7 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
     HIP_TRY(fill_sigma(sigmas[0]));
     for (int i = 0; i + 1 < n_sigmas; ++i) {
         const float si = sigmas[i], sn = sigmas[i + 1];
-        st = beso_denoise_fwd(cfg, packed, precision, state, x, goal, sig, den, batch, t, 0, cond_lambda, workspace,
+        st = beso_denoise_fwd(cfg, packed, precision, state, x, goal, sig, den, batch, t, plan, cond_lambda, workspace,
                               workspace_bytes, stream);
         if (st != BESO_OK) return st;
         if (sampler == BESO_SAMPLER_DDIM) {
@@ -492,7 +506,7 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
         } else {
             // Heun: predictor, second evaluation at sigma_{i+1}, trapezoid corrector (:304-310)
             HIP_TRY(launch_sampler_step(BESO_STEP_HEUN_PREDICT, x2, d1, x, nullptr, den, si, sn - si, n, s, sig, sn, batch));
-            st = beso_denoise_fwd(cfg, packed, precision, state, x2, goal, sig, den, batch, t, 0, cond_lambda,
+            st = beso_denoise_fwd(cfg, packed, precision, state, x2, goal, sig, den, batch, t, plan, cond_lambda,
                                   workspace, workspace_bytes, stream);
             if (st != BESO_OK) return st;
             HIP_TRY(launch_sampler_step(BESO_STEP_HEUN_CORRECT, x, d1, x, x2, den, sn, sn - si, n, s));     // (sig already holds sigma_{i+1})
@@ -503,10 +517,10 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
 
 int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precision, const float* state, const float* goal,
                           float* x, int batch, int t, const float* sigmas, int n_sigmas, float cond_lambda, float eta,
-                          const float* noise, void* workspace, size_t workspace_bytes, void* stream) {
+                          const float* noise, int flags, void* workspace, size_t workspace_bytes, void* stream) {
     int st = validate_config(cfg);
     if (st != BESO_OK) return st;
-    if (!sigmas || n_sigmas < 2 || !x || !workspace || !noise || !(eta >= 0.f)) return BESO_ERR_BAD_ARG;
+    if (!sigmas || n_sigmas < 2 || !x || !workspace || !noise || !(eta >= 0.f) || (flags & ~BESO_PLAN_MASK)) return BESO_ERR_BAD_ARG;
     if (batch < 1 || t < 1 || t > cfg->obs_seq_len) return BESO_ERR_BAD_SHAPE;
     Layout lay;
     Workspace ws;
@@ -531,7 +545,7 @@ int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precis
         }
         uint32_t bits; memcpy(&bits, &sf, 4);
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)sig, (int)bits, (size_t)batch, s));
-        st = beso_denoise_fwd(cfg, packed, precision, state, x, goal, sig, den, batch, t, 0, cond_lambda, workspace,
+        st = beso_denoise_fwd(cfg, packed, precision, state, x, goal, sig, den, batch, t, flags, cond_lambda, workspace,
                               workspace_bytes, stream);
         if (st != BESO_OK) return st;
         HIP_TRY(launch_sampler_step(BESO_STEP_EULER, x, nullptr, x, nullptr, den, sf, down - sf, n, s));     // :240-245
@@ -540,15 +554,10 @@ int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precis
     return BESO_OK;
 }
 
+#if BESO_DEV_API
+// development builds only (include/beso_hip_debug.h; `python -m beso_amd.build --dev` -> libbeso_hip_dev.so)
 void beso_debug_set_stamps(void* device_buf, int capacity_u64) { fused_set_stamps(device_buf, capacity_u64); }
-void beso_debug_set_small_batch_max(int n) { fused_set_small_batch_max(n); }
-void beso_debug_set_fused_level_max(int n) { fused_set_level_max(n); }
-void beso_debug_set_train_tail(int on) { train_set_tail_forward(on); }
-void beso_debug_set_train_option(int what, int value) {
-    if (what == 0) train_set_tail_forward(value);
-    else if (what == 1) train_set_tail_backward(value);
-    else if (what == 2) train_set_wgrad_side(value);
-}
+#endif
 
 int beso_adam_step(const beso_optim_chunk* chunks, int n_chunks, float* exp_avg, float* exp_avg_sq, float* ema,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,
@@ -631,6 +640,7 @@ int beso_grad_early_range(const beso_config* cfg, size_t* begin, size_t* end) {
     return BESO_OK;
 }
 
+#if BESO_DEV_API
 int beso_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,
                     int ldc, int M, int N, int K, int splits, void* stream) {
     hipError_t e = hipSuccess;
@@ -642,14 +652,11 @@ int beso_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int 
     }
     return st;
 }
+#endif
 
-void beso_profile_enable(int site) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_site = site;
-}
+void beso_profile_enable(int site) { g_prof_site = site; }
 
 int beso_profile_read(double* total_ms, int* launches) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
     double tot = 0.0;
     int n = 0;
     for (auto& pr : g_prof_events) {

@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/beso_hip.h"
+#ifndef BESO_DEV_API
+#define BESO_DEV_API 0     // 1: the development build (libbeso_hip_dev.so, include/beso_hip_debug.h)
+#endif
 
 namespace beso {
 
@@ -165,6 +168,7 @@ struct FwdArgs {
     int uncond_from;  // virtual samples >= uncond_from use zero goals
     float cond_lambda;
     float sigma_data;
+    int plan = 0;     // BESO_PLAN_* bits of the call's flags: which kernels run (never what they compute)
 };
 
 hipError_t launch_pack_matrix(const float* src, int rows, int cols, void* dst, int rows_p,

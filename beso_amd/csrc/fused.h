@@ -17,9 +17,7 @@ struct SampleSteps {
 constexpr int kLoopMaxElems = 512;   // action-window elements per workgroup the loop can carry (one per thread)
 
 size_t fused_packed_bytes(const Layout& lay, int precision);
-size_t fused_workspace_bytes(const Layout& lay, int vbatch, int T, int precision);
 int    fused_pack(const Layout& lay, const float* const* params, char* packed, int precision, hipStream_t s);
-bool   fused_supported(const Layout& lay, const FwdArgs& a, int precision);
 int    fused_level(const Layout& lay, const FwdArgs& a, int precision);   // 0 none, 1 MLP block, 2 whole layers
 int    fused_layer_edges(const Layout& lay);        // bit 0: fused_layers embeds, bit 1: it runs the head
 int    fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, int precision,
@@ -38,17 +36,16 @@ int    fused_train_pack(const Layout& lay, const float* const* params, char* img
 int    fused_train_tail(const Layout& lay, const char* img, int layer, int M, const float* x_in, const void* y, int ld_y,
                         float* x_mid, float* x_out, float* st2, void* xn2, void* h, void* g, float* st1n, void* xn1n,
                         void* qkvn, hipStream_t s);
-// training backward through the mirrored tail block: transposed-weight image + one launch per layer boundary
-size_t fused_train_bwd_image_bytes(const Layout& lay);
-int    fused_train_bwd_pack(const Layout& lay, const float* const* params, char* img, hipStream_t s);
-int    fused_train_bwd_tiles(int M);
-int    fused_train_bwd_tail(const Layout& lay, const char* img, int layer, int M, const void* dqkv, const float* x_in,
-                            const float* st1, float* gres, void* dyo, const void* h, void* dh, float* db1, const float* x_mid,
-                            const float* st2, void* dym, void* dy, float* part1, float* part2, hipStream_t s);
-void   fused_set_stamps(void* buf, int cap);
-void   fused_set_small_batch_max(int n);
-void   fused_set_level_max(int n);
-int    forward_fused(const Layout& lay, const Workspace& ws, const char* packed, int precision, const FwdArgs& a,
-                     char* wsp, hipStream_t s);
+void   fused_set_stamps(void* buf, int cap);     // development builds (BESO_DEV_API): phase stamps of workgroup 0
+
+// The fp16-operand build of layers_kernel (fused_f16.hip = fused.hip compiled with BESO_OPERAND_F16 = 1): BESO_PREC_FP16.
+// Same image layout and sizes with fp16 weight fragments; `precision` arguments take BESO_PREC_BF16 ("the plain mode").
+size_t fused_packed_bytes_f16(const Layout& lay, int precision);
+int    fused_pack_f16(const Layout& lay, const float* const* params, char* packed, int precision, hipStream_t s);
+int    fused_level_f16(const Layout& lay, const FwdArgs& a, int precision);
+int    fused_layer_edges_f16(const Layout& lay);
+int    fused_layers_f16(const Layout& lay, const char* packed, const FwdArgs& a, float* x, int* fused_edges, int precision,
+                        hipStream_t s, const SampleSteps* steps = nullptr);
+bool   fused_can_loop_f16(const Layout& lay, const FwdArgs& a, int precision);
 
 }  // namespace beso

@@ -30,6 +30,22 @@
 #include <stdlib.h>
 #include "fused.h"
 
+// BESO_OPERAND_F16 = 1 (fused_f16.hip): the same kernels with fp16 GEMM operands -- v_mfma_f32_16x16x32_f16 runs at the bf16
+// rate and carries three more mantissa bits (the accumulators, the residual stream, LayerNorm, softmax, GELU stay fp32 as in
+// every mode).  That build holds layers_kernel only (BESO_PREC_FP16: the shapes with the one-launch kernel), under its own
+// entry-point names.
+#ifndef BESO_OPERAND_F16
+#define BESO_OPERAND_F16 0
+#endif
+#if BESO_OPERAND_F16
+#define fused_packed_bytes fused_packed_bytes_f16
+#define fused_pack fused_pack_f16
+#define fused_level fused_level_f16
+#define fused_layer_edges fused_layer_edges_f16
+#define fused_layers fused_layers_f16
+#define fused_can_loop fused_can_loop_f16
+#endif
+
 namespace beso {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -152,7 +168,7 @@ bool fused_dims(const Layout& lay, FusedDims* d) {
     return true;
 }
 
-// The kernels run the last k-step of the K = D contractions as a HALF k-step (mfma_bf16_half): the shapes
+// The kernels run the last k-step of the K = D contractions as a HALF k-step (mfma_op_half): the shapes
 // they are used for must have at most 16 real indices there.
 // (KS = 12: D = 360 and KS = 8: D = 240 qualify; the KS = 16 instance serves D = 512, a full tail.)
 constexpr bool kt16(int KS) { return KS == 12 || KS == 8; }
@@ -171,9 +187,19 @@ bool shape_has_kernel(const FusedDims& d) {
 // consumes together in one k-step are contiguous (grp KiB), so a k-step's loads of all 8 waves spread
 // over the L2 channels instead of striding by a whole row of k-steps.
 // part: 0 = bf16(v); 1 = bf16(v - bf16(v)), the low half of the split-bf16 pair of the BF16X3 mode (hi + lo = v to 2^-16)
-__device__ __forceinline__ uint16_t f2bf_part(float v, int part) {
-    const uint16_t h = f2bf(v);
-    return part ? f2bf(v - bf2f(h)) : h;
+#if BESO_OPERAND_F16
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ uint16_t f2op(float v) { return __builtin_bit_cast(uint16_t, (_Float16)v); }     // v_cvt_f16_f32 (RNE)
+__device__ __forceinline__ float op2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+#else
+__device__ __forceinline__ uint16_t f2op(float v) { return f2bf(v); }
+__device__ __forceinline__ float op2f(uint16_t h) { return bf2f(h); }
+#endif
+__device__ __forceinline__ uint16_t f2op_part(float v, int part) {
+    const uint16_t h = f2op(v);
+    return part ? f2op(v - op2f(h)) : h;
 }
 
 __global__ void pack_mfma_a_kernel(const float* __restrict__ src, int rows, int cols, const float* __restrict__ colscale,
@@ -192,7 +218,7 @@ __global__ void pack_mfma_a_kernel(const float* __restrict__ src, int rows, int 
             v = src[(size_t)r * cols + c];
             if (colscale) v *= colscale[c];
         }
-        dst[i] = f2bf_part(v, part);
+        dst[i] = f2op_part(v, part);
     }
 }
 
@@ -217,7 +243,7 @@ __global__ void pack_qkv_kernel(const float* __restrict__ wq, const float* __res
             const float* w = part == 0 ? wq : (part == 1 ? wk : wv);
             v = w[(size_t)(h * hd + d) * D + c] * gamma[c];
         }
-        dst[i] = f2bf_part(v, split);
+        dst[i] = f2op_part(v, split);
     }
 }
 
@@ -255,7 +281,7 @@ __global__ void pack_proj_kernel(const float* __restrict__ wp, uint16_t* __restr
         int d = 32 * (kk & 1) + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
         float v = 0.f;
         if (o < D && d < hd) v = wp[(size_t)o * D + h * hd + d];
-        dst[i] = f2bf_part(v, part);
+        dst[i] = f2op_part(v, part);
     }
 }
 
@@ -318,9 +344,14 @@ __device__ __forceinline__ float rows_allreduce(float v) {
     return IS_MAX ? fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1])) : __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+// two fp32 values -> one dword of GEMM operands (RNE): v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32
+__device__ __forceinline__ uint32_t pack_op2(float lo, float hi) {
     f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+#if BESO_OPERAND_F16
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+#else
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+#endif
 }
 
 // GELU(v) = v * Phi(v) with the exact-erf Phi of nn.GELU() (score_gpts.py:107), evaluated without
@@ -345,18 +376,30 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 v) {
     return v * u;
 }
 
-__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+__device__ __forceinline__ f32x4 mfma_op(const u32x4& a, const u32x4& b, const f32x4& c) {
+#if BESO_OPERAND_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
                                                    0, 0, 0);
+#endif
+}
+
+// v_mfma_f32_16x16x16 on four operands per lane (the attention core's P.V; the half k-step below)
+__device__ __forceinline__ f32x4 mfma_op16(const uint2& a, const uint2& b, const f32x4& c) {
+#if BESO_OPERAND_F16
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+#endif
 }
 
 // Half k-step: contraction over the FIRST 16 indices of a k-step only.  The low 8 bytes of a lane's
-// A / B fragment (slots j = 0..3) are exactly the operands of v_mfma_f32_16x16x16_bf16 for those indices
+// A / B fragment (slots j = 0..3) are exactly the operands of the 16x16x16 MFMA for those indices
 // (index 32kk + 4g + j), so a k-step whose upper 16 indices are all padding (D = 360: indices 352..359 of
 // 352..383 are real) costs half an MFMA instead of a whole one.
-__device__ __forceinline__ f32x4 mfma_bf16_half(const u32x4& a, const u32x4& b, const f32x4& c) {
-    const uint2 a2 = make_uint2(a[0], a[1]), b2 = make_uint2(b[0], b[1]);
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a2), __builtin_bit_cast(s16x4, b2), c, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma_op_half(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return mfma_op16(make_uint2(a[0], a[1]), make_uint2(b[0], b[1]), c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -433,7 +476,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NTA], u32x4 (&aE)[R],
 #pragma unroll
         for (int t = 0; t < H1; ++t)
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aE[r], bf[t], acc[r][t]);
+            for (int r = 0; r < R; ++r) acc[r][t] = mfma_op(aE[r], bf[t], acc[r][t]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < H1; ++t) if (!(BESO_ABL_MASK & 32)) bf[t] = b[t * b_ts + (kk + 1) * b_ks];
@@ -441,7 +484,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NTA], u32x4 (&aE)[R],
 #pragma unroll
         for (int t = H1; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aE[r], bf[t], acc[r][t]);
+            for (int r = 0; r < R; ++r) acc[r][t] = mfma_op(aE[r], bf[t], acc[r][t]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = H1; t < NT; ++t) if (!(BESO_ABL_MASK & 32)) bf[t] = b[t * b_ts + (kk + 1) * b_ks];
@@ -456,13 +499,13 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NTA], u32x4 (&aE)[R],
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(aO[r], bf[t], acc[r][t]);
+                for (int r = 0; r < R; ++r) acc[r][t] = mfma_op_half(aO[r], bf[t], acc[r][t]);
             break;
         }
 #pragma unroll
         for (int t = 0; t < H1; ++t)
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aO[r], bf[t], acc[r][t]);
+            for (int r = 0; r < R; ++r) acc[r][t] = mfma_op(aO[r], bf[t], acc[r][t]);
         __builtin_amdgcn_sched_barrier(0);
         if (kk + 2 < ksteps && !(BESO_ABL_MASK & 32)) {
 #pragma unroll
@@ -472,7 +515,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NTA], u32x4 (&aE)[R],
 #pragma unroll
         for (int t = H1; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(aO[r], bf[t], acc[r][t]);
+            for (int r = 0; r < R; ++r) acc[r][t] = mfma_op(aO[r], bf[t], acc[r][t]);
         __builtin_amdgcn_sched_barrier(0);
         if (kk + 2 < ksteps && !(BESO_ABL_MASK & 32)) {
 #pragma unroll
@@ -516,12 +559,12 @@ __device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(ar[p][r], bb[p & 1][t], acc[r][t]);
+                    for (int r = 0; r < R; ++r) acc[r][t] = mfma_op_half(ar[p][r], bb[p & 1][t], acc[r][t]);
             } else {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(ar[p][r], bb[p & 1][t], acc[r][t]);
+                    for (int r = 0; r < R; ++r) acc[r][t] = mfma_op(ar[p][r], bb[p & 1][t], acc[r][t]);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (BESO_FUSED_ABLATE != 2 && !(BESO_ABL_MASK & 32) && kk + 2 < ksteps) {
@@ -545,10 +588,15 @@ __device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)
 // (FusedDims); activation fragments: the low fragment `b_lo` u32x4 behind the high one in LDS.
 // ---------------------------------------------------------------------------------------------
 struct SplitPair { uint32_t hi, lo; };
-__device__ __forceinline__ SplitPair split_bf16x2(float a, float b) {
+__device__ __forceinline__ SplitPair split_op2(float a, float b) {
     SplitPair p;
-    p.hi = pack_bf16x2(a, b);
-    p.lo = pack_bf16x2(a - __uint_as_float(p.hi << 16), b - __uint_as_float(p.hi & 0xffff0000u));
+    p.hi = pack_op2(a, b);
+#if BESO_OPERAND_F16
+    const f32x2 back = __builtin_convertvector(__builtin_bit_cast(f16x2, p.hi), f32x2);
+    p.lo = pack_op2(a - back.x, b - back.y);
+#else
+    p.lo = pack_op2(a - __uint_as_float(p.hi << 16), b - __uint_as_float(p.hi & 0xffff0000u));
+#endif
     return p;
 }
 
@@ -591,28 +639,28 @@ __device__ __forceinline__ void gemm_x3(f32x4 (&acc)[R][NTA], WPtr a, int a_ks, 
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(alo[p][r], bh[p & 1][t], acc[r][t]);
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_op_half(alo[p][r], bh[p & 1][t], acc[r][t]);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(ah[p][r], bl[p & 1][t], acc[r][t]);
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_op_half(ah[p][r], bl[p & 1][t], acc[r][t]);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16_half(ah[p][r], bh[p & 1][t], acc[r][t]);
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_op_half(ah[p][r], bh[p & 1][t], acc[r][t]);
                 } else {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(alo[p][r], bh[p & 1][t], acc[r][t]);
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_op(alo[p][r], bh[p & 1][t], acc[r][t]);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(ah[p][r], bl[p & 1][t], acc[r][t]);
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_op(ah[p][r], bl[p & 1][t], acc[r][t]);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_bf16(ah[p][r], bh[p & 1][t], acc[r][t]);
+                        for (int r = 0; r < R; ++r) acc[r][t] = mfma_op(ah[p][r], bh[p & 1][t], acc[r][t]);
                 }
             }
             load_b(p & 1, kk + 2);
@@ -851,20 +899,20 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         if constexpr (LX::on) {
             // gamma / beta applied here (zero for padding features: their xnT entries are exact zeros), and the
             // operand-typed copy for the weight gradients goes out row-major
-            pk.x = pack_bf16x2(fmaf(fmaf(T.acc[i][t][0], a, b), gam[i][0], bet[i][0]), fmaf(fmaf(T.acc[i][t][1], a, b), gam[i][1], bet[i][1]));
-            pk.y = pack_bf16x2(fmaf(fmaf(T.acc[i][t][2], a, b), gam[i][2], bet[i][2]), fmaf(fmaf(T.acc[i][t][3], a, b), gam[i][3], bet[i][3]));
+            pk.x = pack_op2(fmaf(fmaf(T.acc[i][t][0], a, b), gam[i][0], bet[i][0]), fmaf(fmaf(T.acc[i][t][1], a, b), gam[i][1], bet[i][1]));
+            pk.y = pack_op2(fmaf(fmaf(T.acc[i][t][2], a, b), gam[i][2], bet[i][2]), fmaf(fmaf(T.acc[i][t][3], a, b), gam[i][3], bet[i][3]));
             const int tok = lx.m0 + 16 * t + (lane & 15), f0 = 16 * (w * RPW + i) + 4 * g;
             if (tok < lx.M && f0 < lx.D) *(uint2*)(lx.xn + (size_t)tok * lx.D + f0) = pk;
         } else {
-            pk.x = pack_bf16x2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
-            pk.y = pack_bf16x2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
+            pk.x = pack_op2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
+            pk.y = pack_op2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
         }
         return pk;
     };
     auto half_x3 = [&](int i, int t, uint2& hi, uint2& lo) {
         const float a = rstd[t], b = -mean[t] * rstd[t];
-        const SplitPair p0 = split_bf16x2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
-        const SplitPair p1 = split_bf16x2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
+        const SplitPair p0 = split_op2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
+        const SplitPair p1 = split_op2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
         hi = make_uint2(p0.hi, p1.hi);
         lo = make_uint2(p0.lo, p1.lo);
     };
@@ -1093,14 +1141,14 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
                 const int c0 = 16 * (q >> 1) + 4 * g + 2 * (q & 1);
                 const float x0 = (kind[t] == 1 && c0 < d.obs) ? vt[t][2 * q] : 0.f;
                 const float x1 = (kind[t] == 1 && c0 + 1 < d.obs) ? vt[t][2 * q + 1] : 0.f;
-                const SplitPair p = split_bf16x2(x0, x1);
+                const SplitPair p = split_op2(x0, x1);
                 bh[q] = p.hi; bl[q] = p.lo;
             }
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
-                T.acc[i][t] = mfma_bf16(atl[i], bh, T.acc[i][t]);
-                T.acc[i][t] = mfma_bf16(ath[i], bl, T.acc[i][t]);
-                T.acc[i][t] = mfma_bf16(ath[i], bh, T.acc[i][t]);
+                T.acc[i][t] = mfma_op(atl[i], bh, T.acc[i][t]);
+                T.acc[i][t] = mfma_op(ath[i], bl, T.acc[i][t]);
+                T.acc[i][t] = mfma_op(ath[i], bh, T.acc[i][t]);
             }
             u32x4 ch = {0, 0, 0, 0}, cl = {0, 0, 0, 0};
 #pragma unroll
@@ -1108,14 +1156,14 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
                 const int c0 = 4 * g + 2 * q;
                 const float x0 = (kind[t] == 2 && c0 < d.act) ? va[t][2 * q] * scale[t] : 0.f;
                 const float x1 = (kind[t] == 2 && c0 + 1 < d.act) ? va[t][2 * q + 1] * scale[t] : 0.f;
-                const SplitPair p = split_bf16x2(x0, x1);
+                const SplitPair p = split_op2(x0, x1);
                 ch[q] = p.hi; cl[q] = p.lo;
             }
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
-                T.acc[i][t] = mfma_bf16_half(aal[i], ch, T.acc[i][t]);
-                T.acc[i][t] = mfma_bf16_half(aah[i], cl, T.acc[i][t]);
-                T.acc[i][t] = mfma_bf16_half(aah[i], ch, T.acc[i][t]);
+                T.acc[i][t] = mfma_op_half(aal[i], ch, T.acc[i][t]);
+                T.acc[i][t] = mfma_op_half(aah[i], cl, T.acc[i][t]);
+                T.acc[i][t] = mfma_op_half(aah[i], ch, T.acc[i][t]);
             }
         }
         return;
@@ -1296,10 +1344,10 @@ __device__ __forceinline__ void gelu_pair(const f32x4 (&h)[RC][NT], float (&gq)[
     gq[j + 1] = r.y;
     asm volatile("" : "+v"(gq[j]), "+v"(gq[j + 1]));      // keep the evaluation HERE (between the MFMAs), not sunk to its use
     if ((pi & 3) == 3) {
-        hb[j2][t][0] = pack_bf16x2(gq[0], gq[1]);
-        hb[j2][t][1] = pack_bf16x2(gq[2], gq[3]);
-        hb[j2][t][2] = pack_bf16x2(gq[4], gq[5]);
-        hb[j2][t][3] = pack_bf16x2(gq[6], gq[7]);
+        hb[j2][t][0] = pack_op2(gq[0], gq[1]);
+        hb[j2][t][1] = pack_op2(gq[2], gq[3]);
+        hb[j2][t][2] = pack_op2(gq[4], gq[5]);
+        hb[j2][t][3] = pack_op2(gq[6], gq[7]);
     }
 }
 
@@ -1356,10 +1404,10 @@ __device__ __forceinline__ void gelu_slot(const f32x4 (&h)[RC][NT], GeluChain& c
         else if constexpr (step == 10) asm volatile("" : "+v"(gq[j]), "+v"(gq[j + 1]));
     }
     if constexpr (step == 11 && (pi & 3) == 3) {
-        hb[j2][t][0] = pack_bf16x2(gq[0], gq[1]);
-        hb[j2][t][1] = pack_bf16x2(gq[2], gq[3]);
-        hb[j2][t][2] = pack_bf16x2(gq[4], gq[5]);
-        hb[j2][t][3] = pack_bf16x2(gq[6], gq[7]);
+        hb[j2][t][0] = pack_op2(gq[0], gq[1]);
+        hb[j2][t][1] = pack_op2(gq[2], gq[3]);
+        hb[j2][t][2] = pack_op2(gq[4], gq[5]);
+        hb[j2][t][3] = pack_op2(gq[6], gq[7]);
     }
 }
 
@@ -1436,8 +1484,8 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
                 for (int t = 0; t < NT; ++t) {
                     const int tok = mx.m0 + 16 * t + n;
                     if (tok < mx.M && f0 < mx.ld)
-                        *(uint2*)(mx.h + (size_t)tok * mx.ld + f0) = make_uint2(pack_bf16x2(hv[r][t][0], hv[r][t][1]),
-                                                                                 pack_bf16x2(hv[r][t][2], hv[r][t][3]));
+                        *(uint2*)(mx.h + (size_t)tok * mx.ld + f0) = make_uint2(pack_op2(hv[r][t][0], hv[r][t][1]),
+                                                                                 pack_op2(hv[r][t][2], hv[r][t][3]));
                 }
             }
         }
@@ -1513,7 +1561,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
                         constexpr int r = decltype(RR)::value;
                         constexpr int unit = (kk * NT + t) * RPW + r;
                         __builtin_amdgcn_sched_barrier(0);
-                        T.acc[r][t] = mfma_bf16(af2[kk & 1][r], bf[t], T.acc[r][t]);
+                        T.acc[r][t] = mfma_op(af2[kk & 1][r], bf[t], T.acc[r][t]);
                         static_for<unit * SLOTS / MFMAS, (unit + 1) * SLOTS / MFMAS>([&](auto SG) {
                             gelu_slot<RC, NT, decltype(SG)::value>(h, gc0, gc1, gq, hb);
                         });
@@ -1629,8 +1677,8 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
 #pragma unroll
             for (int t = 0; t < NTQ; ++t) {
                 uint2 pk;
-                pk.x = pack_bf16x2(qa[i][t][0], qa[i][t][1]);
-                pk.y = pack_bf16x2(qa[i][t][2], qa[i][t][3]);
+                pk.x = pack_op2(qa[i][t][0], qa[i][t][1]);
+                pk.y = pack_op2(qa[i][t][2], qa[i][t][3]);
                 *(uint2*)(dst + (size_t)row[t] * kQKVRow) = pk;
             }
         }
@@ -1663,8 +1711,8 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                 if (kt <= w) {                                             // wave-uniform
                     const uint16_t* kb = qkv + ((size_t)1 * kQKVRows + 16 * kt + n) * kQKVRow + 8 * g;
                     f32x4 sT = {0.f, 0.f, 0.f, 0.f};
-                    sT = mfma_bf16(*(const u32x4*)kb, q0, sT);
-                    sT = mfma_bf16(*(const u32x4*)(kb + 32), q1, sT);
+                    sT = mfma_op(*(const u32x4*)kb, q0, sT);
+                    sT = mfma_op(*(const u32x4*)(kb + 32), q1, sT);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = 16 * kt + 4 * g + r;
@@ -1690,12 +1738,11 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
 #pragma unroll
             for (int kt = 0; kt < NTQ; ++kt) {
                 if (kt <= w) {
-                    const uint2 pb = make_uint2(pack_bf16x2(e[kt][0], e[kt][1]), pack_bf16x2(e[kt][2], e[kt][3]));
+                    const uint2 pb = make_uint2(pack_op2(e[kt][0], e[kt][1]), pack_op2(e[kt][2], e[kt][3]));
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) {
                         const uint2 va = v_frag(qkv, 16 * kt, dt, n, g);
-                        y[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, va),
-                                                                          __builtin_bit_cast(s16x4, pb), y[dt], 0, 0, 0);
+                        y[dt] = mfma_op16(va, pb, y[dt]);
                     }
                 }
             }
@@ -1703,10 +1750,10 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 u32x4 yb;
-                yb[0] = pack_bf16x2(y[2 * kk][0] * inv, y[2 * kk][1] * inv);
-                yb[1] = pack_bf16x2(y[2 * kk][2] * inv, y[2 * kk][3] * inv);
-                yb[2] = pack_bf16x2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
-                yb[3] = pack_bf16x2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
+                yb[0] = pack_op2(y[2 * kk][0] * inv, y[2 * kk][1] * inv);
+                yb[1] = pack_op2(y[2 * kk][2] * inv, y[2 * kk][3] * inv);
+                yb[2] = pack_op2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
+                yb[3] = pack_op2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
                 yT[((size_t)w * 2 + kk) * 64 + ln] = yb;
             }
         }
@@ -1738,7 +1785,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                         const int d0 = 32 * kk + 8 * g + 2 * m;
                         qm[m] = (d0 >= lo_d && d0 < hi_d) ? qf[kk][m] : 0u;
                     }
-                    sT = mfma_bf16(kf[kk], qm, sT);
+                    sT = mfma_op(kf[kk], qm, sT);
                 }
                 float e[4], mx = -INFINITY;
 #pragma unroll
@@ -1752,13 +1799,12 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                 for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - mx); sum += e[r]; }
                 sum = rows_allreduce<false>(sum);
                 const float inv = __builtin_amdgcn_rcpf(sum);
-                const uint2 pb = make_uint2(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]));
+                const uint2 pb = make_uint2(pack_op2(e[0], e[1]), pack_op2(e[2], e[3]));
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     if (16 * dt < hi_d && 16 * dt + 16 > lo_d) {             // wave-uniform: tile dt holds rows of head h
                         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                        const f32x4 yh = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, va[dt]),
-                                                                                __builtin_bit_cast(s16x4, pb), z, 0, 0, 0);
+                        const f32x4 yh = mfma_op16(va[dt], pb, z);
                         const int d0 = 16 * dt + 4 * g;                        // this lane's rows d0 .. d0+3
                         const bool mine = d0 >= lo_d && d0 < hi_d;
 #pragma unroll
@@ -1771,10 +1817,10 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     u32x4 yb;
-                    yb[0] = pack_bf16x2(y[2 * kk][0], y[2 * kk][1]);
-                    yb[1] = pack_bf16x2(y[2 * kk][2], y[2 * kk][3]);
-                    yb[2] = pack_bf16x2(y[2 * kk + 1][0], y[2 * kk + 1][1]);
-                    yb[3] = pack_bf16x2(y[2 * kk + 1][2], y[2 * kk + 1][3]);
+                    yb[0] = pack_op2(y[2 * kk][0], y[2 * kk][1]);
+                    yb[1] = pack_op2(y[2 * kk][2], y[2 * kk][3]);
+                    yb[2] = pack_op2(y[2 * kk + 1][0], y[2 * kk + 1][1]);
+                    yb[3] = pack_op2(y[2 * kk + 1][2], y[2 * kk + 1][3]);
                     yT[((size_t)(tok >> 4) * 2 + kk) * 64 + (g << 4) + (tok & 15)] = yb;
                 }
             }
@@ -1786,7 +1832,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         f32x4 sT = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-            sT = mfma_bf16(*(const u32x4*)(kb + 32 * kk), *(const u32x4*)(qb + 32 * kk), sT);
+            sT = mfma_op(*(const u32x4*)(kb + 32 * kk), *(const u32x4*)(qb + 32 * kk), sT);
         float e[4], m = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1799,24 +1845,23 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - m); sum += e[r]; }   // exp2(-inf) = 0
         sum = rows_allreduce<false>(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
-        uint2 pb = make_uint2(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]));
+        uint2 pb = make_uint2(pack_op2(e[0], e[1]), pack_op2(e[2], e[3]));
         f32x4 y[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const uint2 va = v_frag(qkv, w * Tn, dt, n, g);
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            y[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, va),
-                                                              __builtin_bit_cast(s16x4, pb), z, 0, 0, 0);
+            y[dt] = mfma_op16(va, pb, z);
         }
         if (n < Tn) {
             const int tok = my_tok;                               // token slot of (sample w, position n)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 u32x4 yb;
-                yb[0] = pack_bf16x2(y[2 * kk][0] * inv, y[2 * kk][1] * inv);
-                yb[1] = pack_bf16x2(y[2 * kk][2] * inv, y[2 * kk][3] * inv);
-                yb[2] = pack_bf16x2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
-                yb[3] = pack_bf16x2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
+                yb[0] = pack_op2(y[2 * kk][0] * inv, y[2 * kk][1] * inv);
+                yb[1] = pack_op2(y[2 * kk][2] * inv, y[2 * kk][3] * inv);
+                yb[2] = pack_op2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
+                yb[3] = pack_op2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
                 yT[((size_t)(tok >> 4) * 2 + kk) * 64 + (g << 4) + (tok & 15)] = yb;
             }
         }
@@ -1903,8 +1948,8 @@ __device__ __forceinline__ void attn_phase_long(Tile<RPW>& T, const u32x4* xnT, 
             if (kt <= qt) {                                            // wave-uniform
                 const uint16_t* kb = hq + ((size_t)kRows + 16 * kt + n) * kQKVRow + 8 * g;
                 f32x4 sT = {0.f, 0.f, 0.f, 0.f};
-                sT = mfma_bf16(*(const u32x4*)kb, q0, sT);
-                sT = mfma_bf16(*(const u32x4*)(kb + 32), q1, sT);
+                sT = mfma_op(*(const u32x4*)kb, q0, sT);
+                sT = mfma_op(*(const u32x4*)(kb + 32), q1, sT);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = 16 * kt + 4 * g + r;
@@ -1931,14 +1976,13 @@ __device__ __forceinline__ void attn_phase_long(Tile<RPW>& T, const u32x4* xnT, 
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             if (kt <= qt) {
-                const uint2 pb = make_uint2(pack_bf16x2(e[kt][0], e[kt][1]), pack_bf16x2(e[kt][2], e[kt][3]));
+                const uint2 pb = make_uint2(pack_op2(e[kt][0], e[kt][1]), pack_op2(e[kt][2], e[kt][3]));
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     // V^T fragment through the transpose read (v_frag's addressing on this phase's row count)
                     const uint16_t* pv = hq + ((size_t)2 * kRows + 16 * kt + 4 * g + (n >> 2)) * kQKVRow + 16 * dt + 4 * (n & 3);
                     const uint2 va = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pv)));
-                    y[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, va),
-                                                                      __builtin_bit_cast(s16x4, pb), y[dt], 0, 0, 0);
+                    y[dt] = mfma_op16(va, pb, y[dt]);
                 }
             }
         }
@@ -1946,10 +1990,10 @@ __device__ __forceinline__ void attn_phase_long(Tile<RPW>& T, const u32x4* xnT, 
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             u32x4 yb;
-            yb[0] = pack_bf16x2(y[2 * kk][0] * inv, y[2 * kk][1] * inv);
-            yb[1] = pack_bf16x2(y[2 * kk][2] * inv, y[2 * kk][3] * inv);
-            yb[2] = pack_bf16x2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
-            yb[3] = pack_bf16x2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
+            yb[0] = pack_op2(y[2 * kk][0] * inv, y[2 * kk][1] * inv);
+            yb[1] = pack_op2(y[2 * kk][2] * inv, y[2 * kk][3] * inv);
+            yb[2] = pack_op2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
+            yb[3] = pack_op2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
             yT[kk * 64 + ln] = yb;
         }
     };
@@ -1977,7 +2021,7 @@ __device__ __forceinline__ void attn_phase_long(Tile<RPW>& T, const u32x4* xnT, 
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 *(uint2*)(dst + (size_t)(16 * t + n) * kQKVRow) =
-                    make_uint2(pack_bf16x2(qa[i][t][0], qa[i][t][1]), pack_bf16x2(qa[i][t][2], qa[i][t][3]));
+                    make_uint2(pack_op2(qa[i][t][0], qa[i][t][1]), pack_op2(qa[i][t][2], qa[i][t][3]));
         }
         stamp(st, 11);
         __syncthreads();
@@ -2058,7 +2102,7 @@ __device__ __forceinline__ void mlp_phase_x3(Tile<RPW>& T, const u32x4* xnT, int
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4& hv = h[2 * j2 + (q >> 1)][t];
-                    const SplitPair p = split_bf16x2(gelu_exact(hv[2 * (q & 1)]), gelu_exact(hv[2 * (q & 1) + 1]));
+                    const SplitPair p = split_op2(gelu_exact(hv[2 * (q & 1)]), gelu_exact(hv[2 * (q & 1) + 1]));
                     hh[j2][t][q] = p.hi;
                     hl[j2][t][q] = p.lo;
                 }
@@ -2165,8 +2209,8 @@ __device__ __forceinline__ void attn_phase_x3(Tile<RPW>& T, const u32x4* xnT, in
             const int tok = tb->slot_of_row[w * Tn + n];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const SplitPair p0 = split_bf16x2(y[2 * kk][0], y[2 * kk][1]), p1 = split_bf16x2(y[2 * kk][2], y[2 * kk][3]);
-                const SplitPair p2 = split_bf16x2(y[2 * kk + 1][0], y[2 * kk + 1][1]), p3 = split_bf16x2(y[2 * kk + 1][2], y[2 * kk + 1][3]);
+                const SplitPair p0 = split_op2(y[2 * kk][0], y[2 * kk][1]), p1 = split_op2(y[2 * kk][2], y[2 * kk][3]);
+                const SplitPair p2 = split_op2(y[2 * kk + 1][0], y[2 * kk + 1][1]), p3 = split_op2(y[2 * kk + 1][2], y[2 * kk + 1][3]);
                 const u32x4 yh = {p0.hi, p1.hi, p2.hi, p3.hi}, yl = {p0.lo, p1.lo, p2.lo, p3.lo};
                 const size_t at = ((size_t)(tok >> 4) * 2 + kk) * 64 + (g << 4) + (tok & 15);
                 yT[at] = yh;
@@ -2269,8 +2313,8 @@ __global__ __launch_bounds__(512, 2) void qkv_block_kernel(const float* __restri
                     const int tok = m0 + 16 * t + nn;
                     if (tok < M) {
                         uint2 pk;
-                        pk.x = pack_bf16x2(qa[i][t][0], qa[i][t][1]);
-                        pk.y = pack_bf16x2(qa[i][t][2], qa[i][t][3]);
+                        pk.x = pack_op2(qa[i][t][0], qa[i][t][1]);
+                        pk.y = pack_op2(qa[i][t][2], qa[i][t][3]);
                         *(uint2*)(qkv + (size_t)tok * ldq + (size_t)part * d.D + f0) = pk;
                     }
                 }
@@ -2414,8 +2458,8 @@ __global__ __launch_bounds__(512, 2) void tail_block_kernel(float* __restrict__ 
                     const int tok = m0 + 16 * t + nn;
                     if (tok < M) {
                         uint2 pk;
-                        pk.x = pack_bf16x2(qa[i][t][0], qa[i][t][1]);
-                        pk.y = pack_bf16x2(qa[i][t][2], qa[i][t][3]);
+                        pk.x = pack_op2(qa[i][t][0], qa[i][t][1]);
+                        pk.y = pack_op2(qa[i][t][2], qa[i][t][3]);
                         *(uint2*)(qkv + (size_t)tok * ldq + (size_t)part * d.D + f0) = pk;
                     }
                 }
@@ -2549,7 +2593,7 @@ __global__ __launch_bounds__(512, 2) void train_tail_kernel(const char* __restri
                     const int tok = m0 + 16 * t + nn;
                     if (tok < M)
                         *(uint2*)(a.qkvn + (size_t)tok * ldq + (size_t)part * d.D + f0) =
-                            make_uint2(pack_bf16x2(qa[i][t][0], qa[i][t][1]), pack_bf16x2(qa[i][t][2], qa[i][t][3]));
+                            make_uint2(pack_op2(qa[i][t][0], qa[i][t][1]), pack_op2(qa[i][t][2], qa[i][t][3]));
                 }
             }
         }
@@ -2586,426 +2630,6 @@ __global__ void train_pack_kernel(TrainPackTable t, char* __restrict__ img) {
         const int R = (int)(tile / ((size_t)g.grp * g.kt)) * g.grp + rin;
         const int r = 16 * R + (lane & 15), c = 32 * kk + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
         dst[i] = f2bf((r < g.rows && c < g.cols) ? (g.tr ? g.src[(size_t)c * g.rows + r] : g.src[(size_t)r * g.cols + c]) : 0.f);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Training backward: the mirror image of train_tail_kernel.  Between two attention backward launches the chain of data
-// gradients of a 96-token tile runs as ONE launch with the residual gradient in registers:
-//     dxn1  = dqkv(l) Wqkv(l)                               (front half of layer l)
-//     G_out(l-1) = G_mid(l) + LN1'(dxn1)                     LayerNorm backward, + gamma / beta / FC2-bias partial sums
-//     dh    = (bf16(G_out) W2(l-1)) * GELU'(h)               (back half of layer l-1; dh kept for the FC1 weight gradient)
-//     dxn2  = dh W1(l-1)
-//     G_mid(l-1) = G_out + LN2'(dxn2)                        + gamma / beta / proj-bias partial sums
-//     dy    = bf16(G_mid) Wproj(l-1)                         -> attention backward of layer l-1
-// i.e. eight launches of the per-op backward (q/k/v, FC2 (+GELU'), FC1, proj data gradients, two LayerNorm backwards)
-// without the fp32 round trips of dxn between them.  Data gradients are X^T-side products: the A operands are the
-// TRANSPOSED weights in fragment order (per-step image, train_bwd_img).  Outputs in the per-op kernels' buffers and formats.
-// ---------------------------------------------------------------------------------------------
-struct TrainBwdImg { uint32_t o_wqkvT, o_w2T, o_w1T, o_wprojT, o_ln1w, o_ln2w, part_bytes, layer_bytes; };
-static TrainBwdImg train_bwd_img(const FusedDims& d) {
-    TrainBwdImg t;
-    const uint32_t rt2 = (uint32_t)d.RPW * kWaves, vec = (uint32_t)round_up_sz((size_t)rt2 * 16 * sizeof(float), 256);
-    uint32_t cur = 0;
-    auto carve = [&](uint32_t bytes) { uint32_t o = cur; cur = (uint32_t)round_up_sz((size_t)cur + bytes, 256); return o; };
-    t.part_bytes = rt2 * d.KS * 1024;
-    t.o_wqkvT = carve(3 * t.part_bytes);
-    t.o_w2T = carve(d.w1_bytes);            // W2^T [4D][D] in the FC1 image layout
-    t.o_w1T = carve(d.w2_bytes);            // W1^T [D][4D] in the FC2 image layout
-    t.o_wprojT = carve(t.part_bytes);
-    t.o_ln1w = carve(vec); t.o_ln2w = carve(vec);
-    t.layer_bytes = cur;
-    return t;
-}
-
-struct TrainBwdArgs {
-    const uint16_t* dqkv;     // [M][3D] layer l
-    const float* x_in;        // [M][D]  input of LN1(l)
-    const float* st1;         // [M][2]
-    float* gres;              // [M][D]  fp32 residual gradient: G_mid(l) on entry, G_mid(l-1) on exit
-    uint16_t* dyo;            // [M][D]  bf16(G_out(l-1))                 (FC2 weight-gradient operand)
-    const uint16_t* h;        // [M][4D] FC1 pre-activation of layer l-1
-    uint16_t* dh;             // [M][4D]
-    float* db1;               // [4D]    FC1 bias gradient (atomics)
-    const float* x_mid;       // [M][D]  input of LN2(l-1)
-    const float* st2;         // [M][2]
-    uint16_t* dym;            // [M][D]  bf16(G_mid(l-1))                 (proj weight-gradient operand)
-    uint16_t* dy;             // [M][D]  gradient of the attention output of layer l-1
-    float* part1; float* part2;   // [tiles][3][D] partial sums of the two LayerNorm backwards
-};
-
-// sum over the 16 lanes of a row (DPP: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror); every lane gets it
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-    return v;
-}
-
-// B fragment (token tile t, k-step kk) of a row-major bf16 matrix [tok][ld] (columns [0, ncols) real): lane (n, g) holds
-// columns 32 kk + 4 g .. +3 and 32 kk + 16 + 4 g .. +3 of token m0 + 16 t + n; zeros outside.
-__device__ __forceinline__ u32x4 load_b_frag(const uint16_t* __restrict__ src, size_t ld, int ncols, int m0, int M, int t, int kk,
-                                             int n, int g) {
-    const int tok = m0 + 16 * t + n, c0 = 32 * kk + 4 * g;
-    uint2 lo = make_uint2(0u, 0u), hi = lo;
-    if (tok < M) {
-        const uint16_t* row = src + (size_t)tok * ld + c0;
-        if (c0 < ncols) lo = *(const uint2*)row;
-        if (c0 + 16 < ncols) hi = *(const uint2*)(row + 16);
-    }
-    return u32x4{lo.x, lo.y, hi.x, hi.y};
-}
-
-// Accumulator-layout values -> bf16 B fragments in LDS: fn(i, t) = the four features 16 (w RPW + i) + 4 g .. +3 of token
-// 16 t + n as two packed pairs (the write pattern of layernorm_to_lds).
-template <int RPW, int KS, class F>
-__device__ __forceinline__ void put_b_frags(u32x4* xnT, int w, int lane, F fn) {
-    auto pair = [&](int i) {
-        const int ks = (w * RPW + i) >> 1;
-        if (ks < KS) {
-#pragma unroll
-            for (int t = 0; t < kNTT; ++t) {
-                const uint2 lo = fn(i, t), hi = fn(i + 1, t);
-                xnT[((size_t)t * KS + ks) * 64 + lane] = u32x4{lo.x, lo.y, hi.x, hi.y};
-            }
-        }
-    };
-    auto single = [&](int i) {
-        const int Rf = w * RPW + i;
-        if ((Rf >> 1) < KS) {
-#pragma unroll
-            for (int t = 0; t < kNTT; ++t) *((uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane) + (Rf & 1)) = fn(i, t);
-        }
-    };
-    if constexpr (RPW % 2 == 0) {
-#pragma unroll
-        for (int i = 0; i < RPW; i += 2) pair(i);
-    } else {
-        static_assert(RPW == 3, "row tiles per wave");
-        if (w & 1) { single(0); pair(1); }
-        else { pair(0); single(2); }
-    }
-}
-
-// LayerNorm backward on the tile (ln_bwd_kernel of train.hip on the accumulator layout).  T.acc holds dxn (gradient of
-// the LayerNorm output, before gamma) on entry and the new residual gradient G = gprev + dLN on exit, which also goes out
-// as fp32 (gout), as bf16 row-major (gb) and as B fragments (xnT).  part: this workgroup's [3][D] slab of partial sums
-// (gamma gradient, beta gradient, column sums of G = bias gradient of the Linear in front).  x is read twice (the second
-// time from L2) instead of being held in 72 registers.  Contains two barriers: one inside the token sums -- which also
-// orders the xnT writes behind every wave's reads of the previous phase -- and one at the end.
-template <int RPW, int KS>
-__device__ __forceinline__ void ln_bwd_tile(Tile<RPW>& T, const float* __restrict__ x, const float* __restrict__ stats,
-                                            const float* __restrict__ gamma, const float* gprev, float* gout,
-                                            uint16_t* __restrict__ gb, u32x4* xnT, float* red, float* __restrict__ part, int D,
-                                            int m0, int M, int w, int lane, Stamps& st) {
-    asm volatile("" : "+v"(lane));
-    stamp(st, 54);
-    const int n = lane & 15, g = lane >> 4, row = g;
-    constexpr int NT = kNTT, NW = kWaves;
-    float mean[NT], rstd[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int tok = m0 + 16 * t + n;
-        float2 ms = make_float2(0.f, 0.f);
-        if (tok < M) ms = *(const float2*)(stats + 2 * (size_t)tok);
-        mean[t] = ms.x; rstd[t] = ms.y;
-    }
-    f32x4 gam[RPW], ag[RPW], ab[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        gam[i] = *(const f32x4*)(gamma + 16 * (w * RPW + i) + 4 * g);
-        ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i];
-    }
-    auto load_xh = [&](int i, int t) {
-        const int tok = m0 + 16 * t + n, f0 = 16 * (w * RPW + i) + 4 * g;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (T.fvalid[i] && tok < M) v = (*(const f32x4*)(x + (size_t)tok * D + f0) - mean[t]) * rstd[t];
-        return v;
-    };
-    // ---- pass 1: per-token sums of dy = dxn * gamma and dy * xhat; per-feature sums of dxn * xhat and dxn
-    float s1[NT], s2[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const f32x4 xh = load_xh(i, t), go = T.acc[i][t], dy = go * gam[i];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { a1 += dy[k]; a2 = fmaf(dy[k], xh[k], a2); }
-            ag[i] += go * xh;
-            ab[i] += go;
-        }
-        s1[t] = a1; s2[t] = a2;
-    }
-    // token sums over all features: lane rows, then the waves through LDS (the exchange of ln_stats)
-    const float invD = 1.0f / (float)D;
-#pragma unroll
-    for (int tp = 0; tp < NT / 2; ++tp) {
-        float r[2];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const u32x2 xx = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1[2 * tp + hh]), __float_as_uint(s2[2 * tp + hh]), false, false);
-            r[hh] = __uint_as_float(xx[0]) + __uint_as_float(xx[1]);
-        }
-        const u32x2 y = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[0]), __float_as_uint(r[1]), false, false);
-        const float v = __uint_as_float(y[0]) + __uint_as_float(y[1]);
-        const int tok = (2 * tp + (row & 1)) * 16 + n;
-        red[tok * kRedTok + w * 2 + (row >> 1)] = v;
-    }
-    stamp(st, 55);
-    __syncthreads();
-    stamp(st, 56);
-    float c1[NT], c2[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const f32x4* pr = (const f32x4*)(red + (size_t)(t * 16 + n) * kRedTok);
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int k = 0; k < NW / 2; ++k) { const f32x4 v = pr[k]; s += v[0] + v[2]; q += v[1] + v[3]; }
-        c1[t] = s * invD; c2[t] = q * invD;
-    }
-    // ---- pass 2: G = gprev + (dy - c1 - xhat c2) rstd
-    f32x4 ac[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        ac[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int f0 = 16 * (w * RPW + i) + 4 * g;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int tok = m0 + 16 * t + n;
-            const bool ok = T.fvalid[i] && tok < M;
-            const f32x4 xh = load_xh(i, t);
-            f32x4 tot = (T.acc[i][t] * gam[i] - c1[t] - xh * c2[t]) * rstd[t];
-            if (ok) {
-                if (gprev) tot += *(const f32x4*)(gprev + (size_t)tok * D + f0);
-                *(f32x4*)(gout + (size_t)tok * D + f0) = tot;
-                *(uint2*)(gb + (size_t)tok * D + f0) = make_uint2(pack_bf16x2(tot[0], tot[1]), pack_bf16x2(tot[2], tot[3]));
-            } else tot = f32x4{0.f, 0.f, 0.f, 0.f};
-            T.acc[i][t] = tot;
-            ac[i] += tot;
-        }
-    }
-    stamp(st, 57);
-    put_b_frags<RPW, KS>(xnT, w, lane, [&](int i, int t) {
-        return make_uint2(pack_bf16x2(T.acc[i][t][0], T.acc[i][t][1]), pack_bf16x2(T.acc[i][t][2], T.acc[i][t][3]));
-    });
-    // ---- per-feature partial sums of the tile (over its 96 tokens: the 16 lanes of a row)
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int f0 = 16 * (w * RPW + i) + 4 * g;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float a = row16_sum(ag[i][k]), b = row16_sum(ab[i][k]), c = row16_sum(ac[i][k]);
-            if (n == 0 && f0 + k < D) { part[f0 + k] = a; part[D + f0 + k] = b; part[2 * D + f0 + k] = c; }
-        }
-    }
-    stamp(st, 58);
-    __syncthreads();
-    stamp(st, 59);
-}
-
-// MLP backward of the tile: xnT holds bf16(G_out) fragments; per hidden chunk  dg = W2^T-side product -> dh = dg *
-// GELU'(h) (h from the forward pass) -> kept (row-major bf16) and, as B fragments in hT, contracted with W1^T into
-// T.acc (= dxn2, zeroed here).  The FC1 bias gradient (column sums of dh as stored) goes out with one atomic per
-// feature and tile.  Plain chunk loop (two barriers per chunk): the phase is bound by the h / dh traffic of the tile.
-template <int RPW, int KS, int NW>
-__device__ __forceinline__ void mlp_bwd_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
-                                              const u32x4* __restrict__ w2p, int HT, int w, int lane,
-                                              const uint16_t* __restrict__ hs, uint16_t* __restrict__ dh, float* db1, int m0,
-                                              int M, int ld, Stamps& st) {
-    asm volatile("" : "+v"(lane));
-    constexpr int NT = kNTT, RC = kChunkTiles / NW, KW = RC / 2, A2KS = NW * RPW, PF1 = kFc1PF;
-    static_assert(KS % PF1 == 0, "FC1 weight ring");
-    const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
-    auto fc1_a = [&](int c) { return wptr(w1p + (size_t)(RC * w) * 64, lane).adv((size_t)c * KS * kChunkTiles); };
-    auto fc2_a = [&](int c) { return wptr(w2p + (size_t)(w * RPW) * 64, lane).adv((size_t)(c * kKC) * (NW * RPW)); };
-    u32x4 a1r[PF1][RC];
-    prefetch_ring<RC, PF1>(a1r, fc1_a(0), kChunkTiles);
-#pragma unroll
-    for (int i = 0; i < RPW; ++i)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) T.acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int c = 0; c < n_chunks; ++c) {
-        asm volatile("" : "+v"(lane));
-        const int n = lane & 15, g = lane >> 4;
-        // the forward pass's pre-activations of this wave's rows of the chunk (in flight across the product)
-        uint2 hv[RC][NT];
-#pragma unroll
-        for (int r = 0; r < RC; ++r) {
-            const int f0 = 16 * (c * kChunkTiles + RC * w + r) + 4 * g;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int tok = m0 + 16 * t + n;
-                hv[r][t] = make_uint2(0u, 0u);
-                if (tok < M && f0 < ld) hv[r][t] = *(const uint2*)(hs + (size_t)tok * ld + f0);
-            }
-        }
-        f32x4 h[RC][NT];
-#pragma unroll
-        for (int r = 0; r < RC; ++r)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) h[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        stamp(st, 60);
-        gemm_phase_ring<RC, NT, PF1, kt16(KS)>(h, a1r, fc1_a(c), kChunkTiles, xnT + lane, KS * 64, 64, KS);
-        stamp(st, 61);
-        if (c + 1 < n_chunks) prefetch_ring<RC, PF1>(a1r, fc1_a(c + 1), kChunkTiles);
-        u32x4 af2[2][RPW];
-        {
-            const WPtr a2 = fc2_a(c);
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) { af2[0][r] = a2.at(r); af2[1][r] = a2.at(r + A2KS); }
-        }
-        u32x4 hb[KW][NT];
-        float cs[RC][4];
-#pragma unroll
-        for (int r = 0; r < RC; ++r) {
-            const int f0 = 16 * (c * kChunkTiles + RC * w + r) + 4 * g;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cs[r][k] = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int tok = m0 + 16 * t + n;
-                const float v0 = __uint_as_float(hv[r][t].x << 16), v1 = __uint_as_float(hv[r][t].x & 0xffff0000u);
-                const float v2 = __uint_as_float(hv[r][t].y << 16), v3 = __uint_as_float(hv[r][t].y & 0xffff0000u);
-                uint2 pk;
-                pk.x = pack_bf16x2(h[r][t][0] * gelu_grad_poly(v0), h[r][t][1] * gelu_grad_poly(v1));
-                pk.y = pack_bf16x2(h[r][t][2] * gelu_grad_poly(v2), h[r][t][3] * gelu_grad_poly(v3));
-                if (tok < M && f0 < ld) *(uint2*)(dh + (size_t)tok * ld + f0) = pk;
-                cs[r][0] += __uint_as_float(pk.x << 16); cs[r][1] += __uint_as_float(pk.x & 0xffff0000u);
-                cs[r][2] += __uint_as_float(pk.y << 16); cs[r][3] += __uint_as_float(pk.y & 0xffff0000u);
-                hb[r >> 1][t][2 * (r & 1)] = pk.x;
-                hb[r >> 1][t][2 * (r & 1) + 1] = pk.y;
-            }
-        }
-        stamp(st, 62);
-        __syncthreads();                     // every wave is done reading hT(c-1)
-        stamp(st, 63);
-#pragma unroll
-        for (int j2 = 0; j2 < KW; ++j2)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) hT[((size_t)t * kKC + KW * w + j2) * 64 + lane] = hb[j2][t];
-#pragma unroll
-        for (int r = 0; r < RC; ++r) {
-            const int f0 = 16 * (c * kChunkTiles + RC * w + r) + 4 * g;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float sum = row16_sum(cs[r][k]);
-                if (n == 0 && f0 + k < ld) unsafeAtomicAdd(db1 + f0 + k, sum);
-            }
-        }
-        stamp(st, 64);
-        __syncthreads();                     // hT(c) complete
-        stamp(st, 65);
-        const int tiles_here = min(kChunkTiles, HT - c * kChunkTiles);
-        gemm_phase<RPW, NT, false, kNTT>(T.acc, af2[0], af2[1], fc2_a(c), A2KS, hT + lane, kKC * 64, 64,
-                                         tiles_here == kChunkTiles ? kKC : (((tiles_here >> 1) + 1) & ~1));
-        stamp(st, 66);
-    }
-    __syncthreads();
-    stamp(st, 67);
-}
-
-template <int RPW, int KS>
-__global__ __launch_bounds__(512, 2) void train_bwd_tail_kernel(const char* __restrict__ lw, const char* __restrict__ lw_prev,
-                                                                FusedDims d, TrainBwdImg bi, int M, TrainBwdArgs a,
-                                                                unsigned long long* stamps, int cap) {
-    Stamps st{stamps, cap, 0};
-    stamp(st, 100);
-    stamp(st, 1);
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int kBuf = kNTT * KS * 1024;                    // one set of B fragments of the tile: 96 tokens x 32 KS columns
-    static_assert(kBuf >= kNTT * kKC * 1024, "hT fits the second buffer");
-    u32x4* buf0 = (u32x4*)lds;
-    u32x4* buf1 = (u32x4*)(lds + kBuf);
-    float* red = (float*)(lds + 2 * kBuf);
-    int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m0 = blockIdx.x * kMT;
-    Tile<RPW> T;
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        T.fvalid[i] = 16 * (w * RPW + i) + 4 * (lane >> 4) < d.D;
-#pragma unroll
-        for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    {
-        // ---- dxn1 = dqkv Wqkv: three contractions over the q, k, v columns; the column blocks alternate between two
-        // LDS buffers, the third one travels through registers under the first product
-        constexpr int NF = kNTT * KS / kWaves;
-        static_assert(kNTT * KS % kWaves == 0, "fragments per wave");
-        const int n = lane & 15, g = lane >> 4;
-        const size_t ldq = (size_t)3 * d.D;
-        u32x4 sr[NF];
-        auto fetch = [&](int part) {
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int f = w + j * kWaves, t = f / KS, kk = f - t * KS;
-                sr[j] = load_b_frag(a.dqkv + (size_t)part * d.D, ldq, d.D, m0, M, t, kk, n, g);
-            }
-        };
-        auto put = [&](u32x4* buf) {
-#pragma unroll
-            for (int j = 0; j < NF; ++j) buf[(size_t)(w + j * kWaves) * 64 + lane] = sr[j];
-        };
-        auto wq = [&](int part) {
-            return wptr((const u32x4*)(lw + bi.o_wqkvT + (size_t)part * bi.part_bytes) + (size_t)(w * RPW) * 64, lane);
-        };
-        u32x4 aE[RPW], aO[RPW];
-        fetch(0); put(buf0);
-        fetch(1); put(buf1);
-        prefetch_a<RPW>(aE, aO, wq(0), kWaves * RPW);
-        stamp(st, 50);
-        __syncthreads();
-        stamp(st, 51);
-        fetch(2);
-        gemm_phase<RPW, kNTT, kt16(KS)>(T.acc, aE, aO, wq(0), kWaves * RPW, (const u32x4*)buf0 + lane, KS * 64, 64, KS);
-        prefetch_a<RPW>(aE, aO, wq(1), kWaves * RPW);
-        stamp(st, 52);
-        __syncthreads();                     // every wave is done with the q block
-        put(buf0);
-        gemm_phase<RPW, kNTT, kt16(KS)>(T.acc, aE, aO, wq(1), kWaves * RPW, (const u32x4*)buf1 + lane, KS * 64, 64, KS);
-        prefetch_a<RPW>(aE, aO, wq(2), kWaves * RPW);
-        __syncthreads();                     // the v block is complete
-        stamp(st, 53);
-        gemm_phase<RPW, kNTT, kt16(KS)>(T.acc, aE, aO, wq(2), kWaves * RPW, (const u32x4*)buf0 + lane, KS * 64, 64, KS);
-    }
-    // ---- LayerNorm-1 backward of layer l: G_out(l-1), kept as fp32 (re-read by the second LayerNorm backward below:
-    // the MLP phase needs its registers), bf16 (FC2 weight gradient) and B fragments
-    ln_bwd_tile<RPW, KS>(T, a.x_in, a.st1, (const float*)(lw + bi.o_ln1w), a.gres, a.gres, a.dyo, buf0, red,
-                         a.part1 + (size_t)blockIdx.x * 3 * d.D, d.D, m0, M, w, lane, st);
-    mlp_bwd_phase<RPW, KS, kWaves>(T, buf0, buf1, (const u32x4*)(lw_prev + bi.o_w2T), (const u32x4*)(lw_prev + bi.o_w1T), d.HT,
-                                   w, lane, a.h, a.dh, a.db1, m0, M, 4 * d.D, st);
-    ln_bwd_tile<RPW, KS>(T, a.x_mid, a.st2, (const float*)(lw_prev + bi.o_ln2w), a.gres, a.gres, a.dym, buf0, red,
-                         a.part2 + (size_t)blockIdx.x * 3 * d.D, d.D, m0, M, w, lane, st);
-    {
-        // ---- dy = bf16(G_mid) Wproj
-        asm volatile("" : "+v"(lane));
-        const int gg = lane >> 4, nn = lane & 15;
-#pragma unroll
-        for (int i = 0; i < RPW; ++i)
-#pragma unroll
-            for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 aE[RPW], aO[RPW];
-        const WPtr wp = wptr((const u32x4*)(lw_prev + bi.o_wprojT) + (size_t)(w * RPW) * 64, lane);
-        prefetch_a<RPW>(aE, aO, wp, kWaves * RPW);
-        gemm_phase<RPW, kNTT, kt16(KS)>(T.acc, aE, aO, wp, kWaves * RPW, (const u32x4*)buf0 + lane, KS * 64, 64, KS);
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int f0 = 16 * (w * RPW + i) + 4 * gg;
-            if (f0 < d.D) {
-#pragma unroll
-                for (int t = 0; t < kNTT; ++t) {
-                    const int tok = m0 + 16 * t + nn;
-                    if (tok < M)
-                        *(uint2*)(a.dy + (size_t)tok * d.D + f0) =
-                            make_uint2(pack_bf16x2(T.acc[i][t][0], T.acc[i][t][1]), pack_bf16x2(T.acc[i][t][2], T.acc[i][t][3]));
-                }
-            }
-        }
-        stamp(st, 68);
-        stamp(st, 101);
     }
 }
 
@@ -3244,8 +2868,6 @@ hipError_t launch_tail_block(float* x, const char* lw, const char* lw_next, cons
     return hipGetLastError();
 }
 
-int g_small_batch_max = 512;           // batches up to this size take the latency instance (beso_debug_set_small_batch_max)
-
 // One instance of layers_kernel: LDS attribute once, then the launch (LOOP = 1: the sampler-loop form, steps.n evaluations).
 template <int RPW, int KS, int HG, int NTL, int SPW, int NTA, int PX, int CORE, int LOOP>
 hipError_t launch_instance(size_t lds_bytes, int grid, float* x, const char* lw0, const FusedDims& d, int l0, int l1,
@@ -3271,11 +2893,18 @@ hipError_t launch_either(size_t lds_bytes, float* x, const char* lw0, const Fuse
 // (the q/k/v rows in LDS run 8 rows past the last slot)
 constexpr bool tiles_hold(int spw, int Tn, int nt) { return spw * Tn <= 16 * nt && (spw - 1) * Tn + 16 <= 16 * nt + 8; }
 
+constexpr int kSmallBatchMax = 512;    // batches up to this size take the two-sample instance, up to twice this the four-sample one
+
+// Which instance of layers_kernel a call runs: by batch size, or as the call's BESO_PLAN_SPW* hint says where the shape allows
+// it (the instances compute the same per-sample arithmetic -- equal bits --, so the hint is a performance / test knob only).
 template <int RPW, int KS, int HG, int NTL>
 hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, int l1, int n_samples, int Tn,
-                         const EdgeArgs& edge, const SampleSteps& steps, int precision, hipStream_t s) {
+                         const EdgeArgs& edge, const SampleSteps& steps, int precision, int plan, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS);
     constexpr int kSmallSPW = 2, kSmallNT = 2, kMidSPW = 4, kMidNT = 4;
+    const int want = plan & BESO_PLAN_SPW_MASK;
+    const bool small_ok = kSmallSPW * Tn <= 16 * kSmallNT && (kSmallSPW - 1) * Tn + 16 <= 16 * kSmallNT;
+#if !BESO_OPERAND_F16
     if (precision == BESO_PREC_BF16X3) {
         // The split-bf16 instances keep both halves of every activation fragment in LDS, which bounds the token tiles per
         // workgroup at three (145 KiB; four would need 182 KiB).  Every workgroup streams BOTH weight images (40 MB, kitchen):
@@ -3284,23 +2913,26 @@ hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, 
         // L2 -> CU weight stream of the two-sample instance (82 GB per B = 4096 forward), at 1.5x its MFMAs per workgroup.
         // (NTL = all three tiles: the last layer is not trimmed to the action-token tiles in this instance -- with the trimmed
         // copy of the layer code beside the full one this instance, and no other, produced run-to-run differences in whole
-        // workgroups on the MI355X, in every combination of trimmed phases (tools/.. round-3 notes in DESIGN.md); untrimmed it
-        // is bit-stable and bit-identical to the two-sample instance)
+        // workgroups on the MI355X, in every combination of trimmed phases; untrimmed it is bit-stable
+        // and bit-identical to the two-sample instance)
         constexpr int kX3SPW = 4, kX3NT = 3;
-        if (n_samples > g_small_batch_max && tiles_hold(kX3SPW, Tn, kX3NT)) {
+        const bool four_ok = tiles_hold(kX3SPW, Tn, kX3NT);
+        if (four_ok && (want == BESO_PLAN_SPW4 || (want != BESO_PLAN_SPW2 && n_samples > kSmallBatchMax) || !small_ok)) {
             constexpr LdsMapX3 X = lds_map_x3(KS, kX3NT);
             static_assert(X.total <= 160 * 1024, "LDS of the four-sample split-bf16 instance");
             return launch_either<RPW, KS, HG, kX3NT, kX3SPW, kX3NT, 1, 0>(X.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
         }
-        if (!(kSmallSPW * Tn <= 16 * kSmallNT && (kSmallSPW - 1) * Tn + 16 <= 16 * kSmallNT)) return hipErrorInvalidValue;
+        if (!small_ok) return hipErrorInvalidValue;
         constexpr LdsMapX3 X = lds_map_x3(KS, kSmallNT);
         return launch_either<RPW, KS, HG, NTL, kSmallSPW, kSmallNT, 1, 0>(X.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
     }
+#endif
+    const bool mid_ok = kMidSPW * Tn <= 16 * kMidNT && (kMidSPW - 1) * Tn + 16 <= 16 * kMidNT;
     // latency instances: the samples' tokens and the last sample's 16-row attention window must fit the token tiles
-    if (n_samples <= g_small_batch_max && kSmallSPW * Tn <= 16 * kSmallNT && (kSmallSPW - 1) * Tn + 16 <= 16 * kSmallNT)
+    if (small_ok && (want == BESO_PLAN_SPW2 || (!want && n_samples <= kSmallBatchMax)))
         return launch_either<RPW, KS, HG, NTL, kSmallSPW, kSmallNT, 0, 0>(L.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
     // up to one workgroup of four samples per CU: two thirds of the throughput instance's work per workgroup
-    if (n_samples <= 2 * g_small_batch_max && kMidSPW * Tn <= 16 * kMidNT && (kMidSPW - 1) * Tn + 16 <= 16 * kMidNT)
+    if (mid_ok && (want == BESO_PLAN_SPW4 || (!want && n_samples <= 2 * kSmallBatchMax)))
         return launch_either<RPW, KS, HG, NTL, kMidSPW, kMidNT, 0, 0>(L.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
     return launch_either<RPW, KS, HG, NTL, kSPW, kNTT, 0, 0>(L.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
 }
@@ -3329,7 +2961,6 @@ size_t fused_packed_bytes(const Layout& lay, int precision) {
     return d.layer_bytes * lay.L + d.global_bytes;
 }
 
-size_t fused_workspace_bytes(const Layout&, int, int, int) { return 0; }
 
 #define FTRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return BESO_ERR_HIP; } while (0)
 
@@ -3427,38 +3058,25 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
     return BESO_OK;
 }
 
-// Batches below BESO_FUSED_MIN_BATCH (virtual samples) take the per-op path.  Default 0: measured on MI355X
-// (tools/latency.py) the one-launch kernel wins at every batch size -- 0.53 ms flat from B = 1 to 2048 (one
-// workgroup per 8 samples, one round) against 0.60 ms (B = 1) .. 1.6 ms (B = 1024) for ~45 launches.
-static int fused_min_batch() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("BESO_FUSED_MIN_BATCH");
-        v = e ? atoi(e) : 0;
-        if (v < 0) v = 0;
-    }
-    return v;
-}
-
-// 0: no fused kernel, 1: MLP block only, 2: whole layers
-static int g_level_max = -1;           // bf16 only: cap for tests / kernel experiments (beso_debug_set_fused_level_max)
+// 0: no fused kernel, 1: MLP block / tail block kernels, 2: the whole network in one launch.  The call's plan hint caps it
+// (BESO_PLAN_PER_OP: 0, BESO_PLAN_BLOCKS: 1): the per-op kernels are the parity reference of the fused ones in the same
+// arithmetic.  (The one-launch kernel wins at every batch size: 0.29 ms flat from B = 1 to 512 against 0.60 ms (B = 1) ..
+// 1.6 ms (B = 1024) for ~45 per-op launches, tools/latency.py.)
 int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     FusedDims d;
-    if (a.vbatch < fused_min_batch()) return 0;
     if ((precision != BESO_PREC_BF16 && precision != BESO_PREC_BF16X3) || lay.fused == lay.total || !fused_dims(lay, &d) ||
         !shape_has_kernel(d)) return 0;
     const bool whole = x3_shape(d) && kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused) &&
                        d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK;
     if (precision == BESO_PREC_BF16X3) return whole ? 2 : 0;     // BF16X3 is an instance of layers_kernel and nothing else
-    if (g_level_max < 0) g_level_max = getenv("BESO_FUSED_LEVEL_MAX") ? atoi(getenv("BESO_FUSED_LEVEL_MAX")) : 2;   // kernel experiments
-    if (g_level_max < 2) return g_level_max;
+    const int cap = (a.plan & BESO_PLAN_PER_OP) ? 0 : (a.plan & BESO_PLAN_BLOCKS) ? 1 : 2;
+    if (cap < 2) return cap;
     // long sequences: the whole network in one launch, a sample per workgroup (so no classifier-free pairs, whose halves share one)
     const bool whole_long = d.seq1 && a.T <= 16 * kLongNT && a.vbatch == a.batch && d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK;
     return (whole || whole_long) ? 2 : 1;
 }
 
-void fused_set_level_max(int n) { g_level_max = n < 0 ? 2 : n; }
-
+#if !BESO_OPERAND_F16
 bool fused_supported(const Layout& lay, const FwdArgs& a, int precision) { return fused_level(lay, a, precision) > 0; }
 
 int fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, int M, hipStream_t s) {
@@ -3596,81 +3214,7 @@ int fused_train_tail(const Layout& lay, const char* img, int layer, int M, const
     return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
-// ---- training backward through the mirrored tail block -------------------------------------------------------------
-size_t fused_train_bwd_image_bytes(const Layout& lay) {
-    FusedDims d;
-    if (!train_tail_dims(lay, &d)) return 0;
-    return (size_t)train_bwd_img(d).layer_bytes * lay.L;
-}
-
-// Transposed weights of layers [0, L) in fragment order + LayerNorm gammas into img (one launch).
-int fused_train_bwd_pack(const Layout& lay, const float* const* p, char* img, hipStream_t s) {
-    FusedDims d;
-    if (!train_tail_dims(lay, &d)) return BESO_ERR_UNSUPPORTED;
-    const TrainBwdImg bi = train_bwd_img(d);
-    if (lay.L * 8 > kTrainPackSegs) return BESO_ERR_UNSUPPORTED;
-    TrainPackTable t;
-    t.n = 0;
-    int blocks = 0;
-    const int D = lay.D, rt1 = d.NCH * kChunkTiles, rt2 = d.RPW * kWaves;
-    auto matT = [&](const float* src, uint32_t dst, int rows, int cols, int rt, int kt, int grp) {   // the matrix is src^T: [rows][cols]
-        t.seg[t.n] = TrainPackSeg{src, dst, rows, cols, rt, kt, grp, blocks, 1};
-        blocks += (rt * kt * 512 + 256 * 16 - 1) / (256 * 16);
-        ++t.n;
-    };
-    auto vec = [&](const float* src, uint32_t dst, int n, int n_pad) {
-        t.seg[t.n] = TrainPackSeg{src, dst, n, n_pad, 0, 0, 0, blocks, 0};
-        blocks += 1;
-        ++t.n;
-    };
-    for (int l = 0; l < lay.L; ++l) {
-        const float* const* q = p + 3 + 16 * l;        // (order as in fused_train_pack)
-        const uint32_t base = (uint32_t)l * bi.layer_bytes;
-        const float* w3[3] = {q[6], q[4], q[8]};       // query, key, value
-        for (int part = 0; part < 3; ++part) matT(w3[part], base + bi.o_wqkvT + (uint32_t)part * bi.part_bytes, D, D, rt2, d.KS, rt2);
-        matT(q[14], base + bi.o_w2T, 4 * D, D, rt1, d.KS, kChunkTiles);      // fc2.weight [D][4D] -> W2^T [4D][D]
-        matT(q[12], base + bi.o_w1T, D, 4 * D, rt2, d.KS2p, rt2);            // fc1.weight [4D][D] -> W1^T [D][4D]
-        matT(q[10], base + bi.o_wprojT, D, D, rt2, d.KS, rt2);
-        vec(q[0], base + bi.o_ln1w, D, rt2 * 16);
-        vec(q[2], base + bi.o_ln2w, D, rt2 * 16);
-    }
-    t.blocks = blocks;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(train_pack_kernel, dim3(blocks), dim3(256), 0, s, t, img);
-    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
-}
-
-int fused_train_bwd_tiles(int M) { return (M + kMT - 1) / kMT; }
-
-// Front half of `layer` (>= 1) and back half of layer - 1 on M token rows (see train_bwd_tail_kernel).
-int fused_train_bwd_tail(const Layout& lay, const char* img, int layer, int M, const void* dqkv, const float* x_in,
-                         const float* st1, float* gres, void* dyo, const void* h, void* dh, float* db1, const float* x_mid,
-                         const float* st2, void* dym, void* dy, float* part1, float* part2, hipStream_t s) {
-    FusedDims d;
-    if (!train_tail_dims(lay, &d) || layer < 1) return BESO_ERR_UNSUPPORTED;
-    const TrainBwdImg bi = train_bwd_img(d);
-    const char* lw = img + (size_t)layer * bi.layer_bytes;
-    const char* lw_prev = lw - bi.layer_bytes;
-    TrainBwdArgs a{(const uint16_t*)dqkv, x_in, st1, gres, (uint16_t*)dyo, (const uint16_t*)h, (uint16_t*)dh, db1, x_mid, st2,
-                   (uint16_t*)dym, (uint16_t*)dy, part1, part2};
-    const dim3 grid((M + kMT - 1) / kMT), block(512);
-    hipError_t e;
-    (void)hipGetLastError();
-    if (d.RPW == 3) {
-        constexpr int lds_bytes = 2 * kNTT * 12 * 1024 + kRedTok * kMT * 4;
-        static bool attr = false;
-        e = ensure_lds(train_bwd_tail_kernel<3, 12>, lds_bytes, &attr);
-        if (e != hipSuccess) return BESO_ERR_HIP;
-        hipLaunchKernelGGL((train_bwd_tail_kernel<3, 12>), grid, block, lds_bytes, s, lw, lw_prev, d, bi, M, a, g_stamps, g_stamps_cap);
-    } else {
-        constexpr int lds_bytes = 2 * kNTT * 8 * 1024 + kRedTok * kMT * 4;
-        static bool attr = false;
-        e = ensure_lds(train_bwd_tail_kernel<2, 8>, lds_bytes, &attr);
-        if (e != hipSuccess) return BESO_ERR_HIP;
-        hipLaunchKernelGGL((train_bwd_tail_kernel<2, 8>), grid, block, lds_bytes, s, lw, lw_prev, d, bi, M, a, g_stamps, g_stamps_cap);
-    }
-    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
-}
+#endif   // !BESO_OPERAND_F16
 
 // Whole network (embed -> all layers -> head) or layers only.  Returns in *fused_edges whether the token
 // embedding / action head ran inside the kernel (bit 0 / bit 1).
@@ -3710,22 +3254,19 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     if (fused_edges) *fused_edges = (e.fuse_embed ? 1 : 0) | (e.fuse_head ? 2 : 0);
     if (S.n > 0 && !(e.fuse_embed && e.fuse_head)) return BESO_ERR_UNSUPPORTED;
     hipError_t err;
-    if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1, 2>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, precision, s);    // kitchen: 8 x 4 action tokens
-    else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3, 4>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, precision, s);   // block-push: 8 x 5
+    if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1, 2>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, precision, a.plan, s);    // kitchen: 8 x 4 action tokens
+    else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3, 4>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, precision, a.plan, s);   // block-push: 8 x 5
     else if (d.seq1 && precision == BESO_PREC_BF16) err = launch_layers_long<4, 16, kLongNT>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, s);   // long horizon: 1 x 67 tokens
     else return BESO_ERR_UNSUPPORTED;
     return err == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
-void fused_set_small_batch_max(int n) { g_small_batch_max = n; }
-
+#if !BESO_OPERAND_F16
 void fused_set_stamps(void* buf, int cap) {
     g_stamps = (unsigned long long*)buf;
     g_stamps_cap = cap;
 }
 
-int forward_fused(const Layout&, const Workspace&, const char*, int, const FwdArgs&, char*, hipStream_t) {
-    return BESO_ERR_UNSUPPORTED;   // orchestration lives in api.hip
-}
+#endif   // !BESO_OPERAND_F16
 
 }  // namespace beso

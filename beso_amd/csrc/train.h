@@ -13,12 +13,11 @@ int    train_loss_grad(const beso_config* c, const float* const* params, int n_p
                        float goal_drop, uint32_t seed, float grad_scale, void* workspace, size_t workspace_bytes, hipStream_t s, hipStream_t early_stream,
                        hipError_t* err, int* err_line);
 int    train_goal_mask(float* mask, size_t n, float goal_drop, uint32_t seed, hipStream_t s, hipError_t* err, int* err_line);
-void   train_set_tail_forward(int on);
-void   train_set_tail_backward(int on);
-void   train_set_wgrad_side(int on);
 int    train_early_layer(const beso_config* c);
 void   train_early_range(const beso_config* c, size_t* begin, size_t* end);
+#if BESO_DEV_API
 int    train_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,
                         int ldc, int M, int N, int K, int splits, hipStream_t s, hipError_t* err, int* err_line);
+#endif
 
 }  // namespace beso

@@ -452,6 +452,7 @@ template <typename E> struct EpiSiluBwd {        // dz = da * SiLU'(z); column s
         return Vec4<E>::rounded(d);
     }
 };
+#if BESO_DEV_API
 struct EpiAtomic {                               // split-K partial sums accumulated with atomics (debug entry point)
     static constexpr bool kColSum = false;
     float* out; int ld;
@@ -462,6 +463,7 @@ struct EpiAtomic {                               // split-K partial sums accumul
     }
 };
 inline EpiAtomic epi_atomic(float* out, int ld) { return EpiAtomic{out, ld}; }
+#endif
 template <typename E, bool AKS, bool BKS, typename Epi>
 hipError_t tgemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int splits, Epi epi, hipStream_t s) {
     (void)hipGetLastError();
@@ -1197,7 +1199,6 @@ struct TrainWs {
     size_t dx, dx0b, dxn, dy, ln_part;
     size_t ya, xa, dxa, dya;                                        // compact action rows of the last layer
     size_t fimg;                                                    // per-step fragment image of the weights (tail-block forward)
-    size_t bimg;                                                    // ... of the transposed weights (tail-block backward)
     TrainLayerWs layer[kMaxLayers];
     size_t total;
 };
@@ -1240,7 +1241,6 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
         Layout lay;
         const bool img = precision == BESO_PREC_BF16 && make_layout(c, BESO_PREC_BF16, &lay);
         w->fimg = carve_t(cur, img ? fused_train_image_bytes(lay) : 0);
-        w->bimg = carve_t(cur, img ? fused_train_bwd_image_bytes(lay) : 0);
     }
     for (int l = 0; l < c->n_layers; ++l) {
         TrainLayerWs& y = w->layer[l];
@@ -1315,34 +1315,26 @@ size_t train_grad_floats(const beso_config* c) {
 
 // The tail-block forward pays off once its 96-token tiles are several rounds of workgroups (measured on MI355X, kitchen:
 // 8192 samples = 939 tiles 16.57 vs 17.41 ms per step; 1024 samples = 118 tiles 3.43 vs 3.39 ms -- at under one round both
-// forms are bound by a lone workgroup's latency).  0: never, 1: from kTailMinRows token rows on, 2: always (tests).
-static int g_tail_forward = 1;
+// forms are bound by a lone workgroup's latency): taken from kTailMinRows token rows on, unless the call's plan hint says
+// otherwise (BESO_TRAIN_PLAN_PER_OP: never, BESO_TRAIN_PLAN_TILES: always -- the two forms write the same kept activations).
 constexpr int kTailMinRows = 16000;       // kitchen: 3.39 = 3.40 ms at 1024 samples (11 k rows), 4.99 vs 5.37 at 2048, 8.61 vs 8.96 at 4096
-static bool tail_forward_enabled(int rows) { return g_tail_forward == 2 || (g_tail_forward == 1 && rows >= kTailMinRows); }
-void train_set_tail_forward(int on) { g_tail_forward = on; }
-// The same for the chain of data gradients (fused.hip: train_bwd_tail_kernel): 0 (default) never, 1 where the shape has the
-// kernel.  Measured SLOWER than the eight per-op launches it replaces (209 us vs 164 us + launch gaps per layer at 1024
-// kitchen samples): off unless asked for.
-static int g_tail_backward = 0;
-void train_set_tail_backward(int on) { g_tail_backward = on; }
-// Weight gradients on a side stream: the grouped weight-gradient launch of a layer is independent of the chain of data
-// gradients of the layers in front of it and can run under it on a second stream.  0 (default): one grouped launch behind
-// the chain on the main stream -- the concurrent form measures SLOWER (3.63 vs 3.39 ms per 1024-sample kitchen step,
-// 16.9 vs 16.5 ms per 8192: the two streams evict each other's operands from L2 / MALL).
-static int g_wgrad_side = 0;
-void train_set_wgrad_side(int on) { g_wgrad_side = on; }
+static bool tail_forward_enabled(int rows, int flags) {
+    if (flags & BESO_TRAIN_PLAN_PER_OP) return false;
+    return (flags & BESO_TRAIN_PLAN_TILES) || rows >= kTailMinRows;
+}
 
 #define TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { *err = _e; *err_line = __LINE__; return BESO_ERR_HIP; } } while (0)
 
 template <typename E>
 static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat, int precision, const float* state,
                        const float* action, const float* goal, const float* noise, const float* sigma, float* loss_out,
-                       int batch, int t, int last_only, float embed_p, float attn_p, float resid_p, float goal_p, uint32_t seed,
+                       int batch, int t, int flags, float embed_p, float attn_p, float resid_p, float goal_p, uint32_t seed,
                        float grad_scale, char* ws,
                        const TrainWs& w, hipStream_t s, hipStream_t early_stream, hipError_t* err, int* err_line) {
     const int D = c->embed_dim, H = c->n_heads, hd = D / H, L = c->n_layers, G = c->goal_seq_len;
     const int obs = c->obs_dim, act = c->act_dim, seq = G + c->obs_seq_len + 1;
     const int M = w.M, T = w.T, Ke = w.Ke, ap = w.ap, D3 = 3 * D, D4 = 4 * D;
+    const int last_only = flags & BESO_TRAIN_LAST_ACTION_ONLY;
     const float scale = 1.0f / sqrtf((float)hd);
     const float attn_ik = attn_p > 0.f ? 1.0f / (1.0f - attn_p) : 1.f, resid_ik = resid_p > 0.f ? 1.0f / (1.0f - resid_p) : 1.f;
     auto F = [&](size_t off) { return (float*)(ws + off); };
@@ -1444,7 +1436,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // the same formats.  The last layer stays per-op (it continues on the compact action rows).
     Layout flay;
     const bool use_tail = sizeof(E) == 2 && resid_p == 0.f && L >= 2 && L * 13 <= 96 && make_layout(c, BESO_PREC_BF16, &flay) &&
-                          fused_train_supported(flay) && fused_train_image_bytes(flay) > 0 && tail_forward_enabled(M);
+                          fused_train_supported(flay) && fused_train_image_bytes(flay) > 0 && tail_forward_enabled(M, flags);
     if (use_tail) {
         const int pst = fused_train_pack(flay, p, ws + w.fimg, s);
         if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
@@ -1542,36 +1534,14 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     GTable gt;
     gt.n = 0;
     int g_tiles = 0;
-    static thread_local hipStream_t side = nullptr;
-    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    const bool use_side = g_wgrad_side != 0;
-    if (use_side && !side) {
-        TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    }
-    bool side_busy = false;
-    // launches the collected weight gradients: behind everything issued on `s` so far, on the side stream (or on `s`)
+    // launches the collected weight gradients behind everything issued on `s` so far.  (Measured and rejected, round 2: the
+    // grouped launch of a layer on a side stream under the data gradients of the layers in front of it -- 3.63 vs 3.39 ms per
+    // 1024-sample kitchen step, the two streams evict each other's operands from L2 / MALL.)
     auto flush_group = [&]() -> hipError_t {
         if (gt.n == 0) return hipSuccess;
-        hipStream_t ws_s = s;
-        if (use_side) {
-            hipError_t e = hipEventRecord(ev_fork, s);
-            if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
-            if (e != hipSuccess) return e;
-            ws_s = side;
-            side_busy = true;
-        }
-        hipLaunchKernelGGL(tgemm_wgrad_group_kernel<E>, dim3(g_tiles), dim3(kGT), 0, ws_s, gt);
+        hipLaunchKernelGGL(tgemm_wgrad_group_kernel<E>, dim3(g_tiles), dim3(kGT), 0, s, gt);
         gt.n = 0; g_tiles = 0;
         return hipGetLastError();
-    };
-    // orders `to` behind the weight gradients issued so far
-    auto join_side = [&](hipStream_t to) -> hipError_t {
-        if (!side_busy) return hipSuccess;
-        hipError_t e = hipEventRecord(ev_join, side);
-        if (e == hipSuccess) e = hipStreamWaitEvent(to, ev_join, 0);
-        return e;
     };
     auto wgrad = [&](const E* A, int lda, int Mo, const E* B, int ldb, int No, int rows, float* out) -> hipError_t {
         if (gt.n == kMaxGroup) { hipError_t e = flush_group(); if (e != hipSuccess) return e; }
@@ -1595,40 +1565,27 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     }
     TRY(ln_bwd(x_last, w.stf, lnfw.p, nullptr, F(w.dxa), P(w.layer[L - 1].dyo), Ma, lnfw.g, lnfb.g, lp[L - 1].f2b.g, resid_p,
                (uint32_t)(4 * (L - 1) + 2)));
-    // bf16, no dropout on the proj / MLP outputs, a shape with the tile kernels: between two attention backwards the whole
-    // chain of data gradients (q/k/v of layer l, LayerNorm-1, FC2 (+GELU'), FC1, LayerNorm-2, proj of layer l-1) is ONE
-    // launch (fused.hip: train_bwd_tail_kernel) writing the same kept gradients in the same formats.  The last layer's
-    // back half (compact action rows) and layer 0's front half (embedding dropout) stay per-op.
-    const bool use_btail = sizeof(E) == 2 && resid_p == 0.f && L >= 2 && L * 8 <= 96 && g_tail_backward != 0 &&
-                           make_layout(c, BESO_PREC_BF16, &flay) && fused_train_supported(flay) &&
-                           fused_train_bwd_image_bytes(flay) > 0 && fused_train_bwd_tiles(M) <= lnb_grid;
-    if (use_btail) {
-        const int pst = fused_train_bwd_pack(flay, p, ws + w.bimg, s);
-        if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
-    }
+    // (Measured and rejected, round 2: the chain of data gradients between two attention backwards as ONE tile kernel, the mirror
+    // image of the tail-block forward -- parity-green, 209 us per launch against 164 us + gaps for the eight per-op launches it
+    // replaces: 3.60 vs 3.43 ms per 1024-sample step.  DESIGN.md section 7.)
     for (int l = L - 1; l >= 0; --l) {
         const TrainLayerWs& y = w.layer[l];
         const float* x_in = l == 0 ? F(w.x0) : F(w.layer[l - 1].x_out);
         const bool last = l == L - 1;
         const int rows = last ? Ma : M;
         float* dres = last ? F(w.dxa) : F(w.dx);          // residual gradient of this layer's second half
-        const bool back_fused = use_btail && !last;       // (done by the launch of layer l + 1)
         // FC2: dW2 = dyo^T g, dh = (dyo W2) * GELU'(h)
         TRY(wgrad(P(y.dyo), D, D, P(y.g), D4, D4, rows, lp[l].f2w.g));
-        if (!back_fused)
-            TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), lp[l].f1b.g, D4}, s)));
+        TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), lp[l].f1b.g, D4}, s)));
         // FC1: dW1 = dh^T xn2, db1, dxn2 = dh W1
         TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, rows, lp[l].f1w.g));
-        if (!back_fused) {
-            TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, rows, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
-            TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, dres, dres, P(y.dym), rows, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
-                       (uint32_t)(4 * l + 1)));
-        }
+        TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, rows, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+        TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, dres, dres, P(y.dym), rows, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
+                   (uint32_t)(4 * l + 1)));
         // proj: dWp = dym^T y, dy = dym Wp
         TRY(wgrad(P(y.dym), D, D, last ? P(w.ya) : P(y.y), D, D, rows, lp[l].pw.g));
-        if (!back_fused)
-            TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, rows, D, D, 1,
-                                       EpiStore<E>{nullptr, last ? P(w.dya) : P(w.dy), nullptr, D}, s)));
+        TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, rows, D, D, 1,
+                                   EpiStore<E>{nullptr, last ? P(w.dya) : P(w.dy), nullptr, D}, s)));
         if (last) {
             // back to all token rows: dy and the residual gradient are zero off the action rows
             const size_t n4 = (size_t)M * (D / 4);
@@ -1652,31 +1609,17 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(wgrad(P(y.dqkv) + 2 * D, D3, D, P(y.xn1), D, D, M, lp[l].vw.g));
         TRY(colsum(P(y.dqkv), D3, D3, M, lp[l].qb.g, lp[l].kb.g, lp[l].vb.g, D));
         const bool first = l == 0;
-        if (use_btail && !first) {
-            const TrainLayerWs& pv = w.layer[l - 1];
-            const int nt = fused_train_bwd_tiles(M);
-            float* part1 = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
-            lrt.nb[ln_calls] = nt;
-            lrt.c[ln_calls++] = LnRedCall{lp[l].ln1w.g, lp[l].ln1b.g, lp[l - 1].f2b.g};
-            float* part2 = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
-            lrt.nb[ln_calls] = nt;
-            lrt.c[ln_calls++] = LnRedCall{lp[l - 1].ln2w.g, lp[l - 1].ln2b.g, lp[l - 1].pb.g};
-            const int bst = fused_train_bwd_tail(flay, ws + w.bimg, l, M, P(y.dqkv), x_in, F(y.st1), F(w.dx), P(pv.dyo), P(pv.h),
-                                                 P(pv.dh), lp[l - 1].f1b.g, F(pv.x_mid), F(pv.st2), P(pv.dym), P(w.dy), part1, part2, s);
-            if (bst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return bst; }
-        } else {
+        {
             TRY((tgemm<E, false, true>(P(y.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
             TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, F(w.dx), F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo), M, lp[l].ln1w.g,
                        lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? embed_p : resid_p,
                        first ? kEmbedSite : (uint32_t)(4 * (l - 1) + 2), first ? T : 0));
         }
-        if (use_side) TRY(flush_group());     // this layer's weight gradients run under the data gradients of the layers in front
         if (early_stream && l == train_early_layer(c) && l > 0) {
             // the gradients of layers l .. L-1 and ln_f are complete once their weight gradients and LayerNorm sums
             // have run: do those now and order `early_stream` behind this point (the C1 exchange of that range can
             // start under the backward of layers l-1 .. 0)
             TRY(flush_group());
-            TRY(join_side(early_stream));
             hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls), dim3(256), 0, s, (const float*)F(w.ln_part),
                                lrt, lnb_grid, D, 0);
             TRY(hipGetLastError());
@@ -1690,7 +1633,6 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // embeddings: dWcat[Ke][D] = Xemb^T dx0, routed to pos_emb / tok_emb / action_emb / sigma_emb after the launch
     TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dx0b), D, D, M, F(w.dw_cat)));
     TRY(flush_group());
-    TRY(join_side(s));
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls - ln_reduced), dim3(256), 0, s,
                        (const float*)F(w.ln_part), lrt, lnb_grid, D, ln_reduced);
     TRY(hipGetLastError());
@@ -1721,7 +1663,7 @@ int train_loss_grad(const beso_config* c, const float* const* params, int n_para
     if (c->goal_seq_len > 0 && !goal) return BESO_ERR_BAD_ARG;
     if (n_params != 3 + 16 * c->n_layers + 6 + (c->linear_output ? 2 : 4)) return BESO_ERR_BAD_ARG;
     for (int i = 0; i < n_params; ++i) if (!params[i]) return BESO_ERR_BAD_ARG;
-    if (flags & ~BESO_TRAIN_LAST_ACTION_ONLY) return BESO_ERR_BAD_ARG;
+    if (flags & ~(BESO_TRAIN_LAST_ACTION_ONLY | BESO_TRAIN_PLAN_PER_OP | BESO_TRAIN_PLAN_TILES)) return BESO_ERR_BAD_ARG;
     if (!(attn_pdrop >= 0.f && attn_pdrop < 1.f && resid_pdrop >= 0.f && resid_pdrop < 1.f && embed_pdrop >= 0.f &&
           embed_pdrop < 1.f && goal_drop >= 0.f && goal_drop <= 1.f))
         return BESO_ERR_BAD_ARG;
@@ -1730,10 +1672,10 @@ int train_loss_grad(const beso_config* c, const float* const* params, int n_para
     if (workspace_bytes < w.total) return BESO_ERR_WORKSPACE;
     if (precision == BESO_PREC_FP32)
         return loss_grad_e<float>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
-                                  flags & BESO_TRAIN_LAST_ACTION_ONLY, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale,
+                                  flags, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale,
                                   (char*)workspace, w, s, early_stream, err, err_line);
     return loss_grad_e<uint16_t>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
-                                 flags & BESO_TRAIN_LAST_ACTION_ONLY, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale,
+                                 flags, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale,
                                  (char*)workspace, w, s, early_stream, err, err_line);
 }
 
@@ -1747,6 +1689,7 @@ int train_goal_mask(float* mask, size_t n, float goal_drop, uint32_t seed, hipSt
     return BESO_OK;
 }
 
+#if BESO_DEV_API
 // development aid: C[M][N] = op(A) op(B)^T through tgemm (fp32 output), for the layout tests
 int train_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,
                      int ldc, int M, int N, int K, int splits, hipStream_t s, hipError_t* err, int* err_line) {
@@ -1769,5 +1712,6 @@ int train_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int
 #undef DBG
     return BESO_ERR_UNSUPPORTED;
 }
+#endif
 
 }  // namespace beso

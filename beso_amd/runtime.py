@@ -6,13 +6,48 @@ constructor raises (``beso_amd._lib.load``).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
 import torch
 
 from . import _lib
+
+_hints = threading.local()
+
+
+@contextlib.contextmanager
+def plan(forward: int = 0, train: int = 0):
+    """Execution-plan hints for the library calls the CALLING THREAD makes inside the block: ``forward`` = BESO_PLAN_* bits
+    (``_lib.PLAN_PER_OP``, ``PLAN_BLOCKS``, ``PLAN_SPW2 / 4 / 8``) added to the flags of every forward / sampler call,
+    ``train`` = ``_lib.TRAIN_PLAN_PER_OP`` / ``TRAIN_PLAN_TILES`` for ``beso_loss_grad``.  They select WHICH kernels run,
+    never what is computed (parity tests: per-op kernels against the fused ones; measurements); each library call carries
+    its own flags, so nothing process-wide changes."""
+    old = (getattr(_hints, "forward", 0), getattr(_hints, "train", 0))
+    _hints.forward, _hints.train = forward, train
+    try:
+        yield
+    finally:
+        _hints.forward, _hints.train = old
+
+
+def set_plan(forward: Optional[int] = None, train: Optional[int] = None) -> None:
+    """The same hints without a block: they stay with the calling thread until set again (0 = the library's own choice)."""
+    if forward is not None:
+        _hints.forward = forward
+    if train is not None:
+        _hints.train = train
+
+
+def forward_hints() -> int:
+    return getattr(_hints, "forward", 0)
+
+
+def train_hints() -> int:
+    return getattr(_hints, "train", 0)
 
 
 @dataclass(frozen=True)
@@ -163,7 +198,7 @@ class ScoreNetRuntime:
         ws = self._workspace(B, t, two, dev)
         out = torch.empty((B, t, self.shape.act_dim), dtype=torch.float32, device=dev)
         gp = goal.data_ptr() if goal is not None else None
-        flags = _lib.FLAG_UNCOND if uncond else 0
+        flags = (_lib.FLAG_UNCOND if uncond else 0) | forward_hints()
         with torch.cuda.device(dev):
             if precondition:
                 st = self.lib.beso_denoise_fwd(C.byref(self.cfg), packed.buf.data_ptr(), packed.precision,
@@ -196,7 +231,7 @@ class ScoreNetRuntime:
         with torch.cuda.device(dev):
             st = self.lib.beso_sample(C.byref(self.cfg), packed.buf.data_ptr(), packed.precision,
                                       _lib.SAMPLER_IDS[sampler], state.data_ptr(), gp, x.data_ptr(), B, t, arr,
-                                      len(sig), float(cond_lambda), _lib.SAMPLE_STEPWISE if stepwise else 0,
+                                      len(sig), float(cond_lambda), (_lib.SAMPLE_STEPWISE if stepwise else 0) | forward_hints(),
                                       ws.data_ptr(), ws.numel(), _stream_ptr(dev))
         _lib.check(st, f"sample[{sampler}]")
         return x
@@ -230,7 +265,7 @@ class ScoreNetRuntime:
         with torch.cuda.device(dev):
             st = self.lib.beso_sample_ancestral(C.byref(self.cfg), packed.buf.data_ptr(), packed.precision, state.data_ptr(), gp,
                                                 x.data_ptr(), B, t, arr, len(sig), float(cond_lambda), float(eta),
-                                                noise.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+                                                noise.data_ptr(), forward_hints(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
         _lib.check(st, "sample[euler_ancestral]")
         return x
 

@@ -12,8 +12,10 @@ Two ways in:
   persistent flat buffer (stable addresses for the fused optimizer's chunk table, one flat tensor for the
   data-parallel all-reduce) and returns the loss.
 
-There is no CPU implementation; what the kernels do not cover (``embed_dim`` not a multiple of 8) stays on the
-torch-autograd evaluation of the same function.
+There is no CPU implementation and no second evaluation of the network behind it: what the kernels do not cover
+(``embed_dim`` not a multiple of 8, attention windows beyond the LDS budget, unknown ``loss`` kwargs) raises
+(``GCDenoiser.loss``); the torch-autograd evaluation of the same function lives in ``tests/autograd_reference.py`` as
+the comparator of this step.
 """
 from __future__ import annotations
 
@@ -23,6 +25,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib
+from .runtime import train_hints
 
 
 class HipTrainStep:
@@ -133,8 +136,8 @@ class HipTrainStep:
                 # the seed is a host scalar: a captured graph would replay one mask forever
                 raise RuntimeError("beso_amd: the HIP training step with dropout cannot be captured into a graph")
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,), device="cpu").item())
-        # the split-bf16 mode is an inference instance of the fused kernel; its training step is the fp32 one
-        precision = _lib.PRECISIONS["fp32" if inner.precision == "bf16x3" else inner.precision]
+        # the split-bf16 and fp16 modes are inference instances of the fused kernel; their training steps are the fp32 / bf16 ones
+        precision = _lib.PRECISIONS[{"bf16x3": "fp32", "fp16": "bf16"}.get(inner.precision, inner.precision)]
         params = [p.detach() for p in inner.parameters()]
         arr = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
         flat, views = self._grad_buffer(dev, fresh_grads)
@@ -144,7 +147,7 @@ class HipTrainStep:
             st = self.lib.beso_loss_grad_overlap(
                 C.byref(self.cfg), arr, len(params), flat.data_ptr(), precision,
                 state.data_ptr(), action.data_ptr(), gptr, noise.data_ptr(), sigma.data_ptr(),
-                loss.data_ptr(), B, t, 1 if last_action_only else 0, float(embed_p), float(attn_p), float(resid_p),
+                loss.data_ptr(), B, t, (_lib.TRAIN_LAST_ACTION_ONLY if last_action_only else 0) | train_hints(), float(embed_p), float(attn_p), float(resid_p),
                 float(goal_p), C.c_uint(seed & 0xFFFFFFFF), float(grad_scale), ws.data_ptr(), ws.numel(),
                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
                 C.c_void_p(early_stream.cuda_stream) if early_stream is not None else None)

@@ -28,8 +28,11 @@
  *     `stream` and the call returns.
  *   - return value: 0 = ok, negative = error (see beso_status_string).  Bad shapes and unsupported
  *     configurations are rejected before anything is enqueued.
- *   - thread-safety: calls on distinct workspaces/streams are independent; a workspace must not be
- *     shared by concurrent calls.
+ *   - thread-safety: the library keeps no mutable process-wide state; calls on distinct workspaces/streams are
+ *     independent (a workspace must not be shared by concurrent calls).  What a call may vary -- which kernels run --
+ *     travels in its own `flags` (BESO_PLAN_*); the launch-site timers (beso_profile_*) are per calling thread.
+ *   - development aids (phase stamps, the GEMM layout probe) are not part of this library: they exist in the
+ *     development build only (include/beso_hip_debug.h, libbeso_hip_dev.so).
  */
 #ifndef BESO_HIP_H
 #define BESO_HIP_H
@@ -59,20 +62,40 @@ typedef struct beso_config {
 enum {
     BESO_PREC_BF16 = 0,   /* bf16 MFMA inputs, fp32 accumulate: throughput mode                 */
     BESO_PREC_FP32 = 1,   /* fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32: parity mode  */
-    BESO_PREC_BF16X3 = 2  /* split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate): fp32-class
+    BESO_PREC_BF16X3 = 2, /* split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate): fp32-class
                              accuracy from the fused kernel (an instance of layers_kernel: the shipped shapes --
                              kitchen, block-push -- only; other shapes return BESO_ERR_UNSUPPORTED); inference only */
+    BESO_PREC_FP16 = 3    /* fp16 MFMA inputs (v_mfma_f32_16x16x32_f16: the bf16 rate, three more mantissa bits), fp32
+                             accumulate: the one-launch kernel's shapes only (kitchen, block-push, long-horizon without
+                             classifier-free pairs); operands must stay inside fp16's range (|v| < 65504: LayerNorm
+                             outputs, GELU outputs, probabilities and N(0, 0.02)-scale weights do); inference only */
 };
 
 /* beso_loss_grad flags */
 enum {
-    BESO_TRAIN_LAST_ACTION_ONLY = 1  /* GCDenoiser.loss(pred_last_action_only=True): only the last step of every window
+    BESO_TRAIN_LAST_ACTION_ONLY = 1, /* GCDenoiser.loss(pred_last_action_only=True): only the last step of every window
                                         is scored (score_wrappers.py:59-63,76-77; the caller zeroes the other steps' noise) */
+    /* execution-plan hints (bf16): which kernels run the forward half, never what it computes -- both forms write the same
+     * kept activations.  Default: the per-op kernels below 16,000 token rows, the tile kernel (a layer's out-projection ..
+     * the next layer's q/k/v as one launch) from there on, where it measures faster. */
+    BESO_TRAIN_PLAN_PER_OP = 2,      /* per-op kernels for every layer */
+    BESO_TRAIN_PLAN_TILES = 4        /* the tile kernel wherever the shape has it */
 };
 
-/* beso_denoise_fwd / beso_score_fwd flags */
+/* flags of the forward calls (beso_score_fwd, beso_denoise_fwd, beso_sample, beso_sample_ancestral) */
 enum {
-    BESO_FLAG_UNCOND = 1  /* DiffusionGPT.forward(uncond=True): goals := 0 (score_gpts.py:301-302) */
+    BESO_FLAG_UNCOND = 1,     /* DiffusionGPT.forward(uncond=True): goals := 0 (score_gpts.py:301-302); forwards only */
+    /* Execution-plan hints: WHICH kernels run, never what they compute.  They exist for parity tests (the per-op kernels are
+     * the reference of the fused ones in the same arithmetic; the instances of the one-launch kernel agree bit for bit) and
+     * for measurements; a hint the shape or precision cannot honour is ignored. */
+    BESO_PLAN_PER_OP = 0x10,  /* per-op kernels only: LayerNorm, GEMMs, attention (bf16 / fp32; any shape) */
+    BESO_PLAN_BLOCKS = 0x20,  /* at most the block kernels (LN2 + MLP block, tail block), not the one-launch kernel */
+    BESO_PLAN_SPW2 = 0x100,   /* samples per workgroup of the one-launch kernel: 2 (default up to 512 samples), */
+    BESO_PLAN_SPW4 = 0x200,   /*   4 (up to 1024; the split-bf16 mode: above 512), */
+    BESO_PLAN_SPW8 = 0x300,   /*   8 (larger batches) */
+    BESO_PLAN_SPW_MASK = 0x300,
+    BESO_PLAN_MASK = 0x330,
+    BESO_SAMPLE_STEPWISE = 0x1000  /* beso_sample: enqueue evaluation by evaluation (see there) */
 };
 
 /* sampler ids for beso_sample / beso_sampler_step */
@@ -151,9 +174,6 @@ int beso_sampler_step(int mode, float* out, float* aux, const float* x, const fl
  * embedding to the head also applies the step's update and feeds itself the next evaluation (up to 128 evaluations per
  * launch; longer loops are cut at step boundaries).  Otherwise, and with BESO_SAMPLE_STEPWISE, every evaluation is
  * enqueued as the forward launch(es) + one update launch.  Both forms run the same arithmetic (bit-identical results). */
-enum {
-    BESO_SAMPLE_STEPWISE = 1   /* beso_sample flags: enqueue evaluation by evaluation */
-};
 int beso_sample(const beso_config* cfg, const void* packed, int precision, int sampler,
                 const float* state, const float* goal, float* x, int batch, int t,
                 const float* sigmas, int n_sigmas, float cond_lambda, int flags,
@@ -163,10 +183,11 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
  * while sigma_down > 0, x += noise_i * sigma_up (get_ancestral_step: :107-114, fp32).  `noise` is a DEVICE array of
  * n_sigmas - 1 standard-normal tensors [batch,t,act] back to back -- the reference's `torch.randn_like(action)` of each
  * step, drawn by the caller (the library has no random number generator); entries of steps with sigma_down = 0 are not
- * read.  Everything else as beso_sample.                                                                            */
+ * read.  One forward launch + one or two update launches per step (the noise makes the steps the caller's business).
+ * `flags`: BESO_PLAN_* hints.  Everything else as beso_sample.                                                        */
 int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precision, const float* state, const float* goal,
                           float* x, int batch, int t, const float* sigmas, int n_sigmas, float cond_lambda, float eta,
-                          const float* noise, void* workspace, size_t workspace_bytes, void* stream);
+                          const float* noise, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One Adam / AdamW step over ALL parameter tensors in one launch, optionally followed by the EMA update
  * of the shadow copy on the updated parameters.  Replaces `self.optimizer.step()` + `self.ema_helper.update`
@@ -254,43 +275,17 @@ int beso_loss_grad_overlap(const beso_config* cfg, const float* const* params, i
                            float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
                            float goal_drop, unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes,
                            void* stream, void* early_stream);
-/* Development aid (tests of the operand layouts of the training GEMM): C[M][N] (fp32, ldc) = sum_k A(m,k) B(n,k);
- * a_kslow / b_kslow = 1: the operand is stored [K][ld] (contraction index slow), 0: [rows][ld] (k contiguous).
- * Supported pairs: (0,0), (0,1), (1,1).  splits > 1 accumulates split-K partial sums into a ZEROED C.      */
-int beso_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,
-                    int ldc, int M, int N, int K, int splits, void* stream);
-
-/* Timing hooks for bench.py: HIP events are recorded on the launch stream around every launch of
- * the selected launch site while enabled (site 0 = off).  beso_profile_read synchronises the
- * recorded events, returns their summed elapsed time and count, and clears them.               */
+/* Launch-site timers (bench.py's roofline, the launch-count assertions of the tests): while a site is selected ON THE
+ * CALLING THREAD, HIP events are recorded on the launch stream around every launch that thread makes at that site (site 0 =
+ * off).  beso_profile_read synchronises the events the calling thread recorded, returns their summed elapsed time and count,
+ * and clears them.  Thread-local: other threads' calls are neither timed nor affected.                                      */
 enum {
     BESO_SITE_OFF = 0, BESO_SITE_GEMM_QKV = 1, BESO_SITE_GEMM_PROJ = 2, BESO_SITE_GEMM_FC1 = 3,
     BESO_SITE_GEMM_FC2 = 4, BESO_SITE_ATTENTION = 5, BESO_SITE_LAYERNORM = 6, BESO_SITE_EMBED = 7,
     BESO_SITE_HEAD = 8, BESO_SITE_FORWARD = 9 /* one whole score-net forward */,
-    BESO_SITE_FUSED_LAYER = 10 /* fused per-layer kernel (fused path) */
+    BESO_SITE_FUSED_LAYER = 10 /* the fused kernels (one-launch kernel, block kernels) */
 };
 void beso_profile_enable(int site);
-/* Development aid: install a device buffer of `capacity_u64` uint64 slots; workgroup 0 of the fused
- * kernels appends {phase id, shader clock} pairs to it (NULL / 0 switches it off).               */
-void beso_debug_set_stamps(void* device_buf, int capacity_u64);
-/* Development aid: batches of at most `n` (virtual) samples run the latency instance of the fused kernel (two samples per
- * workgroup), up to 2n the four-sample instance, larger ones the throughput instance (eight).  Default 512; 0 switches
- * both latency instances off.                                                                                          */
-void beso_debug_set_small_batch_max(int n);
-/* Development aid (tests): cap what the BESO_PREC_BF16 forward may fuse -- 2 (default): one launch for the whole network
- * where the shape has such a kernel; 1: LN2 + MLP blocks only; 0: the per-op kernels (LayerNorm, GEMMs, attention) only.
- * The comparison "fused kernel against per-op kernels in the same arithmetic" is a test of the former.               */
-void beso_debug_set_fused_level_max(int n);
-/* Development aid (tests, A/B timing): how the bf16 beso_loss_grad runs its forward -- 0: per-op kernels for every layer;
- * 1 (default): each layer's out-projection .. next layer's q/k/v as one tile kernel once there are enough token rows for
- * a round of workgroups (>= 16,000: that is where it measures faster), per-op below; 2: the tile kernel always. */
-void beso_debug_set_train_tail(int on);
-/* Development aid (tests, A/B timing), bf16 beso_loss_grad.  what = 0: as beso_debug_set_train_tail.  what = 1: the chain
- * of data gradients between two attention backwards (q/k/v of a layer, both LayerNorm backwards, FC2 (+GELU'), FC1 and
- * out-projection of the layer in front) as one tile kernel where the shape has it -- 0 (default) off: it measures slower
- * than the per-op kernels; 1 on.  what = 2: the grouped weight-gradient launches -- 0 (default): one launch behind the
- * chain on the caller's stream; 1: per layer on a side stream under the data gradients of the layers in front (slower). */
-void beso_debug_set_train_option(int what, int value);
 int  beso_profile_read(double* total_ms, int* launches);
 
 #ifdef __cplusplus

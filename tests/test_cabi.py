@@ -34,10 +34,16 @@ def test_library_is_built_from_the_sources_in_the_tree(lib):
     assert B.is_current()
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "beso_hip.h")).read()
+def declared_symbols(header="beso_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(beso_[a-z_0-9]+)\s*\(", text)))
+
+
+def exported_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("beso_")})
 
 
 def test_header_symbols_are_exported(lib):
@@ -46,6 +52,19 @@ def test_header_symbols_are_exported(lib):
     assert sorted(_lib.EXPORTS) == names, "binding list and header disagree"
     for n in names:
         assert getattr(lib, n) is not None
+
+
+def test_product_library_has_no_development_entry_points(lib):
+    """libbeso_hip.so exports exactly what include/beso_hip.h declares: no beso_debug_* symbol, nothing that mutates
+    process-wide state (what a call may vary travels in its flags; the launch-site timers are thread-local).  The
+    development aids of include/beso_hip_debug.h exist in libbeso_hip_dev.so only."""
+    from beso_amd.build import build
+    assert exported_symbols(_lib.LIB_PATH) == declared_symbols()
+    assert not [n for n in exported_symbols(_lib.LIB_PATH) if "debug" in n]
+    dev = build(verbose=False, dev=True)
+    assert dev == _lib.DEV_LIB_PATH
+    assert exported_symbols(dev) == sorted(declared_symbols() + declared_symbols("beso_hip_debug.h"))
+    assert sorted(_lib.DEV_EXPORTS) == declared_symbols("beso_hip_debug.h")
 
 
 def test_version_and_status_strings(lib):

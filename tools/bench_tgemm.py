@@ -32,7 +32,7 @@ def run(lib, prec, aks, bks, M, N, K, splits, iters=20):
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_dev()
     T = 11264
     shapes = [("fwd qkv   NT", 0, 0, T, 1080, 360, 1), ("fwd fc1   NT", 0, 0, T, 1440, 360, 1), ("fwd fc2   NT", 0, 0, T, 360, 1440, 1),
               ("fwd proj  NT", 0, 0, T, 360, 360, 1), ("long-K    NT", 0, 0, T, 1440, 1440, 1), ("square    NT", 0, 0, 4096, 4096, 4096, 1),

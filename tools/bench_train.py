@@ -25,19 +25,13 @@ def main():
     if "--per-op-forward" in sys.argv:          # A/B: every layer of the training forward through the per-op kernels
         sys.argv.remove("--per-op-forward")
         from beso_amd import _lib
-        _lib.load().beso_debug_set_train_tail(0)
-    if "--tail-backward" in sys.argv:           # A/B: the chain of data gradients through the tile kernel (default: per-op)
-        sys.argv.remove("--tail-backward")
-        from beso_amd import _lib
-        _lib.load().beso_debug_set_train_option(1, 1)
-    if "--wgrad-side-stream" in sys.argv:       # A/B: the weight gradients per layer on a side stream (default: one launch behind the chain)
-        sys.argv.remove("--wgrad-side-stream")
-        from beso_amd import _lib
-        _lib.load().beso_debug_set_train_option(2, 1)
+        from beso_amd.runtime import set_plan
+        set_plan(train=_lib.TRAIN_PLAN_PER_OP)
     if "--tail-forward" in sys.argv:            # ... or through the tile kernel whatever the batch size
         sys.argv.remove("--tail-forward")
         from beso_amd import _lib
-        _lib.load().beso_debug_set_train_tail(2)
+        from beso_amd.runtime import set_plan
+        set_plan(train=_lib.TRAIN_PLAN_TILES)
     if "--autograd" in sys.argv:
         sys.argv.remove("--autograd")
         sys.path.insert(0, os.path.join(ROOT, "tests"))

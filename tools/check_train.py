@@ -35,7 +35,7 @@ from autograd_reference import loss_autograd  # noqa: E402   (the comparator liv
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_dev()
     worst = 0.0
     for prec in (1, 0):
         for aks, bks in ((0, 0), (0, 1), (1, 1)):

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import beso_oracle as O
 from conftest import load_golden, weights_from_fixture, rel_err
-from test_gpu_parity import make_module, G, _weights
+from test_gpu_parity import make_module, G, _weights, set_level
 
 for fixture, cfg_name in [("kitchen_forward_std002.npz", "kitchen"), ("kitchen_forward_std008.npz", "kitchen"),
                           ("block_push_forward.npz", "block_push")]:
@@ -70,8 +70,8 @@ for cfg_name in ("kitchen", "block_push"):
         outs = {}
         with torch.no_grad():
             for lvl in (2, 1, 0):
-                lib.beso_debug_set_fused_level_max(lvl)
+                set_level(lvl)
                 outs[lvl] = m(s, a, g, sg).cpu().numpy()
-        lib.beso_debug_set_fused_level_max(2)
+        set_level(2)
         print(f"{cfg_name} std={std}: fused-vs-perop {rel_err(outs[2], outs[0]):.3e}  mlpblock-vs-perop {rel_err(outs[1], outs[0]):.3e}  "
               f"fused-vs-oracle {rel_err(outs[2], ref):.3e}  perop-vs-oracle {rel_err(outs[0], ref):.3e}", flush=True)

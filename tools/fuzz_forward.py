@@ -45,10 +45,10 @@ def main():
         try:
             with torch.no_grad():
                 for lvl in (2, 0):
-                    lib.beso_debug_set_fused_level_max(lvl)
+                    T.set_level(lvl)
                     outs[lvl] = model(T.G(s_np), T.G(a_np), T.G(g_np), T.G(sg_np)).cpu().numpy()
         finally:
-            lib.beso_debug_set_fused_level_max(2)
+            T.set_level(2)
         e = T.rel_err(outs[2], outs[0])
         eo = -1.0
         if B <= 9:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid: latency of one GCDenoiser.forward and of a 3-step DDIM loop vs batch size, with the
-fused kernel forced on / off (BESO_FUSED_MIN_BATCH).  Run on the GPU box:  python tools/latency.py"""
+fused kernel on / off (BESO_PLAN_PER_OP hint).  Run on the GPU box:  python tools/latency.py"""
 import os
 import subprocess
 import sys
@@ -10,9 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def child(min_batch):
-    os.environ["BESO_FUSED_MIN_BATCH"] = str(min_batch)
     sys.path.insert(0, ROOT)
     import torch
+    from beso_amd import _lib
+    from beso_amd.runtime import set_plan
+    set_plan(forward=_lib.PLAN_PER_OP if min_batch else 0)
     from bench import build_model
     from beso_amd import synthetic as O
     from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks

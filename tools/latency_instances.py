@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Latency of one GCDenoiser.forward (fused bf16 path) vs batch size through the two instances of the fused kernel:
 the throughput instance (8 samples per workgroup) and the latency instance (2 per workgroup), selected with
-beso_debug_set_small_batch_max.   python tools/latency_instances.py [kitchen|block_push]"""
+the BESO_PLAN_SPW8 hint.   python tools/latency_instances.py [kitchen|block_push]"""
 import os
 import sys
 import time
@@ -13,6 +13,7 @@ import torch  # noqa: E402
 
 from bench import build_model  # noqa: E402
 from beso_amd import _lib, synthetic as S  # noqa: E402
+from beso_amd.runtime import set_plan  # noqa: E402
 
 
 def main():
@@ -26,7 +27,7 @@ def main():
         sg = torch.full((B,), 0.3, device=dev)
         row, outs = [], []
         for limit in (0, 512):
-            lib.beso_debug_set_small_batch_max(limit)
+            set_plan(forward=_lib.PLAN_SPW8 if limit == 0 else 0)
             with torch.no_grad():
                 for _ in range(5):
                     out = model(s, a, g, sg)

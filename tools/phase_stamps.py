@@ -26,7 +26,15 @@ def main():
     model = build_model(cfg, O.make_weights(cfg, seed=0, std=0.02), "bf16", dev)
     s, g, a = (torch.from_numpy(v).to(dev) for v in O.make_inputs(cfg, B, seed=1))
     sig = torch.full((B,), 0.3, device=dev)
+    # the stamps exist in a development build with the stamp code compiled in -- the library the model itself runs on:
+    #   python tools/variants.py build st=-DBESO_DEV_API=1,-DBESO_FUSED_STAMPS=1
+    #   BESO_HIP_LIB=beso_amd/lib/variants/libbeso_hip_st.so python tools/phase_stamps.py
+    import ctypes as C
     lib = _lib.load()
+    if not hasattr(lib, "beso_debug_set_stamps"):
+        raise SystemExit("run with BESO_HIP_LIB=<a -DBESO_DEV_API=1 -DBESO_FUSED_STAMPS=1 build> (see the comment above)")
+    lib.beso_debug_set_stamps.restype = None
+    lib.beso_debug_set_stamps.argtypes = [C.c_void_p, C.c_int]
     buf = torch.zeros(8 * 2048, dtype=torch.int64, device=dev)
     with torch.no_grad():
         for _ in range(3):

@@ -40,11 +40,12 @@ def build(specs):
             csrc = os.path.join(tree, "beso_amd", "csrc")
             units = sorted(f[:-4] for f in os.listdir(csrc) if f.endswith(".hip"))
         else:
-            csrc, units = B.CSRC, ["fused"]
+            csrc, units = B.CSRC, (list(B.UNITS) if "-DBESO_DEV_API=1" in flags else ["fused", "fused_f16"])
         procs = []
         for u in units:
             obj = os.path.join(B.OBJDIR, f"{u}_{name}.o")
-            extra = flags if u == "fused" else []
+            # (-DBESO_DEV_API=1 changes the entry points of api.hip / train.hip too: such a variant rebuilds every unit)
+            extra = flags if (u in ("fused", "fused_f16") or "-DBESO_DEV_API=1" in flags) else []
             cmd = [B._hipcc(), *B.FLAGS, *extra, "-c", os.path.join(csrc, u + ".hip"), "-o", obj]
             procs.append((u, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
         jobs.append((name, bool(rev), procs))
@@ -56,7 +57,8 @@ def build(specs):
                 raise SystemExit(f"variant {name}/{u}: hipcc failed\n{err}")
             objs.append(obj)
         if not is_rev:
-            objs += [os.path.join(B.OBJDIR, u + ".o") for u in B.UNITS if u != "fused"]
+            built = {u for u, _, _ in procs}
+            objs += [os.path.join(B.OBJDIR, u + ".o") for u in B.UNITS if u not in built]
         lib = os.path.join(VDIR, f"libbeso_hip_{name}.so")
         subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", lib, *objs])
         print("built", lib)
