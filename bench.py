@@ -479,9 +479,9 @@ def other_configs(args, dev):
     from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
     out = []
 
-    def sampler_run(name, shape, B, sampler, n_steps, smin, smax, lam, reps):
+    def sampler_run(name, shape, B, sampler, n_steps, smin, smax, lam, reps, precision="bf16"):
         cfg = S.SHAPES[shape]
-        model = build_model(cfg, S.make_weights(cfg, seed=0, std=0.02), "bf16", dev)
+        model = build_model(cfg, S.make_weights(cfg, seed=0, std=0.02), precision, dev)
         call = model if lam is None else ClassifierFreeSampleModel(model, lam)
         s, g, a = (torch.from_numpy(v).to(dev) for v in S.make_inputs(cfg, B, seed=1))
         x_t = torch.randn_like(a) * smax
@@ -499,7 +499,7 @@ def other_configs(args, dev):
             dt = (time.perf_counter() - t0) / reps
         assert torch.isfinite(res).all()
         flops = cfg.flops_per_sample() * B * nfe * per_nfe
-        out.append({"config": name, "batch": B, "sampler": sampler, "steps": n_steps, "nfe": nfe, "cond_lambda": lam, "dtype": "bf16",
+        out.append({"config": name, "batch": B, "sampler": sampler, "steps": n_steps, "nfe": nfe, "cond_lambda": lam, "dtype": precision,
                     "calls_timed": reps, "ms_per_call": 1e3 * dt, "denoise_steps_per_s": n_steps / dt,
                     "sample_nfe_per_s": B * nfe / dt, "tflops": flops / dt / 1e12, "frac_of_bf16_mfma_peak": flops / dt / 1e12 / PEAK_TFLOPS["bf16"]})
 
@@ -509,6 +509,11 @@ def other_configs(args, dev):
     # (a sample per workgroup: 256 is exactly one workgroup per CU; 384 = 1.5 rounds and 1024 = 4 rounds beside it)
     sampler_run("configs[4] at B=384 per GPU", "long_horizon", 384, "euler", 100, 0.005, 1.0, None, 2)
     sampler_run("configs[4] at B=1024 per GPU", "long_horizon", 1024, "euler", 100, 0.005, 1.0, None, 1)
+    # the other precisions of the one-launch kernel on the sampler configurations (fp16 operands; the 1e-4 mode)
+    sampler_run("configs[3] in fp16", "block_push", 2048, "heun", 50, 0.05, 1.0, 2.0, 2, "fp16")
+    sampler_run("configs[4] in fp16", "long_horizon", 256, "euler", 100, 0.005, 1.0, None, 2, "fp16")
+    sampler_run("configs[3] in bf16x3 (1e-4 mode)", "block_push", 2048, "heun", 50, 0.05, 1.0, 2.0, 1, "bf16x3")
+    sampler_run("configs[4] in bf16x3 (1e-4 mode: split-bf16 block kernels + fp32 attention)", "long_horizon", 256, "euler", 100, 0.005, 1.0, None, 1, "bf16x3")
     targs = copy.copy(args)
     targs.workload, targs.batch, targs.steps, targs.warmup, targs.settle_ms, targs.config = "train", 1024, 20, 3, 100.0, "kitchen"
     tr = run_train(targs, 1, 0, dev)

@@ -78,10 +78,10 @@ bool make_workspace(const beso_config* c, const Layout& lay, int batch, int t, i
     if (batch < 1 || t < 1 || t > c->obs_seq_len) return false;
     memset(w, 0, sizeof(*w));
     const size_t vb = (size_t)batch * (cfg_guidance ? 2 : 1);
-    (void)precision;
     const size_t T = 1 + lay.G + 2 * (size_t)t;
     const size_t M = round_up_sz(vb * T, kTileMN);        // rows padded so tile loads never need a clamp
-    const size_t e = lay.elem_bytes, f = sizeof(float);
+    // (the split-bf16 block kernels of the long-sequence shape exchange q/k/v and the attention output as fp32 rows)
+    const size_t e = (precision == BESO_PREC_BF16X3 && fused_has_lin_blocks(lay, precision)) ? 4 : lay.elem_bytes, f = sizeof(float);
     size_t cur = 0;
     w->x = carve(cur, f * M * lay.D);
     w->xn = carve(cur, e * M * lay.Kd);
@@ -169,7 +169,23 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
     const bool lin_blocks = fused == 1 && fused_has_lin_blocks(lay, precision);
     for (int l = 0; l < (fused == 2 ? 0 : lay.L); ++l) {
         const LayerOff& o = lay.layer[l];
-        if (lin_blocks) {
+        if (lin_blocks && precision == BESO_PREC_BF16X3) {
+            // the same two-launch form in split-bf16 arithmetic: lin_block_x3_kernel around the exact-fp32 attention kernel
+            if (l == 0) {
+                profile_begin(BESO_SITE_FUSED_LAYER, s);
+                int st0 = fused_lin_x3(lay, packed, -1, 0, x, nullptr, 0, (float*)qkv, M, s);
+                profile_end(BESO_SITE_FUSED_LAYER, s);
+                if (st0 != BESO_OK) return st0;
+            }
+            profile_begin(BESO_SITE_ATTENTION, s);
+            HIP_TRY(launch_attention(qkv, y, a.vbatch, a.T, lay.D, lay.H, lay.Kd, BESO_PREC_FP32, s));
+            profile_end(BESO_SITE_ATTENTION, s);
+            profile_begin(BESO_SITE_FUSED_LAYER, s);
+            int st = fused_lin_x3(lay, packed, l, l + 1 < lay.L ? l + 1 : -1, x, (const float*)y, lay.Kd, (float*)qkv, M, s);
+            profile_end(BESO_SITE_FUSED_LAYER, s);
+            if (st != BESO_OK) return st;
+            continue;
+        } else if (lin_blocks) {
             // long sequences (no fused attention phase): two launches per layer --
             //   attention(q/k/v of this layer)  ->  [proj + residual -> LN2 -> MLP -> LN1 + q/k/v of the NEXT layer]
             // with the residual tile in registers through the second one; layer 0's q/k/v come from their own block
@@ -261,8 +277,10 @@ static int forward(const beso_config* cfg, const void* packed, int precision, co
     a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
     a.plan = flags & BESO_PLAN_MASK;
     const int level = precision == BESO_PREC_FP16 ? fused_level_f16(lay, a, BESO_PREC_BF16) : fused_level(lay, a, precision);
-    // BF16X3 / FP16 are instances of the one-launch kernel (layers_kernel) and have no per-op form
-    if ((precision == BESO_PREC_BF16X3 || precision == BESO_PREC_FP16) && level != 2) return BESO_ERR_UNSUPPORTED;
+    // BF16X3 / FP16 are instances of the one-launch kernel (layers_kernel) -- BF16X3 also of its block-kernel form on the
+    // long-sequence shape -- and have no per-op form
+    if (precision == BESO_PREC_FP16 && level != 2) return BESO_ERR_UNSUPPORTED;
+    if (precision == BESO_PREC_BF16X3 && level != 2 && !(level == 1 && fused_has_lin_blocks(lay, precision))) return BESO_ERR_UNSUPPORTED;
     profile_begin(BESO_SITE_FORWARD, s);
     int r = forward_generic(lay, ws, (const char*)packed, precision, a, (char*)workspace, s, level);
     profile_end(BESO_SITE_FORWARD, s);

@@ -27,6 +27,8 @@ int    fused_mlp_block(const Layout& lay, const char* packed, int layer, float* 
 bool   fused_has_lin_blocks(const Layout& lay, int precision);
 int    fused_lin_block(const Layout& lay, const char* packed, int layer, int which, float* x, void* buf, int ld, int M,
                        hipStream_t s);
+int    fused_lin_x3(const Layout& lay, const char* packed, int layer, int next_layer, float* x, const float* y, int ld_y,
+                    float* qkv_next, int M, hipStream_t s);
 int    fused_lin_tail(const Layout& lay, const char* packed, int layer, float* x, const void* y, int ld_y, void* qkv_next,
                       int M, hipStream_t s);
 // training forward through the tail block (train.hip): per-step fragment image of the weights + one launch per layer

@@ -771,7 +771,7 @@ struct Tile {
     bool fvalid[RPW];
 };
 
-template <int RPW>
+template <int RPW, int NT = kNTT>
 __device__ __forceinline__ void load_x_tile(Tile<RPW>& T, const float* __restrict__ x, int D, int m0, int m_end,
                                             int w, int n, int g) {
 #pragma unroll
@@ -779,7 +779,7 @@ __device__ __forceinline__ void load_x_tile(Tile<RPW>& T, const float* __restric
         const int f0 = 16 * (w * RPW + i) + 4 * g;
         T.fvalid[i] = f0 < D;
 #pragma unroll
-        for (int t = 0; t < kNTT; ++t) {
+        for (int t = 0; t < NT; ++t) {
             const int tok = m0 + t * 16 + n;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (T.fvalid[i] && tok < m_end) v = *(const f32x4*)(x + (size_t)tok * D + f0);
@@ -788,7 +788,7 @@ __device__ __forceinline__ void load_x_tile(Tile<RPW>& T, const float* __restric
     }
 }
 
-template <int RPW>
+template <int RPW, int NT = kNTT>
 __device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restrict__ x, int D, int m0, int m_end,
                                              int w, int n, int g) {
 #pragma unroll
@@ -796,7 +796,7 @@ __device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restri
         const int f0 = 16 * (w * RPW + i) + 4 * g;
         if (!T.fvalid[i]) continue;
 #pragma unroll
-        for (int t = 0; t < kNTT; ++t) {
+        for (int t = 0; t < NT; ++t) {
             const int tok = m0 + t * 16 + n;
             if (tok < m_end) *(f32x4*)(x + (size_t)tok * D + f0) = T.acc[i][t];
         }
@@ -2633,6 +2633,109 @@ __global__ void train_pack_kernel(TrainPackTable t, char* __restrict__ img) {
     }
 }
 
+// BF16X3 for the long-sequence shapes (BASELINE config 5: D = 512, up to 67 tokens -- a sample's tokens do not fit the LDS of
+// a split-bf16 workgroup twice over, so the one-launch form is out): the two-launch-per-layer form of tail_block_kernel in
+// split-bf16 arithmetic, on tiles of 16 NT token rows in natural order --
+//     x += proj(y) + b_proj;  x += fc2(GELU(fc1(LN2 x)))          (tail of layer l:  lw;  y = fp32 attention output)
+//     qkv_next = [q | k | v](LN1' x)                              (front of layer l + 1:  lw_next; fp32 rows for the fp32
+//                                                                  attention kernel, attention.hip)
+// -- either half may be absent (layer 0's q/k/v come from a launch with lw = nullptr, the last layer has no lw_next).
+// Phases, layouts and weight images are the one-launch kernel's (layernorm_to_lds / gemm_x3 / mlp_phase_x3; the `lin`
+// images of the block kernels with their low halves x3_delta behind).  LDS: [yT | xnT] hi + lo (one region: the LayerNorm
+// barrier separates the two uses), hT hi + lo, LayerNorm statistics.
+template <int NT, int KS>
+struct LdsMapLinX3 {
+    static constexpr int a_bytes = NT * KS * 1024, a_lo = a_bytes / 16;          // one half of [yT | xnT]; lo offset in u32x4
+    static constexpr int hT = 2 * a_bytes, h_bytes = NT * kKCc * 1024, h_lo = h_bytes / 16;
+    static constexpr int red = hT + 2 * h_bytes, total = red + kRedTok * kMT * 4;
+};
+template <int RPW, int KS, int NT>
+__global__ __launch_bounds__(512, 2) void lin_block_x3_kernel(float* __restrict__ x, const char* __restrict__ lw,
+                                                              const char* __restrict__ lw_next, FusedDims d, int M,
+                                                              const float* __restrict__ y, int ld_y, float* __restrict__ qkv) {
+    Stamps st{nullptr, 0, 0};
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    using L = LdsMapLinX3<NT, KS>;
+    static_assert(L::total <= 160 * 1024, "LDS of the split-bf16 block kernel");
+    int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.x * 16 * NT;
+    u32x4* aT = (u32x4*)lds;
+    float* red = (float*)(lds + L::red);
+    Tile<RPW> T;
+    load_x_tile<RPW, NT>(T, x, d.D, m0, M, w, lane & 15, lane >> 4);
+    if (lw != nullptr) {
+        // (hT slots the MLP phase reads before it has written them meet zero weights: they must be finite)
+        for (int i = threadIdx.x; i < 2 * L::h_bytes / 16; i += blockDim.x) ((u32x4*)(lds + L::hT))[i] = u32x4{0, 0, 0, 0};
+        {
+            // ---- out-projection + residual: the fp32 attention output as split-bf16 B fragments
+            const int n = lane & 15, g = lane >> 4;
+            for (int f = w; f < NT * KS; f += kWaves) {
+                const int t = f / KS, kk = f - t * KS;
+                const int tok = m0 + 16 * t + n;
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                if (tok < M) {
+                    const float* row = y + (size_t)tok * ld_y + 32 * kk + 4 * g;
+                    v0 = *(const f32x4*)row;
+                    v1 = *(const f32x4*)(row + 16);
+                }
+                const SplitPair p0 = split_op2(v0[0], v0[1]), p1 = split_op2(v0[2], v0[3]);
+                const SplitPair p2 = split_op2(v1[0], v1[1]), p3 = split_op2(v1[2], v1[3]);
+                aT[(size_t)f * 64 + lane] = u32x4{p0.hi, p1.hi, p2.hi, p3.hi};
+                aT[(size_t)f * 64 + lane + L::a_lo] = u32x4{p0.lo, p1.lo, p2.lo, p3.lo};
+            }
+            __syncthreads();
+            gemm_x3<RPW, NT, 2, kt16(KS), kNTT>(T.acc, wptr((const u32x4*)(lw + d.o_wproj_lin) + (size_t)(w * RPW) * 64, lane),
+                                               kWaves * RPW, d.x3_delta, aT + lane, L::a_lo, KS * 64, 64, KS);
+            const float* bp = (const float*)(lw + d.o_bproj_lin);
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const f32x4 bv = *(const f32x4*)(bp + 16 * (w * RPW + i) + 4 * g);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) T.acc[i][t] += bv;
+            }
+        }
+        // ---- LN2 + MLP (the barrier inside the LayerNorm statistics orders the xnT writes behind every wave's yT reads)
+        layernorm_to_lds<RPW, KS, kWaves, true, NT, 1>(T, aT, red, d.D, w, lane, (const float*)(lw + d.o_b2), st, L::a_lo);
+        mlp_phase_x3<RPW, KS, kWaves, NT>(T, aT, L::a_lo, (u32x4*)(lds + L::hT), L::h_lo, (const u32x4*)lw,
+                                          (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.x3_delta, w, lane);
+    }
+    if (lw_next != nullptr)
+        layernorm_to_lds<RPW, KS, kWaves, false, NT, 1>(T, aT, red, d.D, w, lane, nullptr, st, L::a_lo);
+    if (lw != nullptr) {
+        asm volatile("" : "+v"(lane));
+        store_x_tile<RPW, NT>(T, x, d.D, m0, M, w, lane & 15, lane >> 4);
+    }
+    if (lw_next == nullptr) return;
+    const size_t ldq = (size_t)3 * d.D;
+#pragma unroll 1
+    for (int part = 0; part < 3; ++part) {
+        asm volatile("" : "+v"(lane));
+        const int gg = lane >> 4, nn = lane & 15;
+        f32x4 qa[RPW][NT];
+        const float* bq = (const float*)(lw_next + d.o_bqkv_lin) + (size_t)part * (kWaves * RPW * 16);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const f32x4 bv = *(const f32x4*)(bq + 16 * (w * RPW + i) + 4 * gg);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) qa[i][t] = bv;
+        }
+        gemm_x3<RPW, NT, 2, kt16(KS)>(qa, wptr((const u32x4*)(lw_next + d.o_wqkv_lin + (size_t)part * d.part_bytes) + (size_t)(w * RPW) * 64, lane),
+                                      kWaves * RPW, d.x3_delta, aT + lane, L::a_lo, KS * 64, 64, KS);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int f0 = 16 * (w * RPW + i) + 4 * gg;
+            if (f0 < d.D) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int tok = m0 + 16 * t + nn;
+                    if (tok < M) *(f32x4*)(qkv + (size_t)tok * ldq + (size_t)part * d.D + f0) = qa[i][t];
+                }
+            }
+        }
+    }
+}
+
 // Whole transformer layers [l0, l1) over the tile's 8 samples; x stays in registers in between.
 // NTL: token tiles that hold the action tokens of a full tile (8 samples x window, rounded up to an even count):
 // in the LAST layer only those go through the out-projection, LayerNorm-2 and the MLP -- nothing else reaches
@@ -2950,14 +3053,19 @@ hipError_t launch_layers_long(float* x, const char* lw0, const FusedDims& d, int
 
 // ---------------------------------------------------------------------------------------------
 static bool x3_shape(const FusedDims& d) {
-    // BF16X3 exists as an instance of layers_kernel only (the shipped shapes with the fused attention phase)
+    // BF16X3 as an instance of layers_kernel: the shipped shapes with the fused attention phase
     return d.attn && !d.seq1 && ((d.RPW == 3 && d.KS == 12 && d.HG == 1) || (d.RPW == 2 && d.KS == 8 && d.HG == 3));
+}
+static bool x3_long_shape(const FusedDims& d) {
+    // ... and as the split-bf16 block kernels (lin_block_x3_kernel + the fp32 attention kernel) for the long-sequence shape
+    return d.seq1 && d.lin && d.RPW == 4 && d.KS == 16 && d.D == 16 * kWaves * d.RPW;
 }
 
 size_t fused_packed_bytes(const Layout& lay, int precision) {
     FusedDims d;
     if ((precision != BESO_PREC_BF16 && precision != BESO_PREC_BF16X3) || !fused_dims(lay, &d) || !shape_has_kernel(d)) return 0;
-    if (precision == BESO_PREC_BF16X3) return x3_shape(d) ? (size_t)d.x3_delta + (size_t)d.layer_bytes * lay.L : 0;
+    if (precision == BESO_PREC_BF16X3)
+        return (x3_shape(d) || x3_long_shape(d)) ? (size_t)d.x3_delta + (size_t)d.layer_bytes * lay.L : 0;
     return d.layer_bytes * lay.L + d.global_bytes;
 }
 
@@ -2967,7 +3075,7 @@ size_t fused_packed_bytes(const Layout& lay, int precision) {
 int fused_pack(const Layout& lay, const float* const* p, char* packed, int precision, hipStream_t s) {
     FusedDims d;
     if ((precision != BESO_PREC_BF16 && precision != BESO_PREC_BF16X3) || !fused_dims(lay, &d) || !shape_has_kernel(d)) return BESO_OK;
-    if (precision == BESO_PREC_BF16X3 && !x3_shape(d)) return BESO_ERR_UNSUPPORTED;
+    if (precision == BESO_PREC_BF16X3 && !x3_shape(d) && !x3_long_shape(d)) return BESO_ERR_UNSUPPORTED;
     const int D = lay.D;
     const int n_parts = precision == BESO_PREC_BF16X3 ? 2 : 1;
     for (int half = 0; half < n_parts; ++half)               // 0: bf16(w); 1 (BF16X3 only): the low halves
@@ -2991,6 +3099,14 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
             hipLaunchKernelGGL(pack_proj_kernel, dim3(512), dim3(256), 0, s, pw, (uint16_t*)(base + d.o_wproj), D, d.Hv,
                                d.hdv, rt2, half);
         }
+        if (d.lin) {
+            const float* ws3[3] = {qw, kw, vw};
+            for (int part = 0; part < 3; ++part)      // q / k / v in natural row order (block kernels)
+                hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, ws3[part], D, D, ln1w,
+                                   (uint16_t*)(base + d.o_wqkv_lin + (size_t)part * d.part_bytes), rt2, d.KS, rt2, half);
+            hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, pw, D, D, (const float*)nullptr,
+                               (uint16_t*)(base + d.o_wproj_lin), rt2, d.KS, rt2, half);
+        }
         FTRY(hipGetLastError());
         if (half) continue;                      // the low image holds weight fragments only
         hipLaunchKernelGGL(fold_bias_kernel, dim3((rt1 * 16 + 3) / 4), dim3(256), 0, s, f1w, f1b, ln2b,
@@ -3009,13 +3125,9 @@ int fused_pack(const Layout& lay, const float* const* p, char* packed, int preci
             const float* bs3[3] = {qb, kb, vb};
             (void)hipGetLastError();
             for (int part = 0; part < 3; ++part) {      // q / k / v
-                hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, ws3[part], D, D, ln1w,
-                                   (uint16_t*)(base + d.o_wqkv_lin + (size_t)part * d.part_bytes), rt2, d.KS, rt2, 0);
                 hipLaunchKernelGGL(fold_bias_kernel, dim3((rt2 * 16 + 3) / 4), dim3(256), 0, s, ws3[part], bs3[part], ln1b,
                                    (float*)(base + d.o_bqkv_lin) + (size_t)part * rt2 * 16, D, D, rt2 * 16);
             }
-            hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(1024), dim3(256), 0, s, pw, D, D, (const float*)nullptr,
-                               (uint16_t*)(base + d.o_wproj_lin), rt2, d.KS, rt2, 0);
             FTRY(hipGetLastError());
             FTRY(launch_pack_matrix(pb, 1, D, base + d.o_bproj_lin, 1, rt2 * 16, -1, s));
         }
@@ -3068,7 +3180,8 @@ int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
         !shape_has_kernel(d)) return 0;
     const bool whole = x3_shape(d) && kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused) &&
                        d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK;
-    if (precision == BESO_PREC_BF16X3) return whole ? 2 : 0;     // BF16X3 is an instance of layers_kernel and nothing else
+    // BF16X3: an instance of layers_kernel, or -- the long-sequence shape -- its block-kernel form; nothing else
+    if (precision == BESO_PREC_BF16X3) return whole ? 2 : (x3_long_shape(d) ? 1 : 0);
     const int cap = (a.plan & BESO_PLAN_PER_OP) ? 0 : (a.plan & BESO_PLAN_BLOCKS) ? 1 : 2;
     if (cap < 2) return cap;
     // long sequences: the whole network in one launch, a sample per workgroup (so no classifier-free pairs, whose halves share one)
@@ -3096,8 +3209,28 @@ int fused_mlp_block(const Layout& lay, const char* packed, int layer, float* x, 
 // for shapes without the fused attention phase; false if this shape has no such kernels.
 bool fused_has_lin_blocks(const Layout& lay, int precision) {
     FusedDims d;
-    if (precision != BESO_PREC_BF16 || lay.fused == lay.total || !fused_dims(lay, &d) || !shape_has_kernel(d)) return false;
+    if ((precision != BESO_PREC_BF16 && precision != BESO_PREC_BF16X3) || lay.fused == lay.total || !fused_dims(lay, &d) ||
+        !shape_has_kernel(d)) return false;
     return d.lin && d.RPW == 4 && d.KS == 16 && d.D == 16 * kWaves * d.RPW;
+}
+
+// BF16X3, long-sequence shape: [tail of `layer` (y = fp32 attention output, ld_y floats per row)] and / or [LN1 + q/k/v of
+// `next_layer` into qkv_next (fp32 [M][3D])] on M token rows as one launch; layer < 0 / next_layer < 0 leaves that half out.
+int fused_lin_x3(const Layout& lay, const char* packed, int layer, int next_layer, float* x, const float* y, int ld_y,
+                 float* qkv_next, int M, hipStream_t s) {
+    FusedDims d;
+    if (!fused_dims(lay, &d) || !x3_long_shape(d)) return BESO_ERR_UNSUPPORTED;
+    constexpr int NT = 3;
+    using L = LdsMapLinX3<NT, 16>;
+    static bool attr = false;
+    if (ensure_lds(lin_block_x3_kernel<4, 16, NT>, L::total, &attr) != hipSuccess) return BESO_ERR_HIP;
+    const char* base = packed + lay.fused;
+    const char* lw = layer >= 0 ? base + (size_t)layer * d.layer_bytes : nullptr;
+    const char* lwn = next_layer >= 0 ? base + (size_t)next_layer * d.layer_bytes : nullptr;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((lin_block_x3_kernel<4, 16, NT>), dim3((M + 16 * NT - 1) / (16 * NT)), dim3(512), L::total, s, x, lw, lwn, d, M, y,
+                       ld_y, qkv_next);
+    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
 int fused_lin_block(const Layout& lay, const char* packed, int layer, int which, float* x, void* buf, int ld, int M,

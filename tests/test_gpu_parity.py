@@ -228,6 +228,55 @@ def test_bf16x3_forward_through_the_fused_kernel(fixture, cfg_name):
     assert worst < TOL["bf16x3"]
 
 
+def test_bf16x3_long_horizon_through_the_split_bf16_block_kernels():
+    """BASELINE config 5's shape (D = 512, 67 tokens) in the 1e-4 mode: a sample's tokens do not fit a split-bf16 workgroup's
+    LDS twice over, so BF16X3 runs the two-launch-per-layer form -- lin_block_x3_kernel (out-projection + residual -> LN2 ->
+    MLP -> the next layer's LN1 + q/k/v in split-bf16 arithmetic, residual in registers) around the exact-fp32 attention
+    kernel -- against the reference's forward vectors and its 100-step Euler run: <= 1e-4, with the launch sites asserted
+    (L + 1 block launches per forward), classifier-free pairs and short windows included."""
+    from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+    from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
+    cfg = O.CONFIGS["long_horizon"]
+    fx = load_golden("long_horizon_forward.npz")
+    m = make_module(cfg, _weights(fx, cfg), "bf16x3")
+    worst, calls = 0.0, 0
+
+    def run():
+        nonlocal worst, calls
+        for t in fx["ts"]:
+            p = f"t{int(t)}::"
+            s, a, g, sg = (G(fx[p + k]) for k in ("state", "action", "goal", "sigma"))
+            e1 = rel_err(m(s, a, g, sg).cpu().numpy(), fx[p + "denoised"])
+            e2 = rel_err(m(s, a, g, sg, uncond=True).cpu().numpy(), fx[p + "denoised_uncond"])
+            e3 = rel_err(m.inner_model(s, a, g, sg).cpu().numpy(), fx[p + "inner"])
+            worst = max(worst, e1, e2, e3)
+            calls += 3
+
+    with torch.no_grad():
+        launches = count_fused_launches(run)
+    print(f"[parity] long_horizon_forward.npz bf16x3 (block kernels, {launches} launches for {calls} calls): {worst:.3e}")
+    assert launches == calls * (cfg.n_layers + 1) and worst < TOL["bf16x3"]
+    for fixture in ("long_horizon_euler.npz", "long_horizon_euler100.npz"):
+        fe = load_golden(fixture)
+        me = make_module(cfg, _weights(fe, cfg), "bf16x3")
+        for key in sorted(k[:-5] for k in fe if k.endswith("::out")):
+            with torch.no_grad():
+                out = ks.sample_euler(me, G(fe["state"]), G(fe["x_t"]), G(fe["goal"]), torch.from_numpy(fe[key + "::sigmas"]), disable=True)
+            err = rel_err(out.cpu().numpy(), fe[key + "::out"])
+            print(f"[parity] {fixture}:{key} bf16x3: {err:.3e}")
+            assert err < TOL["bf16x3"], key
+    # classifier-free pairs and a ragged batch against the oracle
+    w = O.make_weights(cfg, seed=21, std=0.03)
+    mo = make_module(cfg, w, "bf16x3")
+    with torch.no_grad():
+        for B, t in [(1, cfg.obs_seq_len), (5, 3), (37, 16)]:
+            s_np, g_np, a_np = O.make_inputs(cfg, B, seed=100 * B + t, t=t)
+            sg_np = np.linspace(0.06, 1.0, B).astype(np.float32)
+            out = ClassifierFreeSampleModel(mo, 1.5)(G(s_np), G(a_np), G(g_np), G(sg_np))
+            e = rel_err(out.cpu().numpy(), O.denoise_cfg(w, cfg, s_np, a_np, g_np, sg_np, 1.5))
+            assert e < TOL["bf16x3"], (B, t, e)
+
+
 def test_bf16x3_sampler_loops_and_cfg_through_the_fused_kernel():
     """Sampler loops (DDIM 3 / 10, Euler 10, Heun 5, DPM variants; block-push Heun-50 x classifier-free guidance: 198
     score-net forwards per sample) in the split-bf16 mode against the reference's sampler outputs: <= 1e-4."""
