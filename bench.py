@@ -620,9 +620,12 @@ def main():
         sys.exit("bench.py: no GPU visible (the score-denoising path has no CPU implementation to time)")
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(dev)
+    from beso_amd import distributed as bdist
+    numa = bdist.pin_to_gpu_numa_node(local_rank) if world > 1 else None       # one rank per GPU: host threads beside it
     result = run_forward(args, world, rank, dev) if args.workload == "forward" else run_train(args, world, rank, dev)
     if rank == 0:
         result["ranks_verified"] = verified
+        result["numa_node_of_rank0"] = numa
         print(json.dumps(result))
     if world > 1:
         torch.distributed.barrier()

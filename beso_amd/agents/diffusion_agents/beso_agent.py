@@ -120,10 +120,12 @@ class BesoAgent(BaseAgent):
     def _ema_scope(self):
         """Evaluate with the EMA weights.  HIP model on the GPU: swap in the packed image of the
         shadow.  Anything else: the reference's store / copy_to / restore (beso_agent.py:343-381)."""
+        # (sharded C1: a collective when the shadow is partial -- reached by every rank at the same step, with or without
+        # use_ema, so that no rank enters it alone)
+        self._complete_ema()
         if not self.use_ema:
             yield
             return
-        self._complete_ema()
         den = self._hip_denoiser()
         first = next(iter(self.model.parameters()), None)        # (listing all 113 parameters costs 0.3 ms per call)
         if den is not None and first is not None and first.is_cuda:
@@ -205,8 +207,12 @@ class BesoAgent(BaseAgent):
         best_test_mse, mean_mse, avg_test_mse = 1e10, 1e10, 1e10
         for epoch in range(epochs):
             test_mse = [self.evaluate(batch) for batch in test_loader]
-            if test_mse:
-                mean_mse = avg_test_mse = test_mse[-1]
+            # data parallel: the ranks draw different evaluation noise (and may hold different test shards), so the
+            # early-stopping / checkpoint decision is taken on the job-wide mean -- the same on every rank; a rank deciding
+            # alone would leave the others inside the next gradient exchange
+            last = bdist.job_mean(test_mse[-1] if test_mse else 0.0, 1 if test_mse else 0, self.device)
+            if last is not None:
+                mean_mse = avg_test_mse = last
             stop, best_test_mse = self.early_stopping(best_test_mse, mean_mse, self.patience, epochs)
             if stop:
                 log.info('Early stopping!')
@@ -235,8 +241,10 @@ class BesoAgent(BaseAgent):
         for step in range(self.max_train_steps):
             if not self.steps % self.eval_every_n_steps:
                 scores = [self.evaluate(batch) for batch in test_loader]
-                if scores:
-                    avg_test_mse = sum(scores) / len(scores)
+                # (job-wide mean: every rank takes the same checkpoint decision -- store_model_weights holds a collective)
+                mean = bdist.job_mean(sum(scores), len(scores), self.device)
+                if mean is not None:
+                    avg_test_mse = mean
                 log.info("Step %d: Mean test mse is %s", step, avg_test_mse)
                 if avg_test_mse < best_test_mse:
                     best_test_mse = avg_test_mse

@@ -231,6 +231,52 @@ def all_reduce_mean(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa_node(local_rank: int, sysfs: str = "/sys") -> Optional[int]:
+    """One process per GPU: keep this rank's host threads (launch path, pinned staging buffers, the feed) on the NUMA node
+    its GPU hangs off -- on a two-socket MI355X host half of the GPUs sit behind the other socket's xGMI / PCIe root.
+    The node comes from the GPU's PCI function in sysfs, the CPUs from the node's cpulist; best effort: returns the node,
+    or None when the topology cannot be read (single node, container without sysfs) and nothing is changed."""
+    import os
+    try:
+        props = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        node = int(open(os.path.join(sysfs, "bus", "pci", "devices", bdf, "numa_node")).read().strip())
+        if node < 0:
+            return None
+        cpus = _parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read())
+        cpus = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:      # noqa: BLE001   (a missing sysfs entry must not stop a run)
+        return None
+
+
+def job_mean(total: float, count: int, device=None) -> Optional[float]:
+    """Mean of a host-side metric over the whole job: every rank contributes (sum, count) -- possibly (0, 0): an empty
+    shard --; all ranks get the same value (None if nobody had anything).  A collective: every rank must call it.  What
+    the training loops base early stopping and checkpoint decisions on, so that no rank leaves a loop, or enters the
+    checkpoint's all-gather, alone."""
+    if not is_distributed():
+        return total / count if count else None
+    dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([float(total), float(count)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    s, n = t.tolist()
+    return s / n if n > 0 else None
+
+
 def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0) -> None:
     """C2: make every replica start from rank ``src``'s weights (one flat broadcast)."""
     if not is_distributed():

@@ -153,7 +153,7 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("c1_mode", ["overlap", "sharded"])
+@pytest.mark.parametrize("c1_mode", ["overlap", "sharded", "flat"])
 def test_two_rank_gloo_training_step_matches_single_process(tmp_path, autograd_training, c1_mode, monkeypatch):
     out = str(tmp_path / "dp.pt")
     port = _free_port()
@@ -187,3 +187,75 @@ def test_shard_range_covers_the_batch():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _loop_worker(rank, world, port, out, mode, c1, use_ema):
+    """Two ranks run BesoAgent's own training loops with test metrics that DIFFER between the ranks (different evaluation
+    noise / test shards in a real job; scripted here) and a rank whose test loader is empty."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), BESO_AMD_C1=c1)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from autograd_reference import install_autograd_training
+    install_autograd_training()
+    from beso_amd import distributed as bdist
+    assert bdist.init_from_env("gloo")
+    cfg, agent = _make_agent(seed=300 + rank)
+    agent.use_ema = use_ema
+    agent.working_dir = os.path.dirname(out)
+    script = {0: [1.0, 2.0, 0.5, 9.0, 9.0], 1: [3.0, 0.2, 4.0, 9.0, 9.0]}[rank] if mode == "steps" else \
+             {0: [1.0, 0.9, 0.8, 0.7, 0.6], 1: [1.0, 1.5, 2.0, 2.5, 3.0]}[rank]
+    calls = {"eval": 0, "store": 0}
+
+    def fake_evaluate(batch):
+        agent._complete_ema()                                  # (what the real evaluate reaches through _ema_scope)
+        v = script[min(calls["eval"], len(script) - 1)]
+        calls["eval"] += 1
+        return v
+
+    real_store = agent.store_model_weights
+
+    def counting_store(path):
+        calls["store"] += 1
+        return real_store(path)
+
+    agent.evaluate = fake_evaluate
+    agent.store_model_weights = counting_store
+    train = [_batch(cfg, 4, seed=11 + rank), _batch(cfg, 4, seed=21 + rank)]
+    test = [_batch(cfg, 4, seed=31)] if (rank == 0 or mode == "epochs") else []      # steps mode: rank 1 has no test data
+    if mode == "steps":
+        agent.train_method, agent.max_train_steps, agent.eval_every_n_steps = "steps", 6, 2
+    else:
+        agent.train_method, agent.epochs, agent.patience, agent.eval_every_n_steps = "epochs", 5, 0, 100
+        agent.epochs_no_improvement = 0
+    agent.train_agent(train, test)
+    after = torch.cat([q.detach().reshape(-1) for q in agent.model.get_params()])
+    gathered = [torch.zeros_like(after) for _ in range(world)]
+    dist.all_gather(gathered, after)
+    assert torch.equal(gathered[0], gathered[1]), "replicas diverged"
+    counts = torch.tensor([calls["eval"], calls["store"], agent.steps], dtype=torch.float64)
+    both = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(both, counts)
+    if rank == 0:
+        torch.save({"counts": [b.tolist() for b in both]}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode,c1,use_ema", [("steps", "sharded", False), ("steps", "sharded", True), ("steps", "overlap", True),
+                                             ("epochs", "sharded", True), ("epochs", "flat", False)])
+def test_two_rank_training_loops_take_joint_decisions(tmp_path, mode, c1, use_ema):
+    """BesoAgent.train_agent on two gloo ranks whose rank-local test MSEs point different ways (and, in steps mode, one rank
+    without test data): checkpoints and early stopping follow the JOB-WIDE mean, so both ranks store the same number of
+    times, stop at the same epoch and end with identical weights -- with the sharded C1 exchange (whose checkpoint path
+    holds an all-gather of the EMA shadow) and without EMA evaluation included.  A rank deciding alone would hang here."""
+    out = str(tmp_path / "loops.pt")
+    mp.spawn(_loop_worker, args=(2, _free_port(), out, mode, c1, use_ema), nprocs=2, join=True)
+    c = torch.load(out)["counts"]
+    assert c[0][1:] == c[1][1:], c                      # same number of checkpoints, same number of optimizer steps
+    if mode == "steps":
+        # job means of the scripted evaluations: 2.0, 1.1, 2.25 -> two improvements + the final store; 6 steps
+        assert c[0][1] == 3 and c[0][2] == 6, c
+    else:
+        # job means 1.0, 1.2, ...: epoch 0 improves, epoch 1 does not -> both stop there (rank 0 alone never would)
+        assert c[0][0] == 2 and c[1][0] == 2 and c[0][1] == 2, c

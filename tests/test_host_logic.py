@@ -593,3 +593,26 @@ def test_shipped_block_push_config_surface():
     assert type(agent.optimizer).__name__ in ("Adam", "FusedAdam") and agent.sigma_min == 0.05
     assert sum(p.numel() for p in agent.model.parameters()) == sum(int(np.prod(sh)) for _, sh in O.param_shapes(O.BLOCK_PUSH))
     assert agent.obs_context.maxlen == 5 and agent.goal_context.maxlen == 1
+
+
+def test_numa_pinning_reads_the_topology_and_is_best_effort(tmp_path, monkeypatch):
+    """pin_to_gpu_numa_node: the GPU's PCI function -> numa_node -> that node's cpulist -> sched_setaffinity, from a fake
+    sysfs tree; an unreadable topology changes nothing and returns None."""
+    import os
+    import types
+    from beso_amd import distributed as bdist
+    sysfs = tmp_path / "sys"
+    dev = sysfs / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = sysfs / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    have = sorted(os.sched_getaffinity(0))
+    (node / "cpulist").write_text(f"{have[0]}-{have[0]},{have[-1]}\n")
+    monkeypatch.setattr(torch.cuda, "get_device_properties",
+                        lambda i: types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0xc1, pci_device_id=0))
+    pinned = []
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: pinned.append(sorted(cpus)))
+    assert bdist.pin_to_gpu_numa_node(0, sysfs=str(sysfs)) == 1
+    assert pinned == [sorted({have[0], have[-1]})]
+    assert bdist.pin_to_gpu_numa_node(0, sysfs=str(tmp_path / "nothing")) is None and len(pinned) == 1
