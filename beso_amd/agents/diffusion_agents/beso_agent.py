@@ -297,7 +297,18 @@ class BesoAgent(BaseAgent):
     def _use_train_graph(self, state) -> bool:
         # opt-in: measured 16.6 vs 17.4 ms per 1024-sample step -- the eager step is bound by its fp32 kernels,
         # not by launches
-        return state.is_cuda and self._train_graph_ok and os.environ.get("BESO_AMD_TRAIN_GRAPH", "0") == "1"
+        if not (state.is_cuda and self._train_graph_ok and os.environ.get("BESO_AMD_TRAIN_GRAPH", "0") == "1"):
+            return False
+        # the dropout / goal-mask seed of the HIP step is a host scalar: a captured graph would replay one mask forever, so
+        # models with any dropout or cond_mask_prob > 0 are not captured at all (no warm-up steps spent on a doomed capture)
+        den = self._hip_denoiser()
+        if den is not None:
+            inner = den.inner_model
+            if any(float(p) > 0.0 for p in getattr(inner, "_pdrops", ())) or float(getattr(inner, "cond_mask_prob", 0.0) or 0.0) > 0.0:
+                self._train_graph_ok = False
+                log.info("BESO_AMD_TRAIN_GRAPH=1 ignored: the model has dropout / cond_mask_prob > 0 (host-drawn seed)")
+                return False
+        return True
 
     def _graphed_loss_backward(self, state, action, goal):
         """The same forward + backward replayed as ONE HIP graph per batch shape.  The eager training step

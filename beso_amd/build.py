@@ -77,9 +77,9 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
         _hipcc()
     except RuntimeError:
         # no compiler on this box (e.g. a runtime-only image): the shipped binary is all there is; say what it is
-        if os.path.exists(LIB) and have:
-            sys.stderr.write(f"beso_amd.build: hipcc not found; using the prebuilt library (source hash {have[:12]}, "
-                             f"tree is {want[:12]})\n")
+        if os.path.exists(LIB):
+            sys.stderr.write(f"beso_amd.build: hipcc not found; using the prebuilt library (source hash "
+                             f"{have[:12] if have else 'unknown: no stamp file'}, tree is {want[:12]})\n")
             return LIB
         raise
     with cf.ThreadPoolExecutor(max_workers=len(UNITS)) as ex:

@@ -1203,6 +1203,8 @@ def test_hip_loss_and_gradients_match_autograd(cfg_name, B, precision, monkeypat
     assert abs(loss.item() - ref_loss.item()) < ltol * abs(ref_loss.item())
     errs = _grad_errors(got, ref, 1e-4 if precision == "fp32" else 2e-3)
     worst = max(range(len(errs)), key=lambda i: errs[i])
+    print(f"[parity] train grads {cfg_name} B={B} {precision}: loss {abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()):.2e}, "
+          f"worst gradient {errs[worst]:.2e} ({list(dict(m.named_parameters()))[worst]})")
     assert errs[worst] < gtol, (list(dict(m.named_parameters()))[worst], errs[worst])
     # a second backward through a scaled loss scales the gradients (autograd contract of the custom node); bias and
     # LayerNorm gradients are accumulated with fp32 atomics, so two runs agree to rounding, not bit for bit
