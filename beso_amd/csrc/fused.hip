@@ -402,6 +402,19 @@ __device__ __forceinline__ f32x4 mfma_op_half(const u32x4& a, const u32x4& b, co
     return mfma_op16(make_uint2(a[0], a[1]), make_uint2(b[0], b[1]), c);
 }
 
+// MI355X hazard the compiler does not pad (tools/check_mfma_chains.py): an MFMA whose SrcC is exactly the
+// vDst of an MFMA of ANOTHER shape (here 16x16x32 -> the 16x16x16 of a half k-step) must not issue within about ten wait
+// states of it -- LLVM's recogniser files "same accumulator" under the interlocked back-to-back case and inserts nothing,
+// and the consumer then reads the accumulator before the producer has written it (run-to-run different results, found in
+// one long-horizon instance where the scheduler had put the two MFMAs two instructions apart).  Called between the last
+// full k-step and the half k-step of a phase: every full-shape MFMA stays above, every half-shape one below, ten wait
+// states (40 clocks, once per phase) in between.
+__device__ __forceinline__ void mixed_chain_pad() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 4\n\ts_nop 4");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // One GEMM phase of the transposed formulation:  acc[r][t] += sum_kk A(r,kk) * B(t,kk)
 //   A(r,kk) = fragment r + kk*a_ks of `a`   weights, L2 -> registers (WPtr: uniform base + lane offset)
@@ -496,6 +509,7 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[R][NTA], u32x4 (&aE)[R],
         const bool tail = TAIL16 && kk + 2 >= ksteps;
         __builtin_amdgcn_sched_barrier(0);
         if (tail) {
+            mixed_chain_pad();
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -556,6 +570,7 @@ __device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)
             const int kk = k0 + p;
             __builtin_amdgcn_sched_barrier(0);
             if (TAIL16 && kk + 1 >= ksteps) {                // the last k-step of the phase is a half k-step
+                mixed_chain_pad();
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -636,6 +651,7 @@ __device__ __forceinline__ void gemm_x3(f32x4 (&acc)[R][NTA], WPtr a, int a_ks, 
             if (kk < ksteps) {
                 // the small terms first; R*NT independent accumulators between two MFMAs on the same one
                 if (TAIL16 && kk + 1 >= ksteps) {
+                    mixed_chain_pad();
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -1022,7 +1038,6 @@ struct EdgeArgs {
     float* aux;            // [B][t][act] scratch of the sampler loop (Heun's first slope), or nullptr
     int B, t, precondition, uncond_all, two;   // two: classifier-free pair (cond, uncond) = virtual samples (2b, 2b+1)
     float cond_lambda, sigma_data;
-    int fuse_embed, fuse_head;
 };
 
 constexpr int kEmbObsK = 8, kEmbActK = 3;     // k-steps (4 inputs each) of the fused embedding GEMMs: obs <= 32, act <= 12
@@ -1150,6 +1165,11 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
                 T.acc[i][t] = mfma_op(ath[i], bl, T.acc[i][t]);
                 T.acc[i][t] = mfma_op(ath[i], bh, T.acc[i][t]);
             }
+        }
+        // (the action embedding's K = act <= 16 is a half k-step: the other shape of MFMA on the same accumulators)
+        mixed_chain_pad();
+#pragma unroll
+        for (int t = 0; t < kNTT; ++t) {
             u32x4 ch = {0, 0, 0, 0}, cl = {0, 0, 0, 0};
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -2772,16 +2792,15 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     constexpr int PF1 = CORE == 1 ? BESO_LONG_PF1 : (NTA < kNTT ? BESO_LAT_PF1 : kFc1PF);
     const int s0 = blockIdx.x * SPW;
     const int n_samples = min(SPW, n_samples_total - s0);
-    const int m0 = s0 * Tn, m_end = m0 + n_samples * Tn;
     // action tokens first whenever both network edges are inside the kernel (otherwise x travels in natural order)
     SlotTabs* tb = (SlotTabs*)(lds + L.tab);
     float* xs = (float*)(lds + L.xs);
     // (CORE = 1: natural order -- the long-sequence core addresses slots by position, and five tiles leave nothing to peel)
-    const bool actions_first = CORE == 0 && e.fuse_embed && e.fuse_head;
+    const bool actions_first = CORE == 0;
     build_slot_tabs(tb, n_samples, Tn, e.t, d.G, actions_first, CORE == 1 ? 7 : 4);
     // the action windows of the workgroup's real samples (contiguous in `action`): x_T of the sampler loop / the noisy action
     LoopState ls{-1, 0.f, 0.f, 0.f, true};
-    if (e.fuse_embed) {
+    {
         int b0; bool un0;
         sample_of(e, s0, b0, un0);
         const int n_el = (n_samples / (e.two ? 2 : 1)) * e.t * d.act;
@@ -2812,15 +2831,14 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     }
     __syncthreads();
     stamp(st, 1);
-    if ((BESO_ABL_MASK & 4) && e.fuse_embed) {
+    if (BESO_ABL_MASK & 4) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             T.fvalid[i] = 16 * (w * RPW + i) + 4 * g < d.D;
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.1f * n, 0.2f, 0.3f * g, 0.4f};
         }
-    } else if (e.fuse_embed) embed_tile<RPW, PX, CORE == 1 ? 7 : 4>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, xs, ls.sigma, st);
-    else load_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
+    } else embed_tile<RPW, PX, CORE == 1 ? 7 : 4>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, xs, ls.sigma, st);
     stamp(st, 43);
     // The last layer (when this launch contains it and the action tokens of the tile fit NTL token tiles) runs its
     // out-projection, LayerNorm-2 and MLP on the action-token tiles only; it is peeled off the loop -- a branch
@@ -2905,13 +2923,12 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         ls.mode = rec.mode; ls.c0 = rec.c0; ls.c1 = rec.c1;
         ls.last = ev + 1 == n_evals;
     }
-    if (e.fuse_head) {
+    {
         // (peel: the action tokens are the first n_samples * t slots, i.e. inside the first NTLa token tiles)
         if constexpr (CORE == 1) head_tile<RPW, NTA>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, xs, ls, st);
         else if (peel && NTLa < kNTT) head_tile<RPW, NTLa>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, xs, ls, st);
         else head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, xs, ls, st);
     }
-    else store_x_tile<RPW>(T, x, d.D, m0, m_end, w, n, g);
     stamp(st, 5);
     if (LOOP && ev + 1 < n_evals) __syncthreads();      // the head's partial sums are read, the next input is in xs
     }
@@ -3014,16 +3031,15 @@ hipError_t launch_layers(float* x, const char* lw0, const FusedDims& d, int l0, 
         // samples per weight byte is what sets this mode's speed, so batches beyond one workgroup of two samples per CU take
         // FOUR samples in three token tiles (4 x 11 = 44 or 4 x 12 = 48 of 48 slots) -- half the workgroups and half the
         // L2 -> CU weight stream of the two-sample instance (82 GB per B = 4096 forward), at 1.5x its MFMAs per workgroup.
-        // (NTL = all three tiles: the last layer is not trimmed to the action-token tiles in this instance -- with the trimmed
-        // copy of the layer code beside the full one this instance, and no other, produced run-to-run differences in whole
-        // workgroups on the MI355X, in every combination of trimmed phases; untrimmed it is bit-stable
-        // and bit-identical to the two-sample instance)
-        constexpr int kX3SPW = 4, kX3NT = 3;
+        // (The last layer runs on the action-token tiles only, as in every instance: half the eight-sample instance's NTL.
+        // Round 3 first shipped this instance untrimmed -- the trimmed copy differed from run to run in whole workgroups --
+        // until the cause was found in the half k-steps: mixed_chain_pad above.)
+        constexpr int kX3SPW = 4, kX3NT = 3, kX3NTL = (NTL + 1) / 2;
         const bool four_ok = tiles_hold(kX3SPW, Tn, kX3NT);
         if (four_ok && (want == BESO_PLAN_SPW4 || (want != BESO_PLAN_SPW2 && n_samples > kSmallBatchMax) || !small_ok)) {
             constexpr LdsMapX3 X = lds_map_x3(KS, kX3NT);
             static_assert(X.total <= 160 * 1024, "LDS of the four-sample split-bf16 instance");
-            return launch_either<RPW, KS, HG, kX3NT, kX3SPW, kX3NT, 1, 0>(X.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
+            return launch_either<RPW, KS, HG, kX3NTL, kX3SPW, kX3NT, 1, 0>(X.total, x, lw0, d, l0, l1, n_samples, Tn, edge, steps, s);
         }
         if (!small_ok) return hipErrorInvalidValue;
         constexpr LdsMapX3 X = lds_map_x3(KS, kSmallNT);
@@ -3178,14 +3194,16 @@ int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     FusedDims d;
     if ((precision != BESO_PREC_BF16 && precision != BESO_PREC_BF16X3) || lay.fused == lay.total || !fused_dims(lay, &d) ||
         !shape_has_kernel(d)) return 0;
-    const bool whole = x3_shape(d) && kSPW * a.T <= kMT && (a.vbatch == a.batch || d.head_fused) &&
-                       d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK;
+    // (the one-launch kernel runs both network edges itself: the Linear(D, act) head -- the shipped configs' linear_output: True
+    // -- with act <= 16; a model with the MLP head takes the block / per-op kernels)
+    const bool whole = x3_shape(d) && kSPW * a.T <= kMT && d.head_fused && d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK;
     // BF16X3: an instance of layers_kernel, or -- the long-sequence shape -- its block-kernel form; nothing else
     if (precision == BESO_PREC_BF16X3) return whole ? 2 : (x3_long_shape(d) ? 1 : 0);
     const int cap = (a.plan & BESO_PLAN_PER_OP) ? 0 : (a.plan & BESO_PLAN_BLOCKS) ? 1 : 2;
     if (cap < 2) return cap;
     // long sequences: the whole network in one launch, a sample per workgroup (so no classifier-free pairs, whose halves share one)
-    const bool whole_long = d.seq1 && a.T <= 16 * kLongNT && a.vbatch == a.batch && d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK;
+    const bool whole_long = d.seq1 && a.T <= 16 * kLongNT && a.vbatch == a.batch && d.head_fused && d.obs <= 4 * kEmbObsK &&
+                            d.act <= 4 * kEmbActK;
     return (whole || whole_long) ? 2 : 1;
 }
 
@@ -3379,13 +3397,10 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     e.two = a.vbatch > a.batch ? 1 : 0;
     e.uncond_all = (!e.two && a.uncond_from == 0) ? 1 : 0;
     e.cond_lambda = a.cond_lambda; e.sigma_data = a.sigma_data;
-    e.fuse_embed = 1;
-    e.fuse_head = d.head_fused;
     // with a classifier-free pair the virtual samples are interleaved (2b, 2b+1) so that both halves of a
     // pair live in one workgroup; that ordering only exists inside the kernel, so the head must be fused too
-    if (e.two && !e.fuse_head) return BESO_ERR_UNSUPPORTED;
-    if (fused_edges) *fused_edges = (e.fuse_embed ? 1 : 0) | (e.fuse_head ? 2 : 0);
-    if (S.n > 0 && !(e.fuse_embed && e.fuse_head)) return BESO_ERR_UNSUPPORTED;
+    if (!d.head_fused) return BESO_ERR_UNSUPPORTED;
+    if (fused_edges) *fused_edges = 3;
     hipError_t err;
     if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1, 2>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, precision, a.plan, s);    // kitchen: 8 x 4 action tokens
     else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3, 4>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, precision, a.plan, s);   // block-push: 8 x 5
