@@ -1198,7 +1198,8 @@ _LONG_WINDOW = O.ScoreGPTConfig(obs_dim=6, act_dim=4, embed_dim=64, n_layers=2, 
 def test_hip_loss_and_gradients_match_autograd(cfg_name, B, precision, monkeypatch):
     """Loss and every parameter gradient of the HIP training step against torch autograd on the same function
     (itself pinned to the reference: tests/test_host_logic.py).  fp32 mode: 2e-4 per tensor; bf16 mode (bf16 GEMM
-    operands and kept activations, fp32 accumulation): 1e-1 per tensor, 3e-3 on the loss."""
+    operands and kept activations, fp32 accumulation): 2.6e-2 per tensor and 2e-3 on the loss -- twice the worst the five
+    shapes measure on the MI355X (round 3: gradients 8.4e-3 .. 1.28e-2, loss 7.8e-5 .. 8.3e-4; fp32: 3e-6 .. 1.4e-5)."""
     cfg = {"tiny": O.TINY, "kitchen": O.KITCHEN, "block_push": O.BLOCK_PUSH, "long_window": _LONG_WINDOW,
            "tiny_mlp_head": O.TINY_MLP_HEAD}[cfg_name]         # (the last: Linear(D,100) - SiLU - Linear(100,act) action head)
     m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), precision)
@@ -1213,7 +1214,7 @@ def test_hip_loss_and_gradients_match_autograd(cfg_name, B, precision, monkeypat
     assert "ScoreMatchingLoss" in type(loss.grad_fn).__name__
     loss.backward()
     got = [p.grad for p in m.parameters()]
-    ltol, gtol = (2e-5, 2e-4) if precision == "fp32" else (3e-3, 1e-1)
+    ltol, gtol = (2e-5, 1e-4) if precision == "fp32" else (2e-3, 2.6e-2)
     assert abs(loss.item() - ref_loss.item()) < ltol * abs(ref_loss.item())
     errs = _grad_errors(got, ref, 1e-4 if precision == "fp32" else 2e-3)
     worst = max(range(len(errs)), key=lambda i: errs[i])
@@ -1286,7 +1287,7 @@ def test_hip_training_goal_masking(cfg_name, B, precision):
     """DiffusionGPT.mask_cond in training mode (score_gpts.py:298-299, 360-371; BASELINE configs 3 / 4: cond_mask_prob =
     0.1) inside the HIP step: goals are zeroed ELEMENTWISE over [B, G, obs] with probability goal_drop, kept elements are
     not rescaled.  The kernel's mask for (goal_drop, seed) is read back through beso_goal_mask and injected into the
-    torch-autograd comparator: loss and every parameter gradient must agree (fp32 2e-4 / bf16 1e-1 per tensor)."""
+    torch-autograd comparator: loss and every parameter gradient must agree (fp32 1e-4 / bf16 2.6e-2 per tensor: twice the 1.26e-2 measured)."""
     from autograd_reference import loss_autograd
     cfg = O.CONFIGS[cfg_name]
     m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), precision, goal_drop=0.1)
@@ -1319,7 +1320,7 @@ def test_hip_training_goal_masking(cfg_name, B, precision):
         inner.cond_mask_prob = 0.1
         for p in m.parameters():
             p.grad = None
-    ltol, gtol, floor = (2e-5, 2e-4, 1e-4) if precision == "fp32" else (3e-3, 1e-1, 2e-3)
+    ltol, gtol, floor = (2e-5, 1e-4, 1e-4) if precision == "fp32" else (2e-3, 2.6e-2, 2e-3)
     assert abs(loss.item() - ref_loss.item()) < ltol * abs(ref_loss.item())
     errs = _grad_errors(got, ref, floor)
     worst = max(range(len(errs)), key=lambda i: errs[i])
@@ -1344,7 +1345,7 @@ def test_training_forward_tail_block_equals_the_per_op_forward(cfg_name, B, t):
     """bf16 training step: the forward runs each layer's out-projection .. next layer's q/k/v as one tile kernel
     (train_tail_kernel, fused.hip) instead of six per-op launches.  Same kept activations in the same formats, same
     arithmetic type; only the accumulation order inside the GEMMs differs -- so loss and gradients of the two forms of
-    the forward must agree far inside the bf16 bound that holds them to autograd (1e-1): here 2e-2 per tensor (measured
+    the forward must agree inside the bf16 bound that holds them to autograd (2.6e-2): here 2e-2 per tensor (measured
     ~5e-3), loss 1e-3; ragged token counts (M not a multiple of the 96-token tile) and a short window included."""
     from beso_amd import _lib
     lib = _lib.load()
