@@ -40,12 +40,13 @@ def build(specs):
             csrc = os.path.join(tree, "beso_amd", "csrc")
             units = sorted(f[:-4] for f in os.listdir(csrc) if f.endswith(".hip"))
         else:
-            csrc, units = B.CSRC, (list(B.UNITS) if "-DBESO_DEV_API=1" in flags else ["fused", "fused_f16"])
+            every = "-DBESO_DEV_API=1" in flags or any(f.startswith("-DBESO_TGEMM") for f in flags)     # flags of train.hip too
+            csrc, units = B.CSRC, (list(B.UNITS) if every else ["fused", "fused_f16"])
         procs = []
         for u in units:
             obj = os.path.join(B.OBJDIR, f"{u}_{name}.o")
             # (-DBESO_DEV_API=1 changes the entry points of api.hip / train.hip too: such a variant rebuilds every unit)
-            extra = flags if (u in ("fused", "fused_f16") or "-DBESO_DEV_API=1" in flags) else []
+            extra = flags if (u in ("fused", "fused_f16") or not rev and every) else []
             cmd = [B._hipcc(), *B.FLAGS, *extra, "-c", os.path.join(csrc, u + ".hip"), "-o", obj]
             procs.append((u, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
         jobs.append((name, bool(rev), procs))
