@@ -24,6 +24,51 @@ __global__ __launch_bounds__(512) void k_mfma(float* out, int iters) {
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// the other MFMA shapes at the same occupancy (round 3): 32x32x16 bf16 (half the A/B operand reads per FLOP), 16x16x16 bf16
+// (the half k-step of fused.hip), 16x16x32 f16 (BESO_PREC_FP16)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void k_mfma32(float* out, int iters) {
+    u32x4 fa, fb;
+    for (int i = 0; i < 4; ++i) { fa[i] = 0x3f803f80u ^ ((threadIdx.x * 2654435761u + i * 40503u) & 0x007f007fu); fb[i] = fa[i] ^ 0x00150015u; }
+    f32x16 a[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) a[i][j] = 0.f;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            a[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), a[i], 0, 0, 0);
+    float s = 0;
+    for (int i = 0; i < 4; ++i) s += a[i][0];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(512) void k_mfma16(float* out, int iters) {
+    u32x4 fa, fb;
+    for (int i = 0; i < 4; ++i) { fa[i] = 0x3f803f80u ^ ((threadIdx.x * 2654435761u + i * 40503u) & 0x007f007fu); fb[i] = fa[i] ^ 0x00150015u; }
+    const s16x4 ha = __builtin_bit_cast(s16x4, uint2{fa[0], fa[1]}), hb = __builtin_bit_cast(s16x4, uint2{fb[0], fb[1]});
+    f32x4 a[8];
+    for (int i = 0; i < 8; ++i) a[i] = f32x4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ha, hb, a[i], 0, 0, 0);
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += a[i][0];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(512) void k_mfmaf16(float* out, int iters) {
+    u32x4 fa, fb;
+    for (int i = 0; i < 4; ++i) { fa[i] = 0x3c003c00u ^ ((threadIdx.x * 2654435761u + i * 40503u) & 0x03ff03ffu); fb[i] = fa[i] ^ 0x01550155u; }
+    f32x4 a[8];
+    for (int i = 0; i < 8; ++i) a[i] = f32x4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            a[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb), a[i], 0, 0, 0);
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += a[i][0];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 __global__ __launch_bounds__(512) void k_lds(float* out, int iters) {
     extern __shared__ u32x4 lds[];
     for (int i = threadIdx.x; i < 8192; i += 512) lds[i] = u32x4{(unsigned)i * 2654435761u, (unsigned)i, 7u * i, 3u * i};
@@ -78,6 +123,9 @@ int main(int argc, char** argv) {
     int launches = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         if (!strcmp(mode, "mfma")) { hipLaunchKernelGGL(k_mfma, dim3(256), dim3(512), 0, 0, out, 1 << 17); units += 8.0 * 16384 * (1 << 17) * 8 * 256; }
+        else if (!strcmp(mode, "mfma32")) { hipLaunchKernelGGL(k_mfma32, dim3(256), dim3(512), 0, 0, out, 1 << 17); units += 4.0 * 32768 * (1 << 17) * 8 * 256; }
+        else if (!strcmp(mode, "mfma16")) { hipLaunchKernelGGL(k_mfma16, dim3(256), dim3(512), 0, 0, out, 1 << 17); units += 8.0 * 8192 * (1 << 17) * 8 * 256; }
+        else if (!strcmp(mode, "mfmaf16")) { hipLaunchKernelGGL(k_mfmaf16, dim3(256), dim3(512), 0, 0, out, 1 << 17); units += 8.0 * 16384 * (1 << 17) * 8 * 256; }
         else if (!strcmp(mode, "lds")) { hipLaunchKernelGGL(k_lds, dim3(256), dim3(512), 131072, 0, out, 1 << 15); units += 16.0 * 1024 * (1 << 15) * 8 * 256; }
         else if (!strcmp(mode, "l2")) { hipLaunchKernelGGL(k_l2, dim3(256), dim3(512), 0, 0, out, buf, (int)(bytes / 1024), 1 << 13); units += 8.0 * 1024 * (1 << 13) * 8 * 256; }
         else if (!strcmp(mode, "valu")) { hipLaunchKernelGGL(k_valu, dim3(256), dim3(512), 0, 0, out, 1 << 19, 1.0001f, 0.5f); units += 8.0 * 64 * (1 << 19) * 8 * 256; }
@@ -85,7 +133,7 @@ int main(int argc, char** argv) {
         ++launches;
     }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    const char* unit = !strcmp(mode, "mfma") ? "TFLOP/s" : (!strcmp(mode, "valu") ? "T lane-fma/s" : "TB/s");
+    const char* unit = !strncmp(mode, "mfma", 4) ? "TFLOP/s" : (!strcmp(mode, "valu") ? "T lane-fma/s" : "TB/s");
     printf("%s: %d launches in %.2f s -> %.1f %s\n", mode, launches, dt, units / dt / 1e12, unit);
     return 0;
 }
