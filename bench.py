@@ -133,7 +133,7 @@ def cpu_baseline(cfg, w, batch, budget_s=12.0):
     W = OT.to_torch(w)
     cores = os.cpu_count() or 1
     # ATen's intra-op pool stops scaling on these [B*11, 360] x [360, 1440] problems early: measured on the GPU box's
-    # host (2 x EPYC 9575F, 256 hardware threads; tools/cpu_scan.py) 8 / 16 / 32 / 64 / 128 threads give 1465 / 1709 /
+    # host (2 x EPYC 9575F, 256 hardware threads; tests/cpu_scan.py) 8 / 16 / 32 / 64 / 128 threads give 1465 / 1709 /
     # 1734 / 973 / 430 samples/s at B = 4096 and 2408 / 3629 / 2071 / 908 / 205 at B = 64 -- 16 is the best setting
     threads = min(cores, 16)
     torch.set_num_threads(threads)

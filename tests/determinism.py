@@ -1,15 +1,15 @@
 """Run-to-run stability of every instance of the one-launch kernel on the MI355X: each (config, precision, batch, window)
 is evaluated REPS times -- one forward, one classifier-free forward where the shape has it, one sampler loop -- and every
 repetition must equal the first one bit for bit; the first one is also compared with the block / per-op kernels of the
-same library (a nondeterministic instance shows up as either).  Usage: python tools/determinism.py [--reps 16] [--quick]
+same library (a nondeterministic instance shows up as either).  Usage: python tests/determinism.py [--reps 16] [--quick]
 Exit code 1 on any difference.  (tests/test_gpu_parity.py::test_one_launch_kernels_are_stable_from_run_to_run runs the
 --quick set.)"""
 import argparse
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import torch
 

@@ -3,7 +3,7 @@
 per-op / block-kernel form of the same library (beso_debug_set_fused_level_max) -- bf16, both carry their own rounding, so
 the bound is the test suite's: relative difference < 2e-2 of the output's max (4e-2 under classifier-free guidance) -- and,
 for small batches, against the oracle.  (A miss is examined with the BF16X3 / fp32 modes of the same kernels: 1e-5 / 2e-6
-there means rounding, not a defect.)   python tools/fuzz_forward.py [cases] [seed]"""
+there means rounding, not a defect.)   python tests/fuzz_forward.py [cases] [seed]"""
 import os
 import sys
 

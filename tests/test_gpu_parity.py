@@ -1012,14 +1012,12 @@ def test_bf16x3_instances_are_bit_identical_and_stable_from_run_to_run(cfg_name)
 
 @pytest.mark.gpu
 def test_one_launch_kernels_are_stable_from_run_to_run():
-    """Every repetition of a forward / sampler loop equals the first one bit for bit (tools/determinism.py, its quick
+    """Every repetition of a forward / sampler loop equals the first one bit for bit (tests/determinism.py, its quick
     set: the long-horizon instance at windows that leave the fifth token tile nearly empty, and the throughput instances
     of both modes at B = 4096).  Round 3: one instance issued a half k-step's 16x16x16 MFMA two instructions behind the
     16x16x32 MFMA that produced its accumulator -- a distance the MI355X does not interlock and the compiler does not
     pad -- and differed between runs."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import determinism
+    import determinism                  # tests/determinism.py (the stand-alone form runs the full case list)
     bad = determinism.run(determinism.QUICK, reps=12, verbose=False)
     assert not bad, bad
 
