@@ -412,6 +412,17 @@ __device__ __forceinline__ f32x4 mfma_op_half(const u32x4& a, const u32x4& b, co
 // one long-horizon instance where the scheduler had put the two MFMAs two instructions apart).  Called between the last
 // full k-step and the half k-step of a phase: every full-shape MFMA stays above, every half-shape one below, ten wait
 // states (40 clocks, once per phase) in between.
+// Empty token slots (kitchen: 8 of a workgroup's 96, long-horizon: 13 of 80) are given exact zeros as GEMM B operands
+// (layernorm_to_lds, mlp_phase): the matrix pipe draws 44 % less dynamic power on zero columns
+// (tools/microbench/power_modes mfmaz: 1018 W against 1240 W with half of B's columns zero), and a kernel at the board's
+// power cap runs as fast as its energy allows -- same-box A/B, round 3: kitchen B = 4096 -0.9 % (0.8106 vs 0.8177 ms),
+// long-horizon Euler-100 -1 ... -2 %.  Only the instances that run at the power cap AND have such slots carry the two
+// compare-and-select instructions: the block-push shape fills its tiles (8 x 12 = 96), the latency instances are bound
+// by a lone workgroup's weight stream (+0.3 % with the mask).
+#ifndef BESO_ZERO_PAD
+#define BESO_ZERO_PAD 1              // 0: A/B builds
+#endif
+__host__ __device__ constexpr bool zero_pad_instance(int RPW, int NT) { return BESO_ZERO_PAD && RPW != 2 && NT >= 5; }
 __device__ __forceinline__ void mixed_chain_pad() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 4\n\ts_nop 4");
@@ -884,7 +895,7 @@ __device__ __forceinline__ void ln_stats(const Tile<RPW>& T, float* red, int D, 
 template <int RPW, int KS, int NW, bool ADD_BIAS = true, int NT = kNTT, int PX = 0, class LX = LnPlain>
 __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float* red, int D, int w, int lane,
                                                  const float* __restrict__ bias, Stamps& st, int lo_off = 0,
-                                                 const LX lx = LX{}) {
+                                                 const LX lx = LX{}, int n_valid = 1 << 30) {
     // `lane` is made opaque at the top of every phase: otherwise the per-lane address arithmetic of ALL
     // phases is hoisted out of the layer loop and kept live across it (46 spilled VGPRs).
     asm volatile("" : "+v"(lane));
@@ -894,6 +905,9 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
 #pragma unroll
         for (int t = 0; t < NT; ++t) { mean[t] = 0.01f * lane; rstd[t] = 0.5f; }
     } else ln_stats<RPW, NW, NT>(T, red, D, w, lane, mean, rstd, st);
+    // empty token slots of the last tile (slots >= n_valid): rstd = 0, i.e. exact zeros as B operands (zero_pad_instance);
+    // nothing a real token reads changes
+    if (zero_pad_instance(RPW, NT)) rstd[NT - 1] = 16 * (NT - 1) + (lane & 15) < n_valid ? rstd[NT - 1] : 0.f;
     // Padding features (>= D) are NOT masked here: their xnT entries only ever meet the zero-padded
     // contraction columns of the packed QKV / FC1 weights, and (0 - mean) * rstd is finite.
     f32x4 gam[LX::on ? RPW : 1], bet[LX::on ? RPW : 1];
@@ -1464,7 +1478,7 @@ template <int RPW, int KS, int NW, int NT = kNTT, int PF1 = kFc1PF, class MX = M
 __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4* hT, const u32x4* __restrict__ w1p,
                                           const float* __restrict__ b1f, const u32x4* __restrict__ w2p, int HT,
                                           int KS2p, int w, int lane, u32x4 (&a1r)[PF1][kChunkTiles / NW],
-                                          Stamps& st, const MX mx = MX{}) {
+                                          Stamps& st, const MX mx = MX{}, int n_valid = 1 << 30) {
     asm volatile("" : "+v"(lane));
     const int n_chunks = (HT + kChunkTiles - 1) / kChunkTiles;
     constexpr int RC = kChunkTiles / NW, KW = RC / 2;       // row tiles / FC2 k-steps of a chunk per wave
@@ -1486,6 +1500,14 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
             const f32x4 bias = *(const f32x4*)(b1f + 16 * (R0 + r) + 4 * g);
 #pragma unroll
             for (int t = 0; t < NT; ++t) h[r][t] = bias;
+        }
+        // (empty token slots: no bias either -- with their zero xnT columns the hidden activations are GELU(0) = 0,
+        // zero B operands of FC2: layernorm_to_lds)
+        if (zero_pad_instance(RPW, NT)) {
+            if (!(16 * (NT - 1) + (lane & 15) < n_valid)) {
+#pragma unroll
+                for (int r = 0; r < RC; ++r) h[r][NT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         gemm_phase_ring<RC, NT, PF1, kt16(KS)>(h, ar, fc1_a(c), kChunkTiles, xnT + lane, KS * 64, 64, KS);
     };
@@ -2846,6 +2868,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     // The last layer (when this launch contains it and the action tokens of the tile fit NTL token tiles) runs its
     // out-projection, LayerNorm-2 and MLP on the action-token tiles only; it is peeled off the loop -- a branch
     // between the two variants INSIDE the loop costs 150 spilled VGPRs.
+    const int n_valid = n_samples * Tn;                 // token slots in use (the empty ones are behind them)
     const bool peel = actions_first && l1 == d.L && l1 > l0 && n_samples * e.t <= 16 * NTLa && (!PX || NTLa < NTA);
     const int l_loop_end = peel ? l1 - 1 : l1;
     auto layer_weights = [&](int l) {
@@ -2880,7 +2903,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         u32x4 qE[3], qO[3];
         attn_prefetch<KS>(qE, qO, (const u32x4*)(lw + d.o_wqkv), w, lane);
         layernorm_to_lds<RPW, KS, kWaves, true, NTA>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
-                                          (const float*)(lw + d.o_bproj), st);
+                                          (const float*)(lw + d.o_bproj), st, 0, LnPlain{}, n_valid);
         stamp(st, 7);
         if constexpr (CORE == 1 && BESO_LONG_PAIRED)
             attn_phase_long<RPW, KS, NTA>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
@@ -2894,10 +2917,10 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         u32x4 a1r[PF1][kChunkTiles / kWaves];
         mlp_prefetch<KS, kWaves, PF1>(a1r, (const u32x4*)lw, w, lane);
         layernorm_to_lds<RPW, KS, kWaves, true, NTA>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
-                                          (const float*)(lw + d.o_b2), st);
+                                          (const float*)(lw + d.o_b2), st, 0, LnPlain{}, n_valid);
         stamp(st, 6);
         mlp_phase<RPW, KS, kWaves, NTA, PF1>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u), (const u32x4*)lw,
-                                   (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st);
+                                   (const float*)(lw + d.o_b1), (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st, MlpPlain{}, n_valid);
     }
     if (peel) {
         const char* lw = layer_weights(l1 - 1);
@@ -2905,7 +2928,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         u32x4 qE[3], qO[3];
         attn_prefetch<KS>(qE, qO, (const u32x4*)(lw + d.o_wqkv), w, lane);
         layernorm_to_lds<RPW, KS, kWaves, true, NTA>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
-                                          (const float*)(lw + d.o_bproj), st);
+                                          (const float*)(lw + d.o_bproj), st, 0, LnPlain{}, n_valid);
         stamp(st, 7);
         attn_phase<RPW, KS, HG, NTLa, NTA, CORE>(T, (const u32x4*)(lds + L.xnT), lds + L.u, (const u32x4*)(lw + d.o_wqkv),
                                      (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd, Tn, n_samples, w,

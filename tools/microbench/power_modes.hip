@@ -10,9 +10,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// ZB: the B operand's columns 8..15 (lanes with lane & 8) are zeros -- what padding token slots would cost if they were zeroed
+template <int ZB>
 __global__ __launch_bounds__(512) void k_mfma(float* out, int iters) {
     u32x4 fa, fb;
     for (int i = 0; i < 4; ++i) { fa[i] = 0x3f803f80u ^ ((threadIdx.x * 2654435761u + i * 40503u) & 0x007f007fu); fb[i] = fa[i] ^ 0x00150015u; }
+    if (ZB && (threadIdx.x & 8)) fb = u32x4{0, 0, 0, 0};
     f32x4 a[8];
     for (int i = 0; i < 8; ++i) a[i] = f32x4{0, 0, 0, 0};
     for (int it = 0; it < iters; ++it)
@@ -122,7 +125,8 @@ int main(int argc, char** argv) {
     double units = 0;
     int launches = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
-        if (!strcmp(mode, "mfma")) { hipLaunchKernelGGL(k_mfma, dim3(256), dim3(512), 0, 0, out, 1 << 17); units += 8.0 * 16384 * (1 << 17) * 8 * 256; }
+        if (!strcmp(mode, "mfma")) { hipLaunchKernelGGL(k_mfma<0>, dim3(256), dim3(512), 0, 0, out, 1 << 17); units += 8.0 * 16384 * (1 << 17) * 8 * 256; }
+        else if (!strcmp(mode, "mfmaz")) { hipLaunchKernelGGL(k_mfma<1>, dim3(256), dim3(512), 0, 0, out, 1 << 17); units += 8.0 * 16384 * (1 << 17) * 8 * 256; }
         else if (!strcmp(mode, "mfma32")) { hipLaunchKernelGGL(k_mfma32, dim3(256), dim3(512), 0, 0, out, 1 << 17); units += 4.0 * 32768 * (1 << 17) * 8 * 256; }
         else if (!strcmp(mode, "mfma16")) { hipLaunchKernelGGL(k_mfma16, dim3(256), dim3(512), 0, 0, out, 1 << 17); units += 8.0 * 8192 * (1 << 17) * 8 * 256; }
         else if (!strcmp(mode, "mfmaf16")) { hipLaunchKernelGGL(k_mfmaf16, dim3(256), dim3(512), 0, 0, out, 1 << 17); units += 8.0 * 16384 * (1 << 17) * 8 * 256; }
