@@ -58,7 +58,9 @@ def main():
             torch.cuda.synchronize()
         assert torch.isfinite(out).all(), (name, B, t, mode)
         if ref is not None:
-            err = float(np.abs(out.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12))
+            # relative to the output scale: a B = 1, t = 1 block-push call has TWO output values, and when both happen to be
+            # ~1e-2 the bf16 error of 1.5e-3 (the per-op kernels': the same) is "16 %" of them -- floor at sigma_data / 2
+            err = float(np.abs(out.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 0.5 * cfg.sigma_data))
             worst = max(worst, err)
             assert err < 3e-2, (name, B, t, mode, err)
         n += 1
