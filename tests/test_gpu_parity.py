@@ -950,7 +950,9 @@ def test_bf16x3_ragged_shapes_and_cfg(cfg_name):
 @pytest.mark.parametrize("cfg_name", ["kitchen", "block_push"])
 def test_fused_instances_are_bit_identical(cfg_name):
     """The latency instances (two samples per workgroup up to 512 samples -- 256 with a classifier-free pair --, four up
-    to 1024) and the throughput instance (eight) of the fused kernel run the same per-sample arithmetic: equal bits for every batch size, window, conditioning mode and through a sampler loop."""
+    to 1024) and the throughput instance (eight) of the fused kernel run the same per-sample arithmetic: equal bits for every batch size, window, conditioning mode and through a sampler loop.
+    (Round 3: the eight-sample kitchen instance gives its EMPTY token slots zero GEMM operands -- an energy measure, fused.hip
+    zero_pad_instance -- and the latency instances do not: equal bits here is also the proof that no real token reads them.)"""
     from beso_amd import _lib
     from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
     from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
