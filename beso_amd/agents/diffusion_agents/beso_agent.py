@@ -285,9 +285,18 @@ class BesoAgent(BaseAgent):
                     self._c1_stream = torch.cuda.Stream(state.device)
                 early = self._c1_stream
             self._c1_early = early
+            # the loss value is final a third of the way into the step: a side stream is released at that point, and
+            # train_step reads the loss there -- its `loss.item()` (beso_agent.py:248) then returns while the backward pass
+            # and the optimizer are still running, and the host prepares the next step under them (BESO_AMD_ASYNC_LOSS=0:
+            # the read waits for the whole step, as a plain .item() on the compute stream does)
+            self._loss_ready = None
+            if state.is_cuda and os.environ.get("BESO_AMD_ASYNC_LOSS", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+                if getattr(self, "_loss_stream", None) is None:
+                    self._loss_stream = torch.cuda.Stream(state.device)
+                self._loss_ready = self._loss_stream
             # (goal masking for classifier-free guidance, mask_cond, is applied by the kernel from cond_mask_prob)
             return step.loss_backward(state, action, goal, noise, sigma, grad_scale=1.0 / bdist.world_size(),
-                                      early_stream=early)
+                                      early_stream=early, loss_stream=self._loss_ready)
         self._hip_step = None
         loss = self.model.loss(state, action, goal, noise, sigma)
         self.optimizer.zero_grad()
@@ -365,11 +374,18 @@ class BesoAgent(BaseAgent):
         self.model.train()
         self.model.training = True
         self._c1_early = None
+        self._loss_ready = None
         if self._use_train_graph(state):
             loss = self._graphed_loss_backward(state, action, goal)
         else:
             loss = self._loss_backward(state, action, goal)
         shard = None
+        loss_stream = getattr(self, "_loss_ready", None)
+        if bdist.is_distributed() and loss_stream is not None:
+            # C3 first: the global-batch mean of the loss is exchanged on the loss stream, in front of the gradients' exchange
+            # (every rank issues its collectives in this order), so that it waits for the forward half only
+            with torch.cuda.stream(loss_stream):
+                loss = bdist.all_reduce_mean(loss.detach().clone())
         if bdist.is_distributed():
             flat = self._hip_step.flat_grads() if getattr(self, "_hip_step", None) is not None else None
             sharded = self._c1_mode() == "sharded"
@@ -401,6 +417,9 @@ class BesoAgent(BaseAgent):
             self.lr_scheduler.step()
             if do_ema:
                 self.ema_helper.update(self.model.parameters())
+        if loss_stream is not None:
+            with torch.cuda.stream(loss_stream):
+                return loss.item()
         if bdist.is_distributed():
             loss = bdist.all_reduce_mean(loss.detach().clone())      # C3: the logged loss is the global-batch mean
         return loss.item()

@@ -616,20 +616,30 @@ size_t beso_train_workspace_bytes(const beso_config* cfg, int batch, int t, int 
 
 size_t beso_grad_floats(const beso_config* cfg) { return train_grad_floats(cfg); }
 
+int beso_loss_grad_streams(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
+                           const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
+                           float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
+                           float goal_drop, unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes,
+                           void* stream, void* early_stream, void* loss_stream) {
+    hipError_t e = hipSuccess;
+    int line = 0;
+    int st = train_loss_grad(cfg, params, n_params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch,
+                             t, flags, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale, workspace, workspace_bytes, (hipStream_t)stream,
+                             (hipStream_t)early_stream, (hipStream_t)loss_stream, &e, &line);
+    if (st == BESO_ERR_HIP) {
+        snprintf(g_last_error, sizeof(g_last_error), "%s (%d) at train.hip:%d", hipGetErrorName(e), (int)e, line);
+    }
+    return st;
+}
+
 int beso_loss_grad_overlap(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
                            const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
                            float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
                            float goal_drop, unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes,
                            void* stream, void* early_stream) {
-    hipError_t e = hipSuccess;
-    int line = 0;
-    int st = train_loss_grad(cfg, params, n_params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch,
-                             t, flags, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale, workspace, workspace_bytes, (hipStream_t)stream,
-                             (hipStream_t)early_stream, &e, &line);
-    if (st == BESO_ERR_HIP) {
-        snprintf(g_last_error, sizeof(g_last_error), "%s (%d) at train.hip:%d", hipGetErrorName(e), (int)e, line);
-    }
-    return st;
+    return beso_loss_grad_streams(cfg, params, n_params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
+                                  flags, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale, workspace,
+                                  workspace_bytes, stream, early_stream, nullptr);
 }
 
 int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,

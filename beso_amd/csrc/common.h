@@ -104,6 +104,15 @@ __device__ __forceinline__ float sampler_update(int mode, float xv, float x2v, f
     return xv + s;
 }
 
+// Training-mode dropout: keep-scale of one element from a counter-based hash of (seed, site, element index) -- the
+// backward pass recomputes the mask.  p = 0 never reaches this function.  (train.hip; the attention core of the one-launch
+// training forward in fused.hip draws the same mask as attn_small_kernel.)
+__device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t site, size_t idx, float p, float inv_keep) {
+    uint32_t h = (uint32_t)idx * 0x9E3779B1u + (uint32_t)(idx >> 32) * 0x7FEB352Du + site * 0x85EBCA77u + seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return ((float)(h >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -38,6 +38,19 @@ int    fused_train_pack(const Layout& lay, const float* const* params, char* img
 int    fused_train_tail(const Layout& lay, const char* img, int layer, int M, const float* x_in, const void* y, int ld_y,
                         float* x_mid, float* x_out, float* st2, void* xn2, void* h, void* g, float* st1n, void* xn1n,
                         void* qkvn, hipStream_t s);
+// training forward of ALL layers as one launch (train_fwd_kernel): the kept activations go to the training workspace `ws`
+// at byte offsets x_mid .. g of layer 0 plus l * stride; the last layer's tail runs on the compact action rows (its
+// attention output to `ya`)
+struct TrainWholeBufs {
+    const float* x0; char* ws;
+    size_t x_mid, x_out, st1, st2, xn1, qkv, y, xn2, h, g, stride, ya;
+    int t;                         // steps of the window (action tokens per sample)
+    float p_attn; uint32_t seed;   // attention dropout (the per-op kernels' mask)
+};
+bool   fused_train_whole_supported(const Layout& lay, int T, int t);
+size_t fused_train_whole_image_bytes(const Layout& lay);
+int    fused_train_whole_pack(const Layout& lay, const float* const* params, char* img, hipStream_t s);
+int    fused_train_whole(const Layout& lay, const char* img, int batch, int T, const TrainWholeBufs& a, hipStream_t s);
 void   fused_set_stamps(void* buf, int cap);     // development builds (BESO_DEV_API): phase stamps of workgroup 0
 
 // The fp16-operand build of layers_kernel (fused_f16.hip = fused.hip compiled with BESO_OPERAND_F16 = 1): BESO_PREC_FP16.

@@ -780,19 +780,38 @@ __device__ __forceinline__ void stamp(Stamps& st, int id) {
 // LayerNorm affine themselves (training weights are not gamma-folded) and store what the backward pass keeps -- LayerNorm
 // statistics and output, the FC1 pre-activation h and GELU(h) -- row-major [token][feature] as the per-op training kernels
 // do.  The default types switch all of it off at compile time: the inference instances are unchanged.
+// Which row of the kept [rows][features] buffers a token slot of the tile maps to: slot < n ? base + (tab ? tab[slot] : slot)
+// : none.  tab = nullptr: the tile holds consecutive rows (train_tail_kernel; the compact action rows of the last layer in
+// train_fwd_kernel); tab = SlotTabs::row_of_slot: the action-tokens-first slot order of the one-launch kernels.
+struct Rows {
+    const unsigned char* tab; int base, n;
+    __device__ __forceinline__ int row(int slot) const { return slot < n ? base + (tab ? (int)tab[slot] : slot) : -1; }
+};
 struct LnPlain { static constexpr bool on = false; };
 struct LnTrain {
     static constexpr bool on = true;
     const float* gamma; const float* beta;    // fp32, zero padded to the tile's feature count
     float* stats;                             // [M][2] (mean, rstd)
     uint16_t* xn;                             // [M][D] bf16, LayerNorm output with the affine applied
-    int m0, M, D;
+    Rows rows; int D;
 };
 struct MlpPlain { static constexpr bool on = false; };
 struct MlpTrain {
     static constexpr bool on = true;
     uint16_t* h; uint16_t* g;                 // [M][ld] bf16: FC1 pre-activation (with bias), GELU of it
-    int m0, M, ld;                            // ld = 4 D = number of real hidden features
+    Rows rows; int ld;                        // ld = 4 D = number of real hidden features
+};
+// Attention phase of the training forward: q | k | v rows and the attention output go out row-major for the backward pass
+// (attn_small_kernel<BWD> recomputes the probabilities from the kept q/k/v), dropout on the probabilities with the mask of
+// the per-op training kernels (hash of (seed, site, ((b H + h) T + i) T + j)).
+struct AttnPlain { static constexpr bool on = false; };
+struct AttnTrain {
+    static constexpr bool on = true;
+    uint16_t* qkv;                            // [M][3 D] bf16, columns [q | k | v], heads in natural order
+    uint16_t* y;                              // [rows][D] bf16
+    Rows rows, rows_y;                        // all token rows; rows of y (all, or the compact action rows of the last layer)
+    int D, s0, H;                             // first sample of the workgroup, real heads
+    float p, inv_keep; uint32_t seed, site;
 };
 
 template <int RPW>
@@ -830,6 +849,42 @@ __device__ __forceinline__ void store_x_tile(const Tile<RPW>& T, float* __restri
             const int tok = m0 + t * 16 + n;
             if (tok < m_end) *(f32x4*)(x + (size_t)tok * D + f0) = T.acc[i][t];
         }
+    }
+}
+
+// The same through a slot -> row map (train_fwd_kernel: action tokens first, or the compact action rows of the last layer).
+template <int RPW, int NT>
+__device__ __forceinline__ void load_x_rows(Tile<RPW>& T, const float* __restrict__ x, int D, const Rows& rows, int w, int lane) {
+    const int n = lane & 15, g = lane >> 4;
+    int row[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) row[t] = rows.row(16 * t + n);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int f0 = 16 * (w * RPW + i) + 4 * g;
+        T.fvalid[i] = f0 < D;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (T.fvalid[i] && row[t] >= 0) v = *(const f32x4*)(x + (size_t)row[t] * D + f0);
+            T.acc[i][t] = v;
+        }
+    }
+}
+template <int RPW, int NT>
+__device__ __forceinline__ void store_x_rows(const Tile<RPW>& T, float* __restrict__ x, int D, const Rows& rows, int w, int lane) {
+    asm volatile("" : "+v"(lane));
+    const int n = lane & 15, g = lane >> 4;
+    int row[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) row[t] = rows.row(16 * t + n);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int f0 = 16 * (w * RPW + i) + 4 * g;
+        if (f0 >= D) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (row[t] >= 0) *(f32x4*)(x + (size_t)row[t] * D + f0) = T.acc[i][t];
     }
 }
 
@@ -921,8 +976,8 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         if (w == 0 && g == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int tok = lx.m0 + 16 * t + n;
-                if (tok < lx.M) *(float2*)(lx.stats + 2 * (size_t)tok) = make_float2(mean[t], rstd[t]);
+                const int tok = lx.rows.row(16 * t + n);
+                if (tok >= 0) *(float2*)(lx.stats + 2 * (size_t)tok) = make_float2(mean[t], rstd[t]);
             }
         }
     }
@@ -934,8 +989,8 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
             // operand-typed copy for the weight gradients goes out row-major
             pk.x = pack_op2(fmaf(fmaf(T.acc[i][t][0], a, b), gam[i][0], bet[i][0]), fmaf(fmaf(T.acc[i][t][1], a, b), gam[i][1], bet[i][1]));
             pk.y = pack_op2(fmaf(fmaf(T.acc[i][t][2], a, b), gam[i][2], bet[i][2]), fmaf(fmaf(T.acc[i][t][3], a, b), gam[i][3], bet[i][3]));
-            const int tok = lx.m0 + 16 * t + (lane & 15), f0 = 16 * (w * RPW + i) + 4 * g;
-            if (tok < lx.M && f0 < lx.D) *(uint2*)(lx.xn + (size_t)tok * lx.D + f0) = pk;
+            const int tok = lx.rows.row(16 * t + (lane & 15)), f0 = 16 * (w * RPW + i) + 4 * g;
+            if (tok >= 0 && f0 < lx.D) *(uint2*)(lx.xn + (size_t)tok * lx.D + f0) = pk;
         } else {
             pk.x = pack_op2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
             pk.y = pack_op2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
@@ -1527,8 +1582,8 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
                 const int f0 = 16 * (c * kChunkTiles + RC * w + r) + 4 * g;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const int tok = mx.m0 + 16 * t + n;
-                    if (tok < mx.M && f0 < mx.ld)
+                    const int tok = mx.rows.row(16 * t + n);
+                    if (tok >= 0 && f0 < mx.ld)
                         *(uint2*)(mx.h + (size_t)tok * mx.ld + f0) = make_uint2(pack_op2(hv[r][t][0], hv[r][t][1]),
                                                                                  pack_op2(hv[r][t][2], hv[r][t][3]));
                 }
@@ -1545,8 +1600,8 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
                     const int f0 = 16 * (c * kChunkTiles + RC * w + 2 * j2 + q) + 4 * g;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const int tok = mx.m0 + 16 * t + n;
-                        if (tok < mx.M && f0 < mx.ld)
+                        const int tok = mx.rows.row(16 * t + n);
+                        if (tok >= 0 && f0 < mx.ld)
                             *(uint2*)(mx.g + (size_t)tok * mx.ld + f0) = make_uint2(hb[j2][t][2 * q], hb[j2][t][2 * q + 1]);
                     }
                 }
@@ -1694,12 +1749,13 @@ __device__ __forceinline__ void attn_prefetch(u32x4 (&qE)[3], u32x4 (&qO)[3], co
 // HG > 1: a virtual head is HG real heads of `hd` dims side by side (FusedDims); H counts virtual heads.
 // CORE = 1 (one sample of up to 16 NTQ tokens per workgroup): the core of a head runs on waves 0 .. NTQ-1, wave qt owning
 // query tile qt against key tiles 0 .. qt (causal), softmax over all of its keys in registers.
-template <int RPW, int KS, int HG, int NTP = kNTT, int NTQ = kNTT, int CORE = 0>   // NTP: token tiles that receive the out-projection (last layer:
+template <int RPW, int KS, int HG, int NTP = kNTT, int NTQ = kNTT, int CORE = 0, class AX = AttnPlain>   // NTP: token tiles that receive the out-projection (last layer:
                                                                      // action tokens only); NTQ: token tiles that hold tokens at all
 __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsigned char* u,
                                            const u32x4* __restrict__ wqkv, const float* __restrict__ bqkv,
                                            const u32x4* __restrict__ wproj, int H, int hd, int Tn, int n_samples,
-                                           int w, int lane, const SlotTabs* tb, u32x4 (&qE)[3], u32x4 (&qO)[3], Stamps& st) {
+                                           int w, int lane, const SlotTabs* tb, u32x4 (&qE)[3], u32x4 (&qO)[3], Stamps& st,
+                                           const AX ax = AX{}) {
     asm volatile("" : "+v"(lane));
     uint16_t* qkv = (uint16_t*)u;                         // [3][kQKVRows][kQKVRow] bf16
     u32x4* yT = (u32x4*)(u + kQKVBytes);                  // [(t*2 + kk)*64 + lane]
@@ -1710,7 +1766,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     // `ln` (= lane) is re-made opaque in every pair iteration: the LDS addresses below are loop invariant
     // and would otherwise be hoisted out of the pair loop and spilled (24 VGPRs).
     int ln = lane;
-    auto write_qkv = [&](const f32x4 (&qa)[3][NTQ]) {
+    auto write_qkv = [&](const f32x4 (&qa)[3][NTQ], int vh) {      // vh: the (virtual) head these rows belong to
         const int n = ln & 15, g = ln >> 4;
         int row[NTQ];                                     // natural q/k/v row of this lane's token in each token tile
 #pragma unroll
@@ -1725,6 +1781,11 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                 pk.x = pack_op2(qa[i][t][0], qa[i][t][1]);
                 pk.y = pack_op2(qa[i][t][2], qa[i][t][3]);
                 *(uint2*)(dst + (size_t)row[t] * kQKVRow) = pk;
+                if constexpr (AX::on) {                   // kept for the backward pass: [row][part D + head dims]
+                    const int grow = ax.rows.row(t * 16 + n);
+                    if (grow >= 0 && d0 < HG * hd)
+                        *(uint2*)(ax.qkv + (size_t)grow * (3 * ax.D) + part * ax.D + vh * (HG * hd) + d0) = pk;
+                }
             }
         }
     };
@@ -1738,7 +1799,29 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     // token slot of (sample w, position lane & 15): looked up ONCE (it was an LDS round trip at the tail of every core's
     // serial chain); clamped index, used only where position < Tn
     const int my_tok = tb->slot_of_row[min(w, n_samples - 1) * Tn + min(lane & 15, Tn - 1)];
-    auto core = [&]() {
+    // training instance: dropout keep-scales of this lane's four probabilities (query n, keys 4g..4g+3) of real head rh, and
+    // the attention output of (sample w, query n), dims d0..d0+3 of virtual head vh, row-major
+    auto drop4 = [&](float (&e)[4], int rh, int n, int g) {
+        if constexpr (AX::on) {
+            if (ax.p > 0.f) {
+                const size_t base = (((size_t)(ax.s0 + w) * ax.H + rh) * Tn + n) * Tn + 4 * g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e[r] *= drop_scale(ax.seed, ax.site, base + r, ax.p, ax.inv_keep);
+            }
+        }
+    };
+    auto keep_y = [&](const auto& yb, int vh, int tok, int g) {
+        if constexpr (AX::on) {
+            const int grow = ax.rows_y.row(tok);
+            if (grow >= 0) {
+                uint16_t* dst = ax.y + (size_t)grow * ax.D + vh * (HG * hd) + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    if (16 * dt + 4 * g < HG * hd) *(uint2*)(dst + 16 * dt) = make_uint2(yb[dt >> 1][2 * (dt & 1)], yb[dt >> 1][2 * (dt & 1) + 1]);
+            }
+        }
+    };
+    auto core = [&](int vh) {
     const int n = ln & 15, g = ln >> 4;
     if constexpr (CORE == 1) {
         // ---- long sequence, one sample: S^T tiles [key tile kt][query tile w] for kt <= w, same operand roles and D
@@ -1844,6 +1927,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                 for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - mx); sum += e[r]; }
                 sum = rows_allreduce<false>(sum);
                 const float inv = __builtin_amdgcn_rcpf(sum);
+                if constexpr (AX::on) drop4(e, vh * HG + h, n, g);
                 const uint2 pb = make_uint2(pack_op2(e[0], e[1]), pack_op2(e[2], e[3]));
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -1859,6 +1943,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
             }
             if (n < Tn) {
                 const int tok = my_tok;                               // token slot of (sample w, position n)
+                u32x4 ybk[AX::on ? 2 : 1];
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     u32x4 yb;
@@ -1867,7 +1952,9 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                     yb[2] = pack_op2(y[2 * kk + 1][0], y[2 * kk + 1][1]);
                     yb[3] = pack_op2(y[2 * kk + 1][2], y[2 * kk + 1][3]);
                     yT[((size_t)(tok >> 4) * 2 + kk) * 64 + (g << 4) + (tok & 15)] = yb;
+                    if constexpr (AX::on) ybk[kk] = yb;
                 }
+                if constexpr (AX::on) keep_y(ybk, vh, tok, g);
             }
         }
     } else {
@@ -1890,6 +1977,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(e[r] - m); sum += e[r]; }   // exp2(-inf) = 0
         sum = rows_allreduce<false>(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
+        if constexpr (AX::on) drop4(e, vh, n, g);
         uint2 pb = make_uint2(pack_op2(e[0], e[1]), pack_op2(e[2], e[3]));
         f32x4 y[4];
 #pragma unroll
@@ -1900,6 +1988,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         }
         if (n < Tn) {
             const int tok = my_tok;                               // token slot of (sample w, position n)
+            u32x4 ybk[AX::on ? 2 : 1];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 u32x4 yb;
@@ -1908,7 +1997,9 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                 yb[2] = pack_op2(y[2 * kk + 1][0] * inv, y[2 * kk + 1][1] * inv);
                 yb[3] = pack_op2(y[2 * kk + 1][2] * inv, y[2 * kk + 1][3] * inv);
                 yT[((size_t)(tok >> 4) * 2 + kk) * 64 + (g << 4) + (tok & 15)] = yb;
+                if constexpr (AX::on) ybk[kk] = yb;
             }
+            if constexpr (AX::on) keep_y(ybk, vh, tok, g);
         }
     }
     }
@@ -1930,23 +2021,23 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
         }
         gemm_phase<3, NTQ, kt16(KS)>(qa, qE, qO, qkv_a(pair), 24, xnT + lane, KS * 64, 64, KS);
         prefetch_a<RPW>(aE, aO, proj_a(hA), kWaves * RPW);
-        if (hsel == 0) write_qkv(qa);
+        if (hsel == 0) write_qkv(qa, hA);
         stamp(st, 11);
         __syncthreads();
         stamp(st, 12);
-        core();
+        core(hA);
         stamp(st, 16);
         __syncthreads();
         stamp(st, 17);
         // ---- head A's slice of the out-projection, accumulated into the residual; head B's q/k/v to LDS
         gemm_phase<RPW, NTP, false, kNTT>(T.acc, aE, aO, proj_a(hA), kWaves * RPW, yT + lane, 2 * 64, 64, 2);
         prefetch_a<RPW>(aE, aO, proj_a(hB), kWaves * RPW);
-        if (hsel == 1) write_qkv(qa);
+        if (hsel == 1) write_qkv(qa, hB);
         if (pair + 1 < H / 2) prefetch_a<3>(qE, qO, qkv_a(pair + 1), 24);   // qa's registers are free from here
         stamp(st, 13);
         __syncthreads();
         stamp(st, 14);
-        core();
+        core(hB);
         stamp(st, 15);
         __syncthreads();
         stamp(st, 18);
@@ -2593,16 +2684,18 @@ __global__ __launch_bounds__(512, 2) void train_tail_kernel(const char* __restri
         // ---- LN2 (statistics and affine output kept), MLP (h and GELU(h) kept), x_out
         u32x4 a1r[kFc1PF][kChunkTiles / kWaves];
         mlp_prefetch<KS, kWaves>(a1r, (const u32x4*)(lw + ti.o_w1), w, lane);
-        const LnTrain lx{(const float*)(lw + ti.o_ln2w), (const float*)(lw + ti.o_ln2b), a.st2, a.xn2, m0, M, d.D};
+        const Rows rows{nullptr, m0, min(kMT, M - m0)};
+        const LnTrain lx{(const float*)(lw + ti.o_ln2w), (const float*)(lw + ti.o_ln2b), a.st2, a.xn2, rows, d.D};
         layernorm_to_lds<RPW, KS, kWaves, true, kNTT, 0, LnTrain>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                                                    (const float*)(lw + ti.o_b2), st, 0, lx);
-        const MlpTrain mx{a.h, a.g, m0, M, 4 * d.D};
+        const MlpTrain mx{a.h, a.g, rows, 4 * d.D};
         mlp_phase<RPW, KS, kWaves, kNTT, kFc1PF, MlpTrain>(T, (const u32x4*)(lds + L.xnT), (u32x4*)(lds + L.u),
                                                             (const u32x4*)(lw + ti.o_w1), (const float*)(lw + ti.o_b1),
                                                             (const u32x4*)(lw + ti.o_w2), d.HT, d.KS2p, w, lane, a1r, st, mx);
     }
     if (lw_next != nullptr) {
-        const LnTrain lx{(const float*)(lw_next + ti.o_ln1w), (const float*)(lw_next + ti.o_ln1b), a.st1n, a.xn1n, m0, M, d.D};
+        const LnTrain lx{(const float*)(lw_next + ti.o_ln1w), (const float*)(lw_next + ti.o_ln1b), a.st1n, a.xn1n,
+                         Rows{nullptr, m0, min(kMT, M - m0)}, d.D};
         layernorm_to_lds<RPW, KS, kWaves, false, kNTT, 0, LnTrain>(T, (u32x4*)(lds + L.xnT), (float*)(lds + L.red), d.D, w, lane,
                                                                     nullptr, st, 0, lx);
     }
@@ -2647,7 +2740,7 @@ __global__ __launch_bounds__(512, 2) void train_tail_kernel(const char* __restri
 
 // The per-step training image of ALL layers in one launch: every segment is either a matrix in A-fragment order
 // (pack_mfma_a_kernel's layout) or a zero-padded fp32 vector; a workgroup serves one segment (table in the kernel argument).
-struct TrainPackSeg { const float* src; uint32_t dst; int rows, cols, rt, kt, grp, first_block, tr; };   // rt = 0: vector of `rows` floats padded to `cols`; tr: the matrix is src^T (src is [cols][rows])
+struct TrainPackSeg { const float* src; uint32_t dst; int rows, cols, rt, kt, grp, first_block, tr; };   // rt = 0: vector of `rows` floats padded to `cols`; tr = 1: the matrix is src^T (src is [cols][rows]); 2, 3, 4: the attention phase's q/k/v, out-projection and bias layouts
 constexpr int kTrainPackSegs = 96;                       // 13 per layer; the table travels as a kernel argument (< 4 KiB)
 struct TrainPackTable { TrainPackSeg seg[kTrainPackSegs]; int n, blocks; };
 __global__ void train_pack_kernel(TrainPackTable t, char* __restrict__ img) {
@@ -2663,10 +2756,44 @@ __global__ void train_pack_kernel(TrainPackTable t, char* __restrict__ img) {
     const size_t start = (size_t)(blockIdx.x - g.first_block) * blockDim.x + threadIdx.x, stride = (size_t)nb * blockDim.x;
     if (g.rt == 0) {
         float* dst = (float*)(img + g.dst);
+        if (g.tr == 4) {
+            // q / k / v bias (part = grp) in the attention phase's head layout: dst[(hv 3 + part) 64 + d] = src[hv hdv + d] (hdv = rows)
+            for (size_t i = start; i < (size_t)g.cols; i += stride) {
+                const int hv = (int)(i >> 6), dd = (int)(i & 63);
+                dst[((size_t)hv * 3 + g.grp) * kHDP + dd] = dd < g.rows ? g.src[(size_t)hv * g.rows + dd] : 0.f;
+            }
+            return;
+        }
         for (size_t i = start; i < (size_t)g.cols; i += stride) dst[i] = i < (size_t)g.rows ? g.src[i] : 0.f;
         return;
     }
     uint16_t* dst = (uint16_t*)(img + g.dst);
+    if (g.tr == 2) {
+        // one part (grp: 0 query, 1 key, 2 value) of the head-pair q/k/v image (pack_qkv_kernel's layout, no gamma):
+        // rt = virtual heads, rows = their width hdv, cols = D
+        const size_t total = (size_t)g.rt * g.kt * 4 * 512;
+        for (size_t i = start; i < total; i += stride) {
+            const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+            const size_t tile = i >> 9;
+            const int R4 = (int)(tile & 3), kk = (int)((tile >> 2) % g.kt), h = (int)(tile / ((size_t)4 * g.kt));
+            const int dd = 16 * R4 + (lane & 15), c = 32 * kk + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+            const size_t dtile = ((size_t)(h >> 1) * g.kt + kk) * 24 + (h & 1) * 12 + g.grp * 4 + R4;
+            dst[dtile * 512 + lane * 8 + j] = f2bf((dd < g.rows && c < g.cols) ? g.src[((size_t)h * g.rows + dd) * g.cols + c] : 0.f);
+        }
+        return;
+    }
+    if (g.tr == 3) {
+        // out-projection per head k-step (pack_proj_kernel's layout): rows = D, cols = hdv, kt = 2 x virtual heads
+        const size_t total = (size_t)g.rt * g.kt * 512;
+        for (size_t i = start; i < total; i += stride) {
+            const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+            const size_t tile = i >> 9;
+            const int R = (int)(tile % g.rt), kk = (int)(tile / g.rt);
+            const int o = 16 * R + (lane & 15), h = kk >> 1, dd = 32 * (kk & 1) + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+            dst[i] = f2bf((o < g.rows && dd < g.cols) ? g.src[(size_t)o * g.rows + h * g.cols + dd] : 0.f);
+        }
+        return;
+    }
     const size_t total = (size_t)g.rt * g.kt * 512;
     for (size_t i = start; i < total; i += stride) {
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
@@ -2959,6 +3086,87 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     if (LOOP && ev + 1 < n_evals) __syncthreads();      // the head's partial sums are read, the next input is in xs
     }
     stamp(st, 101);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Training forward of ALL layers as one launch (train.hip, loss_grad_e): the phases of layers_kernel with the store hooks of
+// train_tail_kernel plus the attention phase's (AttnTrain) -- everything the backward pass keeps goes out in the per-op
+// training kernels' buffers and formats: per layer x_mid / x_out fp32, LayerNorm statistics and affine outputs, q|k|v, the
+// attention output, h and GELU(h) as bf16 row-major.  The residual tile is loaded from the embedding kernel's x0 (action
+// tokens first, as in layers_kernel) and never leaves the registers; the LAST layer runs its out-projection, LayerNorm-2 and
+// MLP on the action-token tiles only and writes them as the COMPACT action rows (row b t + i) on which the per-op step
+// continues with ln_f, head and loss.  Weights: the per-step training image (fragment order, LayerNorm affine not folded:
+// the weight gradients need the affine outputs as operands); bf16 operands; attention dropout inside the core
+// (attn_small_kernel's mask); no dropout on the proj / MLP outputs (resid_pdrop = 0).  One launch replaces 44 of the per-op
+// forward at six layers; at 1024 kitchen samples the four-samples-per-workgroup instance is one workgroup per CU.
+// ---------------------------------------------------------------------------------------------
+struct TrainImgW { uint32_t o_ln1w, o_ln1b, o_ln2w, o_ln2b, layer_bytes; };    // behind a layer's FusedDims sections (o_b1 .. o_bproj)
+static TrainImgW train_img_whole(const FusedDims& d) {
+    TrainImgW t;
+    const uint32_t vec = (uint32_t)round_up_sz((size_t)d.RPW * kWaves * 16 * sizeof(float), 256);
+    t.o_ln1w = d.layer_bytes; t.o_ln1b = t.o_ln1w + vec; t.o_ln2w = t.o_ln1b + vec; t.o_ln2b = t.o_ln2w + vec;
+    t.layer_bytes = t.o_ln2b + vec;
+    return t;
+}
+
+template <int RPW, int KS, int HG, int NTL, int SPW, int NTA>
+__global__ __launch_bounds__(512, 2) void train_fwd_kernel(const char* __restrict__ img, FusedDims d, TrainImgW ti,
+                                                           int n_samples_total, int Tn, TrainWholeBufs a) {
+    Stamps st{nullptr, 0, 0};
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr LdsMap L = lds_map(KS);
+    constexpr int NTLa = NTL < NTA ? NTL : NTA;
+    constexpr int PF1 = NTA < kNTT ? BESO_LAT_PF1 : kFc1PF;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s0 = blockIdx.x * SPW;
+    const int n_samples = min(SPW, n_samples_total - s0);
+    SlotTabs* tb = (SlotTabs*)(lds + L.tab);
+    build_slot_tabs(tb, n_samples, Tn, a.t, d.G, true);
+    // LDS that is read but never written by the phases must be finite (layers_kernel): the attention-output fragments of
+    // padding tokens and the 8 q/k/v rows past the last token slot
+    for (int i = threadIdx.x; i < kNTT * 2 * 64; i += blockDim.x) ((u32x4*)(lds + L.u + kQKVBytes))[i] = u32x4{0, 0, 0, 0};
+    for (int i = threadIdx.x; i < 3 * 8 * kQKVRow / 2; i += blockDim.x) {
+        const int part = i / (8 * kQKVRow / 2), rem = i % (8 * kQKVRow / 2);
+        ((uint32_t*)(lds + L.u))[((size_t)part * kQKVRows + kMT) * kQKVRow / 2 + rem] = 0u;
+    }
+    __syncthreads();
+    const Rows rows_all{tb->row_of_slot, s0 * Tn, n_samples * Tn};     // token rows b T + position
+    const Rows rows_act{nullptr, s0 * a.t, n_samples * a.t};            // compact action rows b t + i = the first slots
+    Tile<RPW> T;
+    load_x_rows<RPW, NTA>(T, a.x0, d.D, rows_all, w, lane);
+    u32x4* xnT = (u32x4*)(lds + L.xnT);
+    float* red = (float*)(lds + L.red);
+    const float inv_keep = a.p_attn > 0.f ? 1.0f / (1.0f - a.p_attn) : 1.f;
+    auto layer = [&](int l, auto NTPc, const Rows& rows_tail, uint16_t* ybuf) {
+        constexpr int NTP = decltype(NTPc)::value;             // token tiles behind the attention: all, or the action tiles
+        const char* lw = img + (size_t)l * ti.layer_bytes;
+        char* wl = a.ws + (size_t)l * a.stride;
+        u32x4 qE[3], qO[3];
+        attn_prefetch<KS>(qE, qO, (const u32x4*)(lw + d.o_wqkv), w, lane);
+        const LnTrain lx1{(const float*)(lw + ti.o_ln1w), (const float*)(lw + ti.o_ln1b), (float*)(wl + a.st1),
+                          (uint16_t*)(wl + a.xn1), rows_all, d.D};
+        layernorm_to_lds<RPW, KS, kWaves, true, NTA, 0, LnTrain>(T, xnT, red, d.D, w, lane, (const float*)(lw + d.o_bproj), st, 0, lx1);
+        const AttnTrain ax{(uint16_t*)(wl + a.qkv), ybuf, rows_all, rows_tail, d.D, s0, d.H, a.p_attn, inv_keep, a.seed,
+                           (uint32_t)(4 * l)};
+        attn_phase<RPW, KS, HG, NTP, NTA, 0, AttnTrain>(T, xnT, lds + L.u, (const u32x4*)(lw + d.o_wqkv),
+                                                        (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd,
+                                                        Tn, n_samples, w, lane, tb, qE, qO, st, ax);
+        store_x_rows<RPW, NTP>(T, (float*)(wl + a.x_mid), d.D, rows_tail, w, lane);
+        u32x4 a1r[PF1][kChunkTiles / kWaves];
+        mlp_prefetch<KS, kWaves, PF1>(a1r, (const u32x4*)lw, w, lane);
+        const LnTrain lx2{(const float*)(lw + ti.o_ln2w), (const float*)(lw + ti.o_ln2b), (float*)(wl + a.st2),
+                          (uint16_t*)(wl + a.xn2), rows_tail, d.D};
+        layernorm_to_lds<RPW, KS, kWaves, true, NTP, 0, LnTrain>(T, xnT, red, d.D, w, lane, (const float*)(lw + d.o_b2), st, 0, lx2);
+        const MlpTrain mx{(uint16_t*)(wl + a.h), (uint16_t*)(wl + a.g), rows_tail, 4 * d.D};
+        mlp_phase<RPW, KS, kWaves, NTP, PF1, MlpTrain>(T, xnT, (u32x4*)(lds + L.u), (const u32x4*)lw, (const float*)(lw + d.o_b1),
+                                                       (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st, mx);
+        store_x_rows<RPW, NTP>(T, (float*)(wl + a.x_out), d.D, rows_tail, w, lane);
+    };
+#pragma unroll 1
+    for (int l = 0; l + 1 < d.L; ++l)
+        layer(l, std::integral_constant<int, NTA>{}, rows_all, (uint16_t*)(a.ws + (size_t)l * a.stride + a.y));
+    layer(d.L - 1, std::integral_constant<int, NTLa>{}, rows_act, (uint16_t*)(a.ws + a.ya));
 }
 
 unsigned long long* g_stamps = nullptr;
@@ -3389,6 +3597,91 @@ int fused_train_tail(const Layout& lay, const char* img, int layer, int M, const
         hipLaunchKernelGGL((train_tail_kernel<2, 8>), grid, block, L.total, s, lw, lw_next, d, ti, M, a);
     }
     return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+// ---- training forward of all layers as one launch (train_fwd_kernel) ---------------------------------------------------
+// instance by batch size as for inference: four samples in four token tiles up to 1024 samples (one workgroup per CU at
+// BASELINE config 3's per-GPU share), eight in six beyond
+static bool train_whole_dims(const Layout& lay, int T, int t, FusedDims* d) {
+    if (!train_tail_dims(lay, d) || !d->attn || d->seq1 || d->lin) return false;
+    if (!((d->RPW == 3 && d->KS == 12 && d->HG == 1) || (d->RPW == 2 && d->KS == 8 && d->HG == 3))) return false;
+    if (lay.L < 1 || lay.L * 16 > kTrainPackSegs) return false;
+    const int NTL = d->RPW == 3 ? 2 : 4;                    // the instances' action-token tiles (fused_layers)
+    return kSPW * T <= kMT && tiles_hold(kSPW, T, kNTT) && kSPW * t <= 16 * NTL;
+}
+
+bool fused_train_whole_supported(const Layout& lay, int T, int t) { FusedDims d; return train_whole_dims(lay, T, t, &d); }
+
+size_t fused_train_whole_image_bytes(const Layout& lay) {
+    FusedDims d;
+    if (!train_tail_dims(lay, &d) || !d.attn || d.lin) return 0;
+    return (size_t)train_img_whole(d).layer_bytes * lay.L;
+}
+
+// params: the parameter list of beso_pack_weights.  All layers' fragment images, biases and LayerNorm parameters: one launch.
+int fused_train_whole_pack(const Layout& lay, const float* const* p, char* img, hipStream_t s) {
+    FusedDims d;
+    if (!train_tail_dims(lay, &d) || !d.attn || d.lin || lay.L * 16 > kTrainPackSegs) return BESO_ERR_UNSUPPORTED;
+    const TrainImgW ti = train_img_whole(d);
+    TrainPackTable t;
+    t.n = 0;
+    int blocks = 0;
+    const int D = lay.D, rt1 = d.NCH * kChunkTiles, rt2 = d.RPW * kWaves;
+    auto seg = [&](const float* src, uint32_t dst, int rows, int cols, int rt, int kt, int grp, int tr, size_t elems) {
+        t.seg[t.n++] = TrainPackSeg{src, dst, rows, cols, rt, kt, grp, blocks, tr};
+        blocks += rt == 0 ? 1 : (int)((elems + 256 * 16 - 1) / (256 * 16));
+    };
+    for (int l = 0; l < lay.L; ++l) {
+        const float* const* q = p + 3 + 16 * l;        // ln1.w ln1.b ln2.w ln2.b key.w key.b query.w query.b value.w value.b proj.w proj.b fc1.w fc1.b fc2.w fc2.b
+        const uint32_t base = (uint32_t)l * ti.layer_bytes;
+        seg(q[12], base, 4 * D, D, rt1, d.KS, kChunkTiles, 0, (size_t)rt1 * d.KS * 512);
+        seg(q[13], base + d.o_b1, 4 * D, rt1 * 16, 0, 0, 0, 0, 0);
+        seg(q[14], base + d.o_w2, D, 4 * D, rt2, d.KS2p, rt2, 0, (size_t)rt2 * d.KS2p * 512);
+        seg(q[15], base + d.o_b2, D, rt2 * 16, 0, 0, 0, 0, 0);
+        const float* w3[3] = {q[6], q[4], q[8]};       // query, key, value = parts 0, 1, 2 of the attention phase
+        const float* b3[3] = {q[7], q[5], q[9]};
+        for (int part = 0; part < 3; ++part) {
+            seg(w3[part], base + d.o_wqkv, d.hdv, D, d.Hv, d.KS, part, 2, (size_t)d.Hv * d.KS * 4 * 512);
+            seg(b3[part], base + d.o_bqkv, d.hdv, d.Hv * kHDP, 0, 0, part, 4, 0);
+        }
+        seg(q[10], base + d.o_wproj, D, d.hdv, rt2, 2 * d.Hv, 0, 3, (size_t)rt2 * 2 * d.Hv * 512);
+        seg(q[11], base + d.o_bproj, D, rt2 * 16, 0, 0, 0, 0, 0);
+        seg(q[0], base + ti.o_ln1w, D, rt2 * 16, 0, 0, 0, 0, 0); seg(q[1], base + ti.o_ln1b, D, rt2 * 16, 0, 0, 0, 0, 0);
+        seg(q[2], base + ti.o_ln2w, D, rt2 * 16, 0, 0, 0, 0, 0); seg(q[3], base + ti.o_ln2b, D, rt2 * 16, 0, 0, 0, 0, 0);
+    }
+    t.blocks = blocks;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(train_pack_kernel, dim3(blocks), dim3(256), 0, s, t, img);
+    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+template <int RPW, int KS, int HG, int NTL, int SPW, int NTA>
+static hipError_t launch_train_fwd(const char* img, const FusedDims& d, const TrainImgW& ti, int batch, int T,
+                                   const TrainWholeBufs& a, hipStream_t s) {
+    constexpr LdsMap L = lds_map(KS);
+    static bool attr = false;
+    hipError_t e = ensure_lds(train_fwd_kernel<RPW, KS, HG, NTL, SPW, NTA>, L.total, &attr);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((train_fwd_kernel<RPW, KS, HG, NTL, SPW, NTA>), dim3((batch + SPW - 1) / SPW), dim3(512), L.total, s, img, d,
+                       ti, batch, T, a);
+    return hipGetLastError();
+}
+
+int fused_train_whole(const Layout& lay, const char* img, int batch, int T, const TrainWholeBufs& a, hipStream_t s) {
+    FusedDims d;
+    if (!train_whole_dims(lay, T, a.t, &d)) return BESO_ERR_UNSUPPORTED;
+    const TrainImgW ti = train_img_whole(d);
+    constexpr int kMidSPW = 4, kMidNT = 4;
+    const bool mid = batch <= 2 * kSmallBatchMax && tiles_hold(kMidSPW, T, kMidNT) && (kMidSPW - 1) * T + 16 <= 16 * kMidNT;
+    hipError_t e;
+    if (d.RPW == 3)
+        e = mid ? launch_train_fwd<3, 12, 1, 2, kMidSPW, kMidNT>(img, d, ti, batch, T, a, s)
+                : launch_train_fwd<3, 12, 1, 2, kSPW, kNTT>(img, d, ti, batch, T, a, s);
+    else
+        e = mid ? launch_train_fwd<2, 8, 3, 4, kMidSPW, kMidNT>(img, d, ti, batch, T, a, s)
+                : launch_train_fwd<2, 8, 3, 4, kSPW, kNTT>(img, d, ti, batch, T, a, s);
+    return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
 #endif   // !BESO_OPERAND_F16

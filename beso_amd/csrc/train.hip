@@ -29,15 +29,6 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-// ---------------------------------------------------------------------------------------------
-// dropout: keep-scale of one element.  p = 0 never reaches this function.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t site, size_t idx, float p, float inv_keep) {
-    uint32_t h = (uint32_t)idx * 0x9E3779B1u + (uint32_t)(idx >> 32) * 0x7FEB352Du + site * 0x85EBCA77u + seed;
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return ((float)(h >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.f;
-}
-
 constexpr uint32_t kEmbedSite = 4 * kMaxLayers + 16;     // dropout site of the embeddings (layer sites are 4 l + {0, 1, 2})
 constexpr uint32_t kGoalSite = 4 * kMaxLayers + 17;      // DiffusionGPT.mask_cond: elementwise Bernoulli over goals [B,G,obs]
 
@@ -1240,7 +1231,8 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
     {
         Layout lay;
         const bool img = precision == BESO_PREC_BF16 && make_layout(c, BESO_PREC_BF16, &lay);
-        w->fimg = carve_t(cur, img ? fused_train_image_bytes(lay) : 0);
+        const size_t tail_b = img ? fused_train_image_bytes(lay) : 0, whole_b = img ? fused_train_whole_image_bytes(lay) : 0;
+        w->fimg = carve_t(cur, tail_b > whole_b ? tail_b : whole_b);
     }
     for (int l = 0; l < c->n_layers; ++l) {
         TrainLayerWs& y = w->layer[l];
@@ -1330,7 +1322,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
                        const float* action, const float* goal, const float* noise, const float* sigma, float* loss_out,
                        int batch, int t, int flags, float embed_p, float attn_p, float resid_p, float goal_p, uint32_t seed,
                        float grad_scale, char* ws,
-                       const TrainWs& w, hipStream_t s, hipStream_t early_stream, hipError_t* err, int* err_line) {
+                       const TrainWs& w, hipStream_t s, hipStream_t early_stream, hipStream_t loss_stream, hipError_t* err, int* err_line) {
     const int D = c->embed_dim, H = c->n_heads, hd = D / H, L = c->n_layers, G = c->goal_seq_len;
     const int obs = c->obs_dim, act = c->act_dim, seq = G + c->obs_seq_len + 1;
     const int M = w.M, T = w.T, Ke = w.Ke, ap = w.ap, D3 = 3 * D, D4 = 4 * D;
@@ -1437,11 +1429,29 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     Layout flay;
     const bool use_tail = sizeof(E) == 2 && resid_p == 0.f && L >= 2 && L * 13 <= 96 && make_layout(c, BESO_PREC_BF16, &flay) &&
                           fused_train_supported(flay) && fused_train_image_bytes(flay) > 0 && tail_forward_enabled(M, flags);
-    if (use_tail) {
+    // ... and where the shape has the one-launch kernel (kitchen, block-push; bf16, no dropout on the proj / MLP outputs), ALL
+    // layers run as ONE launch (fused.hip: train_fwd_kernel) -- 44 launches of the per-op forward at six layers; the call's plan
+    // hints keep the other two forms reachable (BESO_TRAIN_PLAN_PER_OP, BESO_TRAIN_PLAN_TILES)
+    const bool use_whole = sizeof(E) == 2 && resid_p == 0.f && !(flags & (BESO_TRAIN_PLAN_PER_OP | BESO_TRAIN_PLAN_TILES)) &&
+                           make_layout(c, BESO_PREC_BF16, &flay) && fused_train_whole_supported(flay, T, t);
+    if (use_whole) {
+        int st = fused_train_whole_pack(flay, p, ws + w.fimg, s);
+        if (st == BESO_OK) {
+            const TrainLayerWs& y0 = w.layer[0];
+            const size_t stride = L > 1 ? w.layer[1].x_mid - y0.x_mid : 0;
+            const TrainWholeBufs b{F(w.x0), ws, y0.x_mid, y0.x_out, y0.st1, y0.st2, y0.xn1, y0.qkv, y0.y, y0.xn2, y0.h, y0.g,
+                                   stride, w.ya, t, attn_p, seed};
+            profile_begin(BESO_SITE_FUSED_LAYER, s);
+            st = fused_train_whole(flay, ws + w.fimg, batch, T, b, s);
+            profile_end(BESO_SITE_FUSED_LAYER, s);
+        }
+        if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
+    }
+    if (use_tail && !use_whole) {
         const int pst = fused_train_pack(flay, p, ws + w.fimg, s);
         if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
     }
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; l < (use_whole ? 0 : L); ++l) {
         const TrainLayerWs& y = w.layer[l];
         const float* x_in = l == 0 ? F(w.x0) : F(w.layer[l - 1].x_out);
         const bool last = l == L - 1;
@@ -1500,6 +1510,14 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
                            P(w.dpred), loss_out, Ma, act, ap,
                            1.0f / (float)((size_t)batch * (last_only ? 1 : t) * act), grad_scale, t, last_only);
         TRY(hipGetLastError());
+        if (loss_stream) {
+            // the loss is final here, long before the step is: a stream of the caller's is ordered behind this point, so that
+            // reading the loss there (beso_agent.py:248 `loss.item()`) does not wait for the backward pass
+            static thread_local hipEvent_t ev_loss = nullptr;
+            if (!ev_loss) TRY(hipEventCreateWithFlags(&ev_loss, hipEventDisableTiming));
+            TRY(hipEventRecord(ev_loss, s));
+            TRY(hipStreamWaitEvent(loss_stream, ev_loss, 0));
+        }
     }
 
     // ---- backward
@@ -1654,8 +1672,8 @@ int train_loss_grad(const beso_config* c, const float* const* params, int n_para
                     const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
                     float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
                     float goal_drop, uint32_t seed, float grad_scale,
-                    void* workspace, size_t workspace_bytes, hipStream_t s, hipStream_t early_stream, hipError_t* err,
-                    int* err_line) {
+                    void* workspace, size_t workspace_bytes, hipStream_t s, hipStream_t early_stream, hipStream_t loss_stream,
+                    hipError_t* err, int* err_line) {
     int st = train_validate(c, batch, t);
     if (st != BESO_OK) return st;
     if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32) return BESO_ERR_BAD_ARG;
@@ -1673,10 +1691,10 @@ int train_loss_grad(const beso_config* c, const float* const* params, int n_para
     if (precision == BESO_PREC_FP32)
         return loss_grad_e<float>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
                                   flags, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale,
-                                  (char*)workspace, w, s, early_stream, err, err_line);
+                                  (char*)workspace, w, s, early_stream, loss_stream, err, err_line);
     return loss_grad_e<uint16_t>(c, params, grads_flat, precision, state, action, goal, noise, sigma, loss_out, batch, t,
                                  flags, embed_pdrop, attn_pdrop, resid_pdrop, goal_drop, seed, grad_scale,
-                                 (char*)workspace, w, s, early_stream, err, err_line);
+                                 (char*)workspace, w, s, early_stream, loss_stream, err, err_line);
 }
 
 int train_goal_mask(float* mask, size_t n, float goal_drop, uint32_t seed, hipStream_t s, hipError_t* err, int* err_line) {

@@ -104,9 +104,12 @@ class HipTrainStep:
         return int(b.value), int(e.value)
 
     def run(self, state, action, goal, noise, sigma, grad_scale: float = 1.0, seed: Optional[int] = None,
-            fresh_grads: bool = False, last_action_only: bool = False, early_stream=None, goal_drop: Optional[float] = None):
+            fresh_grads: bool = False, last_action_only: bool = False, early_stream=None, goal_drop: Optional[float] = None,
+            loss_stream=None):
         """-> (loss 0-d tensor, flat gradient tensor, list of per-parameter views).  Inputs are NOT modified.
         ``early_stream`` (a torch.cuda.Stream): ordered behind the completion of ``early_range()`` by the call.
+        ``loss_stream`` (a torch.cuda.Stream): ordered behind the point where the loss value is final (the end of the forward
+        half) -- a host read of the loss on that stream does not wait for the backward pass.
         ``goal_drop``: None = the module's ``cond_mask_prob`` (training mode); 0 = the goals are taken as they are."""
         inner = self.inner
         dev = action.device
@@ -143,14 +146,17 @@ class HipTrainStep:
         flat, views = self._grad_buffer(dev, fresh_grads)
         ws = self._workspace(B, t, precision, dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
+        if loss_stream is not None:
+            loss.record_stream(loss_stream)          # (read there; the caching allocator must not hand it out before that)
         with torch.cuda.device(dev):
-            st = self.lib.beso_loss_grad_overlap(
+            st = self.lib.beso_loss_grad_streams(
                 C.byref(self.cfg), arr, len(params), flat.data_ptr(), precision,
                 state.data_ptr(), action.data_ptr(), gptr, noise.data_ptr(), sigma.data_ptr(),
                 loss.data_ptr(), B, t, (_lib.TRAIN_LAST_ACTION_ONLY if last_action_only else 0) | train_hints(), float(embed_p), float(attn_p), float(resid_p),
                 float(goal_p), C.c_uint(seed & 0xFFFFFFFF), float(grad_scale), ws.data_ptr(), ws.numel(),
                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
-                C.c_void_p(early_stream.cuda_stream) if early_stream is not None else None)
+                C.c_void_p(early_stream.cuda_stream) if early_stream is not None else None,
+                C.c_void_p(loss_stream.cuda_stream) if loss_stream is not None else None)
         _lib.check(st, "loss_grad")
         return loss, flat, views
 
@@ -167,11 +173,11 @@ class HipTrainStep:
         return mask
 
     def loss_backward(self, state, action, goal, noise, sigma, grad_scale: float = 1.0, seed: Optional[int] = None,
-                      early_stream=None):
+                      early_stream=None, loss_stream=None):
         """The training step's ``loss = model.loss(...); loss.backward()``: returns the loss and leaves the
         gradients in ``p.grad`` (views of the persistent flat buffer; accumulated into an existing ``.grad``)."""
         loss, flat, views = self.run(state, action, goal, noise, sigma, grad_scale, seed, fresh_grads=False,
-                                     early_stream=early_stream)
+                                     early_stream=early_stream, loss_stream=loss_stream)
         for p, v in zip(self.inner.parameters(), views):
             if p.grad is None or p.grad.data_ptr() == v.data_ptr():
                 p.grad = v

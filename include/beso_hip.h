@@ -18,6 +18,7 @@
  *                          (+ DiffusionGPT.mask_cond, training mode     k_diffusion/score_gpts.py:298-299, 360-371)
  *   beso_goal_mask      <- the Bernoulli mask of DiffusionGPT.mask_cond k_diffusion/score_gpts.py:365-368
  *   beso_loss_grad_overlap  (same, with the early gradient range for the overlapped all-reduce: SURVEY 8(e) C1)
+ *   beso_loss_grad_streams  (same, plus a stream that is released as soon as the loss value is final)
  *   beso_adam_step      <- optimizer.step() + ema_helper.update()      beso_agent.py:236-244
  *   beso_gather_windows <- TrajectorySlicerDataset.__getitem__ x batch envs/dataloaders/trajectory_loader.py:160-197
  *
@@ -63,8 +64,9 @@ enum {
     BESO_PREC_BF16 = 0,   /* bf16 MFMA inputs, fp32 accumulate: throughput mode                 */
     BESO_PREC_FP32 = 1,   /* fp32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32: parity mode  */
     BESO_PREC_BF16X3 = 2, /* split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate): fp32-class
-                             accuracy from the fused kernel (an instance of layers_kernel: the shipped shapes --
-                             kitchen, block-push -- only; other shapes return BESO_ERR_UNSUPPORTED); inference only */
+                             accuracy from the fused kernel: an instance of layers_kernel for kitchen and block-push,
+                             split-bf16 block kernels for the long-horizon shape (D = 512); other shapes return
+                             BESO_ERR_UNSUPPORTED; inference only */
     BESO_PREC_FP16 = 3    /* fp16 MFMA inputs (v_mfma_f32_16x16x32_f16: the bf16 rate, three more mantissa bits), fp32
                              accumulate: the one-launch kernel's shapes only (kitchen, block-push, long-horizon without
                              classifier-free pairs); operands must stay inside fp16's range (|v| < 65504: LayerNorm
@@ -75,11 +77,12 @@ enum {
 enum {
     BESO_TRAIN_LAST_ACTION_ONLY = 1, /* GCDenoiser.loss(pred_last_action_only=True): only the last step of every window
                                         is scored (score_wrappers.py:59-63,76-77; the caller zeroes the other steps' noise) */
-    /* execution-plan hints (bf16): which kernels run the forward half, never what it computes -- both forms write the same
-     * kept activations.  Default: the per-op kernels below 16,000 token rows, the tile kernel (a layer's out-projection ..
-     * the next layer's q/k/v as one launch) from there on, where it measures faster. */
+    /* execution-plan hints (bf16): which kernels run the forward half, never what it computes -- all forms write the same
+     * kept activations.  Default: ALL layers as one launch where the shape has that kernel (kitchen, block-push; no dropout
+     * on the proj / MLP outputs); otherwise the per-op kernels below 16,000 token rows and the tile kernel (a layer's
+     * out-projection .. the next layer's q/k/v as one launch) from there on. */
     BESO_TRAIN_PLAN_PER_OP = 2,      /* per-op kernels for every layer */
-    BESO_TRAIN_PLAN_TILES = 4        /* the tile kernel wherever the shape has it */
+    BESO_TRAIN_PLAN_TILES = 4        /* the tile kernel (one launch per layer) wherever the shape has it */
 };
 
 /* flags of the forward calls (beso_score_fwd, beso_denoise_fwd, beso_sample, beso_sample_ancestral) */
@@ -275,6 +278,15 @@ int beso_loss_grad_overlap(const beso_config* cfg, const float* const* params, i
                            float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
                            float goal_drop, unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes,
                            void* stream, void* early_stream);
+/* ... and with a third stream for the LOSS: `loss_stream` (NULL: none) is ordered behind the point where *loss_out is final --
+ * the end of the forward half, a third of the way into the call's work.  The reference's train_step returns `loss.item()`
+ * (beso_agent.py:248); reading the loss on loss_stream lets the host return with it while the backward pass and the optimizer
+ * are still running on `stream`, and prepare the next step under them.                                                   */
+int beso_loss_grad_streams(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
+                           const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
+                           float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
+                           float goal_drop, unsigned int seed, float grad_scale, void* workspace, size_t workspace_bytes,
+                           void* stream, void* early_stream, void* loss_stream);
 /* Launch-site timers (bench.py's roofline, the launch-count assertions of the tests): while a site is selected ON THE
  * CALLING THREAD, HIP events are recorded on the launch stream around every launch that thread makes at that site (site 0 =
  * off).  beso_profile_read synchronises the events the calling thread recorded, returns their summed elapsed time and count,

@@ -1372,6 +1372,40 @@ def test_training_forward_tail_block_equals_the_per_op_forward(cfg_name, B, t):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name,B,t", [("kitchen", 200, None), ("kitchen", 37, 2), ("kitchen", 1030, None),
+                                          ("kitchen", 3, 1), ("block_push", 96, None), ("block_push", 1100, 3)])
+def test_training_forward_as_one_launch_equals_the_per_op_forward(cfg_name, B, t):
+    """bf16 training step, round 4: ALL layers of the forward as ONE launch (train_fwd_kernel, fused.hip: the phases of the
+    inference kernel with store hooks for everything the backward keeps, attention dropout inside the core with the per-op
+    kernels' mask, the last layer's tail on the compact action rows) -- the library's default where the shape has it.  Same
+    kept activations in the same formats and the same dropout mask as the per-op forward; what differs is the accumulation
+    order inside the GEMMs and the bf16 MFMA attention core against the per-op fp32 one.  Loss and every gradient of the two
+    forms must agree inside the bf16 bound that holds them to autograd (2.6e-2): 2e-2 per tensor, loss 2e-3.  Both instances
+    (four samples per workgroup up to 1024 samples, eight beyond), ragged last workgroups and short windows included."""
+    cfg = O.CONFIGS[cfg_name]
+    m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), "bf16", attn_pdrop=0.3)
+    state, action, goal, noise, sigma = _train_inputs(cfg, B, seed=5)
+    if t is not None:
+        state, action, noise = state[:, :t].contiguous(), action[:, :t].contiguous(), noise[:, :t].contiguous()
+    step = m.hip_train_step(state, action, goal, noise, sigma)
+    out = {}
+    try:
+        for on in (1, 0):                                    # 1: the library's choice = one launch; 0: per-op kernels
+            set_train_tail(on)
+            n = count_fused_launches(lambda: out.__setitem__(on, step.run(state, action, goal, noise, sigma, seed=77, fresh_grads=True)))
+            out[on] = (out[on][0].item(), [v.clone() for v in out[on][2]], n)
+    finally:
+        set_train_tail(1)
+    assert (out[1][2], out[0][2]) == (1, 0), (out[1][2], out[0][2])      # launches at the fused kernel's site
+    errs = _grad_errors(out[1][1], out[0][1], 2e-3)
+    worst = max(range(len(errs)), key=lambda i: errs[i])
+    print(f"[parity] one-launch vs per-op training forward {cfg_name} B={B} t={t}: loss {abs(out[1][0] - out[0][0]) / abs(out[0][0]):.2e}, "
+          f"worst gradient {errs[worst]:.2e} ({list(dict(m.named_parameters()))[worst]})")
+    assert abs(out[1][0] - out[0][0]) < 2e-3 * abs(out[0][0])
+    assert errs[worst] < 2e-2
+
+
+@pytest.mark.gpu
 def test_agent_train_step_with_goal_drop_runs_the_hip_step():
     """BesoAgent.train_step on a model built with goal_drop = 0.1 and the kitchen dropouts (configs[2] / [3]): the HIP step
     serves it (no host-side masking, no torch-op network), losses are finite and decrease over a few steps."""
@@ -1391,6 +1425,45 @@ def test_agent_train_step_with_goal_drop_runs_the_hip_step():
     losses = [agent.train_step(batch) for _ in range(30)]
     assert getattr(agent, "_hip_step", None) is not None
     assert all(np.isfinite(l) for l in losses) and np.mean(losses[-5:]) < 0.9 * np.mean(losses[:5]), losses
+
+
+@pytest.mark.gpu
+def test_train_step_reads_the_loss_on_the_loss_stream(monkeypatch):
+    """BesoAgent.train_step returns `loss.item()` (beso_agent.py:248).  The loss is final at the end of the forward half, so
+    the step releases a side stream there (beso_loss_grad_streams) and reads the loss on it: the call returns while backward
+    and optimizer still run.  Same losses, same parameters as the plain read (BESO_AMD_ASYNC_LOSS=0) over several steps --
+    to the rounding of the few atomically accumulated bias gradients --, and the parameters the NEXT step reads are the
+    updated ones (the compute stream's order is untouched)."""
+    from test_host_logic import build_agent
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    cfg = O.KITCHEN
+    w = O.make_weights(cfg, seed=5, std=0.02)
+    rng = np.random.default_rng(0)
+    sc = (rng.standard_normal((64, cfg.obs_dim)).astype(np.float32), rng.standard_normal((64, cfg.act_dim)).astype(np.float32))
+    torch.manual_seed(3)
+    batch = {"observation": torch.randn(256, cfg.obs_seq_len, cfg.obs_dim, device=DEV),
+             "action": torch.tanh(torch.randn(256, cfg.obs_seq_len, cfg.act_dim, device=DEV)),
+             "goal_observation": torch.randn(256, cfg.goal_seq_len, cfg.obs_dim, device=DEV)}
+    runs = {}
+    for tag in ("1", "0", "1 again"):
+        mode = tag[0]
+        monkeypatch.setenv("BESO_AMD_ASYNC_LOSS", mode)
+        agent = build_agent(cfg, lambda: _train_module(cfg, w, "bf16", attn_pdrop=0.3, goal_drop=0.1), device=DEV, lr=1e-3)
+        agent.get_scaler(Scaler(sc[0], sc[1], True, DEV))
+        agent.set_bounds(agent.scaler)
+        torch.manual_seed(11)
+        losses = [agent.train_step(batch) for _ in range(8)]
+        torch.cuda.synchronize()
+        assert (getattr(agent, "_loss_ready", None) is not None) == (mode == "1")
+        runs[tag] = (np.array(losses), torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()]))
+    # (Adam turns the rounding of the atomically accumulated bias gradients into +-lr steps on near-zero gradient elements, so
+    # two runs of ONE mode already differ in the parameters: the other mode must not differ by more than that)
+    dev = lambda a, b: ((runs[a][1] - runs[b][1]).norm() / runs[b][1].norm()).item()
+    ldev = lambda a, b: np.abs(runs[a][0] - runs[b][0]).max() / np.abs(runs[b][0]).max()
+    print(f"[parity] loss stream vs plain read: losses {ldev('1', '0'):.2e} (run to run {ldev('1', '1 again'):.2e}), "
+          f"parameters {dev('1', '0'):.2e} (run to run {dev('1', '1 again'):.2e})")
+    assert np.all(np.isfinite(runs["1"][0])) and ldev("1", "0") < 2e-4
+    assert dev("1", "0") < 3 * dev("1", "1 again") + 1e-5
 
 
 @pytest.mark.gpu
