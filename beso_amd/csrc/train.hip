@@ -131,8 +131,12 @@ __device__ __forceinline__ void op_gload(const E* __restrict__ P, const GOp<NCH>
     }
 }
 
+// `ones`: bit i set = chunk i of this thread is replaced by (1, 0, 0, ...) -- the ONES COLUMN of the weight-gradient tiles: with
+// a column of ones behind the last real column of the activation operand, the product dY^T [X | 1] carries the bias gradient
+// (the column sums of dY) in that column for free (tgemm_wgrad_group_kernel)
 template <typename E, bool KS, int NCH>
-__device__ __forceinline__ void op_lstore(unsigned char* base, int tid, const u32x4 (&r)[NCH]) {
+__device__ __forceinline__ void op_lstore(unsigned char* base, int tid, const u32x4 (&r)[NCH], uint32_t ones = 0u) {
+    const u32x4 one = {sizeof(E) == 2 ? 0x3F80u : 0x3F800000u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = tid + kGT * i;
@@ -151,24 +155,26 @@ __device__ __forceinline__ void op_lstore(unsigned char* base, int tid, const u3
             const int krow = c >> 5, cc = c & 31;
             off = krow * kRowBytes32 + cc * 16;
         }
-        *(u32x4*)(base + off) = r[i];
+        *(u32x4*)(base + off) = (ones >> i) & 1u ? one : r[i];
     }
 }
 
 // op_lstore of a RAW-loaded stage that began at k0: the zeroing of the lanes past k_end happens here, when the data
 // is consumed, so that nothing touches the registers of a load in flight
 template <typename E, bool KS, int NCH>
-__device__ __forceinline__ void op_lstore_masked(unsigned char* base, int tid, const u32x4 (&r)[NCH], int k0, int k_end) {
+__device__ __forceinline__ void op_lstore_masked(unsigned char* base, int tid, const u32x4 (&r)[NCH], int k0, int k_end,
+                                                 uint32_t ones = 0u) {
     constexpr int EPC = 16 / (int)sizeof(E), CPR = 128 / EPC, KSTAGE = 128 / (int)sizeof(E);
     if (k0 + KSTAGE <= k_end) {                 // (wave-uniform) a whole stage: nothing to zero
-        op_lstore<E, KS, NCH>(base, tid, r);
+        op_lstore<E, KS, NCH>(base, tid, r, ones);
         return;
     }
+    const u32x4 one = {sizeof(E) == 2 ? 0x3F80u : 0x3F800000u, 0u, 0u, 0u};
     u32x4 m[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const bool ok = KS ? (k0 + (tid + kGT * i) / CPR < k_end) : (k0 + (tid & 7) * EPC < k_end);
-        m[i] = ok ? r[i] : u32x4{0u, 0u, 0u, 0u};
+        m[i] = ok ? ((ones >> i) & 1u ? one : r[i]) : u32x4{0u, 0u, 0u, 0u};       // (rows past k_end contribute nothing)
     }
     op_lstore<E, KS, NCH>(base, tid, m);
 }
@@ -263,6 +269,15 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
         u32x4 a0[NA], b0[kGL], a1[NA], b1[kGL];
         const GOp<NA> ga = make_gop<E, AKS, NA>(A, lda, m0, M, tid);
         const GOp<kGL> gb = make_gop<E, BKS, kGL>(B, ldb, n0, N, tid);
+        uint32_t b_ones = 0u;                             // chunks of this thread that start at column N of B (the ones column)
+        if constexpr (Epi::kBiasCol) {
+            static_assert(BKS, "the ones column is a column of a k-slow B operand");
+            constexpr int EPC = 16 / (int)sizeof(E), CPR = 128 / EPC;
+            if (epi.bias) {
+#pragma unroll
+                for (int i = 0; i < kGL; ++i) b_ones |= (n0 + ((tid + kGT * i) % CPR) * EPC == N ? 1u : 0u) << i;
+            }
+        }
         auto load0 = [&](int kt) {
             op_gload<E, AKS, NA, true>(A, ga, lda, k_begin + kt * KSTAGE, k_end, tid, a0);
             op_gload<E, BKS, kGL, true>(B, gb, ldb, k_begin + kt * KSTAGE, k_end, tid, b0);
@@ -274,20 +289,20 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
         load0(0);
         load1(1);
         op_lstore_masked<E, AKS, NA>(lds[0][0], tid, a0, k_begin, k_end);
-        op_lstore_masked<E, BKS, kGL>(lds[0][1], tid, b0, k_begin, k_end);
+        op_lstore_masked<E, BKS, kGL>(lds[0][1], tid, b0, k_begin, k_end, b_ones);
         __syncthreads();
         for (int kt = 0; kt < nk; kt += 2) {
             load0(kt + 2);
             __builtin_amdgcn_sched_barrier(0);          // the loads are issued HERE (the scheduler sinks them below the MFMAs)
             op_lstore_masked<E, AKS, NA>(lds[1][0], tid, a1, k_begin + (kt + 1) * KSTAGE, k_end);
-            op_lstore_masked<E, BKS, kGL>(lds[1][1], tid, b1, k_begin + (kt + 1) * KSTAGE, k_end);
+            op_lstore_masked<E, BKS, kGL>(lds[1][1], tid, b1, k_begin + (kt + 1) * KSTAGE, k_end, b_ones);
             compute(lds[0][0], lds[0][1]);
             __syncthreads();
             if (kt + 1 >= nk) break;
             load1(kt + 3);
             __builtin_amdgcn_sched_barrier(0);
             op_lstore_masked<E, AKS, NA>(lds[0][0], tid, a0, k_begin + (kt + 2) * KSTAGE, k_end);
-            op_lstore_masked<E, BKS, kGL>(lds[0][1], tid, b0, k_begin + (kt + 2) * KSTAGE, k_end);
+            op_lstore_masked<E, BKS, kGL>(lds[0][1], tid, b0, k_begin + (kt + 2) * KSTAGE, k_end, b_ones);
             compute(lds[1][0], lds[1][1]);
             __syncthreads();
         }
@@ -309,6 +324,9 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
             if (m < M && n < N) {
                 if constexpr (Epi::kColSum) cs[ni] += epi(m, n, acc[mi][ni]);
                 else epi(m, n, acc[mi][ni]);
+            }
+            if constexpr (Epi::kBiasCol) {
+                if (m < M && n == N && epi.bias) epi.bias[m] = acc[mi][ni][0];      // the ones column: sum over the rows of A's column m
             }
         }
     }
@@ -367,7 +385,7 @@ template <> struct Vec4<uint16_t> {
 };
 
 template <typename E> struct EpiStore {          // out = acc + bias  (fp32 and / or operand-typed copy)
-    static constexpr bool kColSum = false;
+    static constexpr bool kColSum = false; static constexpr bool kBiasCol = false;
     float* o32; E* oe; const float* bias; int ld;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         if (bias) v += *(const f32x4*)(bias + n);
@@ -380,7 +398,7 @@ template <typename E> struct EpiStore {          // out = acc + bias  (fp32 and 
     }
 };
 template <typename E> struct EpiFc1 {            // h = acc + bias (kept for GELU'), g = GELU(h)   (score_gpts.py:105-108)
-    static constexpr bool kColSum = false;
+    static constexpr bool kColSum = false; static constexpr bool kBiasCol = false;
     E* h; E* g; const float* bias; int ld;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         v += *(const f32x4*)(bias + n);
@@ -390,7 +408,7 @@ template <typename E> struct EpiFc1 {            // h = acc + bias (kept for GEL
     }
 };
 struct EpiResid {                                // x_out = x_in + dropout(acc + bias)              (:79,:109,:113-114)
-    static constexpr bool kColSum = false;
+    static constexpr bool kColSum = false; static constexpr bool kBiasCol = false;
     const float* xin; float* xout; const float* bias; int ld; float p, inv_keep; uint32_t seed, site;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         v += *(const f32x4*)(bias + n);
@@ -403,7 +421,7 @@ struct EpiResid {                                // x_out = x_in + dropout(acc +
     }
 };
 template <typename E> struct EpiGeluBwd {        // dh = dg * GELU'(h); its column sums are the FC1 bias gradient
-    static constexpr bool kColSum = true;
+    static constexpr bool kColSum = true; static constexpr bool kBiasCol = false;
     const E* h; E* dh; float* colsum; int ld;
     __device__ __forceinline__ f32x4 operator()(int m, int n, f32x4 v) const {
         const size_t i = (size_t)m * ld + n;
@@ -415,7 +433,7 @@ template <typename E> struct EpiGeluBwd {        // dh = dg * GELU'(h); its colu
     }
 };
 template <typename E> struct EpiSilu {           // z = acc + bias (kept for SiLU'), a = SiLU(z): the hidden layer of the MLP action head
-    static constexpr bool kColSum = false;       // (score_gpts.py:187-191: Linear(D,100) - SiLU - Linear(100,act))
+    static constexpr bool kColSum = false; static constexpr bool kBiasCol = false;       // (score_gpts.py:187-191: Linear(D,100) - SiLU - Linear(100,act))
     E* z; E* a; const float* bias; int ld;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         v += *(const f32x4*)(bias + n);
@@ -428,7 +446,7 @@ template <typename E> struct EpiSilu {           // z = acc + bias (kept for SiL
     }
 };
 template <typename E> struct EpiSiluBwd {        // dz = da * SiLU'(z); column sums = bias gradient of the hidden layer
-    static constexpr bool kColSum = true;
+    static constexpr bool kColSum = true; static constexpr bool kBiasCol = false;
     const E* z; E* dz; float* colsum; int ld;
     __device__ __forceinline__ f32x4 operator()(int m, int n, f32x4 v) const {
         const size_t i = (size_t)m * ld + n;
@@ -445,7 +463,7 @@ template <typename E> struct EpiSiluBwd {        // dz = da * SiLU'(z); column s
 };
 #if BESO_DEV_API
 struct EpiAtomic {                               // split-K partial sums accumulated with atomics (debug entry point)
-    static constexpr bool kColSum = false;
+    static constexpr bool kColSum = false; static constexpr bool kBiasCol = false;
     float* out; int ld;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
         float* o = out + (size_t)m * ld + n;
@@ -482,10 +500,10 @@ hipError_t tgemm(const void* A, int lda, const void* B, int ldb, int M, int N, i
 // the whole token range and stores its result -- no split-K, no atomics (fp32 atomics sustain ~35 G/s on this
 // part: a split-K version spent more time adding partial sums than multiplying), no reduction pass; a few hundred
 // tiles of equal length fill the chip by themselves.
-struct GProb { const void* A; const void* B; float* out; int lda, ldb, Mo, No, tile_begin, nt_n, K; };
-constexpr int kMaxGroup = 64;                          // 6 per layer + 2: up to 11 layers per launch, more launches beyond
+struct GProb { const void* A; const void* B; float* out; float* bias; int lda, ldb, Mo, No, tile_begin, nt_n, K; };   // bias: column sums of A (or nullptr)
+constexpr int kMaxGroup = 56;                          // 6 per layer + 2: up to 9 layers per launch, more launches beyond (a 4 KiB kernel argument)
 struct GTable { GProb p[kMaxGroup]; int n; };
-struct EpiStoreF { static constexpr bool kColSum = false; float* out; int ld;
+struct EpiStoreF { static constexpr bool kColSum = false; static constexpr bool kBiasCol = true; float* out; int ld; float* bias;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const { *(f32x4*)(out + (size_t)m * ld + n) = v; } };
 
 template <typename E>
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(kGT, kOcc) void tgemm_wgrad_group_kernel(GTable t) 
     const int local = b - g.tile_begin, tile_n = local % g.nt_n, tile_m = local / g.nt_n;
     __shared__ __attribute__((aligned(16))) TileLds lds;
     tgemm_tile<E, true, true, EpiStoreF>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
-                                         tile_n * kTileMN, 0, g.K, EpiStoreF{g.out, g.No});
+                                         tile_n * kTileMN, 0, g.K, EpiStoreF{g.out, g.No, g.bias});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1561,16 +1579,25 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         gt.n = 0; g_tiles = 0;
         return hipGetLastError();
     };
-    auto wgrad = [&](const E* A, int lda, int Mo, const E* B, int ldb, int No, int rows, float* out) -> hipError_t {
+    // bias: the gradient of the bias that goes with this weight = the column sums of A.  It rides along as a column of ones
+    // behind B's last real column (free whenever No is not a multiple of the 128-column tile: every shipped shape); otherwise
+    // a colsum launch of its own.
+    auto wgrad = [&](const E* A, int lda, int Mo, const E* B, int ldb, int No, int rows, float* out, float* bias = nullptr) -> hipError_t {
         if (gt.n == kMaxGroup) { hipError_t e = flush_group(); if (e != hipSuccess) return e; }
+        if (bias && No % kTileMN == 0) {
+            hipError_t e = colsum(A, lda, Mo, rows, bias);
+            if (e != hipSuccess) return e;
+            bias = nullptr;
+        }
         const int nt_n = (No + kTileMN - 1) / kTileMN, nt_m = (Mo + kTileMN - 1) / kTileMN;
-        gt.p[gt.n++] = GProb{A, B, out, lda, ldb, Mo, No, g_tiles, nt_n, rows};
+        gt.p[gt.n++] = GProb{A, B, out, bias, lda, ldb, Mo, No, g_tiles, nt_n, rows};
         g_tiles += nt_n * nt_m;
         return hipSuccess;
     };
-    // head (compact rows): dW = dpred^T xf (padded rows, copied out below), db = colsum(dpred), dxf = dpred W
-    TRY(colsum(P(w.dpred), ap, act, Ma, hb.g));
+    // head (compact rows): dW = dpred^T xf (the act real rows of dpred's ap columns, straight into the gradient tensor),
+    // db = its column sums, dxf = dpred W
     if (mlp_head) {
+        TRY(colsum(P(w.dpred), ap, act, Ma, hb.g));
         // second layer: dW1 = dpred^T a, da = dpred W1 -> dz = da * SiLU'(z) (+ its column sums = db0); first layer:
         // dW0 = dz^T xf, dxf = dz W0.  Padded rows / columns are zeros all the way.
         TRY(wgrad(P(w.dpred), ap, ap, P(w.ha), Hp, Hp, Ma, F(w.dw_head)));
@@ -1578,7 +1605,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(wgrad(P(w.hdz), Hp, Hp, P(w.xf), D, D, Ma, F(w.dw_hid)));
         TRY((tgemm<E, false, true>(P(w.hdz), Hp, P(w.w_hid), D, Ma, D, Hp, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
     } else {
-        TRY(wgrad(P(w.dpred), ap, ap, P(w.xf), D, D, Ma, F(w.dw_head)));
+        TRY(wgrad(P(w.dpred), ap, act, P(w.xf), D, D, Ma, hw.g, hb.g));
         TRY((tgemm<E, false, true>(P(w.dpred), ap, P(w.w_head), D, Ma, D, ap, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
     }
     TRY(ln_bwd(x_last, w.stf, lnfw.p, nullptr, F(w.dxa), P(w.layer[L - 1].dyo), Ma, lnfw.g, lnfb.g, lp[L - 1].f2b.g, resid_p,
@@ -1622,10 +1649,9 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
                                P(y.dqkv), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l));
         TRY(hipGetLastError());
         // q/k/v: three weight gradients from the column blocks of dqkv, bias gradients, dxn1 = dqkv Wqkv
-        TRY(wgrad(P(y.dqkv), D3, D, P(y.xn1), D, D, M, lp[l].qw.g));
-        TRY(wgrad(P(y.dqkv) + D, D3, D, P(y.xn1), D, D, M, lp[l].kw.g));
-        TRY(wgrad(P(y.dqkv) + 2 * D, D3, D, P(y.xn1), D, D, M, lp[l].vw.g));
-        TRY(colsum(P(y.dqkv), D3, D3, M, lp[l].qb.g, lp[l].kb.g, lp[l].vb.g, D));
+        TRY(wgrad(P(y.dqkv), D3, D, P(y.xn1), D, D, M, lp[l].qw.g, lp[l].qb.g));
+        TRY(wgrad(P(y.dqkv) + D, D3, D, P(y.xn1), D, D, M, lp[l].kw.g, lp[l].kb.g));
+        TRY(wgrad(P(y.dqkv) + 2 * D, D3, D, P(y.xn1), D, D, M, lp[l].vw.g, lp[l].vb.g));
         const bool first = l == 0;
         {
             TRY((tgemm<E, false, true>(P(y.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
@@ -1659,8 +1685,6 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
                              hipMemcpyDeviceToDevice, s));                                    // [act][Hp] -> [act][100]
         TRY(hipMemcpyAsync(h0w.g, ws + w.dw_hid, sizeof(float) * (size_t)Hh * D, hipMemcpyDeviceToDevice, s));
         TRY(hipMemcpyAsync(h0b.g, ws + w.db_hid, sizeof(float) * Hh, hipMemcpyDeviceToDevice, s));
-    } else {
-        TRY(hipMemcpyAsync(hw.g, ws + w.dw_head, sizeof(float) * (size_t)act * D, hipMemcpyDeviceToDevice, s));
     }
     hipLaunchKernelGGL(scatter_emb_kernel, dim3(64), dim3(256), 0, s, (const float*)F(w.dw_cat), pos.g, tokw.g, tokb.g, sigw.g,
                        sigb.g, actw.g, actb.g, D, obs, act, seq);
