@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <type_traits>
 #include "../../include/beso_hip.h"
 #ifndef BESO_DEV_API
 #define BESO_DEV_API 0     // 1: the development build (libbeso_hip_dev.so, include/beso_hip_debug.h)
@@ -117,6 +118,24 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// The same sum on the VALU: four DPP steps inside the 16-lane rows (quad_perm, row_ror) and gfx950's two lane-swap
+// instructions across the rows, instead of six ds_bpermute_b32 round trips through the LDS pipe -- for kernels whose time is
+// the latency chain of their reductions (LayerNorm backward).  Every lane receives the total.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+    auto dpp = [](float x, auto CTRL) {
+        return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), decltype(CTRL)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x124>{});     // row_ror:4
+    v += dpp(v, std::integral_constant<int, 0x128>{});     // row_ror:8
+    const u32x2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float r = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r), __float_as_uint(r), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -706,40 +706,64 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         ag[i] = zero; ab[i] = zero; ac[i] = zero;
     }
     const int r_begin = wave * rows_per_wave, r_end = min(rows, r_begin + rows_per_wave);
-    for (int row = r_begin; row < r_end; ++row) {
-        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
-        const float* xr = x + (size_t)row * D;
-        const float* gr = dxn + (size_t)row * D;
-        f32x4 xh[kLnVec], dy[kLnVec];
-        float s1 = 0.f, s2 = 0.f;
+    // TWO rows per iteration: the kernel is bound by the latency chain load -> two wave reductions -> store of a row, not by
+    // bytes (bf16 instead of fp32 for dxn changed nothing); with two rows in flight the four reductions interleave
+    constexpr int U = kLnVec == 4 ? 1 : 2;         // (D > 512: the second row would not fit the registers of three waves per SIMD)
+    for (int row0 = r_begin; row0 < r_end; row0 += U) {
+        f32x4 xh[U][kLnVec], dy[U][kLnVec], go[U][kLnVec], xv[U][kLnVec];
+        float mean[U], rstd[U], s1[U], s2[U];
 #pragma unroll
-        for (int i = 0; i < kLnVec; ++i) {
-            const int c = (lane + i * 64) * 4;
-            const f32x4 go = c < D ? *(const f32x4*)(gr + c) : zero;
-            xh[i] = c < D ? (*(const f32x4*)(xr + c) - mean) * rstd : zero;
-            dy[i] = go * gw[i];
-            const f32x4 t = dy[i] * xh[i];
-            s1 += (dy[i][0] + dy[i][1]) + (dy[i][2] + dy[i][3]);
-            s2 += (t[0] + t[1]) + (t[2] + t[3]);
-            ag[i] += go * xh[i];
-            ab[i] += go;
+        for (int u = 0; u < U; ++u) {
+            const int row = min(row0 + u, r_end - 1);        // (a surplus second row re-reads the first; nothing of it is stored)
+            mean[u] = stats[2 * (size_t)row]; rstd[u] = stats[2 * (size_t)row + 1];
+#pragma unroll
+            for (int i = 0; i < kLnVec; ++i) {
+                const int c = (lane + i * 64) * 4;
+                go[u][i] = c < D ? *(const f32x4*)(dxn + (size_t)row * D + c) : zero;
+                xv[u][i] = c < D ? *(const f32x4*)(x + (size_t)row * D + c) : zero;
+            }
         }
-        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
 #pragma unroll
-        for (int i = 0; i < kLnVec; ++i) {
-            const int c = (lane + i * 64) * 4;
-            if (c < D) {
-                const size_t idx = (size_t)row * D + c;
-                f32x4 tot = (dy[i] - c1 - xh[i] * c2) * rstd;
-                if (dres_in) tot += *(const f32x4*)(dres_in + idx);
-                *(f32x4*)(dres_out + idx) = tot;
-                f32x4 op = tot;
-                if (p > 0.f && !(skip_mod > 0 && row % skip_mod == 0)) {      // (the sigma token's embedding has no dropout)
+        for (int u = 0; u < U; ++u) {
+            const bool live = row0 + u < r_end;
+            s1[u] = 0.f; s2[u] = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) op[j] *= drop_scale(seed, site, idx + j, p, inv_keep);
+            for (int i = 0; i < kLnVec; ++i) {
+                const int c = (lane + i * 64) * 4;
+                xh[u][i] = c < D ? (xv[u][i] - mean[u]) * rstd[u] : zero;
+                dy[u][i] = go[u][i] * gw[i];
+                const f32x4 t = dy[u][i] * xh[u][i];
+                s1[u] += (dy[u][i][0] + dy[u][i][1]) + (dy[u][i][2] + dy[u][i][3]);
+                s2[u] += (t[0] + t[1]) + (t[2] + t[3]);
+                if (live) { ag[i] += go[u][i] * xh[u][i]; ab[i] += go[u][i]; }
+            }
+        }
+        float c1[U], c2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { c1[u] = s1[u]; c2[u] = s2[u]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { c1[u] = wave_sum_dpp(c1[u]); c2[u] = wave_sum_dpp(c2[u]); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = row0 + u;
+            if (row >= r_end) break;
+            const float m1 = c1[u] / (float)D, m2 = c2[u] / (float)D;
+#pragma unroll
+            for (int i = 0; i < kLnVec; ++i) {
+                const int c = (lane + i * 64) * 4;
+                if (c < D) {
+                    const size_t idx = (size_t)row * D + c;
+                    f32x4 tot = (dy[u][i] - m1 - xh[u][i] * m2) * rstd[u];
+                    if (dres_in) tot += *(const f32x4*)(dres_in + idx);
+                    *(f32x4*)(dres_out + idx) = tot;
+                    f32x4 op = tot;
+                    if (p > 0.f && !(skip_mod > 0 && row % skip_mod == 0)) {      // (the sigma token's embedding has no dropout)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) op[j] *= drop_scale(seed, site, idx + j, p, inv_keep);
+                    }
+                    Vec4<E>::store(dxb + idx, op);
+                    ac[i] += op;
                 }
-                Vec4<E>::store(dxb + idx, op);
-                ac[i] += op;
             }
         }
     }
