@@ -175,14 +175,43 @@ def cpu_baseline(cfg, w, batch, budget_s=12.0):
                                    "what": "BASELINE configs[0]: kitchen, B=64, 10 DDIM steps, fp32 on CPU"}}
 
 
+def physical_core_sets(threads):
+    """Disjoint sets of `threads` PHYSICAL cores (one hardware thread per core, all of one package) for pinned workers:
+    [[cpu, ...], ...].  Round 3's all-core figure (16 unpinned processes x 16 threads on 256 hardware threads) came out
+    BELOW one 16-thread process -- oversubscribed SMT siblings and threads wandering across the sockets, not a baseline."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return []
+    by_pkg, seen = {}, set()
+    for c in allowed:
+        base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+        try:
+            sib = open(base + "thread_siblings_list").read().strip()
+            pkg = int(open(base + "physical_package_id").read())
+        except (OSError, ValueError):
+            sib, pkg = str(c), 0
+        if sib in seen:
+            continue                                   # an SMT sibling of a core that is already taken
+        seen.add(sib)
+        by_pkg.setdefault(pkg, []).append(c)
+    sets = []
+    for pkg in sorted(by_pkg):
+        cs = by_pkg[pkg]
+        sets += [cs[i:i + threads] for i in range(0, len(cs) - threads + 1, threads)]
+    return sets
+
+
 def cpu_baseline_multiprocess(cfg, batch, cores, run_s=8.0):
-    """The same ATen forward on ALL host cores: samples are independent, so P processes x 16 threads each take a disjoint
-    shard of the batch (ATen's intra-op pool stops scaling at ~16 threads on these GEMMs; processes do not share it).
-    Every worker warms up, waits for a common start time, runs its shard repeatedly for `run_s` seconds and reports
-    (samples processed, elapsed); the figure is sum(samples) / max(elapsed)."""
+    """The same ATen forward on ALL physical host cores: samples are independent, so P processes x 16 threads each take a
+    disjoint shard of the batch (ATen's intra-op pool stops scaling at ~16 threads on these GEMMs; processes do not share
+    it), every process PINNED to its own 16 physical cores of one socket (os.sched_setaffinity).  Every worker warms up,
+    waits for a common start time, runs its shard repeatedly for `run_s` seconds and reports (samples processed,
+    elapsed); the figure is sum(samples) / max(elapsed)."""
     threads = 16
-    procs = max(1, min(cores // threads, 16))
-    if procs == 1:
+    sets = physical_core_sets(threads)[:16]
+    procs = len(sets)
+    if procs <= 1:
         return None
     shard = max(16, batch // procs)
     t_start = time.time() + 12.0                        # (imports + warm-up of the workers)
@@ -191,7 +220,8 @@ def cpu_baseline_multiprocess(cfg, batch, cores, run_s=8.0):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", name,
            str(shard), str(threads), repr(t_start), repr(run_s)]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
-    kids = [subprocess.Popen(cmd + [str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(procs)]
+    kids = [subprocess.Popen(cmd + [str(i), ",".join(map(str, sets[i]))], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             text=True, env=env) for i in range(procs)]
     res = []
     for k in kids:
         try:
@@ -206,13 +236,18 @@ def cpu_baseline_multiprocess(cfg, batch, cores, run_s=8.0):
     samples = sum(r["samples"] for r in res)
     el = max(r["elapsed"] for r in res)
     return {"samples_per_s": samples / el, "denoise_steps_per_s_at_this_batch": samples / el / batch, "processes": procs,
-            "threads_per_process": threads, "cores": procs * threads, "shard": shard, "run_s": el,
-            "what": f"{procs} processes x {threads} ATen threads, each the fp32 forward over its own {shard}-sample shard, "
-                    f"common start, {run_s:.0f} s"}
+            "threads_per_process": threads, "cores": procs * threads, "shard": shard, "run_s": el, "pinned": True,
+            "what": f"{procs} processes x {threads} ATen threads, each pinned to its own {threads} physical cores of one socket, "
+                    f"each the fp32 forward over its own {shard}-sample shard, common start, {run_s:.0f} s"}
 
 
 def cpu_worker(argv):
     name, shard, threads, t_start, run_s, idx = argv[0], int(argv[1]), int(argv[2]), float(argv[3]), float(argv[4]), int(argv[5])
+    if len(argv) > 6 and argv[6]:
+        try:
+            os.sched_setaffinity(0, {int(c) for c in argv[6].split(",")})      # before the thread pools exist
+        except (AttributeError, OSError, ValueError):
+            pass
     from oracle import beso_oracle as O
     from oracle import beso_oracle_torch as OT
     from beso_amd import synthetic as S
@@ -321,10 +356,11 @@ def run_forward(args, world, rank, dev):
     state, goal, action = (torch.from_numpy(v).to(dev) for v in (s_np, g_np, a_np))
     sigma = torch.full((B,), 0.3, device=dev)
     rt = inner.runtime(cfg.sigma_data)
-    packed = inner.packed_weights()
 
     def step():
-        return rt.denoise(packed, state, action, goal, sigma, precondition=True)
+        # one step = the drop-in module's call, as a workspace makes it: GCDenoiser.forward(state, action, goal, sigma)
+        # (score_wrappers.py:81-96) -- incl. the packed-weight cache check of every call, not a pre-fetched image
+        return model(state, action, goal, sigma)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -358,8 +394,8 @@ def run_forward(args, world, rank, dev):
         if world == 1 and not args.no_parity_line and args.precision == "bf16" and args.config in ("kitchen", "block_push"):
             mx = build_model(cfg, w, "bf16x3", dev)
             ix = mx.inner_model
-            rtx, px = ix.runtime(cfg.sigma_data), ix.packed_weights()
-            stepx = lambda: rtx.denoise(px, state, action, goal, sigma, precondition=True)      # noqa: E731
+            rtx = ix.runtime(cfg.sigma_data)
+            stepx = lambda: mx(state, action, goal, sigma)      # noqa: E731
             for _ in range(3):
                 outx = stepx()
             rtx.profile_enable("fused_layer")
@@ -376,8 +412,8 @@ def run_forward(args, world, rank, dev):
             # the fp16-operand build of the same kernel, the same way; its deviation from the parity mode beside bf16's
             mh = build_model(cfg, w, "fp16", dev)
             ih = mh.inner_model
-            rth, ph = ih.runtime(cfg.sigma_data), ih.packed_weights()
-            steph = lambda: rth.denoise(ph, state, action, goal, sigma, precondition=True)      # noqa: E731
+            rth = ih.runtime(cfg.sigma_data)
+            steph = lambda: mh(state, action, goal, sigma)      # noqa: E731
             for _ in range(20):
                 outh = steph()
             rth.profile_enable("fused_layer")

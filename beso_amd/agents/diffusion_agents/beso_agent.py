@@ -206,6 +206,9 @@ class BesoAgent(BaseAgent):
         multiple of eval_every_n_steps (:153-154)."""
         best_test_mse, mean_mse, avg_test_mse = 1e10, 1e10, 1e10
         for epoch in range(epochs):
+            # (the all-gather that completes a sharded EMA shadow is issued HERE, on every rank: a rank whose test loader
+            # is empty never reaches evaluate() and would meet the others' all-gather with job_mean's all-reduce)
+            self._complete_ema()
             test_mse = [self.evaluate(batch) for batch in test_loader]
             # data parallel: the ranks draw different evaluation noise (and may hold different test shards), so the
             # early-stopping / checkpoint decision is taken on the job-wide mean -- the same on every rank; a rank deciding
@@ -240,6 +243,7 @@ class BesoAgent(BaseAgent):
         stream = iter(train_loader)
         for step in range(self.max_train_steps):
             if not self.steps % self.eval_every_n_steps:
+                self._complete_ema()          # on every rank, test batches or not (see train_agent_on_epochs)
                 scores = [self.evaluate(batch) for batch in test_loader]
                 # (job-wide mean: every rank takes the same checkpoint decision -- store_model_weights holds a collective)
                 mean = bdist.job_mean(sum(scores), len(scores), self.device)

@@ -23,7 +23,8 @@ DEV_LIB = os.path.join(LIBDIR, "libbeso_hip_dev.so")
 DEV_STAMP = os.path.join(LIBDIR, "libbeso_hip_dev.sha256")
 UNITS = ["api", "elementwise", "attention", "gemm", "fused", "fused_f16", "optim", "train", "feed"]
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fvisibility=hidden: the dynamic symbol table is exactly include/beso_hip.h (its declarations carry default visibility)
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:

@@ -276,6 +276,7 @@ static int forward(const beso_config* cfg, const void* packed, int precision, co
     a.uncond_from = two ? batch : (uncond ? 0 : a.vbatch);
     a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
     a.plan = flags & BESO_PLAN_MASK;
+    if (precision == BESO_PREC_FP16) a.plan &= ~(BESO_PLAN_PER_OP | BESO_PLAN_BLOCKS);      // (no per-op / block form: the hint is ignored, as the header says)
     const int level = precision == BESO_PREC_FP16 ? fused_level_f16(lay, a, BESO_PREC_BF16) : fused_level(lay, a, precision);
     // BF16X3 / FP16 are instances of the one-launch kernel (layers_kernel) -- BF16X3 also of its block-kernel form on the
     // long-sequence shape -- and have no per-op form
@@ -478,7 +479,7 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
         a.precondition = 1;
         a.uncond_from = two ? batch : (cond_lambda == 0.f ? 0 : a.vbatch);
         a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
-        a.plan = plan;
+        a.plan = precision == BESO_PREC_FP16 ? (plan & ~(BESO_PLAN_PER_OP | BESO_PLAN_BLOCKS)) : plan;      // (fp16 has no per-op / block form)
         if (!packed || !state || (cfg->goal_seq_len > 0 && !goal)) return BESO_ERR_BAD_ARG;
         const bool f16 = precision == BESO_PREC_FP16;
         if (!(flags & BESO_SAMPLE_STEPWISE) && (f16 ? fused_can_loop_f16(lay, a, BESO_PREC_BF16) : fused_can_loop(lay, a, precision))) {

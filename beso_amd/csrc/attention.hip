@@ -338,17 +338,14 @@ hipError_t launch_attention(const void* qkv, void* y, int vbatch, int T, int D, 
     if (precision == BESO_PREC_FP32) return launch_t<float>(qkv, y, vbatch, T, D, H, ld_y, s);
     const int hd = D / H;
     if (hd <= 64 && hd % 8 == 0 && D % 8 == 0 && T > 16 && T <= 16 * kAttMaxTiles) {
-        static bool attr = false;
         const int Tp = ((T + 15) / 16) * 16;
         const size_t pair_bytes = (size_t)(2 * Tp * kAttRow + 64 * (Tp + 8)) * 2;
         int ppw = (int)((size_t)(160 * 1024) / pair_bytes);          // pairs (= waves) per workgroup
         ppw = ppw >= 4 ? 4 : (ppw >= 2 ? 2 : 1);
         const size_t lds = (size_t)ppw * pair_bytes;
-        if (!attr) {
-            if (hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess) return hipErrorInvalidValue;
-            attr = true;
-        }
+        // (every call: the attribute belongs to the kernel on the CURRENT device, and this is not a hot launch site)
+        if (hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) return hipErrorInvalidValue;
         (void)hipGetLastError();
         const int n_pairs = vbatch * H;
         hipLaunchKernelGGL(attention_mfma_kernel, dim3((n_pairs + ppw - 1) / ppw), dim3(64 * ppw), lds, s, (const uint16_t*)qkv,

@@ -9,6 +9,22 @@
 #define BESO_DEV_API 0     // 1: the development build (libbeso_hip_dev.so, include/beso_hip_debug.h)
 #endif
 
+// Compile-time variants -- ablations that produce wrong results for timing, A/B switches of measured-and-decided choices
+// (the `#ifndef BESO_... / #define` blocks in fused.hip and train.hip document each) -- exist in VARIANT builds only
+// (tools/variants.py passes -DBESO_VARIANTS=1): the product sources refuse every override, so the shipped binary is the one
+// configuration the tests run.
+#ifndef BESO_VARIANTS
+#define BESO_VARIANTS 0
+#endif
+#if !BESO_VARIANTS
+#if defined(BESO_ABL_MASK) || defined(BESO_ZERO_PAD) || defined(BESO_FUSED_ABLATE) || defined(BESO_FUSED_WLOAD) || \
+    defined(BESO_RED_PAD) || defined(BESO_FUSED_STAMPS) || defined(BESO_GELU_SCALAR) || defined(BESO_FC1_PF) || \
+    defined(BESO_LAT_PF1) || defined(BESO_V_TR) || defined(BESO_LONG_PAIRED) || defined(BESO_LONG_PF1) || \
+    defined(BESO_TGEMM_WAVES) || defined(BESO_TGEMM_NOSTORE)
+#error "compile-time variants of the kernels need -DBESO_VARIANTS=1 (tools/variants.py); the product build takes none"
+#endif
+#endif
+
 namespace beso {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -28,6 +28,7 @@
 // not hide under MFMAs beyond about one per MFMA, and every workgroup streams all weights out of L2 --
 // so the code below counts VALU instructions, LDS/L2 bytes and padding MFMAs, not stalls.
 #include <stdlib.h>
+#include <atomic>
 #include "fused.h"
 
 // BESO_OPERAND_F16 = 1 (fused_f16.hip): the same kernels with fp16 GEMM operands -- v_mfma_f32_16x16x32_f16 runs at the bf16
@@ -710,6 +711,8 @@ constexpr int kKCc = kChunkTiles / 2;      // FC2 k-steps per hidden chunk (= kK
 // lanes of a row hit 4 banks groups four times over (reads of 16 B at a 64-B stride); 20 floats spread them over all 64 banks
 constexpr int kRedTok = 2 * kWaves + BESO_RED_PAD;
 constexpr int kXsBytes = 2048;        // the workgroup's action windows (n_real x t x act <= 512 floats): input of every evaluation
+// (every instance stages them: the bound is what fused_level admits -- kSPW samples x (kMT / kSPW tokens >= 2 t) x 4 kEmbActK
+//  action dims, or one long-sequence sample of 16 kLongNT / 2 steps)
 struct LdsMap {            // byte offsets inside the dynamic LDS block
     int xnT, u, red, tab, xs, total;
 };
@@ -1113,6 +1116,9 @@ struct EdgeArgs {
 };
 
 constexpr int kEmbObsK = 8, kEmbActK = 3;     // k-steps (4 inputs each) of the fused embedding GEMMs: obs <= 32, act <= 12
+static_assert(kSPW * ((kMT / kSPW - 1) / 2) * 4 * kEmbActK * 4 <= kXsBytes && ((16 * kLongNT - 1) / 2) * 4 * kEmbActK * 4 <= kXsBytes,
+              "xs holds the action windows of every shape fused_level admits (T = 1 + G + 2 t tokens per sample, kSPW T <= kMT or "
+              "one sample of T <= 16 kLongNT; act <= 4 kEmbActK); fused_layers checks the call's own sizes as well");
 
 // Which real sample and which conditioning a virtual sample stands for.
 __device__ __forceinline__ void sample_of(const EdgeArgs& e, int vb, int& b, bool& uncond) {
@@ -3169,21 +3175,35 @@ __global__ __launch_bounds__(512, 2) void train_fwd_kernel(const char* __restric
     layer(d.L - 1, std::integral_constant<int, NTLa>{}, rows_act, (uint16_t*)(a.ws + a.ya));
 }
 
+// phase stamps: the development build only (beso_debug_set_stamps); the product library carries no such state
+#if BESO_DEV_API
 unsigned long long* g_stamps = nullptr;
 int g_stamps_cap = 0;
+#else
+constexpr unsigned long long* g_stamps = nullptr;
+constexpr int g_stamps_cap = 0;
+#endif
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel ON A DEVICE: the "already set" flag of a launch site
+// is a bit per device (a process may drive several GPUs), written with a relaxed atomic (launch sites are reached from any
+// thread; setting the attribute twice is harmless)
+struct LdsAttr { std::atomic<unsigned long long> devices{0}; };
 template <typename K>
-hipError_t ensure_lds(K kernel, size_t bytes, bool* done) {
-    if (*done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) *done = true;
+hipError_t ensure_lds(K kernel, size_t bytes, LdsAttr* done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 64 && (done->devices.load(std::memory_order_relaxed) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev < 64) done->devices.fetch_or(bit, std::memory_order_relaxed);
     return e;
 }
 
 template <int RPW, int KS, int NW>
 hipError_t launch_mlp_block(float* x, const char* lw, const FusedDims& d, int M, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS, true);
-    static bool attr = false;
+    static LdsAttr attr;
     hipError_t e = ensure_lds(mlp_block_kernel<RPW, KS, NW>, L.total, &attr);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
@@ -3194,7 +3214,7 @@ hipError_t launch_mlp_block(float* x, const char* lw, const FusedDims& d, int M,
 template <int RPW, int KS>
 hipError_t launch_lin_blocks(int which, float* x, const char* lw, const FusedDims& d, int M, void* buf, int ld, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS, true);
-    static bool attr_q = false, attr_p = false;
+    static LdsAttr attr_q, attr_p;
     hipError_t e = which == 0 ? ensure_lds(qkv_block_kernel<RPW, KS>, L.total, &attr_q)
                               : ensure_lds(proj_block_kernel<RPW, KS>, L.total, &attr_p);
     if (e != hipSuccess) return e;
@@ -3213,7 +3233,7 @@ template <int RPW, int KS>
 hipError_t launch_tail_block(float* x, const char* lw, const char* lw_next, const FusedDims& d, int M, const void* y, int ld_y,
                              void* qkv, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS, true);
-    static bool attr = false;
+    static LdsAttr attr;
     hipError_t e = ensure_lds(tail_block_kernel<RPW, KS>, L.total, &attr);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
@@ -3226,7 +3246,7 @@ hipError_t launch_tail_block(float* x, const char* lw, const char* lw_next, cons
 template <int RPW, int KS, int HG, int NTL, int SPW, int NTA, int PX, int CORE, int LOOP>
 hipError_t launch_instance(size_t lds_bytes, int grid, float* x, const char* lw0, const FusedDims& d, int l0, int l1,
                            int n_samples, int Tn, const EdgeArgs& edge, const SampleSteps& steps, hipStream_t s) {
-    static bool attr = false;
+    static LdsAttr attr;
     hipError_t e = ensure_lds(layers_kernel<RPW, KS, HG, NTL, SPW, NTA, PX, CORE, LOOP>, lds_bytes, &attr);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
@@ -3474,7 +3494,7 @@ int fused_lin_x3(const Layout& lay, const char* packed, int layer, int next_laye
     if (!fused_dims(lay, &d) || !x3_long_shape(d)) return BESO_ERR_UNSUPPORTED;
     constexpr int NT = 3;
     using L = LdsMapLinX3<NT, 16>;
-    static bool attr = false;
+    static LdsAttr attr;
     if (ensure_lds(lin_block_x3_kernel<4, 16, NT>, L::total, &attr) != hipSuccess) return BESO_ERR_HIP;
     const char* base = packed + lay.fused;
     const char* lw = layer >= 0 ? base + (size_t)layer * d.layer_bytes : nullptr;
@@ -3585,13 +3605,13 @@ int fused_train_tail(const Layout& lay, const char* img, int layer, int M, const
     (void)hipGetLastError();
     if (d.RPW == 3) {
         constexpr LdsMap L = lds_map(12, true);
-        static bool attr = false;
+        static LdsAttr attr;
         e = ensure_lds(train_tail_kernel<3, 12>, L.total, &attr);
         if (e != hipSuccess) return BESO_ERR_HIP;
         hipLaunchKernelGGL((train_tail_kernel<3, 12>), grid, block, L.total, s, lw, lw_next, d, ti, M, a);
     } else {
         constexpr LdsMap L = lds_map(8, true);
-        static bool attr = false;
+        static LdsAttr attr;
         e = ensure_lds(train_tail_kernel<2, 8>, L.total, &attr);
         if (e != hipSuccess) return BESO_ERR_HIP;
         hipLaunchKernelGGL((train_tail_kernel<2, 8>), grid, block, L.total, s, lw, lw_next, d, ti, M, a);
@@ -3659,7 +3679,7 @@ template <int RPW, int KS, int HG, int NTL, int SPW, int NTA>
 static hipError_t launch_train_fwd(const char* img, const FusedDims& d, const TrainImgW& ti, int batch, int T,
                                    const TrainWholeBufs& a, hipStream_t s) {
     constexpr LdsMap L = lds_map(KS);
-    static bool attr = false;
+    static LdsAttr attr;
     hipError_t e = ensure_lds(train_fwd_kernel<RPW, KS, HG, NTL, SPW, NTA>, L.total, &attr);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
@@ -3719,6 +3739,8 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     // with a classifier-free pair the virtual samples are interleaved (2b, 2b+1) so that both halves of a
     // pair live in one workgroup; that ordering only exists inside the kernel, so the head must be fused too
     if (!d.head_fused) return BESO_ERR_UNSUPPORTED;
+    // every instance stages its workgroup's action windows in the kXsBytes of `xs`
+    if ((size_t)(d.seq1 ? 1 : kSPW) * a.t * lay.act * sizeof(float) > (size_t)kXsBytes) return BESO_ERR_UNSUPPORTED;
     if (fused_edges) *fused_edges = 3;
     hipError_t err;
     if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1, 2>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, precision, a.plan, s);    // kitchen: 8 x 4 action tokens
@@ -3728,12 +3750,11 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     return err == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
-#if !BESO_OPERAND_F16
+#if !BESO_OPERAND_F16 && BESO_DEV_API
 void fused_set_stamps(void* buf, int cap) {
     g_stamps = (unsigned long long*)buf;
     g_stamps_cap = cap;
 }
-
-#endif   // !BESO_OPERAND_F16
+#endif
 
 }  // namespace beso

@@ -44,6 +44,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: the entry points declared here are its whole dynamic symbol table */
+#pragma GCC visibility push(default)
 
 /* DiffusionGPT.__init__ kwargs that shape the computation (score_gpts.py:121-139) + GCDenoiser.sigma_data. */
 typedef struct beso_config {
@@ -300,6 +302,7 @@ enum {
 void beso_profile_enable(int site);
 int  beso_profile_read(double* total_ms, int* launches);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: the entry points declared here are its whole dynamic symbol table */
+#pragma GCC visibility push(default)
 
 /* Install a device buffer of `capacity_u64` uint64 slots; workgroup 0 of the fused kernels (built with
  * -DBESO_FUSED_STAMPS=1) appends {phase id, shader clock} pairs to it (NULL / 0 switches it off).               */
@@ -23,6 +25,7 @@ void beso_debug_set_stamps(void* device_buf, int capacity_u64);
 int beso_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,
                     int ldc, int M, int N, int K, int splits, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -220,6 +220,24 @@ def _loop_worker(rank, world, port, out, mode, c1, use_ema):
 
     agent.evaluate = fake_evaluate
     agent.store_model_weights = counting_store
+    if os.environ.get("TEST_FORCE_EMA_PARTIAL") == "1":
+        # On CPU the step never leaves the EMA shadow partial (that needs the HIP step + FusedAdam), so _complete_ema would be
+        # a no-op and the collective ORDER of the loops would go untested: mark the shadow partial after every step, which
+        # makes every _complete_ema a real all-gather over gloo (a rank without test data must still reach it).
+        real_step = agent.train_step
+
+        def step_leaving_the_shadow_partial(batch):
+            v = real_step(batch)
+            agent._ema_partial = True
+            return v
+        agent.train_step = step_leaving_the_shadow_partial
+        gathers = {"n": 0}
+        real_gather = agent._sharded().all_gather_flat_state
+
+        def counting_gather(flat):
+            gathers["n"] += 1
+            return real_gather(flat)
+        agent._sharded().all_gather_flat_state = counting_gather
     train = [_batch(cfg, 4, seed=11 + rank), _batch(cfg, 4, seed=21 + rank)]
     test = [_batch(cfg, 4, seed=31)] if (rank == 0 or mode == "epochs") else []      # steps mode: rank 1 has no test data
     if mode == "steps":
@@ -232,6 +250,11 @@ def _loop_worker(rank, world, port, out, mode, c1, use_ema):
     gathered = [torch.zeros_like(after) for _ in range(world)]
     dist.all_gather(gathered, after)
     assert torch.equal(gathered[0], gathered[1]), "replicas diverged"
+    if os.environ.get("TEST_FORCE_EMA_PARTIAL") == "1":
+        n = torch.tensor([float(gathers["n"])], dtype=torch.float64)
+        ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n)
+        assert ns[0].item() == ns[1].item() and ns[0].item() >= 1, ns     # the same all-gathers on both ranks, and they happened
     counts = torch.tensor([calls["eval"], calls["store"], agent.steps], dtype=torch.float64)
     both = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(both, counts)
@@ -239,6 +262,20 @@ def _loop_worker(rank, world, port, out, mode, c1, use_ema):
         torch.save({"counts": [b.tolist() for b in both]}, out)
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode", ["steps", "epochs"])
+def test_a_rank_without_test_data_still_joins_the_ema_all_gather(tmp_path, mode, monkeypatch):
+    """Sharded C1 leaves the EMA shadow partial; the all-gather that completes it must be reached by EVERY rank at the same
+    point of the loops -- also by a rank whose test loader is empty and therefore never calls evaluate() (steps mode below).
+    The loops issue it themselves in front of the evaluation list; with the gather only inside evaluate() this test hangs
+    (rank 1 goes straight to job_mean's all-reduce)."""
+    monkeypatch.setenv("TEST_FORCE_EMA_PARTIAL", "1")
+    out = str(tmp_path / "loops.pt")
+    mp.spawn(_loop_worker, args=(2, _free_port(), out, mode, "sharded", True), nprocs=2, join=True)
+    c = torch.load(out)["counts"]
+    assert c[0][1:] == c[1][1:], c
 
 
 @pytest.mark.timeout(300)

@@ -30,6 +30,8 @@ def build(specs):
         flags = [f for f in flags.split(",") if f]
         rev = [f for f in flags if f.startswith("@")]
         flags = [f for f in flags if not f.startswith("@")]
+        if any(f.startswith("-DBESO_") and not f.startswith("-DBESO_DEV_API") for f in flags):
+            flags.append("-DBESO_VARIANTS=1")          # (csrc/common.h: the product sources refuse variant macros without it)
         if rev:
             # "@<git revision>": the whole csrc/ + include/ tree as of that commit (A/B against history on one GPU
             # box even when the internal interfaces between the units changed since)
