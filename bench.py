@@ -316,6 +316,11 @@ def measure_traffic(args, kernel_substr="layers_kernel"):
 # ------------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------------
+def _sync():
+    if torch.cuda.is_available():       # (the gloo dry runs of the N > 1 paths have no device to wait for)
+        torch.cuda.synchronize()
+
+
 def settle(step, ms):
     """Untimed: run the step until the clocks have left their idle state (a cold MI355X takes ~100 ms of load to reach
     its sustained clock; with 5 warm-up steps of 0.9 ms the first timed steps run ~4 % slow)."""
@@ -326,20 +331,20 @@ def settle(step, ms):
     while (time.perf_counter() - t0) * 1e3 < ms:
         for _ in range(20):
             step()
-        torch.cuda.synchronize()
+        _sync()
         n += 20
     return n
 
 
 def timed(step, steps, world):
-    torch.cuda.synchronize()
+    _sync()
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     out = None
     for _ in range(steps):
         out = step()
-    torch.cuda.synchronize()
+    _sync()
     if world > 1:
         torch.distributed.barrier()
     return time.perf_counter() - t0, out
@@ -591,9 +596,11 @@ def run_train(args, world, rank, dev):
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    if getattr(args, "keep_agent", None) is not None:
+        args.keep_agent.append(agent)                       # (tests: the replicas' parameters after the run)
     if rank != 0:
         return None
-    assert np.isfinite(loss) and getattr(agent, "_hip_step", None) is not None
+    assert np.isfinite(loss) and (getattr(agent, "_hip_step", None) is not None or str(dev) == "cpu")
     flops = 3.0 * cfg.flops_per_sample() * B                # forward + data gradients + weight gradients, per GPU
     ms = 1e3 * elapsed / args.steps
     ach = flops / (ms * 1e-3) / 1e12

@@ -116,6 +116,6 @@ class GCDenoiser(nn.Module):
             return None
         if sampler == "euler_ancestral":
             return inner.runtime(self.sigma_data).sample_ancestral(inner.packed_weights(), state, x_t, goal, sigmas,
-                                                                   cond_lambda=cond_lambda, eta=eta, noise=noise)
+                                                                   cond_lambda=cond_lambda, eta=eta, noise=noise, stepwise=stepwise)
         return inner.runtime(self.sigma_data).sample(inner.packed_weights(), sampler, state, x_t, goal, sigmas,
                                                      cond_lambda=cond_lambda, stepwise=stepwise)

@@ -458,14 +458,14 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
             // t = -log(sigma); h = t_next - t; x = (sigma_fn(t_next)/sigma_fn(t))*x - expm1(-h)*den
             const float tt = -logf(si), tn = -logf(sn);      // sn == 0 -> tn = +inf -> x = den exactly
             const float h = tn - tt;
-            recs.push_back(StepRec{si, expf(-tn) / expf(-tt), expm1f(-h), BESO_STEP_DDIM});
+            recs.push_back(StepRec{si, expf(-tn) / expf(-tt), expm1f(-h), BESO_STEP_DDIM, 0.f});
         } else if (sampler == BESO_SAMPLER_EULER || sn == 0.f) {
             // gamma = 0: sigma_hat = sigma_i; d = (x - den)/sigma_hat; x += d*(sigma_next - sigma_hat)
-            recs.push_back(StepRec{si, si, sn - si, BESO_STEP_EULER});
+            recs.push_back(StepRec{si, si, sn - si, BESO_STEP_EULER, 0.f});
         } else {
             // Heun: predictor, second evaluation at sigma_{i+1}, trapezoid corrector
-            recs.push_back(StepRec{si, si, sn - si, BESO_STEP_HEUN_PREDICT});
-            recs.push_back(StepRec{sn, sn, sn - si, BESO_STEP_HEUN_CORRECT});
+            recs.push_back(StepRec{si, si, sn - si, BESO_STEP_HEUN_PREDICT, 0.f});
+            recs.push_back(StepRec{sn, sn, sn - si, BESO_STEP_HEUN_CORRECT, 0.f});
         }
     }
     step_first.push_back((int)recs.size());
@@ -539,7 +539,9 @@ int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precis
                           const float* noise, int flags, void* workspace, size_t workspace_bytes, void* stream) {
     int st = validate_config(cfg);
     if (st != BESO_OK) return st;
-    if (!sigmas || n_sigmas < 2 || !x || !workspace || !noise || !(eta >= 0.f) || (flags & ~BESO_PLAN_MASK)) return BESO_ERR_BAD_ARG;
+    if (!sigmas || n_sigmas < 2 || !x || !workspace || !noise || !(eta >= 0.f) || (flags & ~(BESO_PLAN_MASK | BESO_SAMPLE_STEPWISE)))
+        return BESO_ERR_BAD_ARG;
+    const int plan = flags & BESO_PLAN_MASK;
     if (batch < 1 || t < 1 || t > cfg->obs_seq_len) return BESO_ERR_BAD_SHAPE;
     Layout lay;
     Workspace ws;
@@ -553,21 +555,60 @@ int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precis
     float* den = (float*)(wsp + ws.den);
     float* sig = (float*)(wsp + ws.sig);
     const size_t n = (size_t)batch * t * lay.act;
-    for (int i = 0; i + 1 < n_sigmas; ++i) {
-        const float sf = sigmas[i], sn = sigmas[i + 1];
-        // get_ancestral_step (:107-114) in fp32
-        float down = sn, up = 0.f;
+    // get_ancestral_step (:107-114) in fp32
+    auto ancestral = [&](float sf, float sn, float& down, float& up) {
+        down = sn; up = 0.f;
         if (eta != 0.f) {
             up = eta * sqrtf(sn * sn * (sf * sf - sn * sn) / (sf * sf));
             if (sn < up) up = sn;
             down = sqrtf(sn * sn - up * up);
         }
-        uint32_t bits; memcpy(&bits, &sf, 4);
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)sig, (int)bits, (size_t)batch, s));
-        st = beso_denoise_fwd(cfg, packed, precision, state, x, goal, sig, den, batch, t, flags, cond_lambda, workspace,
+    };
+    {
+        // ONE launch for the whole loop (as beso_sample): every step is an Euler update to sigma_down followed by the caller's
+        // noise of that step times sigma_up, both applied in the kernel's head by the workgroup that owns the sample
+        FwdArgs a;
+        a.state = state; a.action = x; a.goal = goal; a.sigma = sig; a.out = x; a.aux = nullptr;
+        a.batch = batch; a.vbatch = two ? 2 * batch : batch; a.t = t; a.T = 1 + lay.G + 2 * t;
+        a.precondition = 1;
+        a.uncond_from = two ? batch : (cond_lambda == 0.f ? 0 : a.vbatch);
+        a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
+        a.plan = precision == BESO_PREC_FP16 ? (plan & ~(BESO_PLAN_PER_OP | BESO_PLAN_BLOCKS)) : plan;
+        if (!packed || !state || (cfg->goal_seq_len > 0 && !goal)) return BESO_ERR_BAD_ARG;
+        const bool f16 = precision == BESO_PREC_FP16;
+        if (!(flags & BESO_SAMPLE_STEPWISE) && (f16 ? fused_can_loop_f16(lay, a, BESO_PREC_BF16) : fused_can_loop(lay, a, precision))) {
+            const int n_steps = n_sigmas - 1;
+            for (int i0 = 0; i0 < n_steps; i0 += kMaxLoopEvals) {
+                SampleSteps S{};
+                S.n = n_steps - i0 < kMaxLoopEvals ? n_steps - i0 : kMaxLoopEvals;
+                for (int k = 0; k < S.n; ++k) {
+                    const float sf = sigmas[i0 + k], sn = sigmas[i0 + k + 1];
+                    float down, up;
+                    ancestral(sf, sn, down, up);
+                    S.rec[k] = StepRec{sf, sf, down - sf, BESO_STEP_EULER | (down > 0.f ? kStepAddNoise : 0), up};      // :240-247
+                }
+                a.noise = noise + (size_t)i0 * n;
+                profile_begin(BESO_SITE_FUSED_LAYER, s);
+                st = f16 ? fused_layers_f16(lay, (const char*)packed, a, (float*)(wsp + ws.x), nullptr, BESO_PREC_BF16, s, &S)
+                         : fused_layers(lay, (const char*)packed, a, (float*)(wsp + ws.x), nullptr, precision, s, &S);
+                profile_end(BESO_SITE_FUSED_LAYER, s);
+                if (st != BESO_OK) return st;
+            }
+            return BESO_OK;
+        }
+    }
+    for (int i = 0; i + 1 < n_sigmas; ++i) {
+        const float sf = sigmas[i], sn = sigmas[i + 1];
+        float down, up;
+        ancestral(sf, sn, down, up);
+        if (i == 0) {        // (the sigma vector of every later step is written by the previous step's update launch)
+            uint32_t bits; memcpy(&bits, &sf, 4);
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)sig, (int)bits, (size_t)batch, s));
+        }
+        st = beso_denoise_fwd(cfg, packed, precision, state, x, goal, sig, den, batch, t, plan, cond_lambda, workspace,
                               workspace_bytes, stream);
         if (st != BESO_OK) return st;
-        HIP_TRY(launch_sampler_step(BESO_STEP_EULER, x, nullptr, x, nullptr, den, sf, down - sf, n, s));     // :240-245
+        HIP_TRY(launch_sampler_step(BESO_STEP_EULER, x, nullptr, x, nullptr, den, sf, down - sf, n, s, sig, sn, batch));     // :240-245
         if (down > 0.f) HIP_TRY(launch_sampler_step(BESO_STEP_ADD_NOISE, x, nullptr, x, noise + (size_t)i * n, x, up, 0.f, n, s));
     }
     return BESO_OK;

@@ -204,6 +204,7 @@ struct FwdArgs {
     const float* state; const float* action; const float* goal; const float* sigma;
     float* out;
     float* aux = nullptr;   // sampler loop only: [B][t][act] scratch (Heun's first slope between its two evaluations)
+    const float* noise = nullptr;   // sampler loop, euler_ancestral: [evaluations of the launch][B][t][act], the steps' randn
     int batch;        // real batch B
     int vbatch;       // virtual batch: B or 2B (classifier-free guidance)
     int t;            // observations in the window

@@ -8,11 +8,14 @@ namespace beso {
 // is evaluated at (the same for every sample) and the update that follows it in the head (BESO_STEP_* with the coefficients
 // of beso_sampler_step).  Travels as a kernel argument: no table in device memory, nothing to copy, graph-capturable.
 constexpr int kMaxLoopEvals = 128;
-struct StepRec { float sigma, c0, c1; int mode; };
+// mode: BESO_STEP_* | kStepAddNoise (euler_ancestral: behind the update, x += noise[evaluation] * c2 -- the caller's randn of
+// that step, gc_sampling.py:246-247)
+constexpr int kStepAddNoise = 0x100;
+struct StepRec { float sigma, c0, c1; int mode; float c2; };
 struct SampleSteps {
     int n;                         // evaluations of this launch; 0: one plain forward (per-sample sigma, out <- denoised)
     int pad[3];
-    StepRec rec[kMaxLoopEvals];
+    StepRec rec[kMaxLoopEvals];          // 20 B each: 2.5 KiB of the 4 KiB kernel argument
 };
 constexpr int kLoopMaxElems = 512;   // action-window elements per workgroup the loop can carry (one per thread)
 

@@ -1111,6 +1111,7 @@ struct EdgeArgs {
     const float* sigma;    // [B]
     float* out;            // [B][t][act]
     float* aux;            // [B][t][act] scratch of the sampler loop (Heun's first slope), or nullptr
+    const float* noise;    // [evaluations][B][t][act]: the randn of every ancestral step of the launch, or nullptr
     int B, t, precondition, uncond_all, two;   // two: classifier-free pair (cond, uncond) = virtual samples (2b, 2b+1)
     float cond_lambda, sigma_data;
 };
@@ -1342,9 +1343,11 @@ __device__ __forceinline__ void embed_tile(Tile<RPW>& T, const EdgeArgs& e, cons
 // `aux`) in global memory between its two evaluations -- written and read back by the same thread.  The caller's barrier
 // behind this function orders the xs write against the next embed.
 struct LoopState {
-    int mode;              // -1: a single forward (out <- denoised); else the BESO_STEP_* update of this evaluation
+    int mode;              // -1: a single forward (out <- denoised); else the BESO_STEP_* update of this evaluation (| kStepAddNoise)
     float c0, c1, sigma;   // the step's coefficients; sigma of this evaluation (> 0: uniform over the batch)
     bool last;             // the last evaluation of the launch: x goes out
+    float c2;              // kStepAddNoise: sigma_up
+    int ev;                // index of the evaluation inside the launch (its slab of EdgeArgs::noise)
 };
 template <int RPW, int NT = kNTT>
 __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw,
@@ -1420,10 +1423,17 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
         else {
             float* daux = e.aux + (size_t)b0 * e.t * act + it;
             float xv = av, x2v = 0.f, d1 = 0.f;
-            if (ls.mode == BESO_STEP_HEUN_CORRECT) { xv = *dst; x2v = av; d1 = *daux; }      // (wave-uniform)
-            const float o = sampler_update(ls.mode, xv, x2v, r, d1, ls.c0, ls.c1);
+            const int mode = ls.mode & 0xff;
+            if (mode == BESO_STEP_HEUN_CORRECT) { xv = *dst; x2v = av; d1 = *daux; }      // (wave-uniform)
+            float o = sampler_update(mode, xv, x2v, r, d1, ls.c0, ls.c1);
+            if (ls.mode & kStepAddNoise) {
+                // sample_euler_ancestral (gc_sampling.py:246-247): x <- x + randn * sigma_up, the step's draw supplied by the
+                // caller; two rounded operations, as BESO_STEP_ADD_NOISE of the step-by-step form
+                const float nz = e.noise[((size_t)ls.ev * e.B + b0) * e.t * act + it] * ls.c2;
+                o = o + nz;
+            }
             xs[it] = o;
-            if (ls.mode == BESO_STEP_HEUN_PREDICT) { *dst = xv; *daux = d1; }
+            if (mode == BESO_STEP_HEUN_PREDICT) { *dst = xv; *daux = d1; }
             else if (ls.last) *dst = o;
         }
     }
@@ -1913,6 +1923,9 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                 f32x4 sT = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
+                    // (a k-half none of whose 32 dims belong to head h contributes exact zeros: skipped -- block-push, three
+                    // heads of 20 in 64: heads 0 and 2 live in one half each, 4 instead of 6 MFMAs per sample and virtual head)
+                    if (!(32 * kk < hi_d && 32 * kk + 32 > lo_d)) continue;          // wave-uniform
                     u32x4 qm;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
@@ -2957,7 +2970,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     const bool actions_first = CORE == 0;
     build_slot_tabs(tb, n_samples, Tn, e.t, d.G, actions_first, CORE == 1 ? 7 : 4);
     // the action windows of the workgroup's real samples (contiguous in `action`): x_T of the sampler loop / the noisy action
-    LoopState ls{-1, 0.f, 0.f, 0.f, true};
+    LoopState ls{-1, 0.f, 0.f, 0.f, true, 0.f, 0};
     {
         int b0; bool un0;
         sample_of(e, s0, b0, un0);
@@ -3079,7 +3092,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     stamp(st, 4);
     if constexpr (LOOP) {
         const StepRec rec = S.rec[ev];
-        ls.mode = rec.mode; ls.c0 = rec.c0; ls.c1 = rec.c1;
+        ls.mode = rec.mode; ls.c0 = rec.c0; ls.c1 = rec.c1; ls.c2 = rec.c2; ls.ev = ev;
         ls.last = ev + 1 == n_evals;
     }
     {
@@ -3732,6 +3745,7 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     EdgeArgs e;
     e.state = a.state; e.action = a.action; e.goal = a.goal; e.sigma = a.sigma; e.out = a.out;
     e.aux = a.aux;
+    e.noise = a.noise;
     e.B = a.batch; e.t = a.t; e.precondition = a.precondition;
     e.two = a.vbatch > a.batch ? 1 : 0;
     e.uncond_all = (!e.two && a.uncond_from == 0) ? 1 : 0;

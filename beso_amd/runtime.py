@@ -237,8 +237,9 @@ class ScoreNetRuntime:
         return x
 
     def sample_ancestral(self, packed: PackedWeights, state, x_t, goal, sigmas, cond_lambda: float = 1.0, eta: float = 1.0,
-                         noise=None) -> torch.Tensor:
-        """sample_euler_ancestral as ONE enqueue of all steps (``beso_sample_ancestral``).  The per-step noise is drawn
+                         noise=None, stepwise: bool = False) -> torch.Tensor:
+        """sample_euler_ancestral as ONE enqueue of all steps (``beso_sample_ancestral``) -- one LAUNCH for the whole loop
+        where the shape has the one-launch kernel (``stepwise``: evaluation by evaluation, bit-identical).  The per-step noise is drawn
         here, one ``torch.randn_like`` per step that adds noise and in the order of the steps -- the calls the reference's
         loop makes, so a seeded generator gives the same draws as the step-by-step loop; ``noise`` [n_steps, B, t, act]
         injects them instead."""
@@ -265,7 +266,8 @@ class ScoreNetRuntime:
         with torch.cuda.device(dev):
             st = self.lib.beso_sample_ancestral(C.byref(self.cfg), packed.buf.data_ptr(), packed.precision, state.data_ptr(), gp,
                                                 x.data_ptr(), B, t, arr, len(sig), float(cond_lambda), float(eta),
-                                                noise.data_ptr(), forward_hints(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+                                                noise.data_ptr(), (_lib.SAMPLE_STEPWISE if stepwise else 0) | forward_hints(),
+                                                ws.data_ptr(), ws.numel(), _stream_ptr(dev))
         _lib.check(st, "sample[euler_ancestral]")
         return x
 

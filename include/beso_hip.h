@@ -188,8 +188,10 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
  * while sigma_down > 0, x += noise_i * sigma_up (get_ancestral_step: :107-114, fp32).  `noise` is a DEVICE array of
  * n_sigmas - 1 standard-normal tensors [batch,t,act] back to back -- the reference's `torch.randn_like(action)` of each
  * step, drawn by the caller (the library has no random number generator); entries of steps with sigma_down = 0 are not
- * read.  One forward launch + one or two update launches per step (the noise makes the steps the caller's business).
- * `flags`: BESO_PLAN_* hints.  Everything else as beso_sample.                                                        */
+ * read.  Where the shape has the one-launch kernel the WHOLE loop is ONE launch, as in beso_sample: the workgroup that owns
+ * a sample applies the Euler update and adds its slice of the step's noise in the kernel's head.  Otherwise, and with
+ * BESO_SAMPLE_STEPWISE, one forward launch + one or two update launches per step (bit-identical results).
+ * `flags`: BESO_PLAN_* hints | BESO_SAMPLE_STEPWISE.  Everything else as beso_sample.                                  */
 int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precision, const float* state, const float* goal,
                           float* x, int batch, int t, const float* sigmas, int n_sigmas, float cond_lambda, float eta,
                           const float* noise, int flags, void* workspace, size_t workspace_bytes, void* stream);

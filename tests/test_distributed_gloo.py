@@ -296,3 +296,40 @@ def test_two_rank_training_loops_take_joint_decisions(tmp_path, mode, c1, use_em
     else:
         # job means 1.0, 1.2, ...: epoch 0 improves, epoch 1 does not -> both stop there (rank 0 alone never would)
         assert c[0][0] == 2 and c[1][0] == 2 and c[0][1] == 2, c
+
+
+def _bench_train_worker(rank, world, port, c1):
+    """bench.py's `--workload train` leg (run_train: BesoAgent.train_step on every rank's own batch, C1 as configured) on two
+    gloo ranks: after 20 + warm-up steps the replicas hold identical parameters and an identical EMA shadow."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      BESO_AMD_C1=c1)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from autograd_reference import install_autograd_training
+    install_autograd_training()
+    import argparse
+    import bench
+    from beso_amd import distributed as bdist
+    assert bdist.init_from_env("gloo")
+    torch.set_num_threads(4)
+    args = argparse.Namespace(config="block_push", batch=2, steps=20, warmup=2, settle_ms=0.0, precision="fp32", c1_overlap=1,
+                              keep_agent=[])
+    res = bench.run_train(args, world, rank, "cpu")
+    assert (res is not None) == (rank == 0)
+    if rank == 0:
+        assert res["n_gpus"] == 2 and res["steps"] == 20 and np.isfinite(res["loss"])
+    agent = args.keep_agent[0]
+    agent._complete_ema()                                    # (sharded C1: the shadow is gathered before it is read)
+    for name, flat in (("parameters", torch.cat([q.detach().reshape(-1) for q in agent.model.get_params()])),
+                       ("EMA shadow", agent.ema_helper._flat.detach().reshape(-1).clone())):
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1]), f"{name} differ between the ranks after the run ({c1})"
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("c1", ["overlap", "sharded", "flat"])
+def test_bench_train_workload_keeps_two_gloo_replicas_identical(c1):
+    mp.spawn(_bench_train_worker, args=(2, _free_port(), c1), nprocs=2, join=True)

@@ -466,6 +466,24 @@ def test_sampler_loop_is_one_launch_and_equals_the_stepwise_loop(cfg_name, preci
                 assert n_step == n_evals, (sampler, n_steps, n_step)
                 assert torch.isfinite(out["loop"]).all()
                 assert torch.equal(out["loop"], out["step"]), (cfg_name, precision, B, t, sampler, n_steps)
+            # sample_euler_ancestral (gc_sampling.py:216-256; the README's recommended kitchen sampler): Euler to sigma_down,
+            # then the caller's noise of the step times sigma_up -- one launch as well (round 4), eta = 1 and eta = 0
+            for n_steps, eta in ((5, 1.0), (3, 0.0), (130, 1.0)):
+                if n_steps == 130 and (B > 200 or t != cfg.obs_seq_len):
+                    continue
+                sig = ks.get_sigmas_exponential(n_steps, 0.05, 1.0)
+                nz = torch.randn((n_steps,) + tuple(x.shape), device=DEV, generator=torch.Generator(DEV).manual_seed(5))
+                out = {}
+                n_loop = count_fused_launches(lambda: out.__setitem__(
+                    "loop", m.fused_sampler("euler_ancestral", s, x, g, sig, cond_lambda=lam, eta=eta, noise=nz)))
+                n_step = count_fused_launches(lambda: out.__setitem__(
+                    "step", m.fused_sampler("euler_ancestral", s, x, g, sig, cond_lambda=lam, eta=eta, noise=nz, stepwise=True)))
+                assert (n_loop, n_step) == ((n_steps + 127) // 128, n_steps), (n_loop, n_step)
+                assert torch.isfinite(out["loop"]).all()
+                assert torch.equal(out["loop"], out["step"]), (cfg_name, precision, B, t, "euler_ancestral", n_steps, eta)
+                if eta == 1.0 and n_steps == 5:      # the noise matters
+                    other = m.fused_sampler("euler_ancestral", s, x, g, sig, cond_lambda=lam, eta=eta, noise=nz * 0.5)
+                    assert not torch.equal(other, out["loop"])
 
 
 def test_stochastic_and_adaptive_samplers_on_gpu():
