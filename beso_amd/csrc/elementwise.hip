@@ -351,7 +351,11 @@ __global__ void sampler_step_kernel(int mode, float* __restrict__ out, float* __
         const float xv = x[i], dv = den[i];
         float r;
         if (mode == BESO_STEP_ADD_NOISE) {
-            r = xv + x2[i] * c0;
+            // action + randn * sigma_up (gc_sampling.py:246-247): a product and a sum, each rounded, as torch evaluates it (not
+            // an fma) -- and as the head of the one-launch loop does, with which this form agrees bit for bit
+#pragma clang fp contract(off)
+            const float nz = x2[i] * c0;
+            r = xv + nz;
         } else {
             float a = (mode == BESO_STEP_HEUN_CORRECT) ? aux[i] : 0.f;
             r = sampler_update(mode, xv, mode == BESO_STEP_HEUN_CORRECT ? x2[i] : 0.f, dv, a, c0, c1);
