@@ -540,9 +540,16 @@ __global__ void pack_table_kernel(PackTable t, uint32_t total4) {
 // ---------------------------------------------------------------------------------------------
 // prep: noised = a + n*sigma; target = (a - c_skip*noised)/c_out            (score_wrappers.py:64-69)
 // ---------------------------------------------------------------------------------------------
+// ... and the step's two small initialisations (launches of their own before): the loss accumulator, and the head bias padded
+// to the ap columns of the head GEMM.
 __global__ void prep_kernel(const float* __restrict__ action, const float* __restrict__ noise,
                             const float* __restrict__ sigma, float* __restrict__ noised, float* __restrict__ target,
-                            int per_sample, size_t n, float sigma_data) {
+                            int per_sample, size_t n, float sigma_data, float* __restrict__ loss, float* __restrict__ b_head,
+                            const float* __restrict__ head_bias, int act, int ap) {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) *loss = 0.f;
+        for (int c = threadIdx.x; c < ap; c += blockDim.x) b_head[c] = c < act ? head_bias[c] : 0.f;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float sg = sigma[i / per_sample];
         const float sd2 = sigma_data * sigma_data, den = sg * sg + sd2;
@@ -1026,12 +1033,27 @@ __device__ __forceinline__ float dot_rows(const float* a, const float* b, int hd
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
+// all-reduce over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15): every lane receives the row's sum / maximum
+template <bool IS_MAX>
+__device__ __forceinline__ float row16_allreduce(float v) {
+    auto dpp = [](float x, auto CTRL) {
+        return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), decltype(CTRL)::value, 0xf, 0xf, false));
+    };
+    auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; };
+    v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));       // quad_perm [1,0,3,2]
+    v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));       // quad_perm [2,3,0,1]
+    v = op(v, dpp(v, std::integral_constant<int, 0x124>{}));      // row_ror:4
+    v = op(v, dpp(v, std::integral_constant<int, 0x128>{}));      // row_ror:8
+    return v;
+}
+
 template <typename E, bool BWD, int TT>          // TT = T rounded up to a multiple of 4 (8, 12 or 16)
 __global__ __launch_bounds__(64) void attn_small_kernel(const E* __restrict__ qkv, const E* __restrict__ dy,
                                                         E* __restrict__ out, int T, int D, int H, int hd, float scale,
                                                         float p, float inv_keep, uint32_t seed, uint32_t site) {
-    __shared__ __attribute__((aligned(16))) float sq[TT][kLdh], sk[TT][kLdh], sv[BWD ? TT : 1][kLdh],
-        sdy[BWD ? TT : 1][kLdh];
+    // q | k rows for the scores; the backward then re-uses the two buffers for dy | v (round 4: 15 -> 9.4 KiB per wave, i.e.
+    // 16 instead of 10 waves per CU -- the kernel is a latency chain per (sample, head), so waves in flight are its rate)
+    __shared__ __attribute__((aligned(16))) float sq[TT][kLdh], sk[TT][kLdh];
     __shared__ __attribute__((aligned(16))) float sP[TT][kLdt], sdP[BWD ? TT : 1][kLdt];
     const int pair = blockIdx.x, b = pair / H, h = pair % H, lane = threadIdx.x;
     const size_t ldq = (size_t)3 * D;
@@ -1062,45 +1084,44 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const E* __restrict__ qk
         }
     }
 #pragma unroll
-    for (int r = 0; r < TT; ++r) {
-        sq[r][lane] = qr[r];
-        sk[r][lane] = kr[r];
-        if (BWD) { sv[r][lane] = vr[r]; sdy[r][lane] = gr[r]; }
-    }
+    for (int r = 0; r < TT; ++r) { sq[r][lane] = qr[r]; sk[r][lane] = kr[r]; }
     __syncthreads();
+    // scores on the 4 x 16 lane grid: lane (il, j) holds S[4 ib + il][j] for ib = 0 .. TT/4 - 1
     const int il = lane >> 4, j = lane & 15;
-    // scores (and, backward, dPd = dy v^T) on the 4 x 16 lane grid
+    float sc[TT / 4], dpd[TT / 4];
 #pragma unroll
     for (int ib = 0; ib < TT / 4; ++ib) {
         const int i = ib * 4 + il;
         const bool in = i < T && j <= i;
-        if (j < kLdt) {
-            sP[i][j] = in ? dot_rows(sq[i], sk[j < TT ? j : 0], hd) * scale : -INFINITY;
-            if (BWD) sdP[i][j] = in ? dot_rows(sdy[i], sv[j < TT ? j : 0], hd) : 0.f;
+        sc[ib] = in ? dot_rows(sq[i], sk[j < TT ? j : 0], hd) * scale : -INFINITY;
+    }
+    if (BWD) {
+        __syncthreads();                              // every score is read: dy | v take the buffers' place
+#pragma unroll
+        for (int r = 0; r < TT; ++r) { sq[r][lane] = gr[r]; sk[r][lane] = vr[r]; }
+        __syncthreads();
+#pragma unroll
+        for (int ib = 0; ib < TT / 4; ++ib) {
+            const int i = ib * 4 + il;
+            dpd[ib] = (i < T && j <= i) ? dot_rows(sq[i], sk[j < TT ? j : 0], hd) : 0.f;      // dPd = dy v^T
         }
     }
-    __syncthreads();
-    // row softmax (lane i), dropout scale folded: sP <- Pd = P * keep-scale; backward also dS (pre-scaled by `scale`)
-    if (lane < T) {
-        const int i = lane;
-        float m = -INFINITY, pr[TT], l = 0.f;
+    // row softmax IN the lane grid (a row's 16 columns are the 16 lanes of a DPP row): max, exp, sum, the dropout keep-scale
+    // of the lane's own element and -- backward -- dS, all lanes busy (round 3: T lanes, each a serial loop over its row)
 #pragma unroll
-        for (int c = 0; c < TT; ++c) m = fmaxf(m, sP[i][c]);
-#pragma unroll
-        for (int c = 0; c < TT; ++c) { pr[c] = c <= i ? expf(sP[i][c] - m) : 0.f; l += pr[c]; }
-        const float inv = 1.0f / l;
-        float ks[TT], dot = 0.f;
-#pragma unroll
-        for (int c = 0; c < TT; ++c) {
-            pr[c] *= inv;
-            ks[c] = (p > 0.f && c <= i) ? drop_scale(seed, site, (size_t)pair * T * T + (size_t)i * T + c, p, inv_keep) : 1.f;
-            if (BWD) dot = fmaf(sdP[i][c] * ks[c], pr[c], dot);
+    for (int ib = 0; ib < TT / 4; ++ib) {
+        const int i = ib * 4 + il;
+        const bool in = i < T && j <= i;
+        const float m = row16_allreduce<true>(sc[ib]);
+        const float e = in ? expf(sc[ib] - m) : 0.f;
+        const float l = row16_allreduce<false>(e);
+        const float pr = in ? e * (1.0f / l) : 0.f;
+        const float ks = (p > 0.f && in) ? drop_scale(seed, site, (size_t)pair * T * T + (size_t)i * T + j, p, inv_keep) : 1.f;
+        if (BWD) {
+            const float dot = row16_allreduce<false>(dpd[ib] * ks * pr);
+            if (i < TT && j < kLdt) sdP[i][j] = pr * (dpd[ib] * ks - dot) * scale;       // dS
         }
-#pragma unroll
-        for (int c = 0; c < TT; ++c) {
-            if (BWD) sdP[i][c] = pr[c] * (sdP[i][c] * ks[c] - dot) * scale;       // dS
-            sP[i][c] = pr[c] * ks[c];                                               // Pd
-        }
+        if (i < TT && j < kLdt) sP[i][j] = pr * ks;                                       // Pd
     }
     __syncthreads();
     if (!act) return;
@@ -1397,9 +1418,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     const PG hw = take((size_t)act * (mlp_head ? Hh : D)), hb = take(act);
     const size_t n_grad = (size_t)(g - gflat);
 
-    TRY(hipMemsetAsync(gflat, 0, sizeof(float) * n_grad, s));
-    TRY(hipMemsetAsync(loss_out, 0, sizeof(float), s));
-    TRY(hipMemsetAsync(ws + w.b_head, 0, sizeof(float) * ap, s));
+    TRY(hipMemsetAsync(gflat, 0, sizeof(float) * n_grad, s));      // (loss_out and the padded head bias: prep_kernel)
 
     // ---- operand-typed weight copies (fused q|k|v rows as in the inference image), one launch per layer
     for (int l = 0; l < L; ++l) {
@@ -1431,14 +1450,13 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     } else {
         TRY(launch_pack_matrix(hw.p, act, D, ws + w.w_head, ap, D, precision, s));
     }
-    TRY(hipMemcpyAsync(ws + w.b_head, hb.p, sizeof(float) * act, hipMemcpyDeviceToDevice, s));
 
     // ---- forward
     {
         const size_t n = (size_t)batch * t * act;
         int grid = (int)((n + 255) / 256); if (grid > 2048) grid = 2048;
         hipLaunchKernelGGL(prep_kernel, dim3(grid), dim3(256), 0, s, action, noise, sigma, F(w.noised), F(w.target),
-                           t * act, n, c->sigma_data);
+                           t * act, n, c->sigma_data, loss_out, F(w.b_head), hb.p, act, ap);
         TRY(hipGetLastError());
         const int threads = D >= 256 ? 256 : round_up(D, 64);
         hipLaunchKernelGGL(train_embed_kernel<E>, dim3(M), dim3(threads), sizeof(float) * (size_t)(obs > act ? obs : act), s,
