@@ -66,6 +66,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 namespace {
 
 constexpr int kWaves = 8;
+constexpr int kBlock = 64 * kWaves;        // threads of a workgroup of the tile kernels (a constant, not blockDim.x: reading the
+                                          // launch size costs the implicit-argument pointer -- two SGPRs carried, and spilled, across layers_kernel)
 constexpr int kChunkTiles = 2 * kWaves;   // hidden row tiles per MLP chunk: 2 per wave = one FC2 k-step per wave
 constexpr int kNTT = 6;                   // token tiles (16 tokens) per workgroup
 constexpr int kMT = kNTT * 16;            // 96 token slots
@@ -1388,7 +1390,7 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
     sample_of(e, s0, b0, un0);
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));            // (the sampler loop: nothing of this block may be hoisted out of it and kept live)
-    for (int it = tid; it < n_real * e.t * act; it += blockDim.x) {
+    for (int it = tid; it < n_real * e.t * act; it += kBlock) {
         const int a = it % act, i = (it / act) % e.t, sr = it / (act * e.t);
         const int sl = sr * per;
         int b; bool un;
@@ -2857,7 +2859,7 @@ __global__ __launch_bounds__(512, 2) void lin_block_x3_kernel(float* __restrict_
     load_x_tile<RPW, NT>(T, x, d.D, m0, M, w, lane & 15, lane >> 4);
     if (lw != nullptr) {
         // (hT slots the MLP phase reads before it has written them meet zero weights: they must be finite)
-        for (int i = threadIdx.x; i < 2 * L::h_bytes / 16; i += blockDim.x) ((u32x4*)(lds + L::hT))[i] = u32x4{0, 0, 0, 0};
+        for (int i = threadIdx.x; i < 2 * L::h_bytes / 16; i += kBlock) ((u32x4*)(lds + L::hT))[i] = u32x4{0, 0, 0, 0};
         {
             // ---- out-projection + residual: the fp32 attention output as split-bf16 B fragments
             const int n = lane & 15, g = lane >> 4;
@@ -2975,7 +2977,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
         int b0; bool un0;
         sample_of(e, s0, b0, un0);
         const int n_el = (n_samples / (e.two ? 2 : 1)) * e.t * d.act;
-        for (int i = threadIdx.x; i < n_el; i += blockDim.x) xs[i] = e.action[(size_t)b0 * e.t * d.act + i];
+        for (int i = threadIdx.x; i < n_el; i += kBlock) xs[i] = e.action[(size_t)b0 * e.t * d.act + i];
     }
     Tile<RPW> T;
     stamp(st, 100);
@@ -2992,10 +2994,10 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     // padding tokens, and the 8 q/k/v rows past the last token slot (a sample's 16-row window reaches them).
     // (Per evaluation: the head's partial sums are laid over them.)
     if constexpr (PX) {
-        for (int i = tid; i < (L.red - L.u) / 16; i += blockDim.x) ((u32x4*)(lds + L.u))[i] = u32x4{0, 0, 0, 0};
+        for (int i = tid; i < (L.red - L.u) / 16; i += kBlock) ((u32x4*)(lds + L.u))[i] = u32x4{0, 0, 0, 0};
     } else {
-    for (int i = tid; i < kNTT * 2 * 64; i += blockDim.x) ((u32x4*)(lds + L.u + kQKVBytes))[i] = u32x4{0, 0, 0, 0};
-    for (int i = tid; i < 3 * 8 * kQKVRow / 2; i += blockDim.x) {
+    for (int i = tid; i < kNTT * 2 * 64; i += kBlock) ((u32x4*)(lds + L.u + kQKVBytes))[i] = u32x4{0, 0, 0, 0};
+    for (int i = tid; i < 3 * 8 * kQKVRow / 2; i += kBlock) {
         const int part = i / (8 * kQKVRow / 2), rem = i % (8 * kQKVRow / 2);
         ((uint32_t*)(lds + L.u))[((size_t)part * kQKVRows + kMT) * kQKVRow / 2 + rem] = 0u;
     }
@@ -3144,8 +3146,8 @@ __global__ __launch_bounds__(512, 2) void train_fwd_kernel(const char* __restric
     build_slot_tabs(tb, n_samples, Tn, a.t, d.G, true);
     // LDS that is read but never written by the phases must be finite (layers_kernel): the attention-output fragments of
     // padding tokens and the 8 q/k/v rows past the last token slot
-    for (int i = threadIdx.x; i < kNTT * 2 * 64; i += blockDim.x) ((u32x4*)(lds + L.u + kQKVBytes))[i] = u32x4{0, 0, 0, 0};
-    for (int i = threadIdx.x; i < 3 * 8 * kQKVRow / 2; i += blockDim.x) {
+    for (int i = threadIdx.x; i < kNTT * 2 * 64; i += kBlock) ((u32x4*)(lds + L.u + kQKVBytes))[i] = u32x4{0, 0, 0, 0};
+    for (int i = threadIdx.x; i < 3 * 8 * kQKVRow / 2; i += kBlock) {
         const int part = i / (8 * kQKVRow / 2), rem = i % (8 * kQKVRow / 2);
         ((uint32_t*)(lds + L.u))[((size_t)part * kQKVRows + kMT) * kQKVRow / 2 + rem] = 0u;
     }
