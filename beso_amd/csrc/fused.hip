@@ -717,6 +717,7 @@ constexpr int kXsBytes = 2048;        // the workgroup's action windows (n_real 
 //  action dims, or one long-sequence sample of 16 kLongNT / 2 steps)
 struct LdsMap {            // byte offsets inside the dynamic LDS block
     int xnT, u, red, tab, xs, total;
+    int cfgc;              // long-sequence instance: the conditional pass's head outputs (classifier-free pairs run as two passes)
 };
 __host__ __device__ constexpr LdsMap lds_map(int KS, bool mlp_only = false, int NT = kNTT) {
     // u is the phase-local region: attention (q/k/v 3*104*72*2 = 44928 | yT 12288) or MLP (hT 6*8 KiB = 49152);
@@ -728,7 +729,8 @@ __host__ __device__ constexpr LdsMap lds_map(int KS, bool mlp_only = false, int 
     m.red = m.u + (mlp_only ? kNTT * kKCc * 1024 : (NT == kLongNT ? 2 * 3 * 16 * kLongNT * kQKVRow * 2 : 59648));
     m.tab = m.red + kRedTok * kMT * 4;
     m.xs = m.tab + 512;
-    m.total = m.xs + kXsBytes;
+    m.cfgc = m.xs + kXsBytes;
+    m.total = m.cfgc + (NT == kLongNT ? kXsBytes : 0);
     return m;
 }
 
@@ -1354,7 +1356,8 @@ struct LoopState {
 template <int RPW, int NT = kNTT>
 __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e, const FusedDims& d, const char* gw,
                                           float* red, float* part, int s0, int n_samples, int Tn, int w, int lane,
-                                          const SlotTabs* tb, float* xs, LoopState& ls, Stamps& st) {
+                                          const SlotTabs* tb, float* xs, LoopState& ls, Stamps& st, int cfg_pass = -1,
+                                          float* cfgc = nullptr) {
 #pragma clang fp contract(off)          // (explicit fmas only: the instances of the kernel agree bit for bit)
     asm volatile("" : "+v"(lane));
     const int n = lane & 15, g = lane >> 4;
@@ -1383,7 +1386,9 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
     }
     __syncthreads();
     // one thread per (real sample slot, step i, action dim): element `it` of the workgroup's action windows
-    const int G = d.G, per = e.two ? 2 : 1;
+    // cfg_pass >= 0 (long-sequence instance): the classifier-free pair runs as TWO passes of the workgroup's one sample --
+    // pass 0 (conditional) leaves its head outputs in `cfgc`, pass 1 (unconditional) combines and applies the update
+    const int G = d.G, per = (e.two && cfg_pass < 0) ? 2 : 1;
     const int n_real = n_samples / per;
     const float* bh = (const float*)(gw + d.g_headb);
     int b0; bool un0;
@@ -1400,7 +1405,11 @@ __device__ __forceinline__ void head_tile(const Tile<RPW>& T, const EdgeArgs& e,
         float fc = bh[a], fu = bh[a];
 #pragma unroll
         for (int ww = 0; ww < kWaves; ++ww) fc += part[((size_t)ww * kMT + tok_c) * 16 + a];
-        if (e.two) {
+        if (cfg_pass >= 0) {
+            if (cfg_pass == 0) { cfgc[it] = fc; continue; }
+            fu = fc;
+            fc = cfgc[it];
+        } else if (e.two) {
             const int tok_u = tb->slot_of_row[(sl + 1) * Tn + G + 2 + 2 * i];
 #pragma unroll
             for (int ww = 0; ww < kWaves; ++ww) fu += part[((size_t)ww * kMT + tok_u) * 16 + a];
@@ -2950,7 +2959,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     static_assert(CORE == 0 || (SPW == 1 && PX == 0), "long-sequence instance");
     constexpr LdsMap Lb = lds_map(KS, false, CORE == 1 ? NTA : kNTT);
     constexpr LdsMapX3 X = lds_map_x3(KS, NTA);
-    constexpr LdsMap L = PX ? LdsMap{0, X.u, X.red, X.tab, X.xs, X.total} : Lb;
+    constexpr LdsMap L = PX ? LdsMap{0, X.u, X.red, X.tab, X.xs, X.total, 0} : Lb;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
@@ -2963,8 +2972,10 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
 #define BESO_LONG_PF1 BESO_FC1_PF        // ... in the long-sequence instance
 #endif
     constexpr int PF1 = CORE == 1 ? BESO_LONG_PF1 : (NTA < kNTT ? BESO_LAT_PF1 : kFc1PF);
-    const int s0 = blockIdx.x * SPW;
-    const int n_samples = min(SPW, n_samples_total - s0);
+    // (CORE = 1 with a classifier-free pair: the workgroup's one REAL sample runs as two passes -- virtual samples 2 b, 2 b + 1)
+    const bool two_pass = CORE == 1 && e.two;
+    const int s0 = two_pass ? 2 * (int)blockIdx.x : (int)blockIdx.x * SPW;
+    const int n_samples = two_pass ? 1 : min(SPW, n_samples_total - s0);
     // action tokens first whenever both network edges are inside the kernel (otherwise x travels in natural order)
     SlotTabs* tb = (SlotTabs*)(lds + L.tab);
     float* xs = (float*)(lds + L.xs);
@@ -2976,7 +2987,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     {
         int b0; bool un0;
         sample_of(e, s0, b0, un0);
-        const int n_el = (n_samples / (e.two ? 2 : 1)) * e.t * d.act;
+        const int n_el = (two_pass ? 1 : n_samples / (e.two ? 2 : 1)) * e.t * d.act;
         for (int i = threadIdx.x; i < n_el; i += kBlock) xs[i] = e.action[(size_t)b0 * e.t * d.act + i];
     }
     Tile<RPW> T;
@@ -2988,6 +2999,9 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
 #pragma unroll 1
     for (int ev = 0; ev < n_evals; ++ev) {
     if constexpr (LOOP) ls.sigma = S.rec[ev].sigma;
+    const int n_pass = CORE == 1 ? (two_pass ? 2 : 1) : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {          // (one trip, known at compile time, in every instance but CORE = 1)
+    const int s0p = s0 + pass;                         // the virtual sample(s) of this pass
     int tid = threadIdx.x;
     if constexpr (LOOP) asm volatile("" : "+v"(tid));      // (per evaluation: nothing thread-derived is kept live across the loop)
     // LDS that is read but never written by the phases must be finite: the attention-output fragments of
@@ -3011,7 +3025,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
 #pragma unroll
             for (int t = 0; t < kNTT; ++t) T.acc[i][t] = f32x4{0.1f * n, 0.2f, 0.3f * g, 0.4f};
         }
-    } else embed_tile<RPW, PX, CORE == 1 ? 7 : 4>(T, e, d, gw, s0, n_samples, Tn, w, lane, tb, xs, ls.sigma, st);
+    } else embed_tile<RPW, PX, CORE == 1 ? 7 : 4>(T, e, d, gw, s0p, n_samples, Tn, w, lane, tb, xs, ls.sigma, st);
     stamp(st, 43);
     // The last layer (when this launch contains it and the action tokens of the tile fit NTL token tiles) runs its
     // out-projection, LayerNorm-2 and MLP on the action-token tiles only; it is peeled off the loop -- a branch
@@ -3099,11 +3113,14 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
     }
     {
         // (peel: the action tokens are the first n_samples * t slots, i.e. inside the first NTLa token tiles)
-        if constexpr (CORE == 1) head_tile<RPW, NTA>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, xs, ls, st);
+        if constexpr (CORE == 1) head_tile<RPW, NTA>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0p, n_samples, Tn, w, lane, tb, xs, ls, st,
+                                                     two_pass ? pass : -1, (float*)(lds + L.cfgc));
         else if (peel && NTLa < kNTT) head_tile<RPW, NTLa>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, xs, ls, st);
         else head_tile<RPW>(T, e, d, gw, (float*)(lds + L.red), (float*)(lds + L.u), s0, n_samples, Tn, w, lane, tb, xs, ls, st);
     }
     stamp(st, 5);
+    if (CORE == 1 && pass + 1 < n_pass) __syncthreads();      // the conditional pass's outputs are in cfgc, its partial sums read
+    }
     if (LOOP && ev + 1 < n_evals) __syncthreads();      // the head's partial sums are read, the next input is in xs
     }
     stamp(st, 101);
@@ -3470,9 +3487,8 @@ int fused_level(const Layout& lay, const FwdArgs& a, int precision) {
     if (precision == BESO_PREC_BF16X3) return whole ? 2 : (x3_long_shape(d) ? 1 : 0);
     const int cap = (a.plan & BESO_PLAN_PER_OP) ? 0 : (a.plan & BESO_PLAN_BLOCKS) ? 1 : 2;
     if (cap < 2) return cap;
-    // long sequences: the whole network in one launch, a sample per workgroup (so no classifier-free pairs, whose halves share one)
-    const bool whole_long = d.seq1 && a.T <= 16 * kLongNT && a.vbatch == a.batch && d.head_fused && d.obs <= 4 * kEmbObsK &&
-                            d.act <= 4 * kEmbActK;
+    // long sequences: the whole network in one launch, a sample per workgroup (a classifier-free pair: two passes of its workgroup)
+    const bool whole_long = d.seq1 && a.T <= 16 * kLongNT && d.head_fused && d.obs <= 4 * kEmbObsK && d.act <= 4 * kEmbActK;
     return (whole || whole_long) ? 2 : 1;
 }
 
@@ -3761,7 +3777,8 @@ int fused_layers(const Layout& lay, const char* packed, const FwdArgs& a, float*
     hipError_t err;
     if (d.RPW == 3 && d.KS == 12 && d.HG == 1) err = launch_layers<3, 12, 1, 2>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, precision, a.plan, s);    // kitchen: 8 x 4 action tokens
     else if (d.RPW == 2 && d.KS == 8 && d.HG == 3) err = launch_layers<2, 8, 3, 4>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, precision, a.plan, s);   // block-push: 8 x 5
-    else if (d.seq1 && precision == BESO_PREC_BF16) err = launch_layers_long<4, 16, kLongNT>(x, base, d, 0, lay.L, a.vbatch, a.T, e, S, s);   // long horizon: 1 x 67 tokens
+    else if (d.seq1 && precision == BESO_PREC_BF16) err = launch_layers_long<4, 16, kLongNT>(x, base, d, 0, lay.L, a.batch, a.T, e, S, s);   // long horizon: 1 x 67 tokens
+                                                                                                             // (one workgroup per REAL sample: pairs run as two passes)
     else return BESO_ERR_UNSUPPORTED;
     return err == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }

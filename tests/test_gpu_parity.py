@@ -385,10 +385,11 @@ def test_long_sequence_layers_kernel_against_block_kernels_and_oracle(B, t):
     assert e_fp < 2.0 * max(e_f, e_p)
 
 
-def test_long_sequence_classifier_free_pairs_take_the_block_kernels():
-    """The one-launch long-sequence instance carries no classifier-free pairs (a pair would have to share a workgroup): a
-    conditional-lambda forward of that shape runs the block kernels (one tail block per layer) and agrees with the oracle's
-    classifier-free combination (classifier_free_sampler.py:35-49)."""
+def test_long_sequence_classifier_free_pairs_are_one_launch_too():
+    """Round 4: the one-launch long-sequence instance (a sample per workgroup) carries classifier-free pairs as TWO PASSES of
+    the sample's workgroup -- the conditional pass leaves its head outputs in LDS, the unconditional pass combines
+    (classifier_free_sampler.py:35-49) and, in a sampler loop, applies the step's update.  One launch per call; agrees with the
+    oracle's combination and with the block-kernel form of the same library (BESO_PLAN_BLOCKS: one tail block per layer)."""
     from beso_amd.agents.diffusion_agents.k_diffusion.classifier_free_sampler import ClassifierFreeSampleModel
     cfg = O.CONFIGS["long_horizon"]
     wts = O.make_weights(cfg, seed=4, std=0.02)
@@ -400,10 +401,21 @@ def test_long_sequence_classifier_free_pairs_take_the_block_kernels():
     out = {}
     with torch.no_grad():
         n = count_fused_launches(lambda: out.__setitem__(0, model(G(s_np), G(a_np), G(g_np), G(sg_np)).cpu().numpy()))
-    assert n == cfg.n_layers
+        set_level(1)
+        try:
+            nb = count_fused_launches(lambda: out.__setitem__(1, model(G(s_np), G(a_np), G(g_np), G(sg_np)).cpu().numpy()))
+        finally:
+            set_level(2)
+    assert (n, nb) == (1, cfg.n_layers), (n, nb)
     err = rel_err(out[0], O.denoise_cfg(wts, cfg, s_np, a_np, g_np, sg_np, lam))
-    print(f"[parity] long_horizon classifier-free lambda={lam}: {err:.3e}")
-    assert err < 1e-2
+    err_b = rel_err(out[0], out[1])
+    print(f"[parity] long_horizon classifier-free lambda={lam}: one launch vs oracle {err:.3e}, vs the block kernels {err_b:.3e}")
+    assert err < 1e-2 and err_b < 1e-2
+    # lambda = 1 / 0 short-circuit to the conditional / unconditional forward (no pair)
+    with torch.no_grad():
+        for lam1, un in ((1.0, False), (0.0, True)):
+            y = ClassifierFreeSampleModel(m, lam1)(G(s_np), G(a_np), G(g_np), G(sg_np))
+            assert torch.equal(y, m(G(s_np), G(a_np), G(g_np), G(sg_np), uncond=un))
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -438,7 +450,7 @@ def test_fused_sampler_loops_vs_reference_vectors(precision):
     ("kitchen", "bf16", 3, 1.0), ("kitchen", "bf16", 64, 1.0), ("kitchen", "bf16", 700, 1.0), ("kitchen", "bf16", 1100, 1.0),
     ("kitchen", "bf16x3", 5, 1.0), ("kitchen", "bf16x3", 600, 1.0),
     ("block_push", "bf16", 130, 2.0), ("block_push", "bf16", 1030, 2.0), ("block_push", "bf16x3", 258, 2.0),
-    ("block_push", "bf16", 9, 0.0), ("long_horizon", "bf16", 5, 1.0)])
+    ("block_push", "bf16", 9, 0.0), ("long_horizon", "bf16", 5, 1.0), ("long_horizon", "bf16", 3, 1.5)])
 def test_sampler_loop_is_one_launch_and_equals_the_stepwise_loop(cfg_name, precision, B, lam):
     """K8 fused into K7: beso_sample runs the whole DDIM / Euler / Heun loop inside ONE launch
     of layers_kernel -- the workgroup that owns a sample applies the step's update in the head and feeds itself the next
