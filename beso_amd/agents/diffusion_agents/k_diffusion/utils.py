@@ -31,8 +31,18 @@ def rand_log_logistic(shape, loc=0., scale=1., min_value=0., max_value=float('in
         z = (math.log(v) - loc) / scale if v != float('inf') else float('inf')
         return 1.0 / (1.0 + math.exp(-z)) if z > -700.0 else 0.0
     lo, hi = cdf(float(min_value)), cdf(float(max_value))
-    u = torch.rand(shape, device=device, dtype=torch.float64) * (hi - lo) + lo
-    return u.logit().mul(scale).add(loc).exp().to(dtype)
+    u = torch.rand(shape, device=device, dtype=torch.float64)
+    if u.is_cuda and dtype == torch.float32:
+        # the transform behind the draw as ONE HIP launch (beso_log_logistic: the same float64 operations in the same order)
+        # instead of seven elementwise ones -- the training step draws its sigmas here every step (beso_agent.py:227)
+        import ctypes as C
+        from .... import _lib
+        out = torch.empty(u.shape, device=u.device, dtype=torch.float32)
+        with torch.cuda.device(u.device):
+            _lib.check(_lib.load().beso_log_logistic(u.data_ptr(), out.data_ptr(), u.numel(), float(loc), float(scale), lo, hi,
+                                                     C.c_void_p(torch.cuda.current_stream(u.device).cuda_stream)), "log_logistic")
+        return out
+    return (u * (hi - lo) + lo).logit().mul(scale).add(loc).exp().to(dtype)
 
 
 def rand_log_uniform(shape, min_value, max_value, device='cpu', dtype=torch.float32):

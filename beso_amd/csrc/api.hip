@@ -693,6 +693,14 @@ int beso_loss_grad(const beso_config* cfg, const float* const* params, int n_par
                                   stream, nullptr);
 }
 
+int beso_log_logistic(const double* u, float* out, size_t n, double loc, double scale, double cdf_lo, double cdf_hi, void* stream) {
+    if (!u || !out || !(scale > 0.0) || !(cdf_lo >= 0.0 && cdf_hi <= 1.0 && cdf_lo <= cdf_hi)) return BESO_ERR_BAD_ARG;
+    if (n == 0) return BESO_OK;
+    hipError_t e = launch_log_logistic(u, out, n, loc, scale, cdf_lo, cdf_hi, (hipStream_t)stream);
+    if (e != hipSuccess) return record_hip_error(e, "log_logistic_kernel", __LINE__);
+    return BESO_OK;
+}
+
 int beso_goal_mask(float* mask, int batch, int goal_seq_len, int obs_dim, float goal_drop, unsigned int seed, void* stream) {
     if (batch < 0 || goal_seq_len < 0 || obs_dim < 0) return BESO_ERR_BAD_ARG;
     hipError_t e = hipSuccess;

@@ -241,6 +241,7 @@ hipError_t launch_gather_windows(const float* observations, const float* actions
                                  long long n_slices, const long long* batch_slices, const long long* draws, int batch,
                                  int window, int goal_len, int goal_mode, int min_future_sep, float* obs_out,
                                  float* act_out, float* goal_out, hipStream_t s);
+hipError_t launch_log_logistic(const double* u, float* out, size_t n, double loc, double scale, double lo, double hi, hipStream_t s);
 hipError_t launch_adam_ema(const void* chunks, int n_chunks, float* m, float* v, float* ema, float lr, float beta1,
                            float beta2, float eps, float wd, int decoupled, int step, float ema_decay, hipStream_t s);
 

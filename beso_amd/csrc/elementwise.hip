@@ -376,4 +376,28 @@ hipError_t launch_sampler_step(int mode, float* out, float* aux, const float* x,
     return hipGetLastError();
 }
 
+// rand_log_logistic (k_diffusion/utils.py:178-185): sigma = exp(logit(u (hi - lo) + lo) scale + loc) in float64, out fp32 -- the
+// chain of seven elementwise launches behind torch.rand as one (the training step draws its sigmas this way every step).
+__global__ void log_logistic_kernel(const double* __restrict__ u, float* __restrict__ out, size_t n, double loc, double scale,
+                                    double lo, double hi) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)          // (torch evaluates every step as its own rounded operation)
+        const double p = u[i] * (hi - lo);
+        const double q = p + lo;
+        const double lg = log(q / (1.0 - q));                // Tensor.logit(): log(x / (1 - x))
+        const double m = lg * scale;
+        const double a = m + loc;
+        out[i] = (float)exp(a);
+    }
+}
+
+hipError_t launch_log_logistic(const double* u, float* out, size_t n, double loc, double scale, double lo, double hi, hipStream_t s) {
+    (void)hipGetLastError();
+    int grid = (int)((n + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(log_logistic_kernel, dim3(grid), dim3(256), 0, s, u, out, n, loc, scale, lo, hi);
+    return hipGetLastError();
+}
+
 }  // namespace beso

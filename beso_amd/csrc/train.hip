@@ -521,16 +521,17 @@ __global__ __launch_bounds__(kGT, kOcc) void tgemm_wgrad_group_kernel(GTable t) 
 // ---------------------------------------------------------------------------------------------
 // operand-typed copies of one layer's weights (and the fused q|k|v bias) in one launch
 // ---------------------------------------------------------------------------------------------
-struct PackSeg { const float* src; void* dst; uint32_t n4; uint32_t f32; };
-struct PackTable { PackSeg seg[10]; int n; };
+struct PackSeg { const float* src; void* dst; uint32_t first; uint32_t f32; };      // first: index of the segment's first float4 in the launch
+constexpr int kPackSegs = 64;                          // 9 per layer: seven layers per launch (24 B each in the kernel argument)
+struct PackTable { PackSeg seg[kPackSegs]; int n; };
 
 template <typename E>
 __global__ void pack_table_kernel(PackTable t, uint32_t total4) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
-        uint32_t k = i;
-        int sgi = 0;
-        while (sgi + 1 < t.n && k >= t.seg[sgi].n4) { k -= t.seg[sgi].n4; ++sgi; }
-        const PackSeg& g = t.seg[sgi];
+        int lo = 0, hi = t.n - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.seg[mid].first <= i) lo = mid; else hi = mid - 1; }
+        const PackSeg& g = t.seg[lo];
+        const uint32_t k = i - g.first;
         const f32x4 v = *(const f32x4*)(g.src + 4 * (size_t)k);
         if (g.f32) *(f32x4*)((float*)g.dst + 4 * (size_t)k) = v;
         else Vec4<E>::store((E*)g.dst + 4 * (size_t)k, v);
@@ -1420,26 +1421,35 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
 
     TRY(hipMemsetAsync(gflat, 0, sizeof(float) * n_grad, s));      // (loss_out and the padded head bias: prep_kernel)
 
-    // ---- operand-typed weight copies (fused q|k|v rows as in the inference image), one launch per layer
-    for (int l = 0; l < L; ++l) {
-        const TrainLayerWs& y = w.layer[l];
-        const size_t e = sizeof(E);
-        const uint32_t dd4 = (uint32_t)((size_t)D * D / 4), d4 = (uint32_t)(D / 4);
+    // ---- operand-typed weight copies (fused q|k|v rows as in the inference image): one launch for up to seven layers
+    {
         PackTable t;
-        t.n = 9;
-        t.seg[0] = PackSeg{lp[l].qw.p, ws + y.w_qkv, dd4, 0};
-        t.seg[1] = PackSeg{lp[l].kw.p, ws + y.w_qkv + e * (size_t)D * D, dd4, 0};
-        t.seg[2] = PackSeg{lp[l].vw.p, ws + y.w_qkv + e * (size_t)2 * D * D, dd4, 0};
-        t.seg[3] = PackSeg{lp[l].pw.p, ws + y.w_proj, dd4, 0};
-        t.seg[4] = PackSeg{lp[l].f1w.p, ws + y.w_fc1, 4 * dd4, 0};
-        t.seg[5] = PackSeg{lp[l].f2w.p, ws + y.w_fc2, 4 * dd4, 0};
-        t.seg[6] = PackSeg{lp[l].qb.p, ws + y.b_qkv, d4, 1};
-        t.seg[7] = PackSeg{lp[l].kb.p, ws + y.b_qkv + sizeof(float) * D, d4, 1};
-        t.seg[8] = PackSeg{lp[l].vb.p, ws + y.b_qkv + sizeof(float) * 2 * D, d4, 1};
-        const uint32_t total4 = 12 * dd4 + 3 * d4;
-        hipLaunchKernelGGL(pack_table_kernel<E>, dim3((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256), dim3(256), 0,
-                           s, t, total4);
-        TRY(hipGetLastError());
+        t.n = 0;
+        uint32_t total4 = 0;
+        auto flush = [&]() -> hipError_t {
+            if (t.n == 0) return hipSuccess;
+            hipLaunchKernelGGL(pack_table_kernel<E>, dim3((total4 + 255) / 256 > 4096 ? 4096 : (total4 + 255) / 256), dim3(256), 0,
+                               s, t, total4);
+            t.n = 0; total4 = 0;
+            return hipGetLastError();
+        };
+        for (int l = 0; l < L; ++l) {
+            const TrainLayerWs& y = w.layer[l];
+            const size_t e = sizeof(E);
+            const uint32_t dd4 = (uint32_t)((size_t)D * D / 4), d4 = (uint32_t)(D / 4);
+            if (t.n + 9 > kPackSegs) TRY(flush());
+            auto seg = [&](const float* src, void* dst, uint32_t n4, uint32_t f32) { t.seg[t.n++] = PackSeg{src, dst, total4, f32}; total4 += n4; };
+            seg(lp[l].qw.p, ws + y.w_qkv, dd4, 0);
+            seg(lp[l].kw.p, ws + y.w_qkv + e * (size_t)D * D, dd4, 0);
+            seg(lp[l].vw.p, ws + y.w_qkv + e * (size_t)2 * D * D, dd4, 0);
+            seg(lp[l].pw.p, ws + y.w_proj, dd4, 0);
+            seg(lp[l].f1w.p, ws + y.w_fc1, 4 * dd4, 0);
+            seg(lp[l].f2w.p, ws + y.w_fc2, 4 * dd4, 0);
+            seg(lp[l].qb.p, ws + y.b_qkv, d4, 1);
+            seg(lp[l].kb.p, ws + y.b_qkv + sizeof(float) * D, d4, 1);
+            seg(lp[l].vb.p, ws + y.b_qkv + sizeof(float) * 2 * D, d4, 1);
+        }
+        TRY(flush());
     }
     if (mlp_head) {
         TRY(launch_pack_matrix(h0w.p, Hh, D, ws + w.w_hid, Hp, D, precision, s));          // zero rows Hh..Hp

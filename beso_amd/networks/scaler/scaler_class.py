@@ -41,15 +41,26 @@ class Scaler:
         if x.shape[-1] == 7 and len(self.x_mean) == 30:      # one-hot kitchen goals pass through
             return x
         if self.scale_data:
-            return ((x - self.x_mean) / (self.x_std + 1e-12)).to(torch.float32)
+            return ((x - self.x_mean) / self._den("x")).to(torch.float32)
         return x
 
     @torch.no_grad()
     def scale_output(self, y):
         y = y.to(self.device)
         if self.scale_data:
-            return ((y - self.y_mean) / (self.y_std + 1e-12)).to(torch.float32)
+            return ((y - self.y_mean) / self._den("y")).to(torch.float32)
         return y
+
+    def _den(self, which: str):
+        """std + 1e-12 (scaler_class.py:129,139): the same tensor every call -- computed once per std tensor instead of one
+        more elementwise launch per scaled batch (three per training step)."""
+        std = self.x_std if which == "x" else self.y_std
+        cache = self.__dict__.setdefault("_den_cache", {})
+        hit = cache.get(which)
+        if hit is None or hit[0] is not std or hit[1] != std._version:
+            hit = (std, std._version, std + 1e-12)
+            cache[which] = hit
+        return hit[2]
 
     @torch.no_grad()
     def inverse_scale_input(self, x):

@@ -17,6 +17,7 @@
  *   beso_loss_grad      <- GCDenoiser.loss + loss.backward()           k_diffusion/score_wrappers.py:45-79, beso_agent.py:228-233
  *                          (+ DiffusionGPT.mask_cond, training mode     k_diffusion/score_gpts.py:298-299, 360-371)
  *   beso_goal_mask      <- the Bernoulli mask of DiffusionGPT.mask_cond k_diffusion/score_gpts.py:365-368
+ *   beso_log_logistic   <- rand_log_logistic (behind the uniform draw)   k_diffusion/utils.py:178-185 (beso_agent.py:227)
  *   beso_loss_grad_overlap  (same, with the early gradient range for the overlapped all-reduce: SURVEY 8(e) C1)
  *   beso_loss_grad_streams  (same, plus a stream that is released as soon as the loss value is final)
  *   beso_adam_step      <- optimizer.step() + ema_helper.update()      beso_agent.py:236-244
@@ -266,6 +267,13 @@ int beso_gather_windows(const float* observations, const float* actions, const i
                         int obs_dim, int act_dim, const int* slice_traj, const int* slice_start, long long n_slices,
                         const long long* batch_slices, const long long* draws, int batch, int window, int goal_len,
                         int goal_mode, int min_future_sep, float* obs_out, float* act_out, float* goal_out, void* stream);
+
+/* rand_log_logistic (k_diffusion/utils.py:178-185), the sigma density of the shipped training configs, behind the caller's
+ * uniform draw: out[i] = (float) exp(logit(u[i] * (cdf_hi - cdf_lo) + cdf_lo) * scale + loc), every operation in float64 as the
+ * reference evaluates it -- one launch instead of seven elementwise ones per training step.  u: n float64 values in [0, 1)
+ * (torch.rand(..., dtype=float64): the library has no random number generator); cdf_lo / cdf_hi: the logistic CDF of
+ * log(min_value) / log(max_value).                                                                                      */
+int beso_log_logistic(const double* u, float* out, size_t n, double loc, double scale, double cdf_lo, double cdf_hi, void* stream);
 
 /* The same call for data-parallel training, where the exchange of the gradients (one all-reduce per range) should start
  * before the backward pass is over.  The gradients of the upper transformer layers l0 .. n_layers-1 and of ln_f are one

@@ -1458,6 +1458,29 @@ def test_agent_train_step_with_goal_drop_runs_the_hip_step():
 
 
 @pytest.mark.gpu
+def test_rand_log_logistic_as_one_launch_equals_the_elementwise_chain():
+    """rand_log_logistic (k_diffusion/utils.py:178-185) on a HIP device: torch.rand in float64, then ONE launch
+    (beso_log_logistic) for logit * scale + loc -> exp -> fp32 instead of seven elementwise ones.  Same draws (the generator
+    is torch's), same float64 operations: equal to the torch chain to fp32 rounding, inside [min_value, max_value], and the
+    quantiles of the shipped density (loc = log 0.5, scale = 0.5, [0.005, 1]) as the reference's."""
+    import math
+    from beso_amd.agents.diffusion_agents.k_diffusion import utils
+    for loc, scale, lo, hi in ((math.log(0.5), 0.5, 0.005, 1.0), (0.0, 1.0, 0.0, float("inf")), (-1.2, 0.3, 0.05, 80.0)):
+        torch.manual_seed(17)
+        got = utils.rand_log_logistic((4099,), loc=loc, scale=scale, min_value=lo, max_value=hi, device=DEV)
+        torch.manual_seed(17)
+        u = torch.rand((4099,), device=DEV, dtype=torch.float64)
+        cdf = lambda v: 0.0 if v <= 0 else (1.0 if v == float("inf") else 1.0 / (1.0 + math.exp(-(math.log(v) - loc) / scale)))      # noqa: E731
+        ref = (u * (cdf(hi) - cdf(lo)) + cdf(lo)).logit().mul(scale).add(loc).exp().to(torch.float32)
+        assert got.dtype == torch.float32 and got.shape == ref.shape
+        rel = ((got - ref).abs() / ref.abs()).max().item()
+        assert rel < 1e-6, (loc, scale, rel)
+        assert got.min().item() >= lo * (1 - 1e-6) and got.max().item() <= hi * (1 + 1e-6)
+    # CPU tensors keep the torch chain (no HIP call)
+    assert utils.rand_log_logistic((5,), loc=0.0, scale=1.0, device="cpu").device.type == "cpu"
+
+
+@pytest.mark.gpu
 def test_train_step_reads_the_loss_on_the_loss_stream(monkeypatch):
     """BesoAgent.train_step returns `loss.item()` (beso_agent.py:248).  The loss is final at the end of the forward half, so
     the step releases a side stream there (beso_loss_grad_streams) and reads the loss on it: the call returns while backward
