@@ -425,6 +425,9 @@ __device__ __forceinline__ f32x4 mfma_op_half(const u32x4& a, const u32x4& b, co
 #ifndef BESO_ZERO_PAD
 #define BESO_ZERO_PAD 1              // 0: A/B builds
 #endif
+#ifndef BESO_TRAIN_FWD_ABL
+#define BESO_TRAIN_FWD_ABL 0         // timing experiments on train_fwd_kernel (results wrong): stores left out -- 1 x_mid / x_out,
+#endif                               // 2 LayerNorm outputs + statistics, 4 q|k|v and y, 8 h, 16 GELU(h)
 __host__ __device__ constexpr bool zero_pad_instance(int RPW, int NT) { return BESO_ZERO_PAD && RPW != 2 && NT >= 5; }
 __device__ __forceinline__ void mixed_chain_pad() {
     __builtin_amdgcn_sched_barrier(0);
@@ -891,7 +894,7 @@ __device__ __forceinline__ void store_x_rows(const Tile<RPW>& T, float* __restri
         if (f0 >= D) continue;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            if (row[t] >= 0) *(f32x4*)(x + (size_t)row[t] * D + f0) = T.acc[i][t];
+            if (row[t] >= 0 && !(BESO_TRAIN_FWD_ABL & 1)) *(f32x4*)(x + (size_t)row[t] * D + f0) = T.acc[i][t];
     }
 }
 
@@ -984,7 +987,7 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int tok = lx.rows.row(16 * t + n);
-                if (tok >= 0) *(float2*)(lx.stats + 2 * (size_t)tok) = make_float2(mean[t], rstd[t]);
+                if (tok >= 0 && !(BESO_TRAIN_FWD_ABL & 2)) *(float2*)(lx.stats + 2 * (size_t)tok) = make_float2(mean[t], rstd[t]);
             }
         }
     }
@@ -997,7 +1000,7 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
             pk.x = pack_op2(fmaf(fmaf(T.acc[i][t][0], a, b), gam[i][0], bet[i][0]), fmaf(fmaf(T.acc[i][t][1], a, b), gam[i][1], bet[i][1]));
             pk.y = pack_op2(fmaf(fmaf(T.acc[i][t][2], a, b), gam[i][2], bet[i][2]), fmaf(fmaf(T.acc[i][t][3], a, b), gam[i][3], bet[i][3]));
             const int tok = lx.rows.row(16 * t + (lane & 15)), f0 = 16 * (w * RPW + i) + 4 * g;
-            if (tok >= 0 && f0 < lx.D) *(uint2*)(lx.xn + (size_t)tok * lx.D + f0) = pk;
+            if (tok >= 0 && f0 < lx.D && !(BESO_TRAIN_FWD_ABL & 2)) *(uint2*)(lx.xn + (size_t)tok * lx.D + f0) = pk;
         } else {
             pk.x = pack_op2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
             pk.y = pack_op2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
@@ -1610,7 +1613,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int tok = mx.rows.row(16 * t + n);
-                    if (tok >= 0 && f0 < mx.ld)
+                    if (tok >= 0 && f0 < mx.ld && !(BESO_TRAIN_FWD_ABL & 8))
                         *(uint2*)(mx.h + (size_t)tok * mx.ld + f0) = make_uint2(pack_op2(hv[r][t][0], hv[r][t][1]),
                                                                                  pack_op2(hv[r][t][2], hv[r][t][3]));
                 }
@@ -1628,7 +1631,7 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int tok = mx.rows.row(16 * t + n);
-                        if (tok >= 0 && f0 < mx.ld)
+                        if (tok >= 0 && f0 < mx.ld && !(BESO_TRAIN_FWD_ABL & 16))
                             *(uint2*)(mx.g + (size_t)tok * mx.ld + f0) = make_uint2(hb[j2][t][2 * q], hb[j2][t][2 * q + 1]);
                     }
                 }
@@ -1810,7 +1813,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
                 *(uint2*)(dst + (size_t)row[t] * kQKVRow) = pk;
                 if constexpr (AX::on) {                   // kept for the backward pass: [row][part D + head dims]
                     const int grow = ax.rows.row(t * 16 + n);
-                    if (grow >= 0 && d0 < HG * hd)
+                    if (grow >= 0 && d0 < HG * hd && !(BESO_TRAIN_FWD_ABL & 4))
                         *(uint2*)(ax.qkv + (size_t)grow * (3 * ax.D) + part * ax.D + vh * (HG * hd) + d0) = pk;
                 }
             }
@@ -1840,7 +1843,7 @@ __device__ __forceinline__ void attn_phase(Tile<RPW>& T, const u32x4* xnT, unsig
     auto keep_y = [&](const auto& yb, int vh, int tok, int g) {
         if constexpr (AX::on) {
             const int grow = ax.rows_y.row(tok);
-            if (grow >= 0) {
+            if (grow >= 0 && !(BESO_TRAIN_FWD_ABL & 4)) {
                 uint16_t* dst = ax.y + (size_t)grow * ax.D + vh * (HG * hd) + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
