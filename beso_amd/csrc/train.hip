@@ -1419,7 +1419,34 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     const PG hw = take((size_t)act * (mlp_head ? Hh : D)), hb = take(act);
     const size_t n_grad = (size_t)(g - gflat);
 
-    TRY(hipMemsetAsync(gflat, 0, sizeof(float) * n_grad, s));      // (loss_out and the padded head bias: prep_kernel)
+    // Which form the forward takes (decided here: its weight image is packed with the other per-step weight copies).
+    // bf16, no dropout on the proj / MLP outputs, a shape with a fused tile kernel: everything of a layer behind its
+    // attention and the LN1 + q/k/v of the next layer run as ONE launch (fused.hip: train_tail_kernel) on 96-token tiles
+    // with the residual in registers -- six launches of the per-op forward below -- writing the same kept activations in
+    // the same formats.  The last layer stays per-op (it continues on the compact action rows).
+    Layout flay;
+    const bool use_tail = sizeof(E) == 2 && resid_p == 0.f && L >= 2 && L * 13 <= 96 && make_layout(c, BESO_PREC_BF16, &flay) &&
+                          fused_train_supported(flay) && fused_train_image_bytes(flay) > 0 && tail_forward_enabled(M, flags);
+    // ... and where the shape has the one-launch kernel (kitchen, block-push; bf16, no dropout on the proj / MLP outputs), ALL
+    // layers run as ONE launch (fused.hip: train_fwd_kernel) -- 44 launches of the per-op forward at six layers; the call's plan
+    // hints keep the other two forms reachable (BESO_TRAIN_PLAN_PER_OP, BESO_TRAIN_PLAN_TILES)
+    const bool use_whole = sizeof(E) == 2 && resid_p == 0.f && !(flags & (BESO_TRAIN_PLAN_PER_OP | BESO_TRAIN_PLAN_TILES)) &&
+                           make_layout(c, BESO_PREC_BF16, &flay) && fused_train_whole_supported(flay, T, t);
+
+    // The per-step weight copies depend on the parameters only, the embedding on the batch only: when the caller handed over a
+    // second stream (loss_stream: idle at this point), the copies run THERE beside the gradient buffer's memset, the
+    // preconditioning and the embedding on `s` -- two short chains of small kernels side by side instead of one after the
+    // other (round 4: -50 us of a 2.5 ms step).  The forward waits for both.
+    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    const bool fork = loss_stream != nullptr;
+    hipStream_t ps = fork ? loss_stream : s;
+    if (fork) {
+        if (!ev_fork) { TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); }
+        TRY(hipEventRecord(ev_fork, s));                 // (behind the optimizer step that wrote the parameters)
+        TRY(hipStreamWaitEvent(ps, ev_fork, 0));
+    }
+    TRY(hipMemsetAsync(gflat, 0, sizeof(float) * n_grad, s));      // (loss_out and the padded head bias: prep_kernel; on `s`: beside the
+                                                                    //  store-bound forward the 37.5 MB memset measured slower)
 
     // ---- operand-typed weight copies (fused q|k|v rows as in the inference image): one launch for up to seven layers
     {
@@ -1429,7 +1456,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         auto flush = [&]() -> hipError_t {
             if (t.n == 0) return hipSuccess;
             hipLaunchKernelGGL(pack_table_kernel<E>, dim3((total4 + 255) / 256 > 4096 ? 4096 : (total4 + 255) / 256), dim3(256), 0,
-                               s, t, total4);
+                               ps, t, total4);
             t.n = 0; total4 = 0;
             return hipGetLastError();
         };
@@ -1452,14 +1479,19 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(flush());
     }
     if (mlp_head) {
-        TRY(launch_pack_matrix(h0w.p, Hh, D, ws + w.w_hid, Hp, D, precision, s));          // zero rows Hh..Hp
-        TRY(hipMemsetAsync(ws + w.b_hid, 0, sizeof(float) * Hp, s));
-        TRY(hipMemcpyAsync(ws + w.b_hid, h0b.p, sizeof(float) * Hh, hipMemcpyDeviceToDevice, s));
-        TRY(hipMemsetAsync(ws + w.db_hid, 0, sizeof(float) * Hp, s));
-        TRY(launch_pack_matrix(hw.p, act, Hh, ws + w.w_head, ap, Hp, precision, s));       // zero columns Hh..Hp, rows act..ap
+        TRY(launch_pack_matrix(h0w.p, Hh, D, ws + w.w_hid, Hp, D, precision, ps));          // zero rows Hh..Hp
+        TRY(hipMemsetAsync(ws + w.b_hid, 0, sizeof(float) * Hp, ps));
+        TRY(hipMemcpyAsync(ws + w.b_hid, h0b.p, sizeof(float) * Hh, hipMemcpyDeviceToDevice, ps));
+        TRY(hipMemsetAsync(ws + w.db_hid, 0, sizeof(float) * Hp, ps));
+        TRY(launch_pack_matrix(hw.p, act, Hh, ws + w.w_head, ap, Hp, precision, ps));       // zero columns Hh..Hp, rows act..ap
     } else {
-        TRY(launch_pack_matrix(hw.p, act, D, ws + w.w_head, ap, D, precision, s));
+        TRY(launch_pack_matrix(hw.p, act, D, ws + w.w_head, ap, D, precision, ps));
     }
+    if (use_whole || use_tail) {
+        const int pst = use_whole ? fused_train_whole_pack(flay, p, ws + w.fimg, ps) : fused_train_pack(flay, p, ws + w.fimg, ps);
+        if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
+    }
+    if (fork) TRY(hipEventRecord(ev_join, ps));
 
     // ---- forward
     {
@@ -1492,34 +1524,16 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     if (lds_b > 64 * 1024) {
         TRY(hipFuncSetAttribute((const void*)attn_bwd_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     }
-    // bf16, no dropout on the proj / MLP outputs, a shape with a fused tile kernel: everything of a layer behind its
-    // attention and the LN1 + q/k/v of the next layer run as ONE launch (fused.hip: train_tail_kernel) on 96-token tiles
-    // with the residual in registers -- six launches of the per-op forward below -- writing the same kept activations in
-    // the same formats.  The last layer stays per-op (it continues on the compact action rows).
-    Layout flay;
-    const bool use_tail = sizeof(E) == 2 && resid_p == 0.f && L >= 2 && L * 13 <= 96 && make_layout(c, BESO_PREC_BF16, &flay) &&
-                          fused_train_supported(flay) && fused_train_image_bytes(flay) > 0 && tail_forward_enabled(M, flags);
-    // ... and where the shape has the one-launch kernel (kitchen, block-push; bf16, no dropout on the proj / MLP outputs), ALL
-    // layers run as ONE launch (fused.hip: train_fwd_kernel) -- 44 launches of the per-op forward at six layers; the call's plan
-    // hints keep the other two forms reachable (BESO_TRAIN_PLAN_PER_OP, BESO_TRAIN_PLAN_TILES)
-    const bool use_whole = sizeof(E) == 2 && resid_p == 0.f && !(flags & (BESO_TRAIN_PLAN_PER_OP | BESO_TRAIN_PLAN_TILES)) &&
-                           make_layout(c, BESO_PREC_BF16, &flay) && fused_train_whole_supported(flay, T, t);
+    if (fork) TRY(hipStreamWaitEvent(s, ev_join, 0));             // the weight copies of the step are in place
     if (use_whole) {
-        int st = fused_train_whole_pack(flay, p, ws + w.fimg, s);
-        if (st == BESO_OK) {
-            const TrainLayerWs& y0 = w.layer[0];
-            const size_t stride = L > 1 ? w.layer[1].x_mid - y0.x_mid : 0;
-            const TrainWholeBufs b{F(w.x0), ws, y0.x_mid, y0.x_out, y0.st1, y0.st2, y0.xn1, y0.qkv, y0.y, y0.xn2, y0.h, y0.g,
-                                   stride, w.ya, t, attn_p, seed};
-            profile_begin(BESO_SITE_FUSED_LAYER, s);
-            st = fused_train_whole(flay, ws + w.fimg, batch, T, b, s);
-            profile_end(BESO_SITE_FUSED_LAYER, s);
-        }
+        const TrainLayerWs& y0 = w.layer[0];
+        const size_t stride = L > 1 ? w.layer[1].x_mid - y0.x_mid : 0;
+        const TrainWholeBufs b{F(w.x0), ws, y0.x_mid, y0.x_out, y0.st1, y0.st2, y0.xn1, y0.qkv, y0.y, y0.xn2, y0.h, y0.g,
+                               stride, w.ya, t, attn_p, seed};
+        profile_begin(BESO_SITE_FUSED_LAYER, s);
+        const int st = fused_train_whole(flay, ws + w.fimg, batch, T, b, s);
+        profile_end(BESO_SITE_FUSED_LAYER, s);
         if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
-    }
-    if (use_tail && !use_whole) {
-        const int pst = fused_train_pack(flay, p, ws + w.fimg, s);
-        if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
     }
     for (int l = 0; l < (use_whole ? 0 : L); ++l) {
         const TrainLayerWs& y = w.layer[l];

@@ -293,7 +293,10 @@ int beso_loss_grad_overlap(const beso_config* cfg, const float* const* params, i
 /* ... and with a third stream for the LOSS: `loss_stream` (NULL: none) is ordered behind the point where *loss_out is final --
  * the end of the forward half, a third of the way into the call's work.  The reference's train_step returns `loss.item()`
  * (beso_agent.py:248); reading the loss on loss_stream lets the host return with it while the backward pass and the optimizer
- * are still running on `stream`, and prepare the next step under them.                                                   */
+ * are still running on `stream`, and prepare the next step under them.  The call also uses loss_stream at its start, for the
+ * step's copies of the weights (they depend on the parameters only and run beside the embedding of the batch on `stream`;
+ * both streams are joined before the first layer): loss_stream must not carry unrelated work of the caller's that the step
+ * should not wait for.                                                                                                   */
 int beso_loss_grad_streams(const beso_config* cfg, const float* const* params, int n_params, float* grads_flat, int precision,
                            const float* state, const float* action, const float* goal, const float* noise, const float* sigma,
                            float* loss_out, int batch, int t, int flags, float embed_pdrop, float attn_pdrop, float resid_pdrop,
