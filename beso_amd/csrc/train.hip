@@ -630,6 +630,65 @@ __global__ void train_embed_kernel(const float* __restrict__ state, const float*
     }
 }
 
+// The embedding as ONE GEMM (round 4): x0[M][D] = Xemb[M][Ke] Wcat[D][Ke]^T with the feature matrix below (the operand of the
+// embedding weight gradients since round 1) and Wcat = [tok_emb.W | action_emb.W | sigma_emb.W | tok_emb.b | action_emb.b |
+// sigma_emb.b | pos_emb^T] -- on the exact-fp32 MFMA (both operands fp32: fp32 products, fp32 accumulation), so the rows
+// equal train_embed_kernel's to summation order.  One block per token row with a strided read of every weight took 48 us per
+// 1024 kitchen samples; the feature kernel + the GEMM take 6 + 9.  (Embedding dropout keeps the old kernel: its mask is an
+// elementwise epilogue this GEMM does not have.)
+template <typename E>
+__global__ __launch_bounds__(256) void train_feat_kernel(const float* __restrict__ state, const float* __restrict__ action,
+                                                         const float* __restrict__ goal, const float* __restrict__ sigma,
+                                                         E* __restrict__ xemb, float* __restrict__ xemb32, int M, int t, int T, int G,
+                                                         int obs, int act, int Ke, float sigma_data, float p_goal, uint32_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * Ke; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / Ke), c = (int)(i % Ke), b = row / T, j = row % T;
+        int kind, posrow = -1;
+        const float* src = nullptr;
+        if (j == 0) kind = 0;
+        else if (j <= G) { kind = 1; posrow = j - 1; src = goal + ((size_t)b * G + (j - 1)) * obs; }
+        else {
+            const int idx = j - G - 1, k = idx >> 1;
+            posrow = G + k;
+            if ((idx & 1) == 0) { kind = 1; src = state + ((size_t)b * t + k) * obs; }
+            else { kind = 2; src = action + ((size_t)b * t + k) * act; }
+        }
+        float v = 0.f;
+        if (c < obs) {
+            if (kind == 1) {
+                v = src[c];
+                if (j <= G && p_goal > 0.f) v *= goal_keep(seed, ((size_t)b * G + (j - 1)) * obs + c, p_goal);     // mask_cond
+            }
+        } else if (c < obs + act) {
+            if (kind == 2) { const float sg = sigma[b]; v = src[c - obs] * (1.0f / sqrtf(sg * sg + sigma_data * sigma_data)); }     // c_in
+        } else if (c == obs + act) v = kind == 0 ? logf(sigma[b]) / 4.0f : 0.f;
+        else if (c == obs + act + 1) v = kind == 1 ? 1.f : 0.f;
+        else if (c == obs + act + 2) v = kind == 2 ? 1.f : 0.f;
+        else if (c == obs + act + 3) v = kind == 0 ? 1.f : 0.f;
+        else v = (c - (obs + act + 4)) == posrow ? 1.f : 0.f;
+        xemb[i] = Act<E>::from(v);
+        if ((const void*)xemb32 != (const void*)xemb) xemb32[i] = v;
+    }
+}
+
+__global__ void wcat_pack_kernel(const float* __restrict__ pos, const float* __restrict__ tok_w, const float* __restrict__ tok_b,
+                                 const float* __restrict__ sig_w, const float* __restrict__ sig_b, const float* __restrict__ act_w,
+                                 const float* __restrict__ act_b, float* __restrict__ wcat, int D, int obs, int act, int seq_size,
+                                 int Ke) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < D * Ke; i += gridDim.x * blockDim.x) {
+        const int d = i / Ke, c = i % Ke;
+        float v = 0.f;
+        if (c < obs) v = tok_w[(size_t)d * obs + c];
+        else if (c < obs + act) v = act_w[(size_t)d * act + (c - obs)];
+        else if (c == obs + act) v = sig_w[d];
+        else if (c == obs + act + 1) v = tok_b[d];
+        else if (c == obs + act + 2) v = act_b[d];
+        else if (c == obs + act + 3) v = sig_b[d];
+        else if (c - (obs + act + 4) < seq_size) v = pos[(size_t)(c - (obs + act + 4)) * D + d];
+        wcat[i] = v;
+    }
+}
+
 // dWcat[Ke][D] -> the individual embedding gradients (accumulated: the flat buffer was zeroed)
 __global__ void scatter_emb_kernel(const float* __restrict__ dw, float* __restrict__ g_pos, float* __restrict__ g_tokw,
                                    float* __restrict__ g_tokb, float* __restrict__ g_sigw, float* __restrict__ g_sigb,
@@ -1249,6 +1308,7 @@ struct TrainLayerWs {
 struct TrainWs {
     int M, T, Ke, ap;
     size_t noised, target, x0, xemb, stf, xf, pred, dpred, w_head, b_head, dw_cat, dw_head;
+    size_t xemb32, wcat;                                            // fp32 feature matrix [M][Ke] and Wcat [D][Ke]: the embedding as one GEMM
     int Hp;                                                         // padded hidden width of the MLP head (0: linear head)
     size_t w_hid, b_hid, hz, ha, hdz, dw_hid, db_hid;
     size_t dx, dx0b, dxn, dy, ln_part;
@@ -1271,6 +1331,8 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
     const size_t na = (size_t)batch * t * c->act_dim;
     w->noised = carve_t(cur, f * na); w->target = carve_t(cur, f * na);
     w->x0 = carve_t(cur, f * M * D); w->xemb = carve_t(cur, e * M * w->Ke);
+    w->xemb32 = carve_t(cur, e == 4 ? 0 : f * M * w->Ke); w->wcat = carve_t(cur, f * (size_t)D * w->Ke);
+    if (e == 4) w->xemb32 = w->xemb;                                // (fp32 mode: the operand-typed matrix IS the fp32 one)
     w->stf = carve_t(cur, f * M * 2); w->xf = carve_t(cur, e * M * D);
     w->pred = carve_t(cur, f * M * w->ap); w->dpred = carve_t(cur, e * M * w->ap);
     w->b_head = carve_t(cur, f * w->ap);
@@ -1437,17 +1499,27 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // second stream (loss_stream: idle at this point), the copies run THERE beside the gradient buffer's memset, the
     // preconditioning and the embedding on `s` -- two short chains of small kernels side by side instead of one after the
     // other (round 4: -50 us of a 2.5 ms step).  The forward waits for both.
-    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_copies = nullptr;
     const bool fork = loss_stream != nullptr;
     hipStream_t ps = fork ? loss_stream : s;
     if (fork) {
-        if (!ev_fork) { TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); }
+        if (!ev_fork) {
+            TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+            TRY(hipEventCreateWithFlags(&ev_copies, hipEventDisableTiming));
+        }
         TRY(hipEventRecord(ev_fork, s));                 // (behind the optimizer step that wrote the parameters)
         TRY(hipStreamWaitEvent(ps, ev_fork, 0));
     }
     TRY(hipMemsetAsync(gflat, 0, sizeof(float) * n_grad, s));      // (loss_out and the padded head bias: prep_kernel; on `s`: beside the
                                                                     //  store-bound forward the 37.5 MB memset measured slower)
 
+    // (first what the forward launch needs -- its fragment image --, then the plain copies the backward pass reads)
+    if (use_whole || use_tail) {
+        const int pst = use_whole ? fused_train_whole_pack(flay, p, ws + w.fimg, ps) : fused_train_pack(flay, p, ws + w.fimg, ps);
+        if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
+    }
+    if (fork) TRY(hipEventRecord(ev_join, ps));
     // ---- operand-typed weight copies (fused q|k|v rows as in the inference image): one launch for up to seven layers
     {
         PackTable t;
@@ -1487,11 +1559,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     } else {
         TRY(launch_pack_matrix(hw.p, act, D, ws + w.w_head, ap, D, precision, ps));
     }
-    if (use_whole || use_tail) {
-        const int pst = use_whole ? fused_train_whole_pack(flay, p, ws + w.fimg, ps) : fused_train_pack(flay, p, ws + w.fimg, ps);
-        if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
-    }
-    if (fork) TRY(hipEventRecord(ev_join, ps));
+    if (fork) TRY(hipEventRecord(ev_copies, ps));
 
     // ---- forward
     {
@@ -1500,11 +1568,23 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         hipLaunchKernelGGL(prep_kernel, dim3(grid), dim3(256), 0, s, action, noise, sigma, F(w.noised), F(w.target),
                            t * act, n, c->sigma_data, loss_out, F(w.b_head), hb.p, act, ap);
         TRY(hipGetLastError());
+        if (embed_p == 0.f) {
+            // the embedding as one exact-fp32 GEMM over the feature matrix (train_feat_kernel)
+            hipLaunchKernelGGL(wcat_pack_kernel, dim3((D * Ke + 255) / 256), dim3(256), 0, s, pos.p, tokw.p, tokb.p, sigw.p, sigb.p,
+                               actw.p, actb.p, F(w.wcat), D, obs, act, seq, Ke);
+            const size_t nf = (size_t)M * Ke;
+            hipLaunchKernelGGL(train_feat_kernel<E>, dim3((unsigned)((nf + 255) / 256 > 4096 ? 4096 : (nf + 255) / 256)), dim3(256), 0, s,
+                               state, (const float*)F(w.noised), goal, sigma, P(w.xemb), F(w.xemb32), M, t, T, G, obs, act, Ke,
+                               c->sigma_data, goal_p, seed);
+            TRY(hipGetLastError());
+            TRY((tgemm<float, false, false>(F(w.xemb32), Ke, F(w.wcat), Ke, M, D, Ke, 1, EpiStore<float>{F(w.x0), nullptr, nullptr, D}, s)));
+        } else {
         const int threads = D >= 256 ? 256 : round_up(D, 64);
         hipLaunchKernelGGL(train_embed_kernel<E>, dim3(M), dim3(threads), sizeof(float) * (size_t)(obs > act ? obs : act), s,
                            state, (const float*)F(w.noised), goal, sigma, pos.p, tokw.p, tokb.p, sigw.p, sigb.p, actw.p,
                            actb.p, F(w.x0), P(w.xemb), t, T, G, D, obs, act, Ke, c->sigma_data, embed_p, goal_p, seed);
         TRY(hipGetLastError());
+        }
     }
     const int nv = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
     const int Ma = batch * t;                             // compact action rows (last layer's projection, MLP, ln_f, head)
@@ -1524,7 +1604,8 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     if (lds_b > 64 * 1024) {
         TRY(hipFuncSetAttribute((const void*)attn_bwd_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     }
-    if (fork) TRY(hipStreamWaitEvent(s, ev_join, 0));             // the weight copies of the step are in place
+    if (fork) TRY(hipStreamWaitEvent(s, ev_join, 0));             // the forward's weight image is in place
+    if (fork && !use_whole) TRY(hipStreamWaitEvent(s, ev_copies, 0));      // (per-op / tile forward: the plain copies too)
     if (use_whole) {
         const TrainLayerWs& y0 = w.layer[0];
         const size_t stride = L > 1 ? w.layer[1].x_mid - y0.x_mid : 0;
@@ -1534,6 +1615,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         const int st = fused_train_whole(flay, ws + w.fimg, batch, T, b, s);
         profile_end(BESO_SITE_FUSED_LAYER, s);
         if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
+        if (fork) TRY(hipStreamWaitEvent(s, ev_copies, 0));       // head weights and the backward's copies: ready long since
     }
     for (int l = 0; l < (use_whole ? 0 : L); ++l) {
         const TrainLayerWs& y = w.layer[l];
