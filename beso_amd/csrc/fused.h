@@ -54,6 +54,15 @@ bool   fused_train_whole_supported(const Layout& lay, int T, int t);
 size_t fused_train_whole_image_bytes(const Layout& lay);
 int    fused_train_whole_pack(const Layout& lay, const float* const* params, char* img, hipStream_t s);
 int    fused_train_whole(const Layout& lay, const char* img, int batch, int T, const TrainWholeBufs& a, hipStream_t s);
+// training backward: the data-gradient GEMMs in the transposed formulation (train_dgrad_kernel; per-step image of the
+// transposed weights).  which: 0 q|k|v, 1 out-projection (bf16 out), 2 FC1, 3 FC2 + GELU' (dh + FC1 bias column sums)
+bool   fused_train_dgrad_supported(const Layout& lay);
+size_t fused_train_dgrad_image_bytes(const Layout& lay);
+int    fused_train_dgrad_pack(const Layout& lay, const float* const* params, char* img, hipStream_t s);
+int    fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, int M, const void* in, float* out32, void* out16,
+                         const void* h, void* dh, float* colsum, hipStream_t s);      // colsum (which = 3): slab [fused_train_dgrad_blocks(M)][4 D]
+int    fused_train_dgrad_blocks(int M);
+int    fused_train_bias_reduce(const float* const* slabs, float* const* outs, const int* blocks, int n, int N, hipStream_t s);
 void   fused_set_stamps(void* buf, int cap);     // development builds (BESO_DEV_API): phase stamps of workgroup 0
 
 // The fp16-operand build of layers_kernel (fused_f16.hip = fused.hip compiled with BESO_OPERAND_F16 = 1): BESO_PREC_FP16.

@@ -3210,6 +3210,167 @@ __global__ __launch_bounds__(512, 2) void train_fwd_kernel(const char* __restric
     layer(d.L - 1, std::integral_constant<int, NTLa>{}, rows_act, (uint16_t*)(a.ws + a.ya));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Training backward: the DATA-GRADIENT GEMMs in the transposed formulation (round 4).  The 128 x 128 tile kernel of train.hip
+// moves both operands of every stage through LDS (128 KiB of LDS traffic per 2.1 MFLOP stage: it is LDS-bandwidth bound at
+// ~20 % of the matrix pipe, and the N = D data gradients fill only half of its workgroup slots).  Here, as in the inference
+// kernels: dX^T = W^T-side A fragments straight from L2 (per-step image of the TRANSPOSED weights in fragment order) x the
+// incoming gradient tile as B fragments, staged ONCE in LDS for all k-steps; a workgroup = 8 waves owns 16 NT token rows and
+// all D output features (N = 4 D: chunks of 8 RPW row tiles), the accumulators leave as row-major stores.
+//   parts = 1: out = in W            (FC1 data gradient K = 4 D -> fp32 dxn; out-projection data gradient K = D -> bf16 dy)
+//   parts = 3: out = sum_p in[:, p D ..] W_p   (q | k | v data gradient: three K = D contractions into one accumulator)
+//   gelu:      dh = (in W2) * GELU'(h) as bf16 + its column sums (FC1 bias gradient)          (N = 4 D, K = D)
+// ---------------------------------------------------------------------------------------------
+struct DgradArgs {
+    const uint16_t* in; int ld_in;        // [M][ld_in] bf16; part p contracts over columns [p K, (p + 1) K)
+    int K, parts, kt;                     // real contraction width per part; k-steps per part in the image (even, zero padded)
+    int N, n_chunks;                      // real output features; chunks of 8 RPW row tiles
+    uint32_t part_bytes;                  // bytes between the weight images of two parts
+    float* out32; uint16_t* out16; int ld_out;
+    const uint16_t* h; uint16_t* dh; float* colsum;      // GELU' epilogue (all three set): h, dh [M][N]; colsum: slab [workgroups][N]
+    int M;
+};
+
+template <int RPW, int NT, int PFA>
+__global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restrict__ wimg, DgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int RT = RPW * kWaves;
+    int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.x * 16 * NT;
+    u32x4* bT = (u32x4*)lds;                               // [part][t][kk][lane]
+    {
+        // the gradient tile as B fragments: lane (n, g) of fragment (t, kk) holds columns 32 kk + 4 g .. +3 and 32 kk + 16 + 4 g .. +3
+        // of token m0 + 16 t + n (zeros beyond K / M: the padded k-steps of the weights are zeros too, but operands must be finite)
+        const int n = lane & 15, g = lane >> 4;
+        const int per = NT * a.kt, total = a.parts * per;
+        // kStage fragments per wave in flight: clamped (always valid) addresses, values selected afterwards -- one fragment at a
+        // time is one L2 round trip per fragment (18 per wave for K = 4 D: two thirds of the kernel's time)
+        constexpr int kStage = 6;
+        for (int f0 = w; f0 < total; f0 += kWaves * kStage) {
+            uint2 lo[kStage], hi[kStage];
+#pragma unroll
+            for (int u = 0; u < kStage; ++u) {
+                const int f = min(f0 + u * kWaves, total - 1);
+                const int p = f / per, r = f - p * per, t = r / a.kt, kk = r - t * a.kt;
+                const int tok = min(m0 + 16 * t + n, a.M - 1), c0 = 32 * kk + 4 * g;
+                const uint16_t* row = a.in + (size_t)tok * a.ld_in + (size_t)p * a.K;
+                lo[u] = *(const uint2*)(row + min(c0, a.K - 4));
+                hi[u] = *(const uint2*)(row + min(c0 + 16, a.K - 4));
+            }
+#pragma unroll
+            for (int u = 0; u < kStage; ++u) {
+                const int f = f0 + u * kWaves;
+                if (f < total) {
+                    const int p = f / per, r = f - p * per, t = r / a.kt, kk = r - t * a.kt;
+                    const int tok = m0 + 16 * t + n, c0 = 32 * kk + 4 * g;
+                    const uint2 z = make_uint2(0u, 0u);
+                    const uint2 l2 = (tok < a.M && c0 < a.K) ? lo[u] : z, h2 = (tok < a.M && c0 + 16 < a.K) ? hi[u] : z;
+                    bT[(size_t)f * 64 + lane] = u32x4{l2.x, l2.y, h2.x, h2.y};
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < a.n_chunks; ++c) {
+        asm volatile("" : "+v"(lane));
+        f32x4 acc[RPW][NT];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int n = lane & 15, g = lane >> 4;
+        // GELU' epilogue: the chunk's h values are requested before the GEMM (they arrive under it)
+        uint2 hu[RPW][NT];
+        if (a.dh != nullptr) {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int f0 = min(16 * (c * RT + w * RPW + i) + 4 * g, a.N - 4);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) hu[i][t] = *(const uint2*)(a.h + (size_t)min(m0 + 16 * t + n, a.M - 1) * a.N + f0);
+            }
+        }
+#pragma unroll 1
+        for (int p = 0; p < a.parts; ++p) {
+            // a workgroup alone on its CU streams the weights: the ring keeps PFA k-steps of fragments in flight per wave (with the
+            // two of gemm_phase the kernel ran at 37 GB/s per CU: the L2 round trip is ~0.8 us, a k-step of MFMAs 0.07 us)
+            u32x4 ar[PFA][RPW];
+            const WPtr wp = wptr((const u32x4*)(wimg + (size_t)p * a.part_bytes) + ((size_t)c * a.kt * RT + (size_t)w * RPW) * 64, lane);
+            prefetch_ring<RPW, PFA>(ar, wp, RT);
+            gemm_phase_ring<RPW, NT, PFA>(acc, ar, wp, RT, (const u32x4*)bT + (size_t)p * NT * a.kt * 64 + lane, a.kt * 64, 64, a.kt);
+        }
+        if (a.dh != nullptr) {
+            // dh = acc * GELU'(h); column sums over the tile's tokens of the values AS STORED (what the weight gradient sees)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int f0 = 16 * (c * RT + w * RPW + i) + 4 * g;
+                f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+                if (f0 < a.N) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int tok = m0 + 16 * t + n;
+                        if (tok < a.M) {
+                            const uint2 hv = hu[i][t];
+                            const float h0 = __uint_as_float(hv.x << 16), h1 = __uint_as_float(hv.x & 0xffff0000u);
+                            const float h2 = __uint_as_float(hv.y << 16), h3 = __uint_as_float(hv.y & 0xffff0000u);
+                            uint2 pk;
+                            pk.x = pack_op2(acc[i][t][0] * gelu_grad_poly(h0), acc[i][t][1] * gelu_grad_poly(h1));
+                            pk.y = pack_op2(acc[i][t][2] * gelu_grad_poly(h2), acc[i][t][3] * gelu_grad_poly(h3));
+                            if (!(BESO_TRAIN_FWD_ABL & 64)) *(uint2*)(a.dh + (size_t)tok * a.N + f0) = pk;
+                            cs[0] += __uint_as_float(pk.x << 16); cs[1] += __uint_as_float(pk.x & 0xffff0000u);
+                            cs[2] += __uint_as_float(pk.y << 16); cs[3] += __uint_as_float(pk.y & 0xffff0000u);
+                        }
+                    }
+                }
+                // sum over the 16 token lanes of the row (DPP); the workgroup's sums go to ITS row of a slab [workgroups][N] that one
+                // small launch adds up (atomics from 235 workgroups onto the same 1440 addresses cost 85 of this kernel's 125 us)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = cs[r];
+                    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false));
+                    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false));
+                    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x124, 0xf, 0xf, false));
+                    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, false));
+                    cs[r] = v;
+                }
+                if (n == 0 && f0 < a.N && !(BESO_TRAIN_FWD_ABL & 32)) *(f32x4*)(a.colsum + (size_t)blockIdx.x * a.N + f0) = cs;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int f0 = 16 * (c * RT + w * RPW + i) + 4 * g;
+                if (f0 >= a.N) continue;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int tok = m0 + 16 * t + n;
+                    if (tok >= a.M) continue;
+                    if (a.out32) *(f32x4*)(a.out32 + (size_t)tok * a.ld_out + f0) = acc[i][t];
+                    else *(uint2*)(a.out16 + (size_t)tok * a.ld_out + f0) =
+                             make_uint2(pack_op2(acc[i][t][0], acc[i][t][1]), pack_op2(acc[i][t][2], acc[i][t][3]));
+                }
+            }
+        }
+    }
+}
+
+// out_j[f] = sum_b slab_j[b][f]: the FC1 bias gradients of several layers from their workgroup slabs, one launch
+struct SlabRed { const float* slab[kMaxLayers]; float* out[kMaxLayers]; int n; };
+__global__ __launch_bounds__(256) void slab_reduce_kernel(SlabRed t, int n_blocks, int N) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, f = blockIdx.x * 64 + cx;
+    const float* src = t.slab[blockIdx.y];
+    float a0 = 0.f, a1 = 0.f;
+    if (f < N) {
+        int b = ry;
+        for (; b + 4 < n_blocks; b += 8) { a0 += src[(size_t)b * N + f]; a1 += src[(size_t)(b + 4) * N + f]; }
+        for (; b < n_blocks; b += 4) a0 += src[(size_t)b * N + f];
+    }
+    red[ry][cx] = a0 + a1;
+    __syncthreads();
+    if (ry == 0 && f < N) t.out[blockIdx.y][f] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+}
+
 // phase stamps: the development build only (beso_debug_set_stamps); the product library carries no such state
 #if BESO_DEV_API
 unsigned long long* g_stamps = nullptr;
@@ -3736,6 +3897,115 @@ int fused_train_whole(const Layout& lay, const char* img, int batch, int T, cons
         e = mid ? launch_train_fwd<2, 8, 3, 4, kMidSPW, kMidNT>(img, d, ti, batch, T, a, s)
                 : launch_train_fwd<2, 8, 3, 4, kSPW, kNTT>(img, d, ti, batch, T, a, s);
     return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+// ---- training backward: data-gradient GEMMs in the transposed formulation (train_dgrad_kernel) ------------------------
+// per-layer image of the TRANSPOSED weights in A-fragment order: [q^T | k^T | v^T | proj^T] (D x D each: kt_d k-steps),
+// W1^T (D x 4 D: kt_h k-steps), W2^T (4 D x D in chunks of 8 RPW row tiles)
+struct TrainBwdImgW { uint32_t o_qkvT, o_pT, o_w1T, o_w2T, dd_bytes, layer_bytes; int kt_d, kt_h, n_chunks; };
+static bool train_dgrad_dims(const Layout& lay, FusedDims* d, TrainBwdImgW* t) {
+    if (!train_tail_dims(lay, d)) return false;
+    const int RT = d->RPW * kWaves;
+    if (lay.D > 16 * RT || lay.D % 8 != 0) return false;
+    const int pfa = d->RPW == 3 ? 6 : 4;                         // k-steps of weight fragments in flight per wave (train_dgrad_kernel)
+    t->kt_d = d->KS;                                             // 12 / 8: a multiple of pfa
+    t->kt_h = ((4 * lay.D + 31) / 32 + pfa - 1) / pfa * pfa;
+    t->n_chunks = (4 * lay.D / 16 + RT - 1) / RT;
+    t->dd_bytes = (uint32_t)RT * t->kt_d * 1024;
+    uint32_t cur = 0;
+    auto carve = [&](uint32_t bytes) { uint32_t o = cur; cur = (uint32_t)round_up_sz((size_t)cur + bytes, 256); return o; };
+    t->o_qkvT = carve(3 * t->dd_bytes);
+    t->o_pT = carve(t->dd_bytes);
+    t->o_w1T = carve((uint32_t)RT * t->kt_h * 1024);
+    t->o_w2T = carve((uint32_t)t->n_chunks * RT * t->kt_d * 1024);
+    t->layer_bytes = cur;
+    // the staged gradient tile: 3 token tiles x k-steps KiB of LDS
+    constexpr int NT = 3;
+    const int lds_kib = NT * (3 * t->kt_d > t->kt_h ? 3 * t->kt_d : t->kt_h);
+    return lds_kib * 1024 <= 150 * 1024 && lay.L * 6 <= kTrainPackSegs;
+}
+bool fused_train_dgrad_supported(const Layout& lay) { FusedDims d; TrainBwdImgW t; return train_dgrad_dims(lay, &d, &t); }
+size_t fused_train_dgrad_image_bytes(const Layout& lay) {
+    FusedDims d; TrainBwdImgW t;
+    return train_dgrad_dims(lay, &d, &t) ? (size_t)t.layer_bytes * lay.L : 0;
+}
+int fused_train_dgrad_pack(const Layout& lay, const float* const* p, char* img, hipStream_t s) {
+    FusedDims d; TrainBwdImgW bi;
+    if (!train_dgrad_dims(lay, &d, &bi)) return BESO_ERR_UNSUPPORTED;
+    TrainPackTable t;
+    t.n = 0;
+    int blocks = 0;
+    const int D = lay.D, RT = d.RPW * kWaves;
+    auto matT = [&](const float* src, uint32_t dst, int rows, int cols, int rt, int kt) {      // A[r][c] = src[c][r], src is [cols][rows]
+        t.seg[t.n++] = TrainPackSeg{src, dst, rows, cols, rt, kt, RT, blocks, 1};
+        blocks += (int)(((size_t)rt * kt * 512 + 256 * 16 - 1) / (256 * 16));
+    };
+    for (int l = 0; l < lay.L; ++l) {
+        const float* const* q = p + 3 + 16 * l;        // ln1.w ln1.b ln2.w ln2.b key.w key.b query.w query.b value.w value.b proj.w proj.b fc1.w fc1.b fc2.w fc2.b
+        const uint32_t base = (uint32_t)l * bi.layer_bytes;
+        const float* w3[3] = {q[6], q[4], q[8]};       // query, key, value: the [q | k | v] column order of dqkv
+        for (int part = 0; part < 3; ++part) matT(w3[part], base + bi.o_qkvT + (uint32_t)part * bi.dd_bytes, D, D, RT, bi.kt_d);
+        matT(q[10], base + bi.o_pT, D, D, RT, bi.kt_d);
+        matT(q[12], base + bi.o_w1T, D, 4 * D, RT, bi.kt_h);                      // fc1.weight [4D][D]: A[n in D][k in 4D]
+        matT(q[14], base + bi.o_w2T, 4 * D, D, bi.n_chunks * RT, bi.kt_d);        // fc2.weight [D][4D]: A[n in 4D][k in D]
+    }
+    t.blocks = blocks;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(train_pack_kernel, dim3(blocks), dim3(256), 0, s, t, img);
+    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+// which: 0 q|k|v data gradient (in = dqkv [M][3D] -> out32 [M][D]); 1 out-projection (in [M][D] -> out16 [M][D]);
+//        2 FC1 (in = dh [M][4D] -> out32 [M][D]); 3 FC2 + GELU' (in = dyo [M][D], h [M][4D] -> dh [M][4D], colsum [4D])
+// rows of a bias slab of fused_train_dgrad(which = 3) over M token rows; fused_train_bias_reduce adds n slabs up into n vectors
+int fused_train_dgrad_blocks(int M) { return (M + 16 * 3 - 1) / (16 * 3); }
+int fused_train_bias_reduce(const float* const* slabs, float* const* outs, const int* blocks, int n, int N, hipStream_t s) {
+    if (n < 1) return BESO_OK;
+    (void)hipGetLastError();
+    // (slabs of different heights -- the compact last layer -- get launches of their own)
+    int i = 0;
+    while (i < n) {
+        SlabRed t;
+        t.n = 0;
+        const int nb = blocks[i];
+        while (i < n && blocks[i] == nb && t.n < kMaxLayers) { t.slab[t.n] = slabs[i]; t.out[t.n] = outs[i]; ++t.n; ++i; }
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((N + 63) / 64, t.n), dim3(256), 0, s, t, nb, N);
+    }
+    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+int fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, int M, const void* in, float* out32, void* out16,
+                      const void* h, void* dh, float* colsum, hipStream_t s) {
+    FusedDims d; TrainBwdImgW bi;
+    if (!train_dgrad_dims(lay, &d, &bi) || which < 0 || which > 3) return BESO_ERR_UNSUPPORTED;
+    constexpr int NT = 3;
+    const int D = lay.D;
+    const char* lw = img + (size_t)layer * bi.layer_bytes;
+    DgradArgs a{};
+    a.in = (const uint16_t*)in; a.M = M; a.out32 = out32; a.out16 = (uint16_t*)out16; a.ld_out = D; a.N = D; a.n_chunks = 1;
+    a.parts = 1; a.part_bytes = 0; a.h = nullptr; a.dh = nullptr; a.colsum = nullptr;
+    const char* wimg;
+    if (which == 0) { wimg = lw + bi.o_qkvT; a.ld_in = 3 * D; a.K = D; a.parts = 3; a.kt = bi.kt_d; a.part_bytes = bi.dd_bytes; }
+    else if (which == 1) { wimg = lw + bi.o_pT; a.ld_in = D; a.K = D; a.kt = bi.kt_d; }
+    else if (which == 2) { wimg = lw + bi.o_w1T; a.ld_in = 4 * D; a.K = 4 * D; a.kt = bi.kt_h; }
+    else { wimg = lw + bi.o_w2T; a.ld_in = D; a.K = D; a.kt = bi.kt_d; a.N = 4 * D; a.n_chunks = bi.n_chunks; a.ld_out = 4 * D;
+           a.h = (const uint16_t*)h; a.dh = (uint16_t*)dh; a.colsum = colsum; }
+    const size_t lds_bytes = (size_t)NT * a.parts * a.kt * 1024;
+    const dim3 grid((M + 16 * NT - 1) / (16 * NT)), block(512);
+    hipError_t e;
+    (void)hipGetLastError();
+    if (d.RPW == 3) {
+        static LdsAttr attr;
+        e = ensure_lds(train_dgrad_kernel<3, NT, 6>, 150 * 1024, &attr);
+        if (e != hipSuccess) return BESO_ERR_HIP;
+        hipLaunchKernelGGL((train_dgrad_kernel<3, NT, 6>), grid, block, lds_bytes, s, wimg, a);
+    } else {
+        static LdsAttr attr;
+        e = ensure_lds(train_dgrad_kernel<2, NT, 4>, 150 * 1024, &attr);
+        if (e != hipSuccess) return BESO_ERR_HIP;
+        hipLaunchKernelGGL((train_dgrad_kernel<2, NT, 4>), grid, block, lds_bytes, s, wimg, a);
+    }
+    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
 #endif   // !BESO_OPERAND_F16

@@ -1314,6 +1314,8 @@ struct TrainWs {
     size_t dx, dx0b, dxn, dy, ln_part;
     size_t ya, xa, dxa, dya;                                        // compact action rows of the last layer
     size_t fimg;                                                    // per-step fragment image of the weights (tail-block forward)
+    size_t bimg;                                                    // ... of the transposed weights (data-gradient kernel)
+    size_t b1slab;                                                  // [L][workgroups][4 D] fp32: FC1 bias sums per workgroup of that kernel
     TrainLayerWs layer[kMaxLayers];
     size_t total;
 };
@@ -1359,6 +1361,9 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
         const bool img = precision == BESO_PREC_BF16 && make_layout(c, BESO_PREC_BF16, &lay);
         const size_t tail_b = img ? fused_train_image_bytes(lay) : 0, whole_b = img ? fused_train_whole_image_bytes(lay) : 0;
         w->fimg = carve_t(cur, tail_b > whole_b ? tail_b : whole_b);
+        w->bimg = carve_t(cur, img ? fused_train_dgrad_image_bytes(lay) : 0);
+        w->b1slab = carve_t(cur, img && fused_train_dgrad_supported(lay)
+                                     ? f * (size_t)c->n_layers * fused_train_dgrad_blocks((int)M) * 4 * D : 0);
     }
     for (int l = 0; l < c->n_layers; ++l) {
         TrainLayerWs& y = w->layer[l];
@@ -1495,6 +1500,11 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     const bool use_whole = sizeof(E) == 2 && resid_p == 0.f && !(flags & (BESO_TRAIN_PLAN_PER_OP | BESO_TRAIN_PLAN_TILES)) &&
                            make_layout(c, BESO_PREC_BF16, &flay) && fused_train_whole_supported(flay, T, t);
 
+    // The data-gradient GEMMs of the backward pass in the transposed formulation (fused.hip: train_dgrad_kernel; bf16, the shapes
+    // with the fused kernels); BESO_TRAIN_PLAN_PER_OP keeps the 128 x 128 tile kernel for them too
+    const bool use_dgrad = sizeof(E) == 2 && !(flags & BESO_TRAIN_PLAN_PER_OP) && make_layout(c, BESO_PREC_BF16, &flay) &&
+                           fused_train_dgrad_supported(flay);
+
     // The per-step weight copies depend on the parameters only, the embedding on the batch only: when the caller handed over a
     // second stream (loss_stream: idle at this point), the copies run THERE beside the gradient buffer's memset, the
     // preconditioning and the embedding on `s` -- two short chains of small kernels side by side instead of one after the
@@ -1520,8 +1530,13 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
     }
     if (fork) TRY(hipEventRecord(ev_join, ps));
+    if (use_dgrad) {
+        const int pst = fused_train_dgrad_pack(flay, p, ws + w.bimg, ps);
+        if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
+    }
     // ---- operand-typed weight copies (fused q|k|v rows as in the inference image): one launch for up to seven layers
-    {
+    // (nobody reads them when the forward is the one-launch kernel and the data gradients take the transposed weights)
+    if (!(use_whole && use_dgrad)) {
         PackTable t;
         t.n = 0;
         uint32_t total4 = 0;
@@ -1718,6 +1733,14 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     GTable gt;
     gt.n = 0;
     int g_tiles = 0;
+    // FC1 bias gradients of the transposed-formulation data-gradient kernel: per-workgroup sums in a slab per layer, added up
+    // (assigned, not accumulated) where the LayerNorm partial sums are
+    const float* b1_slabs[kMaxLayers]; float* b1_outs[kMaxLayers]; int b1_blocks[kMaxLayers]; int b1_n = 0;
+    auto flush_b1 = [&]() -> int {
+        const int st = fused_train_bias_reduce(b1_slabs, b1_outs, b1_blocks, b1_n, D4, s);
+        b1_n = 0;
+        return st;
+    };
     // launches the collected weight gradients behind everything issued on `s` so far.  (Measured and rejected, round 2: the
     // grouped launch of a layer on a side stream under the data gradients of the layers in front of it -- 3.63 vs 3.39 ms per
     // 1024-sample kitchen step, the two streams evict each other's operands from L2 / MALL.)
@@ -1769,14 +1792,27 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         float* dres = last ? F(w.dxa) : F(w.dx);          // residual gradient of this layer's second half
         // FC2: dW2 = dyo^T g, dh = (dyo W2) * GELU'(h)
         TRY(wgrad(P(y.dyo), D, D, P(y.g), D4, D4, rows, lp[l].f2w.g));
+        if (use_dgrad) {
+            float* slab = F(w.b1slab) + (size_t)l * fused_train_dgrad_blocks(M) * D4;
+            const int st = fused_train_dgrad(flay, ws + w.bimg, l, 3, rows, P(y.dyo), nullptr, nullptr, P(y.h), P(y.dh), slab, s);
+            if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
+            b1_slabs[b1_n] = slab; b1_outs[b1_n] = lp[l].f1b.g; b1_blocks[b1_n] = fused_train_dgrad_blocks(rows); ++b1_n;
+        }
+        else
         TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), lp[l].f1b.g, D4}, s)));
         // FC1: dW1 = dh^T xn2, db1, dxn2 = dh W1
         TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, rows, lp[l].f1w.g));
+        if (use_dgrad) { const int st = fused_train_dgrad(flay, ws + w.bimg, l, 2, rows, P(y.dh), F(w.dxn), nullptr, nullptr, nullptr, nullptr, s);
+                         if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; } }
+        else
         TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, rows, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
         TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, dres, dres, P(y.dym), rows, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
                    (uint32_t)(4 * l + 1)));
         // proj: dWp = dym^T y, dy = dym Wp
         TRY(wgrad(P(y.dym), D, D, last ? P(w.ya) : P(y.y), D, D, rows, lp[l].pw.g));
+        if (use_dgrad) { const int st = fused_train_dgrad(flay, ws + w.bimg, l, 1, rows, P(y.dym), nullptr, last ? P(w.dya) : P(w.dy), nullptr, nullptr, nullptr, s);
+                         if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; } }
+        else
         TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, rows, D, D, 1,
                                    EpiStore<E>{nullptr, last ? P(w.dya) : P(w.dy), nullptr, D}, s)));
         if (last) {
@@ -1802,6 +1838,9 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(wgrad(P(y.dqkv) + 2 * D, D3, D, P(y.xn1), D, D, M, lp[l].vw.g, lp[l].vb.g));
         const bool first = l == 0;
         {
+            if (use_dgrad) { const int st = fused_train_dgrad(flay, ws + w.bimg, l, 0, M, P(y.dqkv), F(w.dxn), nullptr, nullptr, nullptr, nullptr, s);
+                             if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; } }
+            else
             TRY((tgemm<E, false, true>(P(y.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
             TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, F(w.dx), F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo), M, lp[l].ln1w.g,
                        lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? embed_p : resid_p,
@@ -1812,6 +1851,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
             // have run: do those now and order `early_stream` behind this point (the C1 exchange of that range can
             // start under the backward of layers l-1 .. 0)
             TRY(flush_group());
+            if (flush_b1() != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return BESO_ERR_HIP; }
             hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls), dim3(256), 0, s, (const float*)F(w.ln_part),
                                lrt, lnb_grid, D, 0);
             TRY(hipGetLastError());
@@ -1825,6 +1865,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // embeddings: dWcat[Ke][D] = Xemb^T dx0, routed to pos_emb / tok_emb / action_emb / sigma_emb after the launch
     TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dx0b), D, D, M, F(w.dw_cat)));
     TRY(flush_group());
+    if (flush_b1() != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return BESO_ERR_HIP; }
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls - ln_reduced), dim3(256), 0, s,
                        (const float*)F(w.ln_part), lrt, lnb_grid, D, ln_reduced);
     TRY(hipGetLastError());
