@@ -59,8 +59,14 @@ int    fused_train_whole(const Layout& lay, const char* img, int batch, int T, c
 bool   fused_train_dgrad_supported(const Layout& lay);
 size_t fused_train_dgrad_image_bytes(const Layout& lay);
 int    fused_train_dgrad_pack(const Layout& lay, const float* const* params, char* img, hipStream_t s);
+// ln (which = 0 or 2): the LayerNorm backward behind this data gradient runs as the kernel's epilogue (dxn is not written)
+struct TrainLnBwd {
+    const float* x; const float* stats; const float* gamma;     // LayerNorm input [M][D], (mean, rstd) [M][2], gamma [D]
+    const float* dres_in; float* dres_out; void* dxb;           // residual gradient in (or nullptr) / out, its bf16 copy
+    float* part;                                                // [fused_train_dgrad_blocks(M)][3][D]: dgamma, dbeta, bias partial sums
+};
 int    fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, int M, const void* in, float* out32, void* out16,
-                         const void* h, void* dh, float* colsum, hipStream_t s);      // colsum (which = 3): slab [fused_train_dgrad_blocks(M)][4 D]
+                         const void* h, void* dh, float* colsum, hipStream_t s, const TrainLnBwd* ln = nullptr);      // colsum (which = 3): slab [fused_train_dgrad_blocks(M)][4 D]
 int    fused_train_dgrad_blocks(int M);
 int    fused_train_bias_reduce(const float* const* slabs, float* const* outs, const int* blocks, int n, int N, hipStream_t s);
 void   fused_set_stamps(void* buf, int cap);     // development builds (BESO_DEV_API): phase stamps of workgroup 0

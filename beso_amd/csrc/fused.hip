@@ -3231,8 +3231,21 @@ struct DgradArgs {
     int M;
 };
 
+// LayerNorm backward as the EPILOGUE of a data gradient whose output is that LayerNorm's dxn (q|k|v -> LN1, FC1 -> LN2): the
+// workgroup holds all D features of its 16 NT tokens in the accumulators, so the two row sums of the backward formula are an
+// exchange through LDS like the forward's statistics, and dxn never exists in memory:
+//     dres_out = dres_in + (dy - mean(dy) - xh mean(dy xh)) rstd,   dy = dxn gamma,  xh = (x - mean) rstd
+// plus the bf16 copy for the next GEMM and the workgroup's partial sums of dgamma, dbeta and the consumer's bias gradient
+// (rows [3][D] of the LayerNorm-reduction slab).  x == nullptr: off.
+struct LnBwdEpi {
+    const float* x; const float* stats; const float* gamma;     // LayerNorm input [M][D], (mean, rstd) [M][2], gamma [D]
+    const float* dres_in; float* dres_out;                      // residual gradient: in (nullptr: none), out [M][D]
+    uint16_t* dxb;                                              // bf16 copy of dres_out [M][D]
+    float* part;                                                // [workgroups][3][D]
+};
+
 template <int RPW, int NT, int PFA>
-__global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restrict__ wimg, DgradArgs a) {
+__global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restrict__ wimg, DgradArgs a, LnBwdEpi e) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int RT = RPW * kWaves;
     int lane = threadIdx.x & 63;
@@ -3335,6 +3348,89 @@ __global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restr
                     cs[r] = v;
                 }
                 if (n == 0 && f0 < a.N && !(BESO_TRAIN_FWD_ABL & 32)) *(f32x4*)(a.colsum + (size_t)blockIdx.x * a.N + f0) = cs;
+            }
+        } else if (e.x != nullptr) {
+            const int D = a.N;
+            float* red = (float*)lds;                      // [16 NT tokens][kRedTok]: (s1, s2) per wave
+            const float invD = 1.0f / (float)D;
+            f32x4 gam[RPW], xh[RPW][NT];
+            float mean[NT], rstd[NT];
+            bool live[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tok = min(m0 + 16 * t + n, a.M - 1);
+                live[t] = m0 + 16 * t + n < a.M;
+                const float2 st2 = *(const float2*)(e.stats + 2 * (size_t)tok);
+                mean[t] = st2.x; rstd[t] = st2.y;
+            }
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int f0 = 16 * (w * RPW + i) + 4 * g;
+                const bool fv = f0 < D;
+                gam[i] = fv ? *(const f32x4*)(e.gamma + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int tok = min(m0 + 16 * t + n, a.M - 1);
+                    const f32x4 xv = *(const f32x4*)(e.x + (size_t)tok * D + (fv ? f0 : 0));
+                    xh[i][t] = (fv && live[t]) ? (xv - mean[t]) * rstd[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            __syncthreads();                               // every wave is through its last B fragments: the region becomes `red`
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    const f32x4 dy = acc[i][t] * gam[i], p2 = dy * xh[i][t];
+                    s1 += (dy[0] + dy[1]) + (dy[2] + dy[3]);
+                    s2 += (p2[0] + p2[1]) + (p2[2] + p2[3]);
+                }
+                s1 = rows_allreduce<false>(s1);
+                s2 = rows_allreduce<false>(s2);
+                if (g == 0) *(float2*)(red + (size_t)(16 * t + n) * kRedTok + 2 * w) = make_float2(s1, s2);
+            }
+            __syncthreads();
+            f32x4 ag[RPW], ab[RPW], ac[RPW];
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; ac[i] = ag[i]; }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4* pr = (const f32x4*)(red + (size_t)(16 * t + n) * kRedTok);
+                float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < kWaves / 2; ++k) { const f32x4 v = pr[k]; c1 += v[0] + v[2]; c2 += v[1] + v[3]; }
+                c1 *= invD; c2 *= invD;
+                const int tok = m0 + 16 * t + n;
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    const int f0 = 16 * (w * RPW + i) + 4 * g;
+                    if (f0 >= D || !live[t]) continue;
+                    const f32x4 go = acc[i][t], dy = go * gam[i];
+                    f32x4 tot = (dy - c1 - xh[i][t] * c2) * rstd[t];
+                    const size_t idx = (size_t)tok * D + f0;
+                    if (e.dres_in) tot += *(const f32x4*)(e.dres_in + idx);
+                    *(f32x4*)(e.dres_out + idx) = tot;
+                    *(uint2*)(e.dxb + idx) = make_uint2(pack_op2(tot[0], tot[1]), pack_op2(tot[2], tot[3]));
+                    ag[i] += go * xh[i][t]; ab[i] += go; ac[i] += tot;
+                }
+            }
+            // the workgroup's partial sums over its tokens: 16 lanes of a row by DPP, lane n == 0 writes
+            auto row_sum = [](float v) {
+                v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false));
+                v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false));
+                v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x124, 0xf, 0xf, false));
+                v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, false));
+                return v;
+            };
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int f0 = 16 * (w * RPW + i) + 4 * g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ag[i][r] = row_sum(ag[i][r]); ab[i][r] = row_sum(ab[i][r]); ac[i][r] = row_sum(ac[i][r]); }
+                if (n == 0 && f0 < D) {
+                    float* o = e.part + (size_t)blockIdx.x * 3 * D + f0;
+                    *(f32x4*)o = ag[i]; *(f32x4*)(o + D) = ab[i]; *(f32x4*)(o + 2 * D) = ac[i];
+                }
             }
         } else {
 #pragma unroll
@@ -3975,7 +4071,7 @@ int fused_train_bias_reduce(const float* const* slabs, float* const* outs, const
 }
 
 int fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, int M, const void* in, float* out32, void* out16,
-                      const void* h, void* dh, float* colsum, hipStream_t s) {
+                      const void* h, void* dh, float* colsum, hipStream_t s, const TrainLnBwd* ln) {
     FusedDims d; TrainBwdImgW bi;
     if (!train_dgrad_dims(lay, &d, &bi) || which < 0 || which > 3) return BESO_ERR_UNSUPPORTED;
     constexpr int NT = 3;
@@ -3990,7 +4086,14 @@ int fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, 
     else if (which == 2) { wimg = lw + bi.o_w1T; a.ld_in = 4 * D; a.K = 4 * D; a.kt = bi.kt_h; }
     else { wimg = lw + bi.o_w2T; a.ld_in = D; a.K = D; a.kt = bi.kt_d; a.N = 4 * D; a.n_chunks = bi.n_chunks; a.ld_out = 4 * D;
            a.h = (const uint16_t*)h; a.dh = (uint16_t*)dh; a.colsum = colsum; }
-    const size_t lds_bytes = (size_t)NT * a.parts * a.kt * 1024;
+    LnBwdEpi ep{};
+    if (ln != nullptr) {
+        if (which != 0 && which != 2) return BESO_ERR_BAD_ARG;
+        ep = LnBwdEpi{ln->x, ln->stats, ln->gamma, ln->dres_in, ln->dres_out, (uint16_t*)ln->dxb, ln->part};
+        a.out32 = nullptr;
+    }
+    size_t lds_bytes = (size_t)NT * a.parts * a.kt * 1024;
+    if (lds_bytes < (size_t)16 * NT * kRedTok * sizeof(float)) lds_bytes = (size_t)16 * NT * kRedTok * sizeof(float);
     const dim3 grid((M + 16 * NT - 1) / (16 * NT)), block(512);
     hipError_t e;
     (void)hipGetLastError();
@@ -3998,12 +4101,12 @@ int fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, 
         static LdsAttr attr;
         e = ensure_lds(train_dgrad_kernel<3, NT, 6>, 150 * 1024, &attr);
         if (e != hipSuccess) return BESO_ERR_HIP;
-        hipLaunchKernelGGL((train_dgrad_kernel<3, NT, 6>), grid, block, lds_bytes, s, wimg, a);
+        hipLaunchKernelGGL((train_dgrad_kernel<3, NT, 6>), grid, block, lds_bytes, s, wimg, a, ep);
     } else {
         static LdsAttr attr;
         e = ensure_lds(train_dgrad_kernel<2, NT, 4>, 150 * 1024, &attr);
         if (e != hipSuccess) return BESO_ERR_HIP;
-        hipLaunchKernelGGL((train_dgrad_kernel<2, NT, 4>), grid, block, lds_bytes, s, wimg, a);
+        hipLaunchKernelGGL((train_dgrad_kernel<2, NT, 4>), grid, block, lds_bytes, s, wimg, a, ep);
     }
     return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }

@@ -1728,6 +1728,16 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
 #undef LNB
         return hipGetLastError();
     };
+    // the same LayerNorm backward as the epilogue of the data gradient in front of it (which = 0: q|k|v, 2: FC1); dxn is never
+    // written.  Without dropout at the site only (the mask would need the site's (row, feature) hash in the GEMM epilogue).
+    auto dgrad_ln = [&](int l, int which, int rows, const E* in, const float* x, size_t st, const float* gamma, float* dres,
+                        E* dxb, float* dgam, float* dbet, float* dbias) -> int {
+        float* part = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
+        lrt.nb[ln_calls] = fused_train_dgrad_blocks(rows);
+        lrt.c[ln_calls++] = LnRedCall{dgam, dbet, dbias};
+        const TrainLnBwd ln{x, (const float*)F(st), gamma, dres, dres, dxb, part};
+        return fused_train_dgrad(flay, ws + w.bimg, l, which, rows, in, nullptr, nullptr, nullptr, nullptr, nullptr, s, &ln);
+    };
     // The weight gradients are collected and run as one grouped launch after the chain of data gradients: every
     // output gradient they need stays in its own buffer until then.
     GTable gt;
@@ -1802,12 +1812,17 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), lp[l].f1b.g, D4}, s)));
         // FC1: dW1 = dh^T xn2, db1, dxn2 = dh W1
         TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, rows, lp[l].f1w.g));
+        if (use_dgrad && resid_p == 0.f) {
+            const int st = dgrad_ln(l, 2, rows, P(y.dh), F(y.x_mid), y.st2, lp[l].ln2w.p, dres, P(y.dym), lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g);
+            if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
+        } else {
         if (use_dgrad) { const int st = fused_train_dgrad(flay, ws + w.bimg, l, 2, rows, P(y.dh), F(w.dxn), nullptr, nullptr, nullptr, nullptr, s);
                          if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; } }
         else
         TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, rows, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
         TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, dres, dres, P(y.dym), rows, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
                    (uint32_t)(4 * l + 1)));
+        }
         // proj: dWp = dym^T y, dy = dym Wp
         TRY(wgrad(P(y.dym), D, D, last ? P(w.ya) : P(y.y), D, D, rows, lp[l].pw.g));
         if (use_dgrad) { const int st = fused_train_dgrad(flay, ws + w.bimg, l, 1, rows, P(y.dym), nullptr, last ? P(w.dya) : P(w.dy), nullptr, nullptr, nullptr, s);
@@ -1837,7 +1852,11 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(wgrad(P(y.dqkv) + D, D3, D, P(y.xn1), D, D, M, lp[l].kw.g, lp[l].kb.g));
         TRY(wgrad(P(y.dqkv) + 2 * D, D3, D, P(y.xn1), D, D, M, lp[l].vw.g, lp[l].vb.g));
         const bool first = l == 0;
-        {
+        if (use_dgrad && (first ? embed_p : resid_p) == 0.f) {
+            const int st = dgrad_ln(l, 0, M, P(y.dqkv), x_in, y.st1, lp[l].ln1w.p, F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo),
+                                    lp[l].ln1w.g, lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g);
+            if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
+        } else {
             if (use_dgrad) { const int st = fused_train_dgrad(flay, ws + w.bimg, l, 0, M, P(y.dqkv), F(w.dxn), nullptr, nullptr, nullptr, nullptr, s);
                              if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; } }
             else
