@@ -65,6 +65,11 @@ struct TrainLnBwd {
     const float* dres_in; float* dres_out; void* dxb;           // residual gradient in (or nullptr) / out, its bf16 copy
     float* part;                                                // [fused_train_dgrad_blocks(M)][3][D]: dgamma, dbeta, bias partial sums
 };
+// FC2 + GELU' -> FC1 -> LayerNorm-2 backward -> out-projection data gradients of a layer in one launch (dh [M][4D], ln.dxb = dym
+// and dy [M][D] are written; colsum: slab [fused_train_dgrad_blocks(M)][4 D])
+bool   fused_train_mlp_bwd_supported(const Layout& lay);
+int    fused_train_mlp_bwd(const Layout& lay, const char* img, int layer, int M, const void* dyo, const void* h, void* dh, float* colsum,
+                           void* dy, const TrainLnBwd& ln, hipStream_t s);
 int    fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, int M, const void* in, float* out32, void* out16,
                          const void* h, void* dh, float* colsum, hipStream_t s, const TrainLnBwd* ln = nullptr);      // colsum (which = 3): slab [fused_train_dgrad_blocks(M)][4 D]
 int    fused_train_dgrad_blocks(int M);

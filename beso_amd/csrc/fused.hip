@@ -3244,6 +3244,182 @@ struct LnBwdEpi {
     float* part;                                                // [workgroups][3][D]
 };
 
+// the gradient tile as B fragments: lane (n, g) of fragment (t, kk) holds columns 32 kk + 4 g .. +3 and 32 kk + 16 + 4 g .. +3
+// of token m0 + 16 t + n (zeros beyond K / M: the padded k-steps of the weights are zeros too, but operands must be finite).
+// bT: [part][t][kk][lane]
+template <int NT>
+__device__ __forceinline__ void stage_grad_tile(u32x4* bT, const uint16_t* __restrict__ in, int ld_in, int K, int parts, int kt,
+                                                int M, int m0, int w, int lane) {
+    const int n = lane & 15, g = lane >> 4;
+    const int per = NT * kt, total = parts * per;
+    // kStage fragments per wave in flight: clamped (always valid) addresses, values selected afterwards -- one fragment at a
+    // time is one L2 round trip per fragment (18 per wave for K = 4 D: two thirds of the kernel's time)
+    constexpr int kStage = 6;
+    for (int f0 = w; f0 < total; f0 += kWaves * kStage) {
+        uint2 lo[kStage], hi[kStage];
+#pragma unroll
+        for (int u = 0; u < kStage; ++u) {
+            const int f = min(f0 + u * kWaves, total - 1);
+            const int p = f / per, r = f - p * per, t = r / kt, kk = r - t * kt;
+            const int tok = min(m0 + 16 * t + n, M - 1), c0 = 32 * kk + 4 * g;
+            const uint16_t* row = in + (size_t)tok * ld_in + (size_t)p * K;
+            lo[u] = *(const uint2*)(row + min(c0, K - 4));
+            hi[u] = *(const uint2*)(row + min(c0 + 16, K - 4));
+        }
+#pragma unroll
+        for (int u = 0; u < kStage; ++u) {
+            const int f = f0 + u * kWaves;
+            if (f < total) {
+                const int p = f / per, r = f - p * per, t = r / kt, kk = r - t * kt;
+                const int tok = m0 + 16 * t + n, c0 = 32 * kk + 4 * g;
+                const uint2 z = make_uint2(0u, 0u);
+                const uint2 l2 = (tok < M && c0 < K) ? lo[u] : z, h2 = (tok < M && c0 + 16 < K) ? hi[u] : z;
+                bT[(size_t)f * 64 + lane] = u32x4{l2.x, l2.y, h2.x, h2.y};
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float row16_sum(float v) {       // sum over the 16 lanes of a DPP row, in every lane
+    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false));
+    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false));
+    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x124, 0xf, 0xf, false));
+    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, false));
+    return v;
+}
+
+// the chunk's h values (GELU' epilogue), requested before the GEMM: they arrive under it
+template <int RPW, int NT>
+__device__ __forceinline__ void load_h_tile(uint2 (&hu)[RPW][NT], const uint16_t* __restrict__ h, int N, int M, int m0, int row0,
+                                            int lane) {
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int f0 = min(16 * (row0 + i) + 4 * g, N - 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) hu[i][t] = *(const uint2*)(h + (size_t)min(m0 + 16 * t + n, M - 1) * N + f0);
+    }
+}
+
+// dh = acc * GELU'(h) as bf16 [M][N] + its column sums over the tile's tokens of the values AS STORED (what the weight gradient
+// sees) into the workgroup's row of a slab [workgroups][N] that one small launch adds up (atomics from 235 workgroups onto the
+// same 1440 addresses cost 85 of this kernel's 125 us).  emit(i, t, pk): the stored pair of words (zeros outside N / M).
+template <int RPW, int NT, class Emit>
+__device__ __forceinline__ void gelu_bwd_epilogue(const f32x4 (&acc)[RPW][NT], const uint2 (&hu)[RPW][NT], uint16_t* __restrict__ dh,
+                                                  float* __restrict__ colsum_row, int N, int M, int m0, int row0, int lane, Emit emit) {
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int f0 = 16 * (row0 + i) + 4 * g;
+        f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int tok = m0 + 16 * t + n;
+            uint2 pk = make_uint2(0u, 0u);
+            if (f0 < N && tok < M) {
+                const uint2 hv = hu[i][t];
+                const float h0 = __uint_as_float(hv.x << 16), h1 = __uint_as_float(hv.x & 0xffff0000u);
+                const float h2 = __uint_as_float(hv.y << 16), h3 = __uint_as_float(hv.y & 0xffff0000u);
+                pk.x = pack_op2(acc[i][t][0] * gelu_grad_poly(h0), acc[i][t][1] * gelu_grad_poly(h1));
+                pk.y = pack_op2(acc[i][t][2] * gelu_grad_poly(h2), acc[i][t][3] * gelu_grad_poly(h3));
+                if (!(BESO_TRAIN_FWD_ABL & 64)) *(uint2*)(dh + (size_t)tok * N + f0) = pk;
+                cs[0] += __uint_as_float(pk.x << 16); cs[1] += __uint_as_float(pk.x & 0xffff0000u);
+                cs[2] += __uint_as_float(pk.y << 16); cs[3] += __uint_as_float(pk.y & 0xffff0000u);
+            }
+            emit(i, t, pk);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[r] = row16_sum(cs[r]);
+        if (n == 0 && f0 < N && !(BESO_TRAIN_FWD_ABL & 32)) *(f32x4*)(colsum_row + f0) = cs;
+    }
+}
+
+// LnBwdEpi on the accumulators acc = dxn^T (row tiles row0 .. of the D features x NT token tiles); red: 16 NT kRedTok floats of
+// LDS that no wave reads any more once every wave has arrived here.  emit(i, t, pk): the bf16 pair of words stored in dxb (zeros
+// outside D / M).
+template <int RPW, int NT, class Emit>
+__device__ __forceinline__ void ln_bwd_epilogue(const f32x4 (&acc)[RPW][NT], const LnBwdEpi& e, int D, int M, int m0, float* red,
+                                                int w, int lane, Emit emit) {
+    const int n = lane & 15, g = lane >> 4;
+    const float invD = 1.0f / (float)D;
+    f32x4 gam[RPW], xh[RPW][NT];
+    float mean[NT], rstd[NT];
+    bool live[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tok = min(m0 + 16 * t + n, M - 1);
+        live[t] = m0 + 16 * t + n < M;
+        const float2 st2 = *(const float2*)(e.stats + 2 * (size_t)tok);
+        mean[t] = st2.x; rstd[t] = st2.y;
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int f0 = 16 * (w * RPW + i) + 4 * g;
+        const bool fv = f0 < D;
+        gam[i] = fv ? *(const f32x4*)(e.gamma + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int tok = min(m0 + 16 * t + n, M - 1);
+            const f32x4 xv = *(const f32x4*)(e.x + (size_t)tok * D + (fv ? f0 : 0));
+            xh[i][t] = (fv && live[t]) ? (xv - mean[t]) * rstd[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();                               // every wave is through its last B fragments: the region becomes `red`
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const f32x4 dy = acc[i][t] * gam[i], p2 = dy * xh[i][t];
+            s1 += (dy[0] + dy[1]) + (dy[2] + dy[3]);
+            s2 += (p2[0] + p2[1]) + (p2[2] + p2[3]);
+        }
+        s1 = rows_allreduce<false>(s1);
+        s2 = rows_allreduce<false>(s2);
+        if (g == 0) *(float2*)(red + (size_t)(16 * t + n) * kRedTok + 2 * w) = make_float2(s1, s2);
+    }
+    __syncthreads();
+    f32x4 ag[RPW], ab[RPW], ac[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; ac[i] = ag[i]; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4* pr = (const f32x4*)(red + (size_t)(16 * t + n) * kRedTok);
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < kWaves / 2; ++k) { const f32x4 v = pr[k]; c1 += v[0] + v[2]; c2 += v[1] + v[3]; }
+        c1 *= invD; c2 *= invD;
+        const int tok = m0 + 16 * t + n;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int f0 = 16 * (w * RPW + i) + 4 * g;
+            uint2 pk = make_uint2(0u, 0u);
+            if (f0 < D && live[t]) {
+                const f32x4 go = acc[i][t], dy = go * gam[i];
+                f32x4 tot = (dy - c1 - xh[i][t] * c2) * rstd[t];
+                const size_t idx = (size_t)tok * D + f0;
+                if (e.dres_in) tot += *(const f32x4*)(e.dres_in + idx);
+                *(f32x4*)(e.dres_out + idx) = tot;
+                pk = make_uint2(pack_op2(tot[0], tot[1]), pack_op2(tot[2], tot[3]));
+                *(uint2*)(e.dxb + idx) = pk;
+                ag[i] += go * xh[i][t]; ab[i] += go; ac[i] += tot;
+            }
+            emit(i, t, pk);
+        }
+    }
+    // the workgroup's partial sums over its tokens: 16 lanes of a row by DPP, lane n == 0 writes
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int f0 = 16 * (w * RPW + i) + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ag[i][r] = row16_sum(ag[i][r]); ab[i][r] = row16_sum(ab[i][r]); ac[i][r] = row16_sum(ac[i][r]); }
+        if (n == 0 && f0 < D) {
+            float* o = e.part + (size_t)blockIdx.x * 3 * D + f0;
+            *(f32x4*)o = ag[i]; *(f32x4*)(o + D) = ab[i]; *(f32x4*)(o + 2 * D) = ac[i];
+        }
+    }
+}
+
 template <int RPW, int NT, int PFA>
 __global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restrict__ wimg, DgradArgs a, LnBwdEpi e) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -3252,38 +3428,7 @@ __global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restr
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * 16 * NT;
     u32x4* bT = (u32x4*)lds;                               // [part][t][kk][lane]
-    {
-        // the gradient tile as B fragments: lane (n, g) of fragment (t, kk) holds columns 32 kk + 4 g .. +3 and 32 kk + 16 + 4 g .. +3
-        // of token m0 + 16 t + n (zeros beyond K / M: the padded k-steps of the weights are zeros too, but operands must be finite)
-        const int n = lane & 15, g = lane >> 4;
-        const int per = NT * a.kt, total = a.parts * per;
-        // kStage fragments per wave in flight: clamped (always valid) addresses, values selected afterwards -- one fragment at a
-        // time is one L2 round trip per fragment (18 per wave for K = 4 D: two thirds of the kernel's time)
-        constexpr int kStage = 6;
-        for (int f0 = w; f0 < total; f0 += kWaves * kStage) {
-            uint2 lo[kStage], hi[kStage];
-#pragma unroll
-            for (int u = 0; u < kStage; ++u) {
-                const int f = min(f0 + u * kWaves, total - 1);
-                const int p = f / per, r = f - p * per, t = r / a.kt, kk = r - t * a.kt;
-                const int tok = min(m0 + 16 * t + n, a.M - 1), c0 = 32 * kk + 4 * g;
-                const uint16_t* row = a.in + (size_t)tok * a.ld_in + (size_t)p * a.K;
-                lo[u] = *(const uint2*)(row + min(c0, a.K - 4));
-                hi[u] = *(const uint2*)(row + min(c0 + 16, a.K - 4));
-            }
-#pragma unroll
-            for (int u = 0; u < kStage; ++u) {
-                const int f = f0 + u * kWaves;
-                if (f < total) {
-                    const int p = f / per, r = f - p * per, t = r / a.kt, kk = r - t * a.kt;
-                    const int tok = m0 + 16 * t + n, c0 = 32 * kk + 4 * g;
-                    const uint2 z = make_uint2(0u, 0u);
-                    const uint2 l2 = (tok < a.M && c0 < a.K) ? lo[u] : z, h2 = (tok < a.M && c0 + 16 < a.K) ? hi[u] : z;
-                    bT[(size_t)f * 64 + lane] = u32x4{l2.x, l2.y, h2.x, h2.y};
-                }
-            }
-        }
-    }
+    stage_grad_tile<NT>(bT, a.in, a.ld_in, a.K, a.parts, a.kt, a.M, m0, w, lane);
     __syncthreads();
 #pragma unroll 1
     for (int c = 0; c < a.n_chunks; ++c) {
@@ -3294,16 +3439,8 @@ __global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restr
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int n = lane & 15, g = lane >> 4;
-        // GELU' epilogue: the chunk's h values are requested before the GEMM (they arrive under it)
         uint2 hu[RPW][NT];
-        if (a.dh != nullptr) {
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                const int f0 = min(16 * (c * RT + w * RPW + i) + 4 * g, a.N - 4);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) hu[i][t] = *(const uint2*)(a.h + (size_t)min(m0 + 16 * t + n, a.M - 1) * a.N + f0);
-            }
-        }
+        if (a.dh != nullptr) load_h_tile<RPW, NT>(hu, a.h, a.N, a.M, m0, c * RT + w * RPW, lane);
 #pragma unroll 1
         for (int p = 0; p < a.parts; ++p) {
             // a workgroup alone on its CU streams the weights: the ring keeps PFA k-steps of fragments in flight per wave (with the
@@ -3314,124 +3451,10 @@ __global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restr
             gemm_phase_ring<RPW, NT, PFA>(acc, ar, wp, RT, (const u32x4*)bT + (size_t)p * NT * a.kt * 64 + lane, a.kt * 64, 64, a.kt);
         }
         if (a.dh != nullptr) {
-            // dh = acc * GELU'(h); column sums over the tile's tokens of the values AS STORED (what the weight gradient sees)
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                const int f0 = 16 * (c * RT + w * RPW + i) + 4 * g;
-                f32x4 cs = {0.f, 0.f, 0.f, 0.f};
-                if (f0 < a.N) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int tok = m0 + 16 * t + n;
-                        if (tok < a.M) {
-                            const uint2 hv = hu[i][t];
-                            const float h0 = __uint_as_float(hv.x << 16), h1 = __uint_as_float(hv.x & 0xffff0000u);
-                            const float h2 = __uint_as_float(hv.y << 16), h3 = __uint_as_float(hv.y & 0xffff0000u);
-                            uint2 pk;
-                            pk.x = pack_op2(acc[i][t][0] * gelu_grad_poly(h0), acc[i][t][1] * gelu_grad_poly(h1));
-                            pk.y = pack_op2(acc[i][t][2] * gelu_grad_poly(h2), acc[i][t][3] * gelu_grad_poly(h3));
-                            if (!(BESO_TRAIN_FWD_ABL & 64)) *(uint2*)(a.dh + (size_t)tok * a.N + f0) = pk;
-                            cs[0] += __uint_as_float(pk.x << 16); cs[1] += __uint_as_float(pk.x & 0xffff0000u);
-                            cs[2] += __uint_as_float(pk.y << 16); cs[3] += __uint_as_float(pk.y & 0xffff0000u);
-                        }
-                    }
-                }
-                // sum over the 16 token lanes of the row (DPP); the workgroup's sums go to ITS row of a slab [workgroups][N] that one
-                // small launch adds up (atomics from 235 workgroups onto the same 1440 addresses cost 85 of this kernel's 125 us)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = cs[r];
-                    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false));
-                    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false));
-                    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x124, 0xf, 0xf, false));
-                    v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, false));
-                    cs[r] = v;
-                }
-                if (n == 0 && f0 < a.N && !(BESO_TRAIN_FWD_ABL & 32)) *(f32x4*)(a.colsum + (size_t)blockIdx.x * a.N + f0) = cs;
-            }
+            gelu_bwd_epilogue<RPW, NT>(acc, hu, a.dh, a.colsum + (size_t)blockIdx.x * a.N, a.N, a.M, m0, c * RT + w * RPW, lane,
+                                       [](int, int, uint2) {});
         } else if (e.x != nullptr) {
-            const int D = a.N;
-            float* red = (float*)lds;                      // [16 NT tokens][kRedTok]: (s1, s2) per wave
-            const float invD = 1.0f / (float)D;
-            f32x4 gam[RPW], xh[RPW][NT];
-            float mean[NT], rstd[NT];
-            bool live[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int tok = min(m0 + 16 * t + n, a.M - 1);
-                live[t] = m0 + 16 * t + n < a.M;
-                const float2 st2 = *(const float2*)(e.stats + 2 * (size_t)tok);
-                mean[t] = st2.x; rstd[t] = st2.y;
-            }
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                const int f0 = 16 * (w * RPW + i) + 4 * g;
-                const bool fv = f0 < D;
-                gam[i] = fv ? *(const f32x4*)(e.gamma + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int tok = min(m0 + 16 * t + n, a.M - 1);
-                    const f32x4 xv = *(const f32x4*)(e.x + (size_t)tok * D + (fv ? f0 : 0));
-                    xh[i][t] = (fv && live[t]) ? (xv - mean[t]) * rstd[t] : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            __syncthreads();                               // every wave is through its last B fragments: the region becomes `red`
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) {
-                    const f32x4 dy = acc[i][t] * gam[i], p2 = dy * xh[i][t];
-                    s1 += (dy[0] + dy[1]) + (dy[2] + dy[3]);
-                    s2 += (p2[0] + p2[1]) + (p2[2] + p2[3]);
-                }
-                s1 = rows_allreduce<false>(s1);
-                s2 = rows_allreduce<false>(s2);
-                if (g == 0) *(float2*)(red + (size_t)(16 * t + n) * kRedTok + 2 * w) = make_float2(s1, s2);
-            }
-            __syncthreads();
-            f32x4 ag[RPW], ab[RPW], ac[RPW];
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; ac[i] = ag[i]; }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const f32x4* pr = (const f32x4*)(red + (size_t)(16 * t + n) * kRedTok);
-                float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < kWaves / 2; ++k) { const f32x4 v = pr[k]; c1 += v[0] + v[2]; c2 += v[1] + v[3]; }
-                c1 *= invD; c2 *= invD;
-                const int tok = m0 + 16 * t + n;
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) {
-                    const int f0 = 16 * (w * RPW + i) + 4 * g;
-                    if (f0 >= D || !live[t]) continue;
-                    const f32x4 go = acc[i][t], dy = go * gam[i];
-                    f32x4 tot = (dy - c1 - xh[i][t] * c2) * rstd[t];
-                    const size_t idx = (size_t)tok * D + f0;
-                    if (e.dres_in) tot += *(const f32x4*)(e.dres_in + idx);
-                    *(f32x4*)(e.dres_out + idx) = tot;
-                    *(uint2*)(e.dxb + idx) = make_uint2(pack_op2(tot[0], tot[1]), pack_op2(tot[2], tot[3]));
-                    ag[i] += go * xh[i][t]; ab[i] += go; ac[i] += tot;
-                }
-            }
-            // the workgroup's partial sums over its tokens: 16 lanes of a row by DPP, lane n == 0 writes
-            auto row_sum = [](float v) {
-                v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false));
-                v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false));
-                v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x124, 0xf, 0xf, false));
-                v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, false));
-                return v;
-            };
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                const int f0 = 16 * (w * RPW + i) + 4 * g;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { ag[i][r] = row_sum(ag[i][r]); ab[i][r] = row_sum(ab[i][r]); ac[i][r] = row_sum(ac[i][r]); }
-                if (n == 0 && f0 < D) {
-                    float* o = e.part + (size_t)blockIdx.x * 3 * D + f0;
-                    *(f32x4*)o = ag[i]; *(f32x4*)(o + D) = ab[i]; *(f32x4*)(o + 2 * D) = ac[i];
-                }
-            }
+            ln_bwd_epilogue<RPW, NT>(acc, e, a.N, a.M, m0, (float*)lds, w, lane, [](int, int, uint2) {});
         } else {
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
@@ -3445,6 +3468,99 @@ __global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restr
                     else *(uint2*)(a.out16 + (size_t)tok * a.ld_out + f0) =
                              make_uint2(pack_op2(acc[i][t][0], acc[i][t][1]), pack_op2(acc[i][t][2], acc[i][t][3]));
                 }
+            }
+        }
+    }
+}
+
+// The second half of a layer's backward in ONE kernel (round 4): dyo -> FC2 data gradient x GELU'(h) = dh -> FC1 data gradient
+// -> LayerNorm-2 backward (+ residual) = dym -> out-projection data gradient = dy.  dh and dym leave for the weight gradients
+// AND stay in LDS as the B fragments of the GEMM behind them (they were written and read back: 10 D of the 44 D bytes per
+// token these three launches moved).  dh is produced in chunks of 8 RPW row tiles (train_dgrad_kernel's), and a chunk is RT / 2
+// k-steps of FC1's contraction: FC1 accumulates chunk c while FC2 computes chunk c + 1 into the other LDS buffer.
+struct MlpBwdArgs {
+    const uint16_t* dyo;                                  // [M][D]
+    const uint16_t* h; uint16_t* dh; float* colsum;       // [M][4 D]; slab [workgroups][4 D]
+    uint16_t* dy;                                         // [M][D]
+    uint32_t o_w2T, o_w1T, o_pT;                          // inside the layer's image of the transposed weights
+    int D, kt_d, kt_h, n_chunks, M;
+};
+
+template <int RPW, int NT, int PFA>
+__global__ __launch_bounds__(512, 2) void train_mlp_bwd_kernel(const char* __restrict__ lw, MlpBwdArgs a, LnBwdEpi e) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int RT = RPW * kWaves, KC = RT / 2;         // k-steps of FC1 per chunk of dh
+    int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.x * 16 * NT, N4 = 4 * a.D;
+    u32x4* bT = (u32x4*)lds;                               // dyo: [t][kk][lane], kt_d k-steps; later the LayerNorm exchange
+    u32x4* hT = bT + (size_t)NT * a.kt_d * 64;             // dh chunk: [2][t][KC][lane]; later dym [t][kt_d][lane]
+    stage_grad_tile<NT>(bT, a.dyo, a.D, a.D, 1, a.kt_d, a.M, m0, w, lane);
+    __syncthreads();
+    f32x4 acc2[RPW][NT];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc2[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the pair of words (i, t) of this lane as half `tile & 1` of B fragment (t, tile >> 1): row tile = 16 features = half a k-step
+    auto put = [&](u32x4* frag, int ks, int i, int t, uint2 pk) {
+        const int tl = w * RPW + i;
+        *((uint2*)(frag + ((size_t)t * ks + (tl >> 1)) * 64 + lane) + (tl & 1)) = pk;
+    };
+#pragma unroll 1
+    for (int c = 0; c < a.n_chunks; ++c) {
+        asm volatile("" : "+v"(lane));
+        u32x4* hc = hT + (size_t)(c & 1) * NT * KC * 64;
+        {
+            f32x4 acc[RPW][NT];
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            uint2 hu[RPW][NT];
+            load_h_tile<RPW, NT>(hu, a.h, N4, a.M, m0, c * RT + w * RPW, lane);
+            u32x4 ar[PFA][RPW];
+            const WPtr wp = wptr((const u32x4*)(lw + a.o_w2T) + ((size_t)c * a.kt_d * RT + (size_t)w * RPW) * 64, lane);
+            prefetch_ring<RPW, PFA>(ar, wp, RT);
+            gemm_phase_ring<RPW, NT, PFA>(acc, ar, wp, RT, (const u32x4*)bT + lane, a.kt_d * 64, 64, a.kt_d);
+            gelu_bwd_epilogue<RPW, NT>(acc, hu, a.dh, a.colsum + (size_t)blockIdx.x * N4, N4, a.M, m0, c * RT + w * RPW, lane,
+                                       [&](int i, int t, uint2 pk) { put(hc, KC, i, t, pk); });
+        }
+        __syncthreads();                                   // chunk c of dh is in LDS (and every wave is through FC1 of chunk c - 1)
+        const int kc = min(KC, a.kt_h - c * KC);
+        if (kc > 0) {
+            u32x4 ar[PFA][RPW];
+            const WPtr wp = wptr((const u32x4*)(lw + a.o_w1T) + ((size_t)c * KC * RT + (size_t)w * RPW) * 64, lane);
+            prefetch_ring<RPW, PFA>(ar, wp, RT);
+            gemm_phase_ring<RPW, NT, PFA>(acc2, ar, wp, RT, (const u32x4*)hc + lane, KC * 64, 64, kc);
+        }
+    }
+    // LayerNorm-2 backward on dxn2 = acc2; dym also as the B fragments of the out-projection's data gradient (the first dh buffer:
+    // the epilogue's two barriers lie between the last FC1 read and these writes)
+    ln_bwd_epilogue<RPW, NT>(acc2, e, a.D, a.M, m0, (float*)bT, w, lane, [&](int i, int t, uint2 pk) { put(hT, a.kt_d, i, t, pk); });
+    __syncthreads();
+    {
+        asm volatile("" : "+v"(lane));
+        f32x4 acc[RPW][NT];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 ar[PFA][RPW];
+        const WPtr wp = wptr((const u32x4*)(lw + a.o_pT) + (size_t)w * RPW * 64, lane);
+        prefetch_ring<RPW, PFA>(ar, wp, RT);
+        gemm_phase_ring<RPW, NT, PFA>(acc, ar, wp, RT, (const u32x4*)hT + lane, a.kt_d * 64, 64, a.kt_d);
+        const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int f0 = 16 * (w * RPW + i) + 4 * g;
+            if (f0 >= a.D) continue;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tok = m0 + 16 * t + n;
+                if (tok < a.M)
+                    *(uint2*)(a.dy + (size_t)tok * a.D + f0) =
+                        make_uint2(pack_op2(acc[i][t][0], acc[i][t][1]), pack_op2(acc[i][t][2], acc[i][t][3]));
             }
         }
     }
@@ -4107,6 +4223,41 @@ int fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, 
         e = ensure_lds(train_dgrad_kernel<2, NT, 4>, 150 * 1024, &attr);
         if (e != hipSuccess) return BESO_ERR_HIP;
         hipLaunchKernelGGL((train_dgrad_kernel<2, NT, 4>), grid, block, lds_bytes, s, wimg, a, ep);
+    }
+    return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
+}
+
+// the second half of a layer's backward (train_mlp_bwd_kernel): the launches which = 3, 2 (with ln), 1 of fused_train_dgrad in one
+bool fused_train_mlp_bwd_supported(const Layout& lay) {
+    FusedDims d; TrainBwdImgW bi;
+    if (!train_dgrad_dims(lay, &d, &bi)) return false;
+    const int KC = d.RPW * kWaves / 2;
+    return bi.kt_d == KC && bi.kt_h <= bi.n_chunks * KC && 3 * 3 * KC * 1024 <= 150 * 1024;
+}
+int fused_train_mlp_bwd(const Layout& lay, const char* img, int layer, int M, const void* dyo, const void* h, void* dh, float* colsum,
+                        void* dy, const TrainLnBwd& ln, hipStream_t s) {
+    FusedDims d; TrainBwdImgW bi;
+    if (!fused_train_mlp_bwd_supported(lay) || !train_dgrad_dims(lay, &d, &bi)) return BESO_ERR_UNSUPPORTED;
+    constexpr int NT = 3;
+    const char* lw = img + (size_t)layer * bi.layer_bytes;
+    const MlpBwdArgs a{(const uint16_t*)dyo, (const uint16_t*)h, (uint16_t*)dh, colsum, (uint16_t*)dy, bi.o_w2T, bi.o_w1T, bi.o_pT,
+                       lay.D, bi.kt_d, bi.kt_h, bi.n_chunks, M};
+    const LnBwdEpi ep{ln.x, ln.stats, ln.gamma, ln.dres_in, ln.dres_out, (uint16_t*)ln.dxb, ln.part};
+    const int KC = d.RPW * kWaves / 2;
+    const size_t lds_bytes = (size_t)NT * (bi.kt_d + 2 * KC) * 1024;
+    const dim3 grid((M + 16 * NT - 1) / (16 * NT)), block(512);
+    hipError_t e;
+    (void)hipGetLastError();
+    if (d.RPW == 3) {
+        static LdsAttr attr;
+        e = ensure_lds(train_mlp_bwd_kernel<3, NT, 6>, 150 * 1024, &attr);
+        if (e != hipSuccess) return BESO_ERR_HIP;
+        hipLaunchKernelGGL((train_mlp_bwd_kernel<3, NT, 6>), grid, block, lds_bytes, s, lw, a, ep);
+    } else {
+        static LdsAttr attr;
+        e = ensure_lds(train_mlp_bwd_kernel<2, NT, 4>, 150 * 1024, &attr);
+        if (e != hipSuccess) return BESO_ERR_HIP;
+        hipLaunchKernelGGL((train_mlp_bwd_kernel<2, NT, 4>), grid, block, lds_bytes, s, lw, a, ep);
     }
     return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }

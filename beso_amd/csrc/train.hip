@@ -500,22 +500,54 @@ hipError_t tgemm(const void* A, int lda, const void* B, int ldb, int M, int N, i
 // the whole token range and stores its result -- no split-K, no atomics (fp32 atomics sustain ~35 G/s on this
 // part: a split-K version spent more time adding partial sums than multiplying), no reduction pass; a few hundred
 // tiles of equal length fill the chip by themselves.
-struct GProb { const void* A; const void* B; float* out; float* bias; int lda, ldb, Mo, No, tile_begin, nt_n, K; };   // bias: column sums of A (or nullptr)
+struct GProb { const void* A; const void* B; float* out; float* bias; int lda, ldb, Mo, No, tile_begin, nt_n, K;
+               uint32_t slab_off; };   // bias: column sums of A (or nullptr); slab_off: this problem's floats in a split's slab (out, then bias)
 constexpr int kMaxGroup = 56;                          // 6 per layer + 2: up to 9 layers per launch, more launches beyond (a 4 KiB kernel argument)
 struct GTable { GProb p[kMaxGroup]; int n; };
 struct EpiStoreF { static constexpr bool kColSum = false; static constexpr bool kBiasCol = true; float* out; int ld; float* bias;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const { *(f32x4*)(out + (size_t)m * ld + n) = v; } };
 
+// splits > 1 (round 4): the contraction -- the TOKEN ROWS of the step -- is cut into `splits` ranges, one workgroup per (tile,
+// range); range z writes its partial tile into slab z (wgrad_reduce_kernel adds the slabs up in a fixed order: deterministic,
+// no atomics).  A 6-layer kitchen step has 75 output tiles for 256 CUs x 2 workgroup slots, each a latency chain over all
+// 11,264 rows (176 stages): 417 us of the 2.26 ms step at 2 % of the matrix pipe.
 template <typename E>
-__global__ __launch_bounds__(kGT, kOcc) void tgemm_wgrad_group_kernel(GTable t) {
-    const int b = xcd_tile(blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(kGT, kOcc) void tgemm_wgrad_group_kernel(GTable t, int n_tiles, int splits, float* slab,
+                                                                      size_t slab_stride) {
+    const int v = xcd_tile(blockIdx.x, gridDim.x);
+    const int z = v / n_tiles, b = v - z * n_tiles;
     int pi = 0;
     while (pi + 1 < t.n && b >= t.p[pi + 1].tile_begin) ++pi;
     const GProb g = t.p[pi];
     const int local = b - g.tile_begin, tile_n = local % g.nt_n, tile_m = local / g.nt_n;
     __shared__ __attribute__((aligned(16))) TileLds lds;
+    constexpr int KSTAGE = 128 / (int)sizeof(E);
+    int k0 = 0, k1 = g.K;
+    float* out = g.out; float* bias = g.bias;
+    if (splits > 1) {
+        const int kc = ((g.K + splits - 1) / splits + KSTAGE - 1) / KSTAGE * KSTAGE;
+        k0 = min(z * kc, g.K); k1 = min(k0 + kc, g.K);
+        out = slab + (size_t)z * slab_stride + g.slab_off;
+        if (bias) bias = out + (size_t)g.Mo * g.No;
+    }
     tgemm_tile<E, true, true, EpiStoreF>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
-                                         tile_n * kTileMN, 0, g.K, EpiStoreF{g.out, g.No, g.bias});
+                                         tile_n * kTileMN, k0, k1, EpiStoreF{out, g.No, bias});
+}
+
+// out (and bias) of every problem of a split launch = the sum of its slabs, z = 0 .. splits-1 in that order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(GTable t, const float* __restrict__ slab, size_t slab_stride,
+                                                           int splits, uint32_t total) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int lo = 0, hi = t.n - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.p[mid].slab_off <= i) lo = mid; else hi = mid - 1; }
+        const GProb& g = t.p[lo];
+        const uint32_t k = i - g.slab_off, no = (uint32_t)g.Mo * (uint32_t)g.No;
+        float* dst = k < no ? g.out + k : ((g.bias && k < no + (uint32_t)g.Mo) ? g.bias + (k - no) : nullptr);
+        if (!dst) continue;                                   // (alignment padding between two problems)
+        float acc = 0.f;
+        for (int z = 0; z < splits; ++z) acc += slab[(size_t)z * slab_stride + i];
+        *dst = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1316,6 +1348,7 @@ struct TrainWs {
     size_t fimg;                                                    // per-step fragment image of the weights (tail-block forward)
     size_t bimg;                                                    // ... of the transposed weights (data-gradient kernel)
     size_t b1slab;                                                  // [L][workgroups][4 D] fp32: FC1 bias sums per workgroup of that kernel
+    size_t wslab; int w_splits; size_t wslab_floats;                // split weight-gradient launch: [w_splits][wslab_floats] partial outputs
     TrainLayerWs layer[kMaxLayers];
     size_t total;
 };
@@ -1364,6 +1397,19 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
         w->bimg = carve_t(cur, img ? fused_train_dgrad_image_bytes(lay) : 0);
         w->b1slab = carve_t(cur, img && fused_train_dgrad_supported(lay)
                                      ? f * (size_t)c->n_layers * fused_train_dgrad_blocks((int)M) * 4 * D : 0);
+    }
+    {
+        // row ranges of the grouped weight-gradient launch: enough workgroups for two per CU (small models: few output tiles,
+        // long contractions); every output of the launch once per range
+        const int tD = (D + kTileMN - 1) / kTileMN, tH = (4 * D + kTileMN - 1) / kTileMN;
+        const int tiles = c->n_layers * (2 * tD * tH + 4 * tD * tD) + 4;
+        int sp = (2 * 256 + tiles - 1) / tiles;
+        if (sp > 8) sp = 8;
+        if ((size_t)sp > M / (4 * (128 / e))) sp = (int)(M / (4 * (128 / e)));      // (ranges of at least four stages)
+        w->w_splits = sp < 2 ? 1 : sp;
+        const size_t Kh = w->Hp ? (size_t)w->Hp : (size_t)D;
+        w->wslab_floats = train_grad_floats(c) + (size_t)w->Ke * D + (size_t)w->ap * Kh + (size_t)w->Hp * D + 8 * (size_t)(6 * c->n_layers + 8);
+        w->wslab = carve_t(cur, w->w_splits > 1 ? f * w->w_splits * w->wslab_floats : 0);
     }
     for (int l = 0; l < c->n_layers; ++l) {
         TrainLayerWs& y = w->layer[l];
@@ -1530,6 +1576,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
     }
     if (fork) TRY(hipEventRecord(ev_join, ps));
+    const bool use_mlp_bwd = use_dgrad && resid_p == 0.f && fused_train_mlp_bwd_supported(flay);
     if (use_dgrad) {
         const int pst = fused_train_dgrad_pack(flay, p, ws + w.bimg, ps);
         if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
@@ -1754,10 +1801,16 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // launches the collected weight gradients behind everything issued on `s` so far.  (Measured and rejected, round 2: the
     // grouped launch of a layer on a side stream under the data gradients of the layers in front of it -- 3.63 vs 3.39 ms per
     // 1024-sample kitchen step, the two streams evict each other's operands from L2 / MALL.)
+    uint32_t g_floats = 0;                                // floats of the collected problems in a range's slab
     auto flush_group = [&]() -> hipError_t {
         if (gt.n == 0) return hipSuccess;
-        hipLaunchKernelGGL(tgemm_wgrad_group_kernel<E>, dim3(g_tiles), dim3(kGT), 0, s, gt);
-        gt.n = 0; g_tiles = 0;
+        const int sp = (w.w_splits > 1 && g_floats <= w.wslab_floats) ? w.w_splits : 1;
+        hipLaunchKernelGGL(tgemm_wgrad_group_kernel<E>, dim3(g_tiles * sp), dim3(kGT), 0, s, gt, g_tiles, sp, F(w.wslab),
+                           w.wslab_floats);
+        if (sp > 1)
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((g_floats + 1023) / 1024), dim3(256), 0, s, gt, (const float*)F(w.wslab),
+                               w.wslab_floats, sp, g_floats);
+        gt.n = 0; g_tiles = 0; g_floats = 0;
         return hipGetLastError();
     };
     // bias: the gradient of the bias that goes with this weight = the column sums of A.  It rides along as a column of ones
@@ -1771,8 +1824,9 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
             bias = nullptr;
         }
         const int nt_n = (No + kTileMN - 1) / kTileMN, nt_m = (Mo + kTileMN - 1) / kTileMN;
-        gt.p[gt.n++] = GProb{A, B, out, bias, lda, ldb, Mo, No, g_tiles, nt_n, rows};
+        gt.p[gt.n++] = GProb{A, B, out, bias, lda, ldb, Mo, No, g_tiles, nt_n, rows, g_floats};
         g_tiles += nt_n * nt_m;
+        g_floats += (uint32_t)round_up(Mo * No + (bias ? Mo : 0), 4);
         return hipSuccess;
     };
     // head (compact rows): dW = dpred^T xf (the act real rows of dpred's ap columns, straight into the gradient tensor),
@@ -1802,6 +1856,20 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         float* dres = last ? F(w.dxa) : F(w.dx);          // residual gradient of this layer's second half
         // FC2: dW2 = dyo^T g, dh = (dyo W2) * GELU'(h)
         TRY(wgrad(P(y.dyo), D, D, P(y.g), D4, D4, rows, lp[l].f2w.g));
+        if (use_mlp_bwd) {
+            // FC2 + GELU' -> FC1 -> LayerNorm-2 backward -> out-projection: one launch, dh and dym stay in LDS between the GEMMs
+            float* slab = F(w.b1slab) + (size_t)l * fused_train_dgrad_blocks(M) * D4;
+            float* part = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
+            lrt.nb[ln_calls] = fused_train_dgrad_blocks(rows);
+            lrt.c[ln_calls++] = LnRedCall{lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g};
+            const TrainLnBwd ln{F(y.x_mid), (const float*)F(y.st2), lp[l].ln2w.p, dres, dres, P(y.dym), part};
+            const int st = fused_train_mlp_bwd(flay, ws + w.bimg, l, rows, P(y.dyo), P(y.h), P(y.dh), slab,
+                                               last ? P(w.dya) : P(w.dy), ln, s);
+            if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
+            b1_slabs[b1_n] = slab; b1_outs[b1_n] = lp[l].f1b.g; b1_blocks[b1_n] = fused_train_dgrad_blocks(rows); ++b1_n;
+            TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, rows, lp[l].f1w.g));
+            TRY(wgrad(P(y.dym), D, D, last ? P(w.ya) : P(y.y), D, D, rows, lp[l].pw.g));
+        } else {
         if (use_dgrad) {
             float* slab = F(w.b1slab) + (size_t)l * fused_train_dgrad_blocks(M) * D4;
             const int st = fused_train_dgrad(flay, ws + w.bimg, l, 3, rows, P(y.dyo), nullptr, nullptr, P(y.h), P(y.dh), slab, s);
@@ -1830,6 +1898,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         else
         TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, rows, D, D, 1,
                                    EpiStore<E>{nullptr, last ? P(w.dya) : P(w.dy), nullptr, D}, s)));
+        }
         if (last) {
             // back to all token rows: dy and the residual gradient are zero off the action rows
             const size_t n4 = (size_t)M * (D / 4);
