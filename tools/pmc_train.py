@@ -15,7 +15,8 @@ for d in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             n = re.sub(r"beso::\(anonymous namespace\)::", "", r["Kernel_Name"])
             n = re.sub(r"\(.*", "", n).replace("void ", "")
-            if not n.startswith(("tgemm", "ln_", "attn_", "colsum", "beso::adam", "train_embed", "train_fwd", "train_pack", "pack_table")):
+            if not n.startswith(("tgemm", "ln_", "attn_", "colsum", "beso::adam", "train_embed", "train_fwd", "train_pack", "pack_table", "train_dgrad", "train_mlp_bwd",
+                                 "slab_reduce", "wgrad_reduce")):
                 continue
             sums[(n, r["Counter_Name"])] += float(r["Counter_Value"])
             cnts[(n, r["Counter_Name"])] += 1
