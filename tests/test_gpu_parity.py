@@ -1436,6 +1436,37 @@ def test_training_forward_as_one_launch_equals_the_per_op_forward(cfg_name, B, t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name,B,resid_p,embed_p", [("kitchen", 100, 0.1, 0.0), ("kitchen", 37, 0.1, 0.1), ("block_push", 96, 0.05, 0.0),
+                                                       ("block_push", 50, 0.0, 0.1)])
+def test_training_backward_kernels_with_residual_and_embedding_dropout_equal_the_per_op_step(cfg_name, B, resid_p, embed_p):
+    """bf16 training step with dropout on the residual branches / the embedding (block-push ships resid_pdrop = 0.05): the
+    transposed-formulation data-gradient kernels (train_dgrad_kernel) run, the LayerNorm backward at a site WITH dropout stays the
+    stand-alone kernel (its mask is a hash of (row, feature) that the GEMM epilogue does not evaluate), sites without it take the
+    epilogue form.  Same seed = same masks in both plans, so the library's choice and the per-op kernels must agree inside the
+    bf16 bound (2e-2 per tensor, loss 2e-3)."""
+    cfg = O.CONFIGS[cfg_name]
+    m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), "bf16", attn_pdrop=0.3, resid_pdrop=resid_p, embed_pdrop=embed_p)
+    m.train()
+    state, action, goal, noise, sigma = _train_inputs(cfg, B, seed=5)
+    step = m.hip_train_step(state, action, goal, noise, sigma)
+    out = {}
+    try:
+        for on in (1, 0):
+            set_train_tail(on)
+            r = step.run(state, action, goal, noise, sigma, seed=77, fresh_grads=True)
+            out[on] = (r[0].item(), [v.clone() for v in r[2]])
+    finally:
+        set_train_tail(1)
+    errs = _grad_errors(out[1][1], out[0][1], 2e-3)
+    worst = max(range(len(errs)), key=lambda i: errs[i])
+    print(f"[parity] library vs per-op training step {cfg_name} B={B} resid_p={resid_p} embed_p={embed_p}: "
+          f"loss {abs(out[1][0] - out[0][0]) / abs(out[0][0]):.2e}, worst gradient {errs[worst]:.2e} "
+          f"({list(dict(m.named_parameters()))[worst]})")
+    assert abs(out[1][0] - out[0][0]) < 2e-3 * abs(out[0][0])
+    assert errs[worst] < 2e-2
+
+
+@pytest.mark.gpu
 def test_agent_train_step_with_goal_drop_runs_the_hip_step():
     """BesoAgent.train_step on a model built with goal_drop = 0.1 and the kitchen dropouts (configs[2] / [3]): the HIP step
     serves it (no host-side masking, no torch-op network), losses are finite and decrease over a few steps."""
