@@ -64,6 +64,7 @@ struct TrainLnBwd {
     const float* x; const float* stats; const float* gamma;     // LayerNorm input [M][D], (mean, rstd) [M][2], gamma [D]
     const float* dres_in; float* dres_out; void* dxb;           // residual gradient in (or nullptr) / out, its bf16 copy
     float* part;                                                // [fused_train_dgrad_blocks(M)][3][D]: dgamma, dbeta, bias partial sums
+    float p; uint32_t seed, site; int skip_mod;                 // dropout of the branch behind the LayerNorm (ln_bwd_kernel's arguments)
 };
 // FC2 + GELU' -> FC1 -> LayerNorm-2 backward -> out-projection data gradients of a layer in one launch (dh [M][4D], ln.dxb = dym
 // and dy [M][D] are written; colsum: slab [fused_train_dgrad_blocks(M)][4 D])

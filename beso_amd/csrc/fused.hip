@@ -3240,8 +3240,11 @@ struct DgradArgs {
 struct LnBwdEpi {
     const float* x; const float* stats; const float* gamma;     // LayerNorm input [M][D], (mean, rstd) [M][2], gamma [D]
     const float* dres_in; float* dres_out;                      // residual gradient: in (nullptr: none), out [M][D]
-    uint16_t* dxb;                                              // bf16 copy of dres_out [M][D]
+    uint16_t* dxb;                                              // bf16 copy of dres_out x keep-scale(site) [M][D]
     float* part;                                                // [workgroups][3][D]
+    float p, inv_keep; uint32_t seed, site; int skip_mod;       // dropout of the branch behind this LayerNorm (p = 0: none): element
+                                                                // (row, f) keeps drop_scale(seed, site, row D + f); rows with
+                                                                // row % skip_mod == 0 carry none (skip_mod > 0: the sigma token)
 };
 
 // the gradient tile as B fragments: lane (n, g) of fragment (t, kk) holds columns 32 kk + 4 g .. +3 and 32 kk + 16 + 4 g .. +3
@@ -3400,6 +3403,10 @@ __device__ __forceinline__ void ln_bwd_epilogue(const f32x4 (&acc)[RPW][NT], con
                 const size_t idx = (size_t)tok * D + f0;
                 if (e.dres_in) tot += *(const f32x4*)(e.dres_in + idx);
                 *(f32x4*)(e.dres_out + idx) = tot;
+                if (e.p > 0.f && !(e.skip_mod > 0 && tok % e.skip_mod == 0)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tot[j] *= drop_scale(e.seed, e.site, idx + j, e.p, e.inv_keep);
+                }
                 pk = make_uint2(pack_op2(tot[0], tot[1]), pack_op2(tot[2], tot[3]));
                 *(uint2*)(e.dxb + idx) = pk;
                 ag[i] += go * xh[i][t]; ab[i] += go; ac[i] += tot;
@@ -4205,7 +4212,8 @@ int fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, 
     LnBwdEpi ep{};
     if (ln != nullptr) {
         if (which != 0 && which != 2) return BESO_ERR_BAD_ARG;
-        ep = LnBwdEpi{ln->x, ln->stats, ln->gamma, ln->dres_in, ln->dres_out, (uint16_t*)ln->dxb, ln->part};
+        ep = LnBwdEpi{ln->x, ln->stats, ln->gamma, ln->dres_in, ln->dres_out, (uint16_t*)ln->dxb, ln->part,
+                      ln->p, ln->p > 0.f ? 1.0f / (1.0f - ln->p) : 1.f, ln->seed, ln->site, ln->skip_mod};
         a.out32 = nullptr;
     }
     size_t lds_bytes = (size_t)NT * a.parts * a.kt * 1024;
@@ -4242,7 +4250,8 @@ int fused_train_mlp_bwd(const Layout& lay, const char* img, int layer, int M, co
     const char* lw = img + (size_t)layer * bi.layer_bytes;
     const MlpBwdArgs a{(const uint16_t*)dyo, (const uint16_t*)h, (uint16_t*)dh, colsum, (uint16_t*)dy, bi.o_w2T, bi.o_w1T, bi.o_pT,
                        lay.D, bi.kt_d, bi.kt_h, bi.n_chunks, M};
-    const LnBwdEpi ep{ln.x, ln.stats, ln.gamma, ln.dres_in, ln.dres_out, (uint16_t*)ln.dxb, ln.part};
+    const LnBwdEpi ep{ln.x, ln.stats, ln.gamma, ln.dres_in, ln.dres_out, (uint16_t*)ln.dxb, ln.part,
+                       ln.p, ln.p > 0.f ? 1.0f / (1.0f - ln.p) : 1.f, ln.seed, ln.site, ln.skip_mod};
     const int KC = d.RPW * kWaves / 2;
     const size_t lds_bytes = (size_t)NT * (bi.kt_d + 2 * KC) * 1024;
     const dim3 grid((M + 16 * NT - 1) / (16 * NT)), block(512);

@@ -1576,7 +1576,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
     }
     if (fork) TRY(hipEventRecord(ev_join, ps));
-    const bool use_mlp_bwd = use_dgrad && resid_p == 0.f && fused_train_mlp_bwd_supported(flay);
+    const bool use_mlp_bwd = use_dgrad && fused_train_mlp_bwd_supported(flay);
     if (use_dgrad) {
         const int pst = fused_train_dgrad_pack(flay, p, ws + w.bimg, ps);
         if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
@@ -1776,13 +1776,13 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         return hipGetLastError();
     };
     // the same LayerNorm backward as the epilogue of the data gradient in front of it (which = 0: q|k|v, 2: FC1); dxn is never
-    // written.  Without dropout at the site only (the mask would need the site's (row, feature) hash in the GEMM epilogue).
+    // written (dropout at the site: the same (row, feature) hash, evaluated in the epilogue).
     auto dgrad_ln = [&](int l, int which, int rows, const E* in, const float* x, size_t st, const float* gamma, float* dres,
-                        E* dxb, float* dgam, float* dbet, float* dbias) -> int {
+                        E* dxb, float* dgam, float* dbet, float* dbias, float p_site, uint32_t site, int skip_mod = 0) -> int {
         float* part = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
         lrt.nb[ln_calls] = fused_train_dgrad_blocks(rows);
         lrt.c[ln_calls++] = LnRedCall{dgam, dbet, dbias};
-        const TrainLnBwd ln{x, (const float*)F(st), gamma, dres, dres, dxb, part};
+        const TrainLnBwd ln{x, (const float*)F(st), gamma, dres, dres, dxb, part, p_site, seed, site, skip_mod};
         return fused_train_dgrad(flay, ws + w.bimg, l, which, rows, in, nullptr, nullptr, nullptr, nullptr, nullptr, s, &ln);
     };
     // The weight gradients are collected and run as one grouped launch after the chain of data gradients: every
@@ -1862,7 +1862,8 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
             float* part = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
             lrt.nb[ln_calls] = fused_train_dgrad_blocks(rows);
             lrt.c[ln_calls++] = LnRedCall{lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g};
-            const TrainLnBwd ln{F(y.x_mid), (const float*)F(y.st2), lp[l].ln2w.p, dres, dres, P(y.dym), part};
+            const TrainLnBwd ln{F(y.x_mid), (const float*)F(y.st2), lp[l].ln2w.p, dres, dres, P(y.dym), part, resid_p, seed,
+                                (uint32_t)(4 * l + 1), 0};
             const int st = fused_train_mlp_bwd(flay, ws + w.bimg, l, rows, P(y.dyo), P(y.h), P(y.dh), slab,
                                                last ? P(w.dya) : P(w.dy), ln, s);
             if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
@@ -1880,13 +1881,11 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), lp[l].f1b.g, D4}, s)));
         // FC1: dW1 = dh^T xn2, db1, dxn2 = dh W1
         TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, rows, lp[l].f1w.g));
-        if (use_dgrad && resid_p == 0.f) {
-            const int st = dgrad_ln(l, 2, rows, P(y.dh), F(y.x_mid), y.st2, lp[l].ln2w.p, dres, P(y.dym), lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g);
+        if (use_dgrad) {
+            const int st = dgrad_ln(l, 2, rows, P(y.dh), F(y.x_mid), y.st2, lp[l].ln2w.p, dres, P(y.dym), lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g,
+                                    resid_p, (uint32_t)(4 * l + 1));
             if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
         } else {
-        if (use_dgrad) { const int st = fused_train_dgrad(flay, ws + w.bimg, l, 2, rows, P(y.dh), F(w.dxn), nullptr, nullptr, nullptr, nullptr, s);
-                         if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; } }
-        else
         TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, rows, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
         TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, dres, dres, P(y.dym), rows, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
                    (uint32_t)(4 * l + 1)));
@@ -1921,14 +1920,12 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(wgrad(P(y.dqkv) + D, D3, D, P(y.xn1), D, D, M, lp[l].kw.g, lp[l].kb.g));
         TRY(wgrad(P(y.dqkv) + 2 * D, D3, D, P(y.xn1), D, D, M, lp[l].vw.g, lp[l].vb.g));
         const bool first = l == 0;
-        if (use_dgrad && (first ? embed_p : resid_p) == 0.f) {
+        if (use_dgrad) {
             const int st = dgrad_ln(l, 0, M, P(y.dqkv), x_in, y.st1, lp[l].ln1w.p, F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo),
-                                    lp[l].ln1w.g, lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g);
+                                    lp[l].ln1w.g, lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? embed_p : resid_p,
+                                    first ? kEmbedSite : (uint32_t)(4 * (l - 1) + 2), first ? T : 0);
             if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
         } else {
-            if (use_dgrad) { const int st = fused_train_dgrad(flay, ws + w.bimg, l, 0, M, P(y.dqkv), F(w.dxn), nullptr, nullptr, nullptr, nullptr, s);
-                             if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; } }
-            else
             TRY((tgemm<E, false, true>(P(y.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
             TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, F(w.dx), F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo), M, lp[l].ln1w.g,
                        lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? embed_p : resid_p,
