@@ -1440,10 +1440,10 @@ def test_training_forward_as_one_launch_equals_the_per_op_forward(cfg_name, B, t
                                                        ("block_push", 50, 0.0, 0.1)])
 def test_training_backward_kernels_with_residual_and_embedding_dropout_equal_the_per_op_step(cfg_name, B, resid_p, embed_p):
     """bf16 training step with dropout on the residual branches / the embedding (block-push ships resid_pdrop = 0.05): the
-    transposed-formulation data-gradient kernels (train_dgrad_kernel) run, the LayerNorm backward at a site WITH dropout stays the
-    stand-alone kernel (its mask is a hash of (row, feature) that the GEMM epilogue does not evaluate), sites without it take the
-    epilogue form.  Same seed = same masks in both plans, so the library's choice and the per-op kernels must agree inside the
-    bf16 bound (2e-2 per tensor, loss 2e-3)."""
+    library's backward is the transposed-formulation data-gradient kernels (train_dgrad_kernel, train_mlp_bwd_kernel) with the
+    LayerNorm backward as their epilogue, which evaluates the site's mask -- the stand-alone kernel's hash of (seed, site,
+    row D + feature); the sigma token's embedding row carries none -- on its own elements.  Same seed = same masks in both plans,
+    so the library's choice and the per-op kernels must agree inside the bf16 bound (2e-2 per tensor, loss 2e-3)."""
     cfg = O.CONFIGS[cfg_name]
     m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), "bf16", attn_pdrop=0.3, resid_pdrop=resid_p, embed_pdrop=embed_p)
     m.train()
