@@ -1266,6 +1266,152 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const E* __restrict__ qk
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same backward on the matrix pipe (bf16 operands, T <= 16, hd <= 64, hd % 4 == 0; round 4).  The VALU kernel above is a
+// latency chain of ~29 k cycles per (sample, head): hundreds of dependent LDS round trips for 72 kFLOP.  Here a wave's products
+// are 20 MFMAs and everything between them stays in registers:
+//   S^T = K Q^T and S = Q K^T, dPd^T = V dY^T and dPd = dY V^T      8 x v_mfma_f32_16x16x32_bf16: both operands of every one are
+//        row chunks (lane (x, g): columns 32 kk + 8 g .. + 7 of row x), loaded from global in fragment order, used as A or B
+//   the two layouts of the T x T matrices -- "T": lane (i, g) holds keys j = 4 g + r; "N": lane (j, g) holds queries i = 4 g + r
+//        -- are what the second stage needs as B operands as they stand (k index 4 g + r), so softmax, dropout and dS are
+//        evaluated in both (T: reductions over r and across the four lane rows; N: over the 16 lanes of a DPP row)
+//   dq^T = K^T dS^T, dk^T = Q^T dS, dv^T = dY^T Pd                  12 x v_mfma_f32_16x16x16_bf16: A = the transposed operand from a
+//        row-major LDS copy (ds_read_b64_tr_b16), D: lane (token, g) holds dims 16 dt + 4 g .. + 3 = one 8-byte store
+// Same dropout mask as attn_small_kernel (hash of (pair T + i) T + j).  Four (sample, head) pairs per workgroup, no barriers.
+// ---------------------------------------------------------------------------------------------
+constexpr int kAmLd = 72;                          // halfwords per LDS row: 64 dims + pad (144 B: the transpose reads spread over banks)
+
+__device__ __forceinline__ u32x4 row_chunk16(const uint16_t* __restrict__ base, size_t ld, int x, int c0, int T, int hd) {
+    const uint16_t* p = base + (size_t)min(x, T - 1) * ld;
+    uint2 lo = *(const uint2*)(p + min(c0, hd - 4)), hi = *(const uint2*)(p + min(c0 + 4, hd - 4));
+    const uint2 z = make_uint2(0u, 0u);
+    if (!(x < T && c0 < hd)) lo = z;
+    if (!(x < T && c0 + 4 < hd)) hi = z;
+    return u32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) {
+    typedef __attribute__((ext_vector_type(2))) float f2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+    const f2_t v0 = {a, b}, v1 = {c, d};                 // v_cvt_pk_bf16_f32 (RNE)
+    return make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(v0, b2_t)),
+                      __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, b2_t)));
+}
+// sum / maximum over the four lane rows (lanes x, x + 16, x + 32, x + 48), in every lane
+template <bool IS_MAX>
+__device__ __forceinline__ float cross_rows_allreduce(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+    const u32x2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float r = IS_MAX ? fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])) : __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r), __float_as_uint(r), false, false);
+    return IS_MAX ? fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1])) : __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+__global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dy,
+                                                            uint16_t* __restrict__ dqkv, int n_pairs, int T, int D, int H, int hd,
+                                                            float scale, float p, float inv_keep, uint32_t seed, uint32_t site) {
+    __shared__ __attribute__((aligned(16))) uint16_t sm[4][3][16][kAmLd];       // per wave: q, k, dy row-major
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, x = lane & 15, g = lane >> 4;
+    const int pair = blockIdx.x * 4 + wid;
+    if (pair >= n_pairs) return;                     // (wave-uniform; the kernel has no workgroup barrier)
+    const int b = pair / H, h = pair % H;
+    const size_t ldq = (size_t)3 * D;
+    const uint16_t* qb = qkv + (size_t)b * T * ldq + (size_t)h * hd;
+    const uint16_t* gb = dy + (size_t)b * T * D + (size_t)h * hd;
+    const int nkk = hd > 32 ? 2 : 1;
+    u32x4 qf[2], kf[2], vf[2], gf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int c0 = 32 * kk + 8 * g;
+        qf[kk] = row_chunk16(qb, ldq, x, c0, T, hd);
+        kf[kk] = row_chunk16(qb + D, ldq, x, c0, T, hd);
+        vf[kk] = row_chunk16(qb + 2 * D, ldq, x, c0, T, hd);
+        gf[kk] = row_chunk16(gb, (size_t)D, x, c0, T, hd);
+    }
+    uint16_t (*sq)[kAmLd] = sm[wid][0], (*sk)[kAmLd] = sm[wid][1], (*sg)[kAmLd] = sm[wid][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        *(u32x4*)&sq[x][32 * kk + 8 * g] = qf[kk];
+        *(u32x4*)&sk[x][32 * kk + 8 * g] = kf[kk];
+        *(u32x4*)&sg[x][32 * kk + 8 * g] = gf[kk];
+    }
+    auto mma32 = [](const u32x4& a, const u32x4& bb, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb), c, 0, 0, 0);
+    };
+    f32x4 sT = {0.f, 0.f, 0.f, 0.f}, sN = sT, pT = sT, pN = sT;
+    for (int kk = 0; kk < nkk; ++kk) {
+        sT = mma32(kf[kk], qf[kk], sT);              // [j][i]: lane (i, g) holds j = 4 g + r
+        sN = mma32(qf[kk], kf[kk], sN);              // [i][j]: lane (j, g) holds i = 4 g + r
+        pT = mma32(vf[kk], gf[kk], pT);              // dPd, the same two layouts
+        pN = mma32(gf[kk], vf[kk], pN);
+    }
+    // softmax, dropout keep-scales, dS -- layout T: query i = x, keys j = 4 g + r
+    float dsT[4], dsN[4], pdN[4];
+    {
+        float e[4], ks[4], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = (4 * g + r <= x) ? sT[r] * scale : -INFINITY; mx = fmaxf(mx, e[r]); }
+        mx = cross_rows_allreduce<true>(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = expf(e[r] - mx); sum += e[r]; }
+        sum = cross_rows_allreduce<false>(sum);
+        const float inv = 1.0f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 4 * g + r;
+            ks[r] = (p > 0.f && x < T && j <= x) ? drop_scale(seed, site, ((size_t)pair * T + x) * T + j, p, inv_keep) : 1.f;
+            e[r] *= inv;
+            dot = fmaf(pT[r] * ks[r], e[r], dot);
+        }
+        dot = cross_rows_allreduce<false>(dot);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsT[r] = e[r] * (pT[r] * ks[r] - dot) * scale;
+    }
+    // layout N: key j = x, queries i = 4 g + r (a query's keys are the 16 lanes of this DPP row)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        const bool in = x <= i;
+        const float ev = in ? sN[r] * scale : -INFINITY;
+        const float mx = row16_allreduce<true>(ev);
+        const float ex = expf(ev - mx);
+        const float pr = ex * (1.0f / row16_allreduce<false>(ex));
+        const float ks = (p > 0.f && i < T && in) ? drop_scale(seed, site, ((size_t)pair * T + i) * T + x, p, inv_keep) : 1.f;
+        const float dot = row16_allreduce<false>(pN[r] * ks * pr);
+        dsN[r] = pr * (pN[r] * ks - dot) * scale;
+        pdN[r] = pr * ks;
+    }
+    const uint2 bdsT = pack4_bf16(dsT[0], dsT[1], dsT[2], dsT[3]);
+    const uint2 bdsN = pack4_bf16(dsN[0], dsN[1], dsN[2], dsN[3]);
+    const uint2 bpdN = pack4_bf16(pdN[0], pdN[1], pdN[2], pdN[3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                // the wave's LDS copies are written (LDS serves a wave's accesses in order)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    auto tr = [&](uint16_t (*m)[kAmLd], int dt) {   // lane (x, g): m[4 g + r][16 dt + x], r = 0 .. 3
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&m[4 * g + (x >> 2)][16 * dt + 4 * (x & 3)]));
+    };
+    auto mma16b = [](const s16x4& a, const uint2& bb, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(s16x4, bb), c, 0, 0, 0);
+    };
+    uint16_t* ob = dqkv + ((size_t)b * T + x) * ldq + (size_t)h * hd;      // row x of this pair's dq | dk | dv
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        if (16 * dt >= hd) break;                    // (wave-uniform)
+        const f32x4 dq = mma16b(tr(sk, dt), bdsT, zero);     // [d][i]: lane (i, g) holds d = 16 dt + 4 g + r
+        const f32x4 dk = mma16b(tr(sq, dt), bdsN, zero);     // [d][j]
+        const f32x4 dv = mma16b(tr(sg, dt), bpdN, zero);
+        const int d0 = 16 * dt + 4 * g;
+        if (x < T && d0 < hd) {
+            *(uint2*)(ob + d0) = pack4_bf16(dq[0], dq[1], dq[2], dq[3]);
+            *(uint2*)(ob + D + d0) = pack4_bf16(dk[0], dk[1], dk[2], dk[3]);
+            *(uint2*)(ob + 2 * D + d0) = pack4_bf16(dv[0], dv[1], dv[2], dv[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The last layer's out-projection, MLP, ln_f and head only matter on the action-token rows (nothing else reaches the
 // loss: score_gpts.py:341-353), so they run on a COMPACT copy of those rows: compact row c = b*t + i <-> token row
 // b*T + G + 2 + 2i.  gather: full -> compact; scatter: compact -> full with zeros on every other row (the gradient
@@ -1906,7 +2052,12 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
                                G, D);
             TRY(hipGetLastError());
         }
-        if (attn_small) {
+        if (attn_small && sizeof(E) == 2 && !(flags & BESO_TRAIN_PLAN_PER_OP)) {
+            const int n_pairs = batch * H;
+            hipLaunchKernelGGL(attn_mfma_bwd_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, s, (const uint16_t*)P(y.qkv),
+                               (const uint16_t*)P(w.dy), (uint16_t*)P(y.dqkv), n_pairs, T, D, H, hd, scale, attn_p, attn_ik, seed,
+                               (uint32_t)(4 * l));
+        } else if (attn_small) {
 #define ATT(TT) hipLaunchKernelGGL((attn_small_kernel<E, true, TT>), dim3(batch * H), dim3(64), 0, s, (const E*)P(y.qkv), \
                                    (const E*)P(w.dy), P(y.dqkv), T, D, H, hd, scale, attn_p, attn_ik, seed, (uint32_t)(4 * l))
             if (T <= 8) ATT(8); else if (T <= 12) ATT(12); else ATT(16);
