@@ -326,7 +326,7 @@ __device__ __forceinline__ void tgemm_tile(TileLds& lds, const E* __restrict__ A
                 else epi(m, n, acc[mi][ni]);
             }
             if constexpr (Epi::kBiasCol) {
-                if (m < M && n == N && epi.bias) epi.bias[m] = acc[mi][ni][0];      // the ones column: sum over the rows of A's column m
+                if (m < M && n == N && epi.bias) epi.bias[m] = acc[mi][ni][0] + (epi.add ? epi.bias[m] : 0.f);      // the ones column: sum over the rows of A's column m
             }
         }
     }
@@ -505,7 +505,11 @@ struct GProb { const void* A; const void* B; float* out; float* bias; int lda, l
 constexpr int kMaxGroup = 56;                          // 6 per layer + 2: up to 9 layers per launch, more launches beyond (a 4 KiB kernel argument)
 struct GTable { GProb p[kMaxGroup]; int n; };
 struct EpiStoreF { static constexpr bool kColSum = false; static constexpr bool kBiasCol = true; float* out; int ld; float* bias;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const { *(f32x4*)(out + (size_t)m * ld + n) = v; } };
+    bool add;                                          // out += v (a later row window of the same product: launches in stream order)
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        f32x4* o = (f32x4*)(out + (size_t)m * ld + n);
+        *o = add ? *o + v : v;
+    } };
 
 // splits > 1 (round 4): the contraction -- the TOKEN ROWS of the step -- is cut into `splits` ranges, one workgroup per (tile,
 // range); range z writes its partial tile into slab z (wgrad_reduce_kernel adds the slabs up in a fixed order: deterministic,
@@ -513,7 +517,7 @@ struct EpiStoreF { static constexpr bool kColSum = false; static constexpr bool 
 // 11,264 rows (176 stages): 417 us of the 2.26 ms step at 2 % of the matrix pipe.
 template <typename E>
 __global__ __launch_bounds__(kGT, kOcc) void tgemm_wgrad_group_kernel(GTable t, int n_tiles, int splits, float* slab,
-                                                                      size_t slab_stride) {
+                                                                      size_t slab_stride, int win, int n_win) {
     const int v = xcd_tile(blockIdx.x, gridDim.x);
     const int z = v / n_tiles, b = v - z * n_tiles;
     int pi = 0;
@@ -530,8 +534,12 @@ __global__ __launch_bounds__(kGT, kOcc) void tgemm_wgrad_group_kernel(GTable t, 
         out = slab + (size_t)z * slab_stride + g.slab_off;
         if (bias) bias = out + (size_t)g.Mo * g.No;
     }
+    if (n_win > 1) {                                  // row window `win` of n_win (one launch per window)
+        const int kc = ((g.K + n_win - 1) / n_win + KSTAGE - 1) / KSTAGE * KSTAGE;
+        k0 = min(win * kc, g.K); k1 = min(k0 + kc, g.K);
+    }
     tgemm_tile<E, true, true, EpiStoreF>(lds, (const E*)g.A, g.lda, (const E*)g.B, g.ldb, g.Mo, g.No, tile_m * kTileMN,
-                                         tile_n * kTileMN, k0, k1, EpiStoreF{out, g.No, bias});
+                                         tile_n * kTileMN, k0, k1, EpiStoreF{out, g.No, bias, n_win > 1 && win > 0});
 }
 
 // out (and bias) of every problem of a split launch = the sum of its slabs, z = 0 .. splits-1 in that order
@@ -1951,8 +1959,16 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     auto flush_group = [&]() -> hipError_t {
         if (gt.n == 0) return hipSuccess;
         const int sp = (w.w_splits > 1 && g_floats <= w.wslab_floats) ? w.w_splits : 1;
+        // Long contractions (M >= ~18 k token rows) run as one launch per ROW WINDOW of ~12 k rows, window w > 0 adding to the
+        // outputs of the windows before it (stream order: deterministic).  The tiles of a weight gradient share operand panels
+        // through an XCD's L2, but the sharers drift apart over a long contraction -- FETCH_SIZE 24 GB for 6.2 GB of operands at
+        // 8192 kitchen samples (90 k rows) against 1.9 GB for 0.78 GB at 1024 -- and a launch boundary lines them up again:
+        // 14.6 -> 14.2 ms per 8192-sample step with 8 windows (4: 14.3, 16: 14.25, 32: 14.6); nothing to gain at 11 k rows.
+        int n_win = (sp > 1 || (flags & BESO_TRAIN_PLAN_PER_OP)) ? 1 : (M + 6144) / 12288;
+        n_win = n_win < 1 ? 1 : (n_win > 16 ? 16 : n_win);
+        for (int win = 0; win < n_win; ++win)
         hipLaunchKernelGGL(tgemm_wgrad_group_kernel<E>, dim3(g_tiles * sp), dim3(kGT), 0, s, gt, g_tiles, sp, F(w.wslab),
-                           w.wslab_floats);
+                           w.wslab_floats, win, n_win);
         if (sp > 1)
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((g_floats + 1023) / 1024), dim3(256), 0, s, gt, (const float*)F(w.wslab),
                                w.wslab_floats, sp, g_floats);

@@ -1403,7 +1403,8 @@ def test_training_forward_tail_block_equals_the_per_op_forward(cfg_name, B, t):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg_name,B,t", [("kitchen", 200, None), ("kitchen", 37, 2), ("kitchen", 1030, None),
-                                          ("kitchen", 3, 1), ("block_push", 96, None), ("block_push", 1100, 3)])
+                                          ("kitchen", 3, 1), ("block_push", 96, None), ("block_push", 1100, 3),
+                                          ("kitchen", 2300, None)])      # (25,300 token rows: the weight gradients in two row windows)
 def test_training_forward_as_one_launch_equals_the_per_op_forward(cfg_name, B, t):
     """bf16 training step, round 4: ALL layers of the forward as ONE launch (train_fwd_kernel, fused.hip: the phases of the
     inference kernel with store hooks for everything the backward keeps, attention dropout inside the core with the per-op
