@@ -80,11 +80,14 @@ enum {
 enum {
     BESO_TRAIN_LAST_ACTION_ONLY = 1, /* GCDenoiser.loss(pred_last_action_only=True): only the last step of every window
                                         is scored (score_wrappers.py:59-63,76-77; the caller zeroes the other steps' noise) */
-    /* execution-plan hints (bf16): which kernels run the forward half, never what it computes -- all forms write the same
-     * kept activations.  Default: ALL layers as one launch where the shape has that kernel (kitchen, block-push; no dropout
-     * on the proj / MLP outputs); otherwise the per-op kernels below 16,000 token rows and the tile kernel (a layer's
-     * out-projection .. the next layer's q/k/v as one launch) from there on. */
-    BESO_TRAIN_PLAN_PER_OP = 2,      /* per-op kernels for every layer */
+    /* execution-plan hints (bf16): which kernels run the step, never what it computes -- all forms write the same kept
+     * activations and evaluate the same dropout masks.  Default forward: ALL layers as one launch where the shape has that
+     * kernel (kitchen, block-push; no dropout on the proj / MLP outputs); otherwise the per-op kernels below 16,000 token rows
+     * and the tile kernel (a layer's out-projection .. the next layer's q/k/v as one launch) from there on.  Default backward:
+     * the data gradients in the transposed formulation (GELU' / LayerNorm backward as GEMM epilogues, FC2 .. out-projection of a
+     * layer as one launch), the attention backward on the matrix pipe, the weight gradients of >= 18 k token rows in row
+     * windows. */
+    BESO_TRAIN_PLAN_PER_OP = 2,      /* per-op kernels for every layer, forward and backward (the comparator of the above) */
     BESO_TRAIN_PLAN_TILES = 4        /* the tile kernel (one launch per layer) wherever the shape has it */
 };
 
