@@ -2010,6 +2010,8 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // (Measured and rejected, round 2: the chain of data gradients between two attention backwards as ONE tile kernel, the mirror
     // image of the tail-block forward -- parity-green, 209 us per launch against 164 us + gaps for the eight per-op launches it
     // replaces: 3.60 vs 3.43 ms per 1024-sample step.  DESIGN.md section 7.)
+    // (status of a fused.hip launch: BESO_OK or the error the caller reports)
+#define FUSED(call) do { const int st_ = (call); if (st_ != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st_; } } while (0)
     for (int l = L - 1; l >= 0; --l) {
         const TrainLayerWs& y = w.layer[l];
         const float* x_in = l == 0 ? F(w.x0) : F(w.layer[l - 1].x_out);
@@ -2018,48 +2020,34 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         float* dres = last ? F(w.dxa) : F(w.dx);          // residual gradient of this layer's second half
         // FC2: dW2 = dyo^T g, dh = (dyo W2) * GELU'(h)
         TRY(wgrad(P(y.dyo), D, D, P(y.g), D4, D4, rows, lp[l].f2w.g));
+        E* dy_out = last ? P(w.dya) : P(w.dy);
+        float* slab = F(w.b1slab) + (size_t)l * fused_train_dgrad_blocks(M) * D4;       // FC1 bias sums per workgroup (use_dgrad)
+        if (use_dgrad) { b1_slabs[b1_n] = slab; b1_outs[b1_n] = lp[l].f1b.g; b1_blocks[b1_n] = fused_train_dgrad_blocks(rows); ++b1_n; }
         if (use_mlp_bwd) {
             // FC2 + GELU' -> FC1 -> LayerNorm-2 backward -> out-projection: one launch, dh and dym stay in LDS between the GEMMs
-            float* slab = F(w.b1slab) + (size_t)l * fused_train_dgrad_blocks(M) * D4;
             float* part = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
             lrt.nb[ln_calls] = fused_train_dgrad_blocks(rows);
             lrt.c[ln_calls++] = LnRedCall{lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g};
             const TrainLnBwd ln{F(y.x_mid), (const float*)F(y.st2), lp[l].ln2w.p, dres, dres, P(y.dym), part, resid_p, seed,
                                 (uint32_t)(4 * l + 1), 0};
-            const int st = fused_train_mlp_bwd(flay, ws + w.bimg, l, rows, P(y.dyo), P(y.h), P(y.dh), slab,
-                                               last ? P(w.dya) : P(w.dy), ln, s);
-            if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
-            b1_slabs[b1_n] = slab; b1_outs[b1_n] = lp[l].f1b.g; b1_blocks[b1_n] = fused_train_dgrad_blocks(rows); ++b1_n;
-            TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, rows, lp[l].f1w.g));
-            TRY(wgrad(P(y.dym), D, D, last ? P(w.ya) : P(y.y), D, D, rows, lp[l].pw.g));
+            FUSED(fused_train_mlp_bwd(flay, ws + w.bimg, l, rows, P(y.dyo), P(y.h), P(y.dh), slab, dy_out, ln, s));
+        } else if (use_dgrad) {
+            // the same chain as three launches (shapes without the one-kernel form)
+            FUSED(fused_train_dgrad(flay, ws + w.bimg, l, 3, rows, P(y.dyo), nullptr, nullptr, P(y.h), P(y.dh), slab, s));
+            FUSED(dgrad_ln(l, 2, rows, P(y.dh), F(y.x_mid), y.st2, lp[l].ln2w.p, dres, P(y.dym), lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g,
+                           resid_p, (uint32_t)(4 * l + 1)));
+            FUSED(fused_train_dgrad(flay, ws + w.bimg, l, 1, rows, P(y.dym), nullptr, dy_out, nullptr, nullptr, nullptr, s));
         } else {
-        if (use_dgrad) {
-            float* slab = F(w.b1slab) + (size_t)l * fused_train_dgrad_blocks(M) * D4;
-            const int st = fused_train_dgrad(flay, ws + w.bimg, l, 3, rows, P(y.dyo), nullptr, nullptr, P(y.h), P(y.dh), slab, s);
-            if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
-            b1_slabs[b1_n] = slab; b1_outs[b1_n] = lp[l].f1b.g; b1_blocks[b1_n] = fused_train_dgrad_blocks(rows); ++b1_n;
+            // per-op: dh = (dyo W2) * GELU'(h) (+ db1), dxn2 = dh W1, LayerNorm-2 backward, dy = dym Wp
+            TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), lp[l].f1b.g, D4}, s)));
+            TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, rows, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
+            TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, dres, dres, P(y.dym), rows, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
+                       (uint32_t)(4 * l + 1)));
+            TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, rows, D, D, 1, EpiStore<E>{nullptr, dy_out, nullptr, D}, s)));
         }
-        else
-        TRY((tgemm<E, false, true>(P(y.dyo), D, P(y.w_fc2), D4, rows, D4, D, 1, EpiGeluBwd<E>{P(y.h), P(y.dh), lp[l].f1b.g, D4}, s)));
-        // FC1: dW1 = dh^T xn2, db1, dxn2 = dh W1
+        // FC1: dW1 = dh^T xn2; proj: dWp = dym^T y
         TRY(wgrad(P(y.dh), D4, D4, P(y.xn2), D, D, rows, lp[l].f1w.g));
-        if (use_dgrad) {
-            const int st = dgrad_ln(l, 2, rows, P(y.dh), F(y.x_mid), y.st2, lp[l].ln2w.p, dres, P(y.dym), lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g,
-                                    resid_p, (uint32_t)(4 * l + 1));
-            if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
-        } else {
-        TRY((tgemm<E, false, true>(P(y.dh), D4, P(y.w_fc1), D, rows, D, D4, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
-        TRY(ln_bwd(F(y.x_mid), y.st2, lp[l].ln2w.p, dres, dres, P(y.dym), rows, lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g, resid_p,
-                   (uint32_t)(4 * l + 1)));
-        }
-        // proj: dWp = dym^T y, dy = dym Wp
         TRY(wgrad(P(y.dym), D, D, last ? P(w.ya) : P(y.y), D, D, rows, lp[l].pw.g));
-        if (use_dgrad) { const int st = fused_train_dgrad(flay, ws + w.bimg, l, 1, rows, P(y.dym), nullptr, last ? P(w.dya) : P(w.dy), nullptr, nullptr, nullptr, s);
-                         if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; } }
-        else
-        TRY((tgemm<E, false, true>(P(y.dym), D, P(y.w_proj), D, rows, D, D, 1,
-                                   EpiStore<E>{nullptr, last ? P(w.dya) : P(w.dy), nullptr, D}, s)));
-        }
         if (last) {
             // back to all token rows: dy and the residual gradient are zero off the action rows
             const size_t n4 = (size_t)M * (D / 4);
@@ -2088,10 +2076,9 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(wgrad(P(y.dqkv) + 2 * D, D3, D, P(y.xn1), D, D, M, lp[l].vw.g, lp[l].vb.g));
         const bool first = l == 0;
         if (use_dgrad) {
-            const int st = dgrad_ln(l, 0, M, P(y.dqkv), x_in, y.st1, lp[l].ln1w.p, F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo),
-                                    lp[l].ln1w.g, lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? embed_p : resid_p,
-                                    first ? kEmbedSite : (uint32_t)(4 * (l - 1) + 2), first ? T : 0);
-            if (st != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return st; }
+            FUSED(dgrad_ln(l, 0, M, P(y.dqkv), x_in, y.st1, lp[l].ln1w.p, F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo),
+                           lp[l].ln1w.g, lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? embed_p : resid_p,
+                           first ? kEmbedSite : (uint32_t)(4 * (l - 1) + 2), first ? T : 0));
         } else {
             TRY((tgemm<E, false, true>(P(y.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
             TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, F(w.dx), F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo), M, lp[l].ln1w.g,
@@ -2114,6 +2101,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
             TRY(hipStreamWaitEvent(early_stream, ev, 0));
         }
     }
+#undef FUSED
     // embeddings: dWcat[Ke][D] = Xemb^T dx0, routed to pos_emb / tok_emb / action_emb / sigma_emb after the launch
     TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dx0b), D, D, M, F(w.dw_cat)));
     TRY(flush_group());
