@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Random model shapes through the bf16 HIP training step: the library's kernels and the per-op plan, each against the fp32 HIP step
+of the same weights (same seed = same dropout masks); the shipped shapes at random batch sizes / windows / dropouts among them:
+    python tools/fuzz_train_bf16.py [seconds] [seed]
+What it exercises beyond the parity tests: the matrix-pipe attention backward (any T <= 16, hd <= 64, hd % 4 == 0), the row ranges
+of the grouped weight-gradient launch (small models), ragged last workgroups of the data-gradient kernels, dropout in the
+LayerNorm-backward epilogue.  Bound: the parity tests' 2.6e-2 per tensor (or 1.5 x the per-op plan's distance), loss 3e-3
+(4e-2 / sqrt(elements) for tiny batches)."""
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from beso_amd import _lib  # noqa: E402
+from beso_amd.runtime import set_plan  # noqa: E402
+from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT  # noqa: E402
+from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    torch.manual_seed(rng.randrange(1 << 30))
+    t0, n, worst, worst_at, worst_ratio = time.time(), 0, 0.0, None, 0.0
+    shipped = [dict(D=360, H=6, W=4, G=2, obs=30, act=9, L=6), dict(D=240, H=12, W=5, G=1, obs=10, act=2, L=4)]      # kitchen, block-push
+    while time.time() - t0 < budget:
+        if rng.random() < 0.3:
+            c = dict(rng.choice(shipped)); c["L"] = rng.randint(1, c["L"])
+            D, H, W, G, obs, act, L = c["D"], c["H"], c["W"], c["G"], c["obs"], c["act"], c["L"]
+            B = rng.choice([1, 3, 4, 5, 37, 100, 257, 1025])
+        else:
+            H = rng.choice([1, 2, 3, 4, 6, 8])
+            hd = rng.choice([4, 8, 12, 16, 20, 32, 40, 60, 64])
+            D = H * hd
+            if D % 8 or D > 512:
+                continue
+            W, G = rng.randint(1, 7), rng.randint(0, 2)
+            obs, act, L, B = rng.randint(1, 40), rng.randint(1, 12), rng.randint(1, 3), rng.randint(1, 70)
+        t = rng.randint(1, W)
+        attn_p = rng.choice([0.0, 0.3]); resid_p = rng.choice([0.0, 0.0, 0.1]); embed_p = rng.choice([0.0, 0.0, 0.1])
+        linear = rng.random() < 0.7
+        inner = DiffusionGPT(state_dim=obs, device="cuda", goal_conditioned=G > 0, action_dim=act, embed_dim=D, embed_pdrob=embed_p,
+                             attn_pdrop=attn_p, resid_pdrop=resid_p, n_layers=L, n_heads=H, goal_seq_len=G, obs_seq_len=W,
+                             linear_output=linear, precision="bf16").cuda()
+        with torch.no_grad():
+            for p in inner.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+        model = GCDenoiser(inner, sigma_data=0.5).cuda().train()
+        state, action = torch.randn(B, t, obs, device="cuda"), torch.randn(B, t, act, device="cuda")
+        goal = torch.randn(B, G, obs, device="cuda") if G > 0 else None
+        noise, sigma = torch.randn_like(action), torch.rand(B, device="cuda") * 0.9 + 0.05
+        # the fp32 HIP step of the same weights (3.5e-5 from torch autograd: tools/fuzz_train.py) with the same seed = the same
+        # dropout masks is the yardstick: a bf16 plan is measured by its distance from it
+        inner32 = DiffusionGPT(state_dim=obs, device="cuda", goal_conditioned=G > 0, action_dim=act, embed_dim=D, embed_pdrob=embed_p,
+                               attn_pdrop=attn_p, resid_pdrop=resid_p, n_layers=L, n_heads=H, goal_seq_len=G, obs_seq_len=W,
+                               linear_output=linear, precision="fp32").cuda()
+        inner32.load_state_dict(inner.state_dict())
+        model32 = GCDenoiser(inner32, sigma_data=0.5).cuda().train()
+        step, step32 = model.hip_train_step(state, action, goal, noise, sigma), model32.hip_train_step(state, action, goal, noise, sigma)
+        assert step is not None and step32 is not None
+        seed = 1234 + n
+        r = step32.run(state, action, goal, noise, sigma, seed=seed, fresh_grads=True)
+        ref = (r[0].item(), [v.clone() for v in r[2]])
+        out = {}
+        try:
+            for plan in (0, _lib.TRAIN_PLAN_PER_OP):
+                set_plan(train=plan)
+                r = step.run(state, action, goal, noise, sigma, seed=seed, fresh_grads=True)
+                out[plan] = (r[0].item(), [v.clone() for v in r[2]])
+        finally:
+            set_plan(train=0)
+        a, b = out[0], out[_lib.TRAIN_PLAN_PER_OP]
+        gmax = max(x.abs().max().item() for x in ref[1])
+        # (key.bias is left out: its exact gradient is zero -- softmax is invariant to a shift of a row's scores -- and what a
+        # plan holds there is the rounding noise of the summands, not a gradient)
+        names = [k for k, _ in inner.named_parameters()]
+        def dist(got, who=False):
+            # (tensors of fewer than 16 elements -- the output bias at act <= 12 -- are left out: each element is a sum over all
+            # B t rows with cancellation, a few rounding errors wide at these batch sizes in ANY bf16 evaluation)
+            d = [(((x - y).norm() / max(y.norm().item(), 2e-3 * gmax * y.numel() ** 0.5, 1e-12)).item(), k)
+                 for k, x, y in zip(names, got[1], ref[1]) if not k.endswith("attn.key.bias") and y.numel() >= 16]
+            return max(d) if who else max(d)[0]
+        e, e_op = dist(a), dist(b)
+        le = abs(a[0] - ref[0]) / abs(ref[0])
+        desc = dict(D=D, H=H, W=W, G=G, obs=obs, act=act, L=L, B=B, t=t, linear=linear, attn_p=attn_p, resid_p=resid_p, embed_p=embed_p)
+        assert all(torch.isfinite(x).all() for x in a[1]), ("non-finite gradient", desc)
+        lb = max(3e-3, 4e-2 / (B * t * act) ** 0.5)          # (a loss over a handful of elements does not average the bf16 rounding)
+        # the library's kernels may not be further from fp32 than the bf16 bound of the parity tests, or -- tiny batches, where
+        # every bf16 evaluation is that far off -- than 1.5 x the per-op plan's own distance
+        assert e < max(2.6e-2, 1.5 * e_op) and le < lb, ("mismatch", dist(a, True), dist(b, True), le, desc)
+        if e > worst:
+            worst, worst_at = e, (dist(a, True)[1], round(e_op, 4), desc)
+        worst_ratio = max(worst_ratio, e / max(e_op, 1e-3))
+        n += 1
+    print(f"fuzz_train_bf16: {n} random cases in {time.time() - t0:.0f} s, largest distance of the library's plan from the fp32 step {worst:.2e} "
+          f"(tensor, the per-op plan's distance, case: {worst_at}); largest library / per-op distance ratio {worst_ratio:.2f}")
+
+
+if __name__ == "__main__":
+    main()
