@@ -3225,7 +3225,6 @@ struct DgradArgs {
     const uint16_t* in; int ld_in;        // [M][ld_in] bf16; part p contracts over columns [p K, (p + 1) K)
     int K, parts, kt;                     // real contraction width per part; k-steps per part in the image (even, zero padded)
     int N, n_chunks;                      // real output features; chunks of 8 RPW row tiles
-    uint32_t part_bytes;                  // bytes between the weight images of two parts
     float* out32; uint16_t* out16; int ld_out;
     const uint16_t* h; uint16_t* dh; float* colsum;      // GELU' epilogue (all three set): h, dh [M][N]; colsum: slab [workgroups][N]
     int M;
@@ -3249,7 +3248,7 @@ struct LnBwdEpi {
 
 // the gradient tile as B fragments: lane (n, g) of fragment (t, kk) holds columns 32 kk + 4 g .. +3 and 32 kk + 16 + 4 g .. +3
 // of token m0 + 16 t + n (zeros beyond K / M: the padded k-steps of the weights are zeros too, but operands must be finite).
-// bT: [part][t][kk][lane]
+// bT: [t][part][kk][lane] -- a token tile's k-steps of all parts in a row: the parts are ONE contraction of parts kt k-steps
 template <int NT>
 __device__ __forceinline__ void stage_grad_tile(u32x4* bT, const uint16_t* __restrict__ in, int ld_in, int K, int parts, int kt,
                                                 int M, int m0, int w, int lane) {
@@ -3277,7 +3276,7 @@ __device__ __forceinline__ void stage_grad_tile(u32x4* bT, const uint16_t* __res
                 const int tok = m0 + 16 * t + n, c0 = 32 * kk + 4 * g;
                 const uint2 z = make_uint2(0u, 0u);
                 const uint2 l2 = (tok < M && c0 < K) ? lo[u] : z, h2 = (tok < M && c0 + 16 < K) ? hi[u] : z;
-                bT[(size_t)f * 64 + lane] = u32x4{l2.x, l2.y, h2.x, h2.y};
+                bT[((size_t)(t * parts + p) * kt + kk) * 64 + lane] = u32x4{l2.x, l2.y, h2.x, h2.y};
             }
         }
     }
@@ -3448,14 +3447,15 @@ __global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restr
         const int n = lane & 15, g = lane >> 4;
         uint2 hu[RPW][NT];
         if (a.dh != nullptr) load_h_tile<RPW, NT>(hu, a.h, a.N, a.M, m0, c * RT + w * RPW, lane);
-#pragma unroll 1
-        for (int p = 0; p < a.parts; ++p) {
+        {
             // a workgroup alone on its CU streams the weights: the ring keeps PFA k-steps of fragments in flight per wave (with the
-            // two of gemm_phase the kernel ran at 37 GB/s per CU: the L2 round trip is ~0.8 us, a k-step of MFMAs 0.07 us)
+            // two of gemm_phase the kernel ran at 37 GB/s per CU: the L2 round trip is ~0.8 us, a k-step of MFMAs 0.07 us).
+            // parts > 1 (q | k | v): the part images lie back to back (part_bytes = RT kt KiB) and so do a token tile's B fragments:
+            // ONE ring over parts kt k-steps instead of a restart per part
             u32x4 ar[PFA][RPW];
-            const WPtr wp = wptr((const u32x4*)(wimg + (size_t)p * a.part_bytes) + ((size_t)c * a.kt * RT + (size_t)w * RPW) * 64, lane);
+            const WPtr wp = wptr((const u32x4*)wimg + ((size_t)c * a.kt * RT + (size_t)w * RPW) * 64, lane);
             prefetch_ring<RPW, PFA>(ar, wp, RT);
-            gemm_phase_ring<RPW, NT, PFA>(acc, ar, wp, RT, (const u32x4*)bT + (size_t)p * NT * a.kt * 64 + lane, a.kt * 64, 64, a.kt);
+            gemm_phase_ring<RPW, NT, PFA>(acc, ar, wp, RT, (const u32x4*)bT + lane, a.parts * a.kt * 64, 64, a.parts * a.kt);
         }
         if (a.dh != nullptr) {
             gelu_bwd_epilogue<RPW, NT>(acc, hu, a.dh, a.colsum + (size_t)blockIdx.x * a.N, a.N, a.M, m0, c * RT + w * RPW, lane,
@@ -4202,9 +4202,9 @@ int fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, 
     const char* lw = img + (size_t)layer * bi.layer_bytes;
     DgradArgs a{};
     a.in = (const uint16_t*)in; a.M = M; a.out32 = out32; a.out16 = (uint16_t*)out16; a.ld_out = D; a.N = D; a.n_chunks = 1;
-    a.parts = 1; a.part_bytes = 0; a.h = nullptr; a.dh = nullptr; a.colsum = nullptr;
+    a.parts = 1; a.h = nullptr; a.dh = nullptr; a.colsum = nullptr;
     const char* wimg;
-    if (which == 0) { wimg = lw + bi.o_qkvT; a.ld_in = 3 * D; a.K = D; a.parts = 3; a.kt = bi.kt_d; a.part_bytes = bi.dd_bytes; }
+    if (which == 0) { wimg = lw + bi.o_qkvT; a.ld_in = 3 * D; a.K = D; a.parts = 3; a.kt = bi.kt_d; }      // (the three images lie dd_bytes = RT kt_d KiB apart: back to back)
     else if (which == 1) { wimg = lw + bi.o_pT; a.ld_in = D; a.K = D; a.kt = bi.kt_d; }
     else if (which == 2) { wimg = lw + bi.o_w1T; a.ld_in = 4 * D; a.K = 4 * D; a.kt = bi.kt_h; }
     else { wimg = lw + bi.o_w2T; a.ld_in = D; a.K = D; a.kt = bi.kt_d; a.N = 4 * D; a.n_chunks = bi.n_chunks; a.ld_out = 4 * D;
