@@ -1956,8 +1956,53 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // grouped launch of a layer on a side stream under the data gradients of the layers in front of it -- 3.63 vs 3.39 ms per
     // 1024-sample kitchen step, the two streams evict each other's operands from L2 / MALL.)
     uint32_t g_floats = 0;                                // floats of the collected problems in a range's slab
+    // Order of the problems inside a launch: each XCD takes a contiguous run of the launch's tiles (xcd_tile), and a problem
+    // whose tiles straddle two runs has its operand panels fetched into two L2s.  Units (problems sharing their B operand:
+    // q | k | v of a layer) are packed into eight bins of ceil(tiles / 8), largest first, and emitted bin by bin -- kitchen:
+    // six bins {FC2, FC1, out-projection} of 81 tiles and two of three q|k|v triples, against runs of 81 / 82.
+    auto arrange_group = [&]() {
+        const int n = gt.n;
+        if (n < 3 || (flags & BESO_TRAIN_PLAN_PER_OP)) return;
+        int ufirst[kMaxGroup], ucnt[kMaxGroup], utiles[kMaxGroup], order[kMaxGroup], bin_of[kMaxGroup], nu = 0;
+        auto tiles_of = [&](const GProb& q) { return q.nt_n * ((q.Mo + kTileMN - 1) / kTileMN); };
+        for (int i = 0; i < n; ++i) {
+            if (i > 0 && gt.p[i].B == gt.p[i - 1].B) { ++ucnt[nu - 1]; utiles[nu - 1] += tiles_of(gt.p[i]); }
+            else { ufirst[nu] = i; ucnt[nu] = 1; utiles[nu] = tiles_of(gt.p[i]); ++nu; }
+        }
+        for (int u = 0; u < nu; ++u) {                    // (stable insertion sort, largest first)
+            int j = u;
+            while (j > 0 && utiles[order[j - 1]] < utiles[u]) { order[j] = order[j - 1]; --j; }
+            order[j] = u;
+        }
+        const int cap = (g_tiles + 7) / 8;
+        int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < nu; ++k) {
+            const int u = order[k];
+            int b = -1;
+            for (int x = 0; x < 8 && b < 0; ++x) if (load[x] + utiles[u] <= cap) b = x;
+            if (b < 0) { b = 0; for (int x = 1; x < 8; ++x) if (load[x] < load[b]) b = x; }
+            bin_of[u] = b; load[b] += utiles[u];
+        }
+        GTable out;
+        out.n = 0;
+        int tiles = 0; uint32_t floats = 0;
+        for (int b = 0; b < 8; ++b)
+            for (int k = 0; k < nu; ++k) {
+                const int u = order[k];
+                if (bin_of[u] != b) continue;
+                for (int i = ufirst[u]; i < ufirst[u] + ucnt[u]; ++i) {
+                    GProb q = gt.p[i];
+                    q.tile_begin = tiles; q.slab_off = floats;
+                    tiles += tiles_of(q);
+                    floats += (uint32_t)round_up(q.Mo * q.No + (q.bias ? q.Mo : 0), 4);
+                    out.p[out.n++] = q;
+                }
+            }
+        gt = out;
+    };
     auto flush_group = [&]() -> hipError_t {
         if (gt.n == 0) return hipSuccess;
+        arrange_group();
         const int sp = (w.w_splits > 1 && g_floats <= w.wslab_floats) ? w.w_splits : 1;
         // Long contractions (M >= ~18 k token rows) run as one launch per ROW WINDOW of ~12 k rows, window w > 0 adding to the
         // outputs of the windows before it (stream order: deterministic).  The tiles of a weight gradient share operand panels
