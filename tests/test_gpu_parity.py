@@ -1468,6 +1468,20 @@ def test_training_backward_kernels_with_residual_and_embedding_dropout_equal_the
 
 
 @pytest.mark.gpu
+def test_bf16_training_step_on_random_shapes_stays_as_close_to_fp32_as_the_per_op_plan():
+    """tools/fuzz_train_bf16.py for ten seconds: random model shapes, batch sizes, windows and dropouts (the shipped shapes among
+    them) through the bf16 HIP step in the library's plan and in the per-op plan, each measured against the fp32 HIP step with
+    the same dropout masks -- the library's kernels (matrix-pipe attention backward, transposed data gradients, split / arranged
+    weight gradients) are never further from fp32 than the bf16 bound or 1.5 x the per-op plan's own distance."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_train_bf16", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_train_bf16.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, worst, ratio = mod.run(10.0, 21)
+    assert n >= 20
+
+
+@pytest.mark.gpu
 def test_agent_train_step_with_goal_drop_runs_the_hip_step():
     """BesoAgent.train_step on a model built with goal_drop = 0.1 and the kitchen dropouts (configs[2] / [3]): the HIP step
     serves it (no host-side masking, no torch-op network), losses are finite and decrease over a few steps."""

@@ -22,9 +22,8 @@ from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
 from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser  # noqa: E402
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(budget=60.0, seed=0):
+    rng = random.Random(seed)
     torch.manual_seed(rng.randrange(1 << 30))
     t0, n, worst, worst_at, worst_ratio = time.time(), 0, 0.0, None, 0.0
     shipped = [dict(D=360, H=6, W=4, G=2, obs=30, act=9, L=6), dict(D=240, H=12, W=5, G=1, obs=10, act=2, L=4)]      # kitchen, block-push
@@ -101,5 +100,8 @@ def main():
           f"(tensor, the per-op plan's distance, case: {worst_at}); largest library / per-op distance ratio {worst_ratio:.2f}")
 
 
+    return n, worst, worst_ratio
+
+
 if __name__ == "__main__":
-    main()
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
