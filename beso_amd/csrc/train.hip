@@ -20,6 +20,7 @@
 //   or a handful of atomics per block): the flat gradient buffer is zeroed first.
 // Dropout masks come from a counter-based hash of (seed, site, element index): the backward recomputes them.
 #include <string.h>
+#include <atomic>
 #include "common.h"
 #include "fused.h"
 #include "train.h"
@@ -556,6 +557,231 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(GTable t, const float
         for (int z = 0; z < splits; ++z) acc += slab[(size_t)z * slab_stride + i];
         *dst = acc;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 5: PANEL-OWNING weight-gradient tiles (bf16).  The 128 x 128 tiles above read every operand panel once per tile that
+// shares it -- 36 tiles of an FC1 / FC2 weight gradient share 15 panels -- and rely on an XCD's 4 MB L2 to serve the
+// sharers, which drift apart over the 176 ... 1408 stages of a contraction: FETCH_SIZE 1.78 GB for 0.78 GB of operands at
+// 1024 kitchen samples (3.7 x at 8192), the launch bound by the fabric behind L2.  Every weight gradient of the network has
+// one side of width D (or less): here a tile covers ALL of that side -- 128 x (128 W) or (128 W) x 128, W = ceil(D / 128)
+// in {2, 3} -- so the LARGE operand (GELU(h), dh, dqkv: 4 D or 3 D wide) is read exactly once by exactly one workgroup, and
+// only the D-wide panel (dyo, xn2, y, xn1) is shared, by all tiles of its problem at the same stage.  Kitchen: 36 tiles per
+// layer, 218 per step = ONE round of one workgroup per CU (no second round to start out of step), a wave tile of 64 x 96
+// (or 96 x 64): 10 fragment reads per 24 MFMAs instead of 6 per 8.  Same operand images in LDS as tgemm_tile (k-slow
+// 16-column subtiles, ds_read_b64_tr_b16), same two-register-set pipeline, same epilogue and ones column.
+// ---------------------------------------------------------------------------------------------
+#ifndef BESO_WG_SETS
+#define BESO_WG_SETS 1                     // register sets of the global -> LDS pipeline (A/B builds: 2)
+#endif
+template <int MT, int NT>
+__device__ __forceinline__ void wgrad_panel_tile(unsigned char* lds, const uint16_t* __restrict__ A, int lda,
+                                                 const uint16_t* __restrict__ B, int ldb, int M, int N, int m0, int n0,
+                                                 int k_begin, int k_end, const EpiStoreF& epi) {
+    typedef uint16_t E;
+    static_assert(kNW == 8 && kGL == 2, "eight waves, two 16-byte chunks per thread and 128-column block");
+    constexpr int KSTAGE = 64;
+    constexpr int WM = MT >= NT ? 4 : 2, WN = 8 / WM;        // waves along m and n
+    constexpr int MI = 8 * MT / WM, NI = 8 * NT / WN;        // 16-row MFMA tiles per wave: 4 x 6, 6 x 4 or 4 x 4
+    constexpr int A_BYTES = 8 * MT * kSubBytes, STAGE = 8 * (MT + NT) * kSubBytes;      // one stage: A's subtiles, then B's
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int nk = (k_end - k_begin + KSTAGE - 1) / KSTAGE;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // One stage = two k-steps of 32.  FRAGMENT PIPELINE: the A fragment of row tile mi + 1 -- in the last group of the first k-step,
+    // the B fragments and the first A fragment of the second k-step -- is requested BEFORE the MFMAs of row tile mi, so the matrix
+    // pipe works on group mi while the LDS pipe fetches group mi + 1 (with the reads issued just in time the two pipes took
+    // turns: LDS 1750 + MFMA 1540 clocks of a 3400-clock stage).  `head` issues the stage's first fragments; the caller puts the
+    // global -> LDS traffic of the next stage between `head` and `body`.
+    u32x4 bf[NI], af;
+    auto head = [&](const unsigned char* st) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bf[ni] = op_frag<E, true>(st + A_BYTES, wn * NI + ni, 0, lane);
+        af = op_frag<E, true>(st, wm * MI, 0, lane);
+    };
+    auto body = [&](const unsigned char* st) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                u32x4 an = af, bn[NI];
+                if (mi + 1 < MI) an = op_frag<E, true>(st, wm * MI + mi + 1, s, lane);
+                else if (s == 0) {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) bn[ni] = op_frag<E, true>(st + A_BYTES, wn * NI + ni, 1, lane);
+                    an = op_frag<E, true>(st, wm * MI, 1, lane);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma16<E>(acc[mi][ni], bf[ni], af);      // D[n][m]: 4 consecutive n per lane
+                af = an;
+                if (mi + 1 == MI && s == 0) {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) bf[ni] = bn[ni];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    if (nk > 0) {
+        // Global side: one 16-byte chunk = (k-row, 8 columns); per-chunk byte offsets inside a stage are formed once, a column
+        // outside the operand gets an offset beyond every range (reads zeros).  The k advance goes into the buffer descriptor:
+        // base = first row of the stage, num_records = the bytes up to k_end -- so rows past the end of the contraction, whole
+        // stages past it included, are zeros BY THE DESCRIPTOR'S RANGE CHECK: no predicates, no masked LDS stores, exact vmcnt.
+        uint32_t va[MT][kGL], vb[NT][kGL];
+#pragma unroll
+        for (int i = 0; i < kGL; ++i) {
+            const int c = tid + kGT * i, krow = c >> 4, cc = c & 15;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int gc = m0 + 128 * j + cc * 8;
+                va[j][i] = gc < M ? (uint32_t)((krow * lda + gc) * 2) : 0x80000000u;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int gc = n0 + 128 * j + cc * 8;
+                vb[j][i] = gc < N ? (uint32_t)((krow * ldb + gc) * 2) : 0x80000000u;
+            }
+        }
+        uint32_t b_ones[NT];                               // chunks of this thread that start at column N of B (the ones column)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            b_ones[j] = 0u;
+            if (epi.bias) {
+#pragma unroll
+                for (int i = 0; i < kGL; ++i) b_ones[j] |= (n0 + 128 * j + ((tid + kGT * i) & 15) * 8 == N ? 1u : 0u) << i;
+            }
+        }
+        auto uniform_ptr = [](const void* p) {
+            const uint64_t pv = (uint64_t)p;
+            return (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pv >> 32)) << 32) |
+                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pv));
+        };
+        auto load = [&](int kt, u32x4 (&ra)[MT][kGL], u32x4 (&rb)[NT][kGL]) {
+            const int k0 = k_begin + kt * KSTAGE;
+            const int rows = k0 < k_end ? k_end - k0 : 0;
+            const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(
+                uniform_ptr(A + (rows ? (size_t)k0 * lda : 0)), 0, rows * lda * 2, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
+                uniform_ptr(B + (rows ? (size_t)k0 * ldb : 0)), 0, rows * ldb * 2, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < kGL; ++i) ra[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, va[j][i], 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < kGL; ++i) rb[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, vb[j][i], 0, 0);
+        };
+        auto store = [&](unsigned char* st, const u32x4 (&ra)[MT][kGL], const u32x4 (&rb)[NT][kGL]) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) op_lstore<E, true, kGL>(st + 8 * j * kSubBytes, tid, ra[j]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) op_lstore<E, true, kGL>(st + A_BYTES + 8 * j * kSubBytes, tid, rb[j], b_ones[j]);
+        };
+#if BESO_WG_SETS == 2
+        // two register sets, ping-pong (tgemm_tile's pipeline): two stages in flight
+        u32x4 a0[MT][kGL], b0[NT][kGL], a1[MT][kGL], b1[NT][kGL];
+        load(0, a0, b0);
+        load(1, a1, b1);
+        store(lds, a0, b0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            load(kt + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);          // the loads are issued HERE (the scheduler sinks them below the MFMAs)
+            head(lds);
+            store(lds + STAGE, a1, b1);
+            body(lds);
+            __syncthreads();
+            // (no exit here when nk is odd: the stage past the end is zeros -- one wasted stage, but an exit in the middle of the
+            //  loop makes the compiler keep TWO copies of the accumulators, 64 ... 96 VGPRs)
+            load(kt + 3, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            head(lds + STAGE);
+            store(lds, a0, b0);
+            body(lds + STAGE);
+            __syncthreads();
+        }
+#else
+        // ONE register set (a stage is 128 B per thread): the stage that landed during the previous iteration's MFMAs is written
+        // to the other LDS buffer, the stage after it requested, then the MFMAs of the current one run -- every load has a whole
+        // compute phase to land
+        u32x4 ar[MT][kGL], br[NT][kGL];
+        load(0, ar, br);
+        store(lds, ar, br);
+        load(1, ar, br);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            head(lds + (kt & 1) * STAGE);
+            __builtin_amdgcn_sched_barrier(0);
+            store(lds + ((kt + 1) & 1) * STAGE, ar, br);      // (a stage past the end is zeros and never read)
+            load(kt + 2, ar, br);
+            __builtin_amdgcn_sched_barrier(0);          // the loads are issued HERE (the scheduler sinks them below the MFMAs)
+            body(lds + (kt & 1) * STAGE);
+            __syncthreads();
+        }
+#endif
+    }
+    int te = tid;
+    asm volatile("" : "+v"(te));          // epilogue addresses are formed HERE, not hoisted above the k loop (spills)
+    const int le = te & 63, wme = (te >> 6) / WN, wne = (te >> 6) % WN;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wme * (16 * MI) + mi * 16 + (le & 15);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wne * (16 * NI) + ni * 16 + (le >> 4) * 4;
+            if (m < M && n < N) epi(m, n, acc[mi][ni]);
+            if (m < M && n == N && epi.bias) epi.bias[m] = acc[mi][ni][0] + (epi.add ? epi.bias[m] : 0.f);      // the ones column
+        }
+    }
+}
+
+constexpr size_t wgrad_panel_lds(int W) { return (size_t)2 * 8 * (W + 1) * kSubBytes; }     // two stages of (1 + W) 128-column blocks
+
+// The grouped launch on panel-owning tiles.  GProb::nt_n carries the orientation: 0 = the tile covers all No columns (128 rows
+// of Mo per tile), -1 = it covers all Mo rows (128 columns of No per tile); tile_begin counts those tiles.
+template <int W>
+__global__ __launch_bounds__(kGT, 2) void wgrad_panel_group_kernel(GTable t, int n_tiles, int splits, float* slab,
+                                                                  size_t slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
+    const int v = xcd_tile(blockIdx.x, gridDim.x);
+    const int z = v / n_tiles, b = v - z * n_tiles;
+    int pi = 0;
+    while (pi + 1 < t.n && b >= t.p[pi + 1].tile_begin) ++pi;
+    const GProb g = t.p[pi];
+    const int local = b - g.tile_begin;
+    int k0 = 0, k1 = g.K;
+    float* out = g.out; float* bias = g.bias;
+    if (splits > 1) {
+        const int kc = ((g.K + splits - 1) / splits + 63) / 64 * 64;
+        k0 = min(z * kc, g.K); k1 = min(k0 + kc, g.K);
+        out = slab + (size_t)z * slab_stride + g.slab_off;
+        if (bias) bias = out + (size_t)g.Mo * g.No;
+    }
+    const EpiStoreF epi{out, g.No, bias, false};
+    if (g.nt_n == 0)
+        wgrad_panel_tile<1, W>(plds, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.B, g.ldb, g.Mo, g.No, local * kTileMN, 0, k0, k1, epi);
+    else
+        wgrad_panel_tile<W, 1>(plds, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.B, g.ldb, g.Mo, g.No, 0, local * kTileMN, k0, k1, epi);
+}
+
+// W of the panel kernel for a model of width D (0: the 128 x 128 tiles stay)
+static int wgrad_panel_w(int D, size_t elem_bytes) {
+    if (elem_bytes != 2) return 0;
+    return D > 128 && D <= 256 ? 2 : (D > 256 && D <= 384 ? 3 : 0);
+}
+// tiles of problem (Mo, No) on panel tiles of width W; *orient = 0 / -1 as GProb::nt_n (a problem with neither side within
+// 128 W does not exist in this network: every weight gradient has a side of width <= D)
+static int wgrad_panel_tiles(int Mo, int No, int W, int* orient) {
+    if (No <= 128 * W) { *orient = 0; return (Mo + kTileMN - 1) / kTileMN; }
+    *orient = -1;
+    return (No + kTileMN - 1) / kTileMN;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1480,6 +1706,19 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pre
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// "the dynamic-LDS attribute of this kernel is set" per device (hipFuncSetAttribute is a driver call: once, not per step)
+struct LdsAttrT { std::atomic<unsigned long long> devices{0}; };
+static hipError_t ensure_lds_t(const void* kernel, size_t bytes, LdsAttrT* done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 64 && (done->devices.load(std::memory_order_relaxed) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev < 64) done->devices.fetch_or(bit, std::memory_order_relaxed);
+    return e;
+}
+
 static size_t carve_t(size_t& cur, size_t bytes) {
     const size_t off = cur;
     cur = round_up_sz(cur + bytes, 256);
@@ -1502,7 +1741,7 @@ struct TrainWs {
     size_t fimg;                                                    // per-step fragment image of the weights (tail-block forward)
     size_t bimg;                                                    // ... of the transposed weights (data-gradient kernel)
     size_t b1slab;                                                  // [L][workgroups][4 D] fp32: FC1 bias sums per workgroup of that kernel
-    size_t wslab; int w_splits; size_t wslab_floats;                // split weight-gradient launch: [w_splits][wslab_floats] partial outputs
+    size_t wslab; int w_splits, w_splits_panel; size_t wslab_floats;   // split weight-gradient launch: [splits][wslab_floats] partial outputs
     TrainLayerWs layer[kMaxLayers];
     size_t total;
 };
@@ -1561,9 +1800,20 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
         if (sp > 8) sp = 8;
         if ((size_t)sp > M / (4 * (128 / e))) sp = (int)(M / (4 * (128 / e)));      // (ranges of at least four stages)
         w->w_splits = sp < 2 ? 1 : sp;
+        // ... and of the panel-owning tiles (one workgroup per CU, one round): as many row ranges as keep the launch within 256
+        w->w_splits_panel = 1;
+        if (const int W = wgrad_panel_w(D, e)) {
+            (void)W;
+            const int ptiles = c->n_layers * (2 * tH + 4 * tD) + 4;
+            int psp = 256 / ptiles;
+            if (psp > 8) psp = 8;
+            if ((size_t)psp > M / (4 * 64)) psp = (int)(M / (4 * 64));
+            w->w_splits_panel = psp < 2 ? 1 : psp;
+        }
+        const int sp_max = w->w_splits > w->w_splits_panel ? w->w_splits : w->w_splits_panel;
         const size_t Kh = w->Hp ? (size_t)w->Hp : (size_t)D;
         w->wslab_floats = train_grad_floats(c) + (size_t)w->Ke * D + (size_t)w->ap * Kh + (size_t)w->Hp * D + 8 * (size_t)(6 * c->n_layers + 8);
-        w->wslab = carve_t(cur, w->w_splits > 1 ? f * w->w_splits * w->wslab_floats : 0);
+        w->wslab = carve_t(cur, sp_max > 1 ? f * sp_max * w->wslab_floats : 0);
     }
     for (int l = 0; l < c->n_layers; ++l) {
         TrainLayerWs& y = w->layer[l];
@@ -1944,6 +2194,9 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     GTable gt;
     gt.n = 0;
     int g_tiles = 0;
+    // bf16, 128 < D <= 384: the grouped launch runs on panel-owning tiles (wgrad_panel_group_kernel); the per-op plan keeps the
+    // 128 x 128 tiles
+    const int panel_w = (flags & BESO_TRAIN_PLAN_PER_OP) ? 0 : wgrad_panel_w(D, sizeof(E));
     // FC1 bias gradients of the transposed-formulation data-gradient kernel: per-workgroup sums in a slab per layer, added up
     // (assigned, not accumulated) where the LayerNorm partial sums are
     const float* b1_slabs[kMaxLayers]; float* b1_outs[kMaxLayers]; int b1_blocks[kMaxLayers]; int b1_n = 0;
@@ -1964,7 +2217,10 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         const int n = gt.n;
         if (n < 3 || (flags & BESO_TRAIN_PLAN_PER_OP)) return;
         int ufirst[kMaxGroup], ucnt[kMaxGroup], utiles[kMaxGroup], order[kMaxGroup], bin_of[kMaxGroup], nu = 0;
-        auto tiles_of = [&](const GProb& q) { return q.nt_n * ((q.Mo + kTileMN - 1) / kTileMN); };
+        auto tiles_of = [&](const GProb& q) {
+            if (panel_w) { int o; return wgrad_panel_tiles(q.Mo, q.No, panel_w, &o); }
+            return q.nt_n * ((q.Mo + kTileMN - 1) / kTileMN);
+        };
         for (int i = 0; i < n; ++i) {
             if (i > 0 && gt.p[i].B == gt.p[i - 1].B) { ++ucnt[nu - 1]; utiles[nu - 1] += tiles_of(gt.p[i]); }
             else { ufirst[nu] = i; ucnt[nu] = 1; utiles[nu] = tiles_of(gt.p[i]); ++nu; }
@@ -2003,6 +2259,28 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     auto flush_group = [&]() -> hipError_t {
         if (gt.n == 0) return hipSuccess;
         arrange_group();
+        if (panel_w) {
+            const int psp = (w.w_splits_panel > 1 && g_floats <= w.wslab_floats) ? w.w_splits_panel : 1;
+            static LdsAttrT attr2, attr3;
+            hipError_t e = hipSuccess;
+            if (panel_w == 2) {
+                e = ensure_lds_t((const void*)wgrad_panel_group_kernel<2>, wgrad_panel_lds(2), &attr2);
+                if (e == hipSuccess)
+                    hipLaunchKernelGGL(wgrad_panel_group_kernel<2>, dim3(g_tiles * psp), dim3(kGT), wgrad_panel_lds(2), s, gt, g_tiles, psp,
+                                       F(w.wslab), w.wslab_floats);
+            } else {
+                e = ensure_lds_t((const void*)wgrad_panel_group_kernel<3>, wgrad_panel_lds(3), &attr3);
+                if (e == hipSuccess)
+                    hipLaunchKernelGGL(wgrad_panel_group_kernel<3>, dim3(g_tiles * psp), dim3(kGT), wgrad_panel_lds(3), s, gt, g_tiles, psp,
+                                       F(w.wslab), w.wslab_floats);
+            }
+            if (e != hipSuccess) return e;
+            if (psp > 1)
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((g_floats + 1023) / 1024), dim3(256), 0, s, gt, (const float*)F(w.wslab),
+                                   w.wslab_floats, psp, g_floats);
+            gt.n = 0; g_tiles = 0; g_floats = 0;
+            return hipGetLastError();
+        }
         const int sp = (w.w_splits > 1 && g_floats <= w.wslab_floats) ? w.w_splits : 1;
         // Long contractions (M >= ~18 k token rows) run as one launch per ROW WINDOW of ~12 k rows, window w > 0 adding to the
         // outputs of the windows before it (stream order: deterministic).  The tiles of a weight gradient share operand panels
@@ -2029,6 +2307,20 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
             hipError_t e = colsum(A, lda, Mo, rows, bias);
             if (e != hipSuccess) return e;
             bias = nullptr;
+        }
+        if (panel_w) {
+            // (the ones column rides in the tile that covers column No: n-wide tiles always hold it unless No == 128 W)
+            if (bias && (No <= 128 * panel_w ? No == 128 * panel_w : No % kTileMN == 0)) {
+                hipError_t e = colsum(A, lda, Mo, rows, bias);
+                if (e != hipSuccess) return e;
+                bias = nullptr;
+            }
+            int orient = 0;
+            const int nt = wgrad_panel_tiles(Mo, No, panel_w, &orient);
+            gt.p[gt.n++] = GProb{A, B, out, bias, lda, ldb, Mo, No, g_tiles, orient, rows, g_floats};
+            g_tiles += nt;
+            g_floats += (uint32_t)round_up(Mo * No + (bias ? Mo : 0), 4);
+            return hipSuccess;
         }
         const int nt_n = (No + kTileMN - 1) / kTileMN, nt_m = (Mo + kTileMN - 1) / kTileMN;
         gt.p[gt.n++] = GProb{A, B, out, bias, lda, ldb, Mo, No, g_tiles, nt_n, rows, g_floats};
@@ -2210,6 +2502,36 @@ int train_goal_mask(float* mask, size_t n, float goal_drop, uint32_t seed, hipSt
 int train_debug_gemm(int precision, int a_kslow, int b_kslow, const void* A, int lda, const void* B, int ldb, float* C,
                      int ldc, int M, int N, int K, int splits, hipStream_t s, hipError_t* err, int* err_line) {
     if (!A || !B || !C) return BESO_ERR_BAD_ARG;
+    if (precision == BESO_PREC_BF16 && ((a_kslow == 1 && (b_kslow == 2 || b_kslow == 3)) || (b_kslow == 1 && (a_kslow == 2 || a_kslow == 3)))) {
+        // the panel-owning weight-gradient tiles: (1, W) = tiles of 128 rows x all N <= 128 W columns, (W, 1) = all M <= 128 W rows
+        // x 128 columns; both operands k-slow, C contiguous (ldc == N); splits > 1: row ranges into slabs behind C's M x N floats
+        const int W = a_kslow > 1 ? a_kslow : b_kslow;
+        if (ldc != N || (a_kslow > 1 ? M : N) > 128 * W || M % 8 || N % 8 || lda % 8 || ldb % 8) return BESO_ERR_BAD_ARG;
+        GTable t;
+        int orient = a_kslow > 1 ? -1 : 0;
+        const int tiles = orient ? (N + kTileMN - 1) / kTileMN : (M + kTileMN - 1) / kTileMN;
+        t.n = 1;
+        t.p[0] = GProb{A, B, C, nullptr, lda, ldb, M, N, 0, orient, K, 0u};
+        if (splits < 1) splits = 1;
+        float* slab = C + (size_t)round_up(M * N, 4);
+        (void)hipGetLastError();
+        if (W == 2) {
+            TRY(hipFuncSetAttribute((const void*)wgrad_panel_group_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_panel_lds(2)));
+            hipLaunchKernelGGL(wgrad_panel_group_kernel<2>, dim3(tiles * splits), dim3(kGT), wgrad_panel_lds(2), s, t, tiles, splits, slab,
+                               (size_t)round_up(M * N, 4));
+        } else {
+            TRY(hipFuncSetAttribute((const void*)wgrad_panel_group_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_panel_lds(3)));
+            hipLaunchKernelGGL(wgrad_panel_group_kernel<3>, dim3(tiles * splits), dim3(kGT), wgrad_panel_lds(3), s, t, tiles, splits, slab,
+                               (size_t)round_up(M * N, 4));
+        }
+        TRY(hipGetLastError());
+        if (splits > 1) {
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((M * N + 1023) / 1024), dim3(256), 0, s, t, (const float*)slab,
+                               (size_t)round_up(M * N, 4), splits, (uint32_t)(M * N));
+            TRY(hipGetLastError());
+        }
+        return BESO_OK;
+    }
 #define DBG(E, AK, BK)                                                                                             \
     do {                                                                                                           \
         if (splits > 1) TRY((tgemm<E, AK, BK>(A, lda, B, ldb, M, N, K, splits, epi_atomic(C, ldc), s)));          \

@@ -1188,6 +1188,24 @@ def test_training_gemm_operand_layouts(precision):
             ref = (A.t() if aks else A).double() @ (B.t() if bks else B).double().t()
             err = ((Cm.double() - ref).abs().max() / ref.abs().max()).item()
             assert err < tol, (precision, aks, bks, M, N, K, S, err)
+    if precision == "bf16":
+        # round 5: the panel-owning weight-gradient tiles (both operands k-slow): (1, W) = tiles of 128 rows x ALL N <= 128 W
+        # columns, (W, 1) = all M <= 128 W rows x 128 columns, W in {2, 3}; with and without row ranges (slabs behind C)
+        for (aks, bks, M, N, K, S) in ((1, 3, 1440, 360, 1000, 1), (3, 1, 360, 1440, 1000, 1), (1, 3, 56, 360, 264, 1),
+                                        (1, 3, 16, 384, 4100, 3), (3, 1, 384, 136, 520, 2), (1, 2, 960, 240, 777, 1),
+                                        (2, 1, 240, 960, 1030, 4), (1, 2, 200, 256, 64, 1), (3, 1, 8, 8, 8, 1),
+                                        (1, 3, 1080, 360, 11264, 1)):
+            A = torch.randn(K, M, generator=g).to(DEV).to(dt)
+            B = torch.randn(K, N, generator=g).to(DEV).to(dt)
+            Cm = torch.full((M * N + 8 + S * (M * N + 8),), float("nan"), device=DEV)      # C, then the slabs of the row ranges
+            st = lib.beso_debug_gemm(prec, aks, bks, A.data_ptr(), M, B.data_ptr(), N, Cm.data_ptr(), N, M, N, K, S,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(st, "debug_gemm (panel tiles)")
+            ref = A.double().t() @ B.double()
+            err = ((Cm[:M * N].view(M, N).double() - ref).abs().max() / ref.abs().max()).item()
+            assert err < tol, ("panel", aks, bks, M, N, K, S, err)
+        with pytest.raises(ValueError):          # a tile cannot cover 400 columns with W = 3
+            _lib.check(lib.beso_debug_gemm(prec, 1, 3, A.data_ptr(), 400, A.data_ptr(), 400, Cm.data_ptr(), 400, 400, 400, 8, 1, None))
     # unsupported layout pair and misaligned leading dimension are refused, not run
     A = torch.zeros(64, 64, device=DEV)
     with pytest.raises(ValueError):
@@ -1197,25 +1215,55 @@ def test_training_gemm_operand_layouts(precision):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("fixture,cfg_name", [("tiny_loss.npz", "tiny"), ("kitchen_loss.npz", "kitchen"),
                                               ("block_push_loss.npz", "block_push"), ("tiny_mlp_head_loss.npz", "tiny_mlp_head")])
-def test_hip_training_step_matches_reference_gradients(fixture, cfg_name):
-    """beso_loss_grad (fp32 mode) against the loss and the per-parameter gradients that the REFERENCE's
-    loss.backward() produced (tests/golden/*_loss.npz: norm and first eight entries of every parameter's gradient, at
-    the kitchen and block-push shapes too), through GCDenoiser.loss + autograd's backward."""
+def test_hip_training_step_matches_reference_gradients(fixture, cfg_name, precision):
+    """beso_loss_grad against the loss and the per-parameter gradients that the REFERENCE's loss.backward() produced
+    (tests/golden/*_loss.npz: norm and first eight entries of every parameter's gradient, at the kitchen and block-push
+    shapes too), through GCDenoiser.loss + autograd's backward.  fp32: the per-op kernels, 5e-4 on the norms.  bf16: the
+    LIBRARY'S PLAN -- what `bench.py --workload train` times: at the kitchen and block-push shapes the one-launch forward
+    (launch site asserted), the transposed-formulation data gradients with their LayerNorm epilogues, the MFMA attention
+    backward and the grouped weight gradients -- held DIRECTLY to the reference's numbers at the bf16 training bound of
+    2.6e-2 per tensor (norms; the eight stored entries against the per-entry share of that bound) and 2e-3 on the loss."""
     fx = load_golden(fixture)
     cfg = O.CONFIGS[cfg_name]
-    m = _train_module(cfg, _weights(fx, cfg), "fp32")
+    m = _train_module(cfg, _weights(fx, cfg), precision)
     T = lambda k: G(fx[k])
-    loss = m.loss(T("state"), T("action"), T("goal"), T("noise"), T("sigma"))
+    box = [None]
+    n_fused = count_fused_launches(lambda: box.__setitem__(0, m.loss(T("state"), T("action"), T("goal"), T("noise"), T("sigma"))))
+    loss = box[0]
     assert "ScoreMatchingLoss" in type(loss.grad_fn).__name__          # the HIP step, not the autograd evaluation
-    assert abs(loss.item() - float(fx["loss"])) < 2e-5 * abs(float(fx["loss"]))
+    if precision == "bf16":
+        assert n_fused == (1 if cfg_name in ("kitchen", "block_push") else 0), n_fused      # all layers of the forward: one launch
+    ltol, ntol = (2e-5, 5e-4) if precision == "fp32" else (2e-3, 2.6e-2)
+    assert abs(loss.item() - float(fx["loss"])) < ltol * abs(float(fx["loss"]))
     loss.backward()
     gmax = max(float(fx["gnorm::" + n]) for n, _ in m.named_parameters())
+    worst_n, worst_s = (0.0, ""), (0.0, "")
     for n, p in m.named_parameters():
         ref_norm = float(fx["gnorm::" + n])
-        assert abs(p.grad.norm().item() - ref_norm) <= 5e-4 * ref_norm + 1e-6 * gmax, n
-        np.testing.assert_allclose(p.grad.reshape(-1)[:8].cpu().numpy(), fx["gslice::" + n], rtol=5e-3, atol=2e-6 * gmax)
+        got8, ref8 = p.grad.reshape(-1)[:8].double().cpu().numpy(), fx["gslice::" + n].astype(np.float64)
+        if precision == "fp32":
+            assert abs(p.grad.norm().item() - ref_norm) <= ntol * ref_norm + 1e-6 * gmax, n
+            np.testing.assert_allclose(got8, ref8, rtol=5e-3, atol=2e-6 * gmax)
+            continue
+        # bf16.  A tensor whose exact gradient is zero (key.bias: softmax is invariant to a shift of a row's scores) is
+        # rounding noise of the summands: measured against 2e-3 x the largest gradient norm, like _grad_errors does
+        floor = 2e-3 * gmax
+        en = abs(p.grad.norm().item() - ref_norm) / max(ref_norm, floor)
+        # the first eight entries: their error against the share of the tensor's error bound that eight of its numel entries
+        # carry (errors spread evenly: |diff8| ~ rel * |g| * sqrt(8 / numel)), or against their own size where that is larger
+        k = min(8, p.numel())
+        share = max(ref_norm, floor) * (k / p.numel()) ** 0.5
+        es = float(np.linalg.norm(got8[:k] - ref8[:k])) / max(share, float(np.linalg.norm(ref8[:k])))
+        worst_n, worst_s = max(worst_n, (en, n)), max(worst_s, (es, n))
+        assert en < ntol, (n, en)
+        assert es < 3 * ntol, (n, es)          # (eight entries: a sample of the tensor's error, not its norm -- 3 x)
+    if precision == "bf16":
+        print(f"[parity] bf16 training step vs the reference's gradients, {cfg_name}: loss "
+              f"{abs(loss.item() - float(fx['loss'])) / abs(float(fx['loss'])):.2e}, worst norm {worst_n[0]:.2e} ({worst_n[1]}), "
+              f"worst 8-entry slice {worst_s[0]:.2e} ({worst_s[1]}), fused forward launches {n_fused}")
 
 
 _LONG_WINDOW = O.ScoreGPTConfig(obs_dim=6, act_dim=4, embed_dim=64, n_layers=2, n_heads=4, goal_seq_len=3, obs_seq_len=9,

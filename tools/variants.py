@@ -43,7 +43,9 @@ def build(specs):
             units = sorted(f[:-4] for f in os.listdir(csrc) if f.endswith(".hip"))
         else:
             every = "-DBESO_DEV_API=1" in flags or any(f.startswith("-DBESO_TGEMM") for f in flags)     # flags of train.hip too
-            csrc, units = B.CSRC, (list(B.UNITS) if every else ["fused", "fused_f16"])
+            train_only = not every and any(f.startswith("-DBESO_WG_") for f in flags)                 # ... of train.hip alone
+            every = every or train_only
+            csrc, units = B.CSRC, (["train"] if train_only else list(B.UNITS) if every else ["fused", "fused_f16"])
         procs = []
         for u in units:
             obj = os.path.join(B.OBJDIR, f"{u}_{name}.o")
