@@ -49,6 +49,7 @@ struct TrainWholeBufs {
     size_t x_mid, x_out, st1, st2, xn1, qkv, y, xn2, h, g, stride, ya;
     int t;                         // steps of the window (action tokens per sample)
     float p_attn; uint32_t seed;   // attention dropout (the per-op kernels' mask)
+    float p_resid;                 // dropout on the out-projection and MLP outputs (sites 4 l + 1, 4 l + 2: EpiResid's mask)
 };
 bool   fused_train_whole_supported(const Layout& lay, int T, int t);
 size_t fused_train_whole_image_bytes(const Layout& lay);

@@ -881,6 +881,44 @@ __device__ __forceinline__ void load_x_rows(Tile<RPW>& T, const float* __restric
         }
     }
 }
+// Residual add behind a dropout (nn.Dropout(resid_pdrop) on the out-projection and on the MLP output, score_gpts.py:79,109,
+// 113-114): T holds the branch output (+ bias) alone, the residual it is added to lies in memory (the previous kept x), and
+// element (row, f) of the branch keeps drop_scale(seed, site, row D + f) -- the per-op forward's EpiResid and the backward
+// kernels' epilogues evaluate the same hash.  rows_x: where the residual's rows lie; rows_m: the rows the mask is indexed by
+// (the same, or the compact action rows of the last layer).
+template <int RPW, int NT>
+__device__ __forceinline__ void resid_dropout_add(Tile<RPW>& T, const float* __restrict__ x, int D, const Rows& rows_x,
+                                                  const Rows& rows_m, float p, float inv_keep, uint32_t seed, uint32_t site,
+                                                  int w, int lane) {
+    asm volatile("" : "+v"(lane));
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int f0 = 16 * (w * RPW + i) + 4 * g;
+        if (f0 >= D) continue;                                   // (padding features stay exact zeros: zero weights, zero bias)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int rx = rows_x.row(16 * t + n), rm = rows_m.row(16 * t + n);
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            if (rx >= 0) xv = *(const f32x4*)(x + (size_t)rx * D + f0);
+            if (rm >= 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) T.acc[i][t][j] *= drop_scale(seed, site, (size_t)rm * D + f0 + j, p, inv_keep);
+            }
+            T.acc[i][t] += xv;
+        }
+    }
+}
+template <int RPW, int NT>
+__device__ __forceinline__ void set_bias_rows(Tile<RPW>& T, const float* __restrict__ bias, int w, int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const f32x4 bv = *(const f32x4*)(bias + 16 * (w * RPW + i) + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) T.acc[i][t] = bv;
+    }
+}
 template <int RPW, int NT>
 __device__ __forceinline__ void store_x_rows(const Tile<RPW>& T, float* __restrict__ x, int D, const Rows& rows, int w, int lane) {
     asm volatile("" : "+v"(lane));
@@ -3138,7 +3176,7 @@ __global__ __launch_bounds__(512, 2) void layers_kernel(float* __restrict__ x, c
 // MLP on the action-token tiles only and writes them as the COMPACT action rows (row b t + i) on which the per-op step
 // continues with ln_f, head and loss.  Weights: the per-step training image (fragment order, LayerNorm affine not folded:
 // the weight gradients need the affine outputs as operands); bf16 operands; attention dropout inside the core
-// (attn_small_kernel's mask); no dropout on the proj / MLP outputs (resid_pdrop = 0).  One launch replaces 44 of the per-op
+// (attn_small_kernel's mask); dropout on the proj / MLP outputs (resid_pdrop > 0: block-push) in the RD = 1 instances.  One launch replaces 44 of the per-op
 // forward at six layers; at 1024 kitchen samples the four-samples-per-workgroup instance is one workgroup per CU.
 // ---------------------------------------------------------------------------------------------
 struct TrainImgW { uint32_t o_ln1w, o_ln1b, o_ln2w, o_ln2b, layer_bytes; };    // behind a layer's FusedDims sections (o_b1 .. o_bproj)
@@ -3150,7 +3188,7 @@ static TrainImgW train_img_whole(const FusedDims& d) {
     return t;
 }
 
-template <int RPW, int KS, int HG, int NTL, int SPW, int NTA>
+template <int RPW, int KS, int HG, int NTL, int SPW, int NTA, int RD = 0>      // RD = 1: dropout on the proj / MLP outputs (resid_pdrop > 0)
 __global__ __launch_bounds__(512, 2) void train_fwd_kernel(const char* __restrict__ img, FusedDims d, TrainImgW ti,
                                                            int n_samples_total, int Tn, TrainWholeBufs a) {
     Stamps st{nullptr, 0, 0};
@@ -3179,6 +3217,13 @@ __global__ __launch_bounds__(512, 2) void train_fwd_kernel(const char* __restric
     u32x4* xnT = (u32x4*)(lds + L.xnT);
     float* red = (float*)(lds + L.red);
     const float inv_keep = a.p_attn > 0.f ? 1.0f / (1.0f - a.p_attn) : 1.f;
+    const float inv_keep_r = RD && a.p_resid > 0.f ? 1.0f / (1.0f - a.p_resid) : 1.f;
+    // RD = 1.  The residual adds of a layer are MFMA accumulations onto the residual registers; with a dropout between the
+    // branch and the add (block-push: resid_pdrop 0.05) the branch must exist alone first.  The residual in front of either
+    // branch already lies in memory -- x0 / the previous layer's kept x_out in front of the attention, the kept x_mid in front
+    // of the MLP (written by this very lane a phase earlier) -- so: once the LayerNorm has read the residual registers they are
+    // set to the branch's bias, the GEMMs accumulate the branch into them, and resid_dropout_add masks the branch and adds the
+    // residual back from memory (an L2 hit: 16 bytes per lane and accumulator).  Same masks as the per-op forward (EpiResid).
     auto layer = [&](int l, auto NTPc, const Rows& rows_tail, uint16_t* ybuf) {
         constexpr int NTP = decltype(NTPc)::value;             // token tiles behind the attention: all, or the action tiles
         const char* lw = img + (size_t)l * ti.layer_bytes;
@@ -3187,21 +3232,29 @@ __global__ __launch_bounds__(512, 2) void train_fwd_kernel(const char* __restric
         attn_prefetch<KS>(qE, qO, (const u32x4*)(lw + d.o_wqkv), w, lane);
         const LnTrain lx1{(const float*)(lw + ti.o_ln1w), (const float*)(lw + ti.o_ln1b), (float*)(wl + a.st1),
                           (uint16_t*)(wl + a.xn1), rows_all, d.D};
-        layernorm_to_lds<RPW, KS, kWaves, true, NTA, 0, LnTrain>(T, xnT, red, d.D, w, lane, (const float*)(lw + d.o_bproj), st, 0, lx1);
+        layernorm_to_lds<RPW, KS, kWaves, !RD, NTA, 0, LnTrain>(T, xnT, red, d.D, w, lane, (const float*)(lw + d.o_bproj), st, 0, lx1);
+        if constexpr (RD) set_bias_rows<RPW, NTP>(T, (const float*)(lw + d.o_bproj), w, lane);
         const AttnTrain ax{(uint16_t*)(wl + a.qkv), ybuf, rows_all, rows_tail, d.D, s0, d.H, a.p_attn, inv_keep, a.seed,
                            (uint32_t)(4 * l)};
         attn_phase<RPW, KS, HG, NTP, NTA, 0, AttnTrain>(T, xnT, lds + L.u, (const u32x4*)(lw + d.o_wqkv),
                                                         (const float*)(lw + d.o_bqkv), (const u32x4*)(lw + d.o_wproj), d.Hv, d.hd,
                                                         Tn, n_samples, w, lane, tb, qE, qO, st, ax);
+        if constexpr (RD)
+            resid_dropout_add<RPW, NTP>(T, l == 0 ? a.x0 : (const float*)(wl - a.stride + a.x_out), d.D, rows_all, rows_tail,
+                                        a.p_resid, inv_keep_r, a.seed, (uint32_t)(4 * l + 1), w, lane);
         store_x_rows<RPW, NTP>(T, (float*)(wl + a.x_mid), d.D, rows_tail, w, lane);
         u32x4 a1r[PF1][kChunkTiles / kWaves];
         mlp_prefetch<KS, kWaves, PF1>(a1r, (const u32x4*)lw, w, lane);
         const LnTrain lx2{(const float*)(lw + ti.o_ln2w), (const float*)(lw + ti.o_ln2b), (float*)(wl + a.st2),
                           (uint16_t*)(wl + a.xn2), rows_tail, d.D};
-        layernorm_to_lds<RPW, KS, kWaves, true, NTP, 0, LnTrain>(T, xnT, red, d.D, w, lane, (const float*)(lw + d.o_b2), st, 0, lx2);
+        layernorm_to_lds<RPW, KS, kWaves, !RD, NTP, 0, LnTrain>(T, xnT, red, d.D, w, lane, (const float*)(lw + d.o_b2), st, 0, lx2);
+        if constexpr (RD) set_bias_rows<RPW, NTP>(T, (const float*)(lw + d.o_b2), w, lane);
         const MlpTrain mx{(uint16_t*)(wl + a.h), (uint16_t*)(wl + a.g), rows_tail, 4 * d.D};
         mlp_phase<RPW, KS, kWaves, NTP, PF1, MlpTrain>(T, xnT, (u32x4*)(lds + L.u), (const u32x4*)lw, (const float*)(lw + d.o_b1),
                                                        (const u32x4*)(lw + d.o_w2), d.HT, d.KS2p, w, lane, a1r, st, mx);
+        if constexpr (RD)
+            resid_dropout_add<RPW, NTP>(T, (const float*)(wl + a.x_mid), d.D, rows_tail, rows_tail, a.p_resid, inv_keep_r, a.seed,
+                                        (uint32_t)(4 * l + 2), w, lane);
         store_x_rows<RPW, NTP>(T, (float*)(wl + a.x_out), d.D, rows_tail, w, lane);
     };
 #pragma unroll 1
@@ -4089,17 +4142,23 @@ int fused_train_whole_pack(const Layout& lay, const float* const* p, char* img, 
     return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
+template <int RPW, int KS, int HG, int NTL, int SPW, int NTA, int RD>
+static hipError_t launch_train_fwd_rd(const char* img, const FusedDims& d, const TrainImgW& ti, int batch, int T,
+                                      const TrainWholeBufs& a, hipStream_t s) {
+    constexpr LdsMap L = lds_map(KS);
+    static LdsAttr attr;
+    hipError_t e = ensure_lds(train_fwd_kernel<RPW, KS, HG, NTL, SPW, NTA, RD>, L.total, &attr);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((train_fwd_kernel<RPW, KS, HG, NTL, SPW, NTA, RD>), dim3((batch + SPW - 1) / SPW), dim3(512), L.total, s, img, d,
+                       ti, batch, T, a);
+    return hipGetLastError();
+}
 template <int RPW, int KS, int HG, int NTL, int SPW, int NTA>
 static hipError_t launch_train_fwd(const char* img, const FusedDims& d, const TrainImgW& ti, int batch, int T,
                                    const TrainWholeBufs& a, hipStream_t s) {
-    constexpr LdsMap L = lds_map(KS);
-    static LdsAttr attr;
-    hipError_t e = ensure_lds(train_fwd_kernel<RPW, KS, HG, NTL, SPW, NTA>, L.total, &attr);
-    if (e != hipSuccess) return e;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((train_fwd_kernel<RPW, KS, HG, NTL, SPW, NTA>), dim3((batch + SPW - 1) / SPW), dim3(512), L.total, s, img, d,
-                       ti, batch, T, a);
-    return hipGetLastError();
+    return a.p_resid > 0.f ? launch_train_fwd_rd<RPW, KS, HG, NTL, SPW, NTA, 1>(img, d, ti, batch, T, a, s)
+                           : launch_train_fwd_rd<RPW, KS, HG, NTL, SPW, NTA, 0>(img, d, ti, batch, T, a, s);
 }
 
 int fused_train_whole(const Layout& lay, const char* img, int batch, int T, const TrainWholeBufs& a, hipStream_t s) {

@@ -1944,10 +1944,11 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     Layout flay;
     const bool use_tail = sizeof(E) == 2 && resid_p == 0.f && L >= 2 && L * 13 <= 96 && make_layout(c, BESO_PREC_BF16, &flay) &&
                           fused_train_supported(flay) && fused_train_image_bytes(flay) > 0 && tail_forward_enabled(M, flags);
-    // ... and where the shape has the one-launch kernel (kitchen, block-push; bf16, no dropout on the proj / MLP outputs), ALL
+    // ... and where the shape has the one-launch kernel (kitchen, block-push; bf16; round 5: with or without dropout on the
+    // proj / MLP outputs), ALL
     // layers run as ONE launch (fused.hip: train_fwd_kernel) -- 44 launches of the per-op forward at six layers; the call's plan
     // hints keep the other two forms reachable (BESO_TRAIN_PLAN_PER_OP, BESO_TRAIN_PLAN_TILES)
-    const bool use_whole = sizeof(E) == 2 && resid_p == 0.f && !(flags & (BESO_TRAIN_PLAN_PER_OP | BESO_TRAIN_PLAN_TILES)) &&
+    const bool use_whole = sizeof(E) == 2 && !(flags & (BESO_TRAIN_PLAN_PER_OP | BESO_TRAIN_PLAN_TILES)) &&
                            make_layout(c, BESO_PREC_BF16, &flay) && fused_train_whole_supported(flay, T, t);
 
     // The data-gradient GEMMs of the backward pass in the transposed formulation (fused.hip: train_dgrad_kernel; bf16, the shapes
@@ -2076,7 +2077,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         const TrainLayerWs& y0 = w.layer[0];
         const size_t stride = L > 1 ? w.layer[1].x_mid - y0.x_mid : 0;
         const TrainWholeBufs b{F(w.x0), ws, y0.x_mid, y0.x_out, y0.st1, y0.st2, y0.xn1, y0.qkv, y0.y, y0.xn2, y0.h, y0.g,
-                               stride, w.ya, t, attn_p, seed};
+                               stride, w.ya, t, attn_p, seed, resid_p};
         profile_begin(BESO_SITE_FUSED_LAYER, s);
         const int st = fused_train_whole(flay, ws + w.fimg, batch, T, b, s);
         profile_end(BESO_SITE_FUSED_LAYER, s);

@@ -1486,13 +1486,17 @@ def test_training_forward_as_one_launch_equals_the_per_op_forward(cfg_name, B, t
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg_name,B,resid_p,embed_p", [("kitchen", 100, 0.1, 0.0), ("kitchen", 37, 0.1, 0.1), ("block_push", 96, 0.05, 0.0),
-                                                       ("block_push", 50, 0.0, 0.1)])
+                                                       ("block_push", 50, 0.0, 0.1), ("block_push", 1100, 0.05, 0.0),
+                                                       ("kitchen", 1030, 0.1, 0.0), ("block_push", 3, 0.05, 0.0)])
 def test_training_backward_kernels_with_residual_and_embedding_dropout_equal_the_per_op_step(cfg_name, B, resid_p, embed_p):
     """bf16 training step with dropout on the residual branches / the embedding (block-push ships resid_pdrop = 0.05): the
     library's backward is the transposed-formulation data-gradient kernels (train_dgrad_kernel, train_mlp_bwd_kernel) with the
     LayerNorm backward as their epilogue, which evaluates the site's mask -- the stand-alone kernel's hash of (seed, site,
     row D + feature); the sigma token's embedding row carries none -- on its own elements.  Same seed = same masks in both plans,
-    so the library's choice and the per-op kernels must agree inside the bf16 bound (2e-2 per tensor, loss 2e-3)."""
+    so the library's choice and the per-op kernels must agree inside the bf16 bound (2e-2 per tensor, loss 2e-3).
+    Round 5: the library's FORWARD is the one-launch kernel with resid_pdrop > 0 too (train_fwd_kernel<..., RD = 1>: the branch
+    accumulated alone, masked with the per-op forward's hash, the residual added back from the kept x) -- one launch at the
+    fused kernel's site is asserted, both instances (four / eight samples per workgroup) and a ragged three-sample batch."""
     cfg = O.CONFIGS[cfg_name]
     m = _train_module(cfg, O.make_weights(cfg, seed=3, std=0.06), "bf16", attn_pdrop=0.3, resid_pdrop=resid_p, embed_pdrop=embed_p)
     m.train()
@@ -1502,10 +1506,12 @@ def test_training_backward_kernels_with_residual_and_embedding_dropout_equal_the
     try:
         for on in (1, 0):
             set_train_tail(on)
-            r = step.run(state, action, goal, noise, sigma, seed=77, fresh_grads=True)
-            out[on] = (r[0].item(), [v.clone() for v in r[2]])
+            n = count_fused_launches(lambda: out.__setitem__(on, step.run(state, action, goal, noise, sigma, seed=77, fresh_grads=True)))
+            r = out[on]
+            out[on] = (r[0].item(), [v.clone() for v in r[2]], n)
     finally:
         set_train_tail(1)
+    assert (out[1][2], out[0][2]) == (1, 0), (out[1][2], out[0][2])      # the forward: one launch / the per-op kernels
     errs = _grad_errors(out[1][1], out[0][1], 2e-3)
     worst = max(range(len(errs)), key=lambda i: errs[i])
     print(f"[parity] library vs per-op training step {cfg_name} B={B} resid_p={resid_p} embed_p={embed_p}: "

@@ -81,7 +81,9 @@ def run(budget=60.0, seed=0):
         # cancellation) are thereby held to the size of a rounding error of the LARGE gradients instead of being left out
         names = [k for k, _ in inner.named_parameters()]
         def dist(got, who=False):
-            d = [(((x - y).norm() / max(y.norm().item(), 2e-3 * gmax * y.numel() ** 0.5, 1e-12)).item(), k)
+            # (key.bias: twice the floor -- nothing but noise is measured there, and its size varies by a factor of two
+            #  between the plans at batches of one or two samples)
+            d = [(((x - y).norm() / max(y.norm().item(), (4e-3 if k.endswith("attn.key.bias") else 2e-3) * gmax * y.numel() ** 0.5, 1e-12)).item(), k)
                  for k, x, y in zip(names, got[1], ref[1])]
             return max(d) if who else max(d)[0]
         e, e_op = dist(a), dist(b)
