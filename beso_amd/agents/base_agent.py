@@ -67,7 +67,14 @@ class BaseAgent(abc.ABC):
         state = self.scaler.scale_input(state)
         goal = self.scaler.scale_input(goal)
         if goal.shape[-1] == 10:
-            goal[..., [2, 5, 6, 7, 8, 9]] = 0
+            # goal[..., [2, 5, 6, 7, 8, 9]] = 0 (base_agent.py:119-120) as a product with a cached 0/1 vector: the indexed
+            # assignment builds its index tensor from the Python list on every call (a host -> device copy per batch)
+            keep = self.__dict__.get("_goal_keep10")
+            if keep is None or keep.device != goal.device:
+                keep = torch.ones(10, dtype=torch.bool, device=goal.device)
+                keep[[2, 5, 6, 7, 8, 9]] = False
+                self._goal_keep10 = keep
+            goal = torch.where(keep, goal, 0.0)
         if self.target_modality in batch:
             return state, self.scaler.scale_output(batch[self.target_modality]), goal
         if not predict:

@@ -49,11 +49,26 @@ class HipTrainStep:
     def supported(inner) -> bool:
         return inner.embed_dim % 8 == 0
 
+    def _params(self):
+        """(Parameter list, their data pointers as a tuple).  Walking the module tree costs ~50 us per traversal and a step
+        used to do four; the list is kept (a module's Parameter objects do not change identity under .to(), load_state_dict
+        or the EMA swap -- their storage may, which the pointer tuple shows) and rebuilt when its length stops matching."""
+        pl = self.__dict__.get("_plist")
+        if pl is None or len(pl) != self.n_params or self.__dict__.get("_plist_epoch") != getattr(self.inner, "_dirty_epoch", 0):
+            pl = list(self.inner.parameters())
+            self._plist, self._plist_epoch = pl, getattr(self.inner, "_dirty_epoch", 0)
+            self._ptrs_ok = None
+        return pl, tuple(p.data_ptr() for p in pl)
+
     def eligible(self, state, action, goal, noise, sigma) -> bool:
-        params = list(self.inner.parameters())
-        if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad for p in params):
-            return False
-        if sum(p.numel() for p in params) != self.n_grad or len(params) != self.n_params:
+        params, ptrs = self._params()
+        if self.__dict__.get("_ptrs_ok") != ptrs:             # (checked once per set of storages)
+            if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad for p in params):
+                return False
+            if sum(p.numel() for p in params) != self.n_grad or len(params) != self.n_params:
+                return False
+            self._ptrs_ok = ptrs
+        elif not all(p.requires_grad for p in params):
             return False
         for x in (state, action, noise, sigma) + ((goal,) if goal is not None else ()):
             if not torch.is_tensor(x) or not x.is_cuda or x.requires_grad:
@@ -77,7 +92,7 @@ class HipTrainStep:
             flat = self._flat
         views, off = [], 0
         if fresh or self._views is None:
-            for p in self.inner.parameters():
+            for p in self._params()[0]:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             if not fresh:
@@ -141,8 +156,10 @@ class HipTrainStep:
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,), device="cpu").item())
         # the split-bf16 and fp16 modes are inference instances of the fused kernel; their training steps are the fp32 / bf16 ones
         precision = _lib.PRECISIONS[{"bf16x3": "fp32", "fp16": "bf16"}.get(inner.precision, inner.precision)]
-        params = [p.detach() for p in inner.parameters()]
-        arr = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        params, ptrs = self._params()
+        if self.__dict__.get("_arr_ptrs") != ptrs:
+            self._arr, self._arr_ptrs = (C.c_void_p * len(ptrs))(*ptrs), ptrs
+        arr = self._arr
         flat, views = self._grad_buffer(dev, fresh_grads)
         ws = self._workspace(B, t, precision, dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
@@ -178,7 +195,7 @@ class HipTrainStep:
         gradients in ``p.grad`` (views of the persistent flat buffer; accumulated into an existing ``.grad``)."""
         loss, flat, views = self.run(state, action, goal, noise, sigma, grad_scale, seed, fresh_grads=False,
                                      early_stream=early_stream, loss_stream=loss_stream)
-        for p, v in zip(self.inner.parameters(), views):
+        for p, v in zip(self._params()[0], views):
             if p.grad is None or p.grad.data_ptr() == v.data_ptr():
                 p.grad = v
             else:
@@ -193,7 +210,7 @@ class HipTrainStep:
         """The flat buffer if every ``p.grad`` currently is its view of it (then one all-reduce covers them)."""
         if self._flat is None or self._views is None:
             return None
-        for p, v in zip(self.inner.parameters(), self._views):
+        for p, v in zip(self._params()[0], self._views):
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 return None
         return self._flat

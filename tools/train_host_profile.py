@@ -127,7 +127,7 @@ def pieces():
     sigma = torch.rand(B, device=dev) * 0.9 + 0.05
     step = m.hip_train_step(state, action, goal, noise, sigma)
     lib = step.lib
-    orig = lib.beso_loss_grad_overlap
+    orig = lib.beso_loss_grad_streams
     acc = [0.0, 0]
 
     class Timed:
@@ -143,7 +143,7 @@ def pieces():
         for _ in range(10):
             step.run(state, action, goal, noise, sigma, seed=1)
         torch.cuda.synchronize()
-        step.lib = type("L", (), {"__getattr__": lambda s, k: Timed() if k == "beso_loss_grad_overlap" else getattr(lib, k)})()
+        step.lib = type("L", (), {"__getattr__": lambda s, k: Timed() if k == "beso_loss_grad_streams" else getattr(lib, k)})()
         acc[0], acc[1] = 0.0, 0
         N = 100
         t0 = time.perf_counter()
