@@ -14,7 +14,7 @@ PREC_BF16, PREC_FP32, PREC_BF16X3, PREC_FP16 = 0, 1, 2, 3
 PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "fp16": PREC_FP16}
 FLAG_UNCOND = 1
 # execution-plan hints of the forward calls (include/beso_hip.h: which kernels run, never what they compute)
-PLAN_PER_OP, PLAN_BLOCKS = 0x10, 0x20
+PLAN_PER_OP, PLAN_BLOCKS, PLAN_SMALL, PLAN_FUSED = 0x10, 0x20, 0x40, 0x80
 PLAN_SPW2, PLAN_SPW4, PLAN_SPW8 = 0x100, 0x200, 0x300
 SAMPLE_STEPWISE = 0x1000
 TRAIN_LAST_ACTION_ONLY, TRAIN_PLAN_PER_OP, TRAIN_PLAN_TILES = 1, 2, 4
@@ -22,7 +22,7 @@ SAMPLER_IDS = {"ddim": 0, "euler": 1, "heun": 2}
 GOAL_RANDOM, GOAL_TAIL, GOAL_SEQ_END = 0, 1, 2
 STEP_DDIM, STEP_EULER, STEP_HEUN_PREDICT, STEP_HEUN_CORRECT = 0, 1, 2, 3
 SITES = {"off": 0, "gemm_qkv": 1, "gemm_proj": 2, "gemm_fc1": 3, "gemm_fc2": 4, "attention": 5,
-         "layernorm": 6, "embed": 7, "head": 8, "forward": 9, "fused_layer": 10}
+         "layernorm": 6, "embed": 7, "head": 8, "forward": 9, "fused_layer": 10, "small": 11}
 
 # every symbol include/beso_hip.h declares (tests check that the library exports all of them)
 EXPORTS = ["beso_version", "beso_status_string", "beso_last_error", "beso_num_params", "beso_packed_bytes", "beso_pack_weights",

@@ -21,7 +21,7 @@ STAMP = os.path.join(LIBDIR, "libbeso_hip.sha256")        # source hash the .so 
 # probe).  Nothing in the package loads it; tools/ and one operand-layout test do.
 DEV_LIB = os.path.join(LIBDIR, "libbeso_hip_dev.so")
 DEV_STAMP = os.path.join(LIBDIR, "libbeso_hip_dev.sha256")
-UNITS = ["api", "elementwise", "attention", "gemm", "fused", "fused_f16", "optim", "train", "feed"]
+UNITS = ["api", "elementwise", "attention", "gemm", "fused", "fused_f16", "optim", "train", "feed", "small"]
 ARCH = "gfx950"
 # -fvisibility=hidden: the dynamic symbol table is exactly include/beso_hip.h (its declarations carry default visibility)
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]

@@ -277,6 +277,14 @@ static int forward(const beso_config* cfg, const void* packed, int precision, co
     a.cond_lambda = cond_lambda; a.sigma_data = cfg->sigma_data;
     a.plan = flags & BESO_PLAN_MASK;
     if (precision == BESO_PREC_FP16) a.plan &= ~(BESO_PLAN_PER_OP | BESO_PLAN_BLOCKS);      // (no per-op / block form: the hint is ignored, as the header says)
+    if (small_wanted(lay, a, precision)) {
+        // few samples: the weights, not the samples, are spread over the chip (small.hip)
+        hipError_t e = hipSuccess;
+        profile_begin(BESO_SITE_FORWARD, s);
+        const int r = forward_small(lay, ws, (const char*)packed, precision, a, (char*)workspace, s, &e);
+        profile_end(BESO_SITE_FORWARD, s);
+        return r == BESO_ERR_HIP ? record_hip_error(e, "forward_small", __LINE__) : r;
+    }
     const int level = precision == BESO_PREC_FP16 ? fused_level_f16(lay, a, BESO_PREC_BF16) : fused_level(lay, a, precision);
     // BF16X3 / FP16 are instances of the one-launch kernel (layers_kernel) -- BF16X3 also of its block-kernel form on the
     // long-sequence shape -- and have no per-op form
@@ -482,7 +490,10 @@ int beso_sample(const beso_config* cfg, const void* packed, int precision, int s
         a.plan = precision == BESO_PREC_FP16 ? (plan & ~(BESO_PLAN_PER_OP | BESO_PLAN_BLOCKS)) : plan;      // (fp16 has no per-op / block form)
         if (!packed || !state || (cfg->goal_seq_len > 0 && !goal)) return BESO_ERR_BAD_ARG;
         const bool f16 = precision == BESO_PREC_FP16;
-        if (!(flags & BESO_SAMPLE_STEPWISE) && (f16 ? fused_can_loop_f16(lay, a, BESO_PREC_BF16) : fused_can_loop(lay, a, precision))) {
+        // (few samples: every evaluation runs on the chip-wide small-batch path, step by step -- one workgroup carrying a sample
+        //  group through the whole loop would stream all the weights alone, evaluation after evaluation)
+        if (!(flags & BESO_SAMPLE_STEPWISE) && !small_wanted(lay, a, precision) &&
+            (f16 ? fused_can_loop_f16(lay, a, BESO_PREC_BF16) : fused_can_loop(lay, a, precision))) {
             size_t i0 = 0;
             const size_t n_steps = step_first.size() - 1;
             while (i0 < n_steps) {
@@ -576,7 +587,10 @@ int beso_sample_ancestral(const beso_config* cfg, const void* packed, int precis
         a.plan = precision == BESO_PREC_FP16 ? (plan & ~(BESO_PLAN_PER_OP | BESO_PLAN_BLOCKS)) : plan;
         if (!packed || !state || (cfg->goal_seq_len > 0 && !goal)) return BESO_ERR_BAD_ARG;
         const bool f16 = precision == BESO_PREC_FP16;
-        if (!(flags & BESO_SAMPLE_STEPWISE) && (f16 ? fused_can_loop_f16(lay, a, BESO_PREC_BF16) : fused_can_loop(lay, a, precision))) {
+        // (few samples: every evaluation runs on the chip-wide small-batch path, step by step -- one workgroup carrying a sample
+        //  group through the whole loop would stream all the weights alone, evaluation after evaluation)
+        if (!(flags & BESO_SAMPLE_STEPWISE) && !small_wanted(lay, a, precision) &&
+            (f16 ? fused_can_loop_f16(lay, a, BESO_PREC_BF16) : fused_can_loop(lay, a, precision))) {
             const int n_steps = n_sigmas - 1;
             for (int i0 = 0; i0 < n_steps; i0 += kMaxLoopEvals) {
                 SampleSteps S{};

@@ -218,7 +218,7 @@ struct FwdArgs {
 
 hipError_t launch_pack_matrix(const float* src, int rows, int cols, void* dst, int rows_p,
                               int cols_p, int precision, hipStream_t s);
-hipError_t launch_embed(const Layout& lay, const char* packed, const FwdArgs& a, float* x, hipStream_t s);
+hipError_t launch_embed(const Layout& lay, const char* packed, const FwdArgs& a, float* x, hipStream_t s, bool per_row = false);
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int rows,
                             int D, int ld_out, int precision, hipStream_t s);
 hipError_t launch_attention(const void* qkv, void* y, int vbatch, int T, int D, int H, int ld_y,
@@ -231,6 +231,17 @@ hipError_t launch_gemm(int precision, int epi, const void* A, int lda, const voi
 hipError_t launch_sampler_step(int mode, float* out, float* aux, const float* x, const float* x2, const float* den,
                                float c0, float c1, size_t n, hipStream_t s, float* sig_next = nullptr, float sigma_next = 0.f,
                                int n_sig = 0);
+
+// small.hip: the chip-wide small-batch path (five short launches per layer)
+// token rows up to which the library takes it by itself (measured, kitchen: bf16 190 ... 228 us for 1 ... 16 samples against
+// 257 ... 264 us of the one-launch kernel's latency instance, equal at 32 samples; fp32 641 ... 1060 us for 1 ... 93 samples
+// against 1620 ... 1960 us of the per-op kernels)
+constexpr int kSmallRows = 256, kSmallRowsF32 = 1024;
+constexpr size_t kSmallMinLDD = 500000;      // bf16: layers x embed_dim^2 from which the path beats the one-launch kernel
+bool small_supported(const Layout& lay, int precision);
+bool small_wanted(const Layout& lay, const FwdArgs& a, int precision);
+int  forward_small(const Layout& lay, const Workspace& ws, const char* packed, int precision, const FwdArgs& a, char* wsp,
+                   hipStream_t s, hipError_t* err);
 
 // profile hooks (api.hip)
 void profile_begin(int site, hipStream_t s);

@@ -1,0 +1,435 @@
+// Small batches CHIP-WIDE (round 5): the score-net forward as a chain of short launches whose grids spread every weight
+// matrix over the CUs, instead of one workgroup streaming all 20 MB of weights alone.
+//   reference: score_gpts.py:272-358 (DiffusionGPT.forward), :50-80 (attention), :105-115 (Block), score_wrappers.py:81-96
+//
+// Why: the rollout workload of the reference is B = 1 (kitchen_workspace_manager.py:286-294).  The one-launch kernel's
+// latency instance puts a sample group on ONE CU, which then reads the whole packed weight image by itself: 0.25 ms per
+// forward flat from B = 1 to 512 -- ~80 GB/s, 1 % of what the chip can stream, 224+ of 256 CUs idle.  Samples are few here,
+// weights are many: so the WEIGHTS are what gets partitioned.  A dependent launch boundary costs ~1.2-1.5 us on this part
+// (MI355X_MICROARCH.md, "boundary"), less than an in-kernel cross-workgroup exchange, and needs no spin-wait protocol.
+//
+// Per layer five launches (bf16 or exact-fp32 MFMA, operands straight from the GENERIC section of the packed image, torch
+// layout [out][in] = k contiguous: an MFMA operand fragment is one 16-byte load per lane, no transposition anywhere):
+//   sb_ln_gemm      LN1 (recomputed per workgroup: 32 rows) -> q|k|v            tile 32 rows x 64 features, 4 waves x 16 features
+//   attention       the per-op kernel (attention.hip): one (sample, head) pair per thread group
+//   sb_gemm_resid   x += y Wp^T + b                                             tile 32 rows x 16 features, the 4 waves split K
+//   sb_ln_gemm      LN2 -> FC1 -> exact GELU -> h
+//   sb_gemm_resid   x += h W2^T + b
+// Every wave requests ALL the weight fragments of its tile at once (one L2 round trip), the activations of a tile come
+// from the fp32 residual through LayerNorm into LDS (or as fragments straight from memory: sb_gemm_resid), so a launch is
+// ~2 dependent memory round trips long.  Weight bytes per workgroup: 46 KB (bf16, kitchen); every matrix is read once per
+// 32-row block of tokens -- for B <= 2 samples exactly once.  The embedding and the head are the per-op kernels.
+// Arithmetic: bf16 mode = the per-op bf16 kernels' (bf16 operands, fp32 accumulate, fp32 LayerNorm / softmax, the fitted
+// GELU); fp32 mode = exact-fp32 MFMA, two-pass LayerNorm, erff -- the per-op fp32 path's results to rounding order.
+#include "common.h"
+#include "fused.h"
+
+namespace beso {
+namespace {
+
+template <typename E> struct SbE;
+template <> struct SbE<uint16_t> {
+    static constexpr int KPL = 8, KSTEP = 32;          // contraction indices per 16-byte lane chunk / per fragment
+    // D[feature][token] += W-fragment x activation-fragment^T: the lane ends up with 4 consecutive features of one token
+    static __device__ __forceinline__ void mma(f32x4& acc, const u32x4& w, const u32x4& a) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float gelu(float v) { return gelu_poly(v); }
+};
+template <> struct SbE<float> {
+    static constexpr int KPL = 4, KSTEP = 16;
+    static __device__ __forceinline__ void mma(f32x4& acc, const u32x4& w, const u32x4& a) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)         // element j of every lane group: k = 4 g + j (the same assignment in both operands)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w[j]), __uint_as_float(a[j]), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+};
+
+template <typename E> __device__ __forceinline__ void store4(E* p, const f32x4& v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4& v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4<uint16_t>(uint16_t* p, const f32x4& v) {
+    uint2 u;
+    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *(uint2*)p = u;
+}
+
+constexpr int kSbRows = 32;            // token rows of a tile (two MFMA tiles)
+
+// LayerNorm of rows [m0, m0 + rows) (eps 1e-5, biased variance, two passes over the registers: score_gpts.py:96-97), eight
+// threads per row, the affine output as operand type E into the LDS tile `at` (32 rows of pitch Kd sizeof(E) + 16); columns
+// D .. Kd and rows past the end are zeros.  Two steps: load() requests the rows and the affine parameters -- the caller issues
+// it BEFORE its weight-fragment loads (a wave's loads return in order, and the LayerNorm is what runs first) -- finish()
+// reduces, normalises and writes the tile.
+template <typename E, int KD64>
+struct LnTile {
+    static constexpr int Kd = 64 * KD64, PITCH = Kd * (int)sizeof(E) + 16, NV = Kd / 32;
+    f32x4 v[NV], g4[NV], b4[NV];
+    __device__ __forceinline__ void load(const float* __restrict__ x, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, int m0, int rows, int D, int tid) {
+        const int r = tid >> 3, q = tid & 7;
+        const bool rv = r < rows;
+        const float* xr = x + (size_t)(m0 + (rv ? r : 0)) * D;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * q + 32 * j;
+            const bool ok = c < D;
+            v[j] = (rv && ok) ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            g4[j] = ok ? *(const f32x4*)(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            b4[j] = ok ? *(const f32x4*)(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __device__ __forceinline__ void finish(unsigned char* at, int rows, int D, int tid) {
+        const int r = tid >> 3, q = tid & 7;
+        const bool rv = r < rows;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+        const float mean = sum / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (4 * q + 32 * j < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float dlt = v[j][e] - mean; sq = fmaf(dlt, dlt, sq); }
+            }
+        }
+        sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+        const float rstd = 1.0f / sqrtf(sq / (float)D + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * q + 32 * j;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (rv && c < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * g4[j][e] + b4[j][e];
+            }
+            store4<E>((E*)(at + r * PITCH) + c, o);
+        }
+    }
+};
+
+// out[m][n] = epi( LayerNorm(x[m][:]) . W[n][:] + bias[n] )     EPI 0: store, 1: exact GELU, store
+// grid (Np / 64, ceil(M / 32)), 256 threads: wave w owns features [64 bx + 16 w, +16) of the tile's 32 rows.
+template <typename E, int KD64, int EPI>
+__global__ __launch_bounds__(256) void sb_ln_gemm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const E* __restrict__ W,
+                                                         const float* __restrict__ bias, E* __restrict__ out, int M, int D,
+                                                         int ld_out, int n_store) {
+    constexpr int Kd = 64 * KD64, KPL = SbE<E>::KPL, KSTEP = SbE<E>::KSTEP, NK = Kd / KSTEP;
+    constexpr int PITCH = Kd * (int)sizeof(E) + 16;        // +16 B: the 16 rows of a fragment read land on different banks
+    __shared__ __attribute__((aligned(16))) unsigned char at[kSbRows * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * kSbRows, rows = min(kSbRows, M - m0);
+    const int n0 = (blockIdx.x * 4 + wave) * 16;
+    const int li = lane & 15, lg = lane >> 4;
+    // 1. the tile's rows, then every weight fragment of this wave's 16 features: all requested at once
+    LnTile<E, KD64> ln;
+    ln.load(x, gamma, beta, m0, rows, D, tid);
+    u32x4 wf[NK];
+    {
+        const E* wp = W + (size_t)(n0 + li) * Kd + KPL * lg;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) wf[ks] = *(const u32x4*)(wp + ks * KSTEP);
+    }
+    const f32x4 bv = *(const f32x4*)(bias + n0 + 4 * lg);
+    // 2. LayerNorm of the tile's rows as operand type E into LDS
+    ln.finish(at, rows, D, tid);
+    __syncthreads();
+    // 3. the tile's product
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const u32x4 a = *(const u32x4*)(at + (16 * rt + li) * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
+            SbE<E>::mma(acc[rt], wf[ks], a);
+        }
+    }
+    // 4. the lane holds features n0 + 4 lg .. +3 of token 16 rt + li
+    const int n = n0 + 4 * lg;
+    if (n < n_store) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int tok = 16 * rt + li;
+            if (tok < rows) {
+                f32x4 v = acc[rt] + bv;
+                if (EPI == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = SbE<E>::gelu(v[e]);
+                }
+                store4<E>(out + (size_t)(m0 + tok) * ld_out + n, v);
+            }
+        }
+    }
+}
+
+// LN1 -> q | k | v of ONE head -> causal attention of that head, for a block of whole samples (spb T <= 32 token rows):
+//   y[m][h hd + d] = sum_j softmax_j( q_i . k_j / sqrt(hd), j <= i ) v_j[d]        (score_gpts.py:58-76)
+// grid (H, ceil(vbatch / spb)), 256 threads.  The attention needs q, k AND v of its head and nothing else, so the q|k|v weight
+// rows are split by HEAD here (3 x hd rows per workgroup: 138 KB in bf16 at the kitchen shape) and a launch boundary between
+// the projections and the attention disappears -- a dependent launch is ~5 us on this part whatever it computes
+// (tools/microbench/launch_chain).  Wave w owns dims [16 w, 16 w + 16) of the head in all three parts; q, k, v go to LDS as fp32;
+// then 16 lanes per (sample, query) item: each lane 4 dims, the score's partial dot products summed over the item's DPP row,
+// softmax and the weighted sum of v in registers (fp32, expf: the reference's operation order).
+constexpr int kSbHP = 68;              // floats per q / k / v row in LDS (64 dims + 4: rows land on different banks)
+template <typename E, int KD64>
+__global__ __launch_bounds__(256) void sb_qkv_attn_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const E* __restrict__ W,
+                                                          const float* __restrict__ bias, E* __restrict__ y, int vbatch, int T,
+                                                          int spb, int D, int hd, int ld_y, float scale) {
+    constexpr int Kd = 64 * KD64, KPL = SbE<E>::KPL, KSTEP = SbE<E>::KSTEP, NK = Kd / KSTEP;
+    constexpr int PITCH = Kd * (int)sizeof(E) + 16;
+    constexpr int NP = sizeof(E) == 2 ? 3 : 1;             // parts whose weight fragments are in flight together
+    __shared__ __attribute__((aligned(16))) unsigned char at[kSbRows * PITCH];
+    __shared__ __attribute__((aligned(16))) float qs[3][kSbRows][kSbHP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, s0 = blockIdx.y * spb;
+    const int ns = min(spb, vbatch - s0), rows = ns * T, m0 = s0 * T;
+    const int li = lane & 15, lg = lane >> 4;
+    // feature (dim of the head) of this lane's weight row; dims past hd read a valid row and are zeroed when stored
+    const int dw = 16 * wave + li, dwc = dw < hd ? dw : 0;
+    auto wrow = [&](int p) { return W + (size_t)(p * D + h * hd + dwc) * Kd + KPL * lg; };
+    LnTile<E, KD64> ln;
+    ln.load(x, gamma, beta, m0, rows, D, tid);
+    u32x4 wf[NP][NK];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const E* wp = wrow(p);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) wf[p][ks] = *(const u32x4*)(wp + ks * KSTEP);
+    }
+    ln.finish(at, rows, D, tid);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (NP == 1 && p > 0) {                            // (fp32: one part's 96 registers of fragments at a time)
+            const E* wp = wrow(p);
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) wf[0][ks] = *(const u32x4*)(wp + ks * KSTEP);
+        }
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const u32x4 a = *(const u32x4*)(at + (16 * rt + li) * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
+                SbE<E>::mma(acc[rt], wf[NP == 1 ? 0 : p][ks], a);
+            }
+        }
+        // the lane holds dims 16 wave + 4 lg .. +3 of token 16 rt + li
+        const int d0 = 16 * wave + 4 * lg;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (d0 < hd) bv = *(const f32x4*)(bias + p * D + h * hd + d0);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x4 v = acc[rt] + bv;
+            if (d0 >= hd) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)&qs[p][16 * rt + li][d0] = v;
+        }
+    }
+    __syncthreads();
+    // attention: item = (sample, query row); 16 lanes of a DPP row per item, lane dq holds dims 4 dq .. +3
+    const int dq = tid & 15;
+#pragma unroll 1
+    for (int pass = 0; pass < (rows > 16 ? 2 : 1); ++pass) {
+        const int item = pass * 16 + (tid >> 4);
+        const bool iv = item < rows;
+        const int sm = iv ? item / T : 0, qi = iv ? item - sm * T : 0, r0 = sm * T;
+        const f32x4 q4 = *(const f32x4*)&qs[0][r0 + qi][4 * dq];
+        float sc[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sc[j] = -INFINITY;
+            if (j < T) {                                   // (wave-uniform; the causal bound is applied to the value)
+                const f32x4 k4 = *(const f32x4*)&qs[1][r0 + j][4 * dq];
+                float part = q4[0] * k4[0];
+                part = fmaf(q4[1], k4[1], part); part = fmaf(q4[2], k4[2], part); part = fmaf(q4[3], k4[3], part);
+                part += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0xB1, 0xf, 0xf, false));
+                part += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0x4E, 0xf, 0xf, false));
+                part += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0x124, 0xf, 0xf, false));
+                part += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0x128, 0xf, 0xf, false));
+                if (j <= qi) { sc[j] = part * scale; mx = fmaxf(mx, sc[j]); }
+            }
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < T) { sc[j] = j <= qi ? expf(sc[j] - mx) : 0.f; den += sc[j]; }
+        }
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < T) {
+                const f32x4 v4 = *(const f32x4*)&qs[2][r0 + j][4 * dq];
+                const float pj = sc[j] / den;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(pj, v4[e], o[e]);
+            }
+        }
+        if (iv && 4 * dq < hd) store4<E>(y + (size_t)(m0 + item) * ld_y + h * hd + 4 * dq, o);
+    }
+    // the K padding of the attention output (columns D .. ld_y of the out-projection's operand): zeros, once per row
+    if (h == 0) {
+        const int padw = ld_y - D;
+        for (int u = tid; u < rows * padw; u += 256) y[(size_t)(m0 + u / padw) * ld_y + D + u % padw] = (E)0;
+    }
+}
+
+// x[m][n] += A[m][:] . W[n][:] + bias[n]      (out-projection: A = attention output, K = Kd; FC2: A = GELU(h), K = Kh)
+// grid (ceil(D / 16), ceil(M / 32)), 256 threads: ONE 16-feature column tile per workgroup, its four waves split the
+// contraction (k-step ks goes to wave ks % 4) and add up through LDS in a fixed order; both operands as fragments straight
+// from memory, all of a wave's fragments requested at once (chunks of kSbChunk k-steps: the instance that covers K / 4 in one chunk where one exists).  A's rows are padded to a multiple
+// of 128 in the workspace (rows past M are never stored), its K padding holds zeros, W's is zeros.
+template <typename E, int kSbChunk>      // k-steps a wave has in flight at once: 3 (K = 384 in bf16), 6 or 12
+__global__ __launch_bounds__(256) void sb_gemm_resid_kernel(const E* __restrict__ A, int lda, const E* __restrict__ W, int K,
+                                                            const float* __restrict__ bias, float* __restrict__ x, int M, int D) {
+    constexpr int KPL = SbE<E>::KPL, KSTEP = SbE<E>::KSTEP;
+    __shared__ __attribute__((aligned(16))) f32x4 red[3][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * kSbRows, rows = min(kSbRows, M - m0);
+    const int n0 = blockIdx.x * 16;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nkt = K / KSTEP;
+    const E* wp = W + (size_t)(n0 + li) * K + KPL * lg;
+    const E* ap0 = A + (size_t)(m0 + li) * lda + KPL * lg;
+    const E* ap1 = ap0 + (size_t)16 * lda;
+    // (wave 0's slice of the residual and the bias: requested first, used last)
+    const int n = n0 + 4 * lg;
+    f32x4 xv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, bv = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0 && n < D) {
+        bv = *(const f32x4*)(bias + n);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+            if (16 * rt + li < rows) xv[rt] = *(const f32x4*)(x + (size_t)(m0 + 16 * rt + li) * D + n);
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int ks0 = wave; ks0 < nkt; ks0 += 4 * kSbChunk) {
+        u32x4 wf[kSbChunk], a0[kSbChunk], a1[kSbChunk];
+#pragma unroll
+        for (int u = 0; u < kSbChunk; ++u) {
+            const int ks = min(ks0 + 4 * u, nkt - 1);          // (wave-uniform; a clamped step is loaded and not used)
+            wf[u] = *(const u32x4*)(wp + ks * KSTEP);
+            a0[u] = *(const u32x4*)(ap0 + ks * KSTEP);
+            a1[u] = *(const u32x4*)(ap1 + ks * KSTEP);
+        }
+#pragma unroll
+        for (int u = 0; u < kSbChunk; ++u) {
+            if (ks0 + 4 * u < nkt) {
+                SbE<E>::mma(acc[0], wf[u], a0[u]);
+                SbE<E>::mma(acc[1], wf[u], a1[u]);
+            }
+        }
+    }
+    if (wave > 0) { red[wave - 1][0][lane] = acc[0]; red[wave - 1][1][lane] = acc[1]; }
+    __syncthreads();
+    if (wave == 0 && n < D) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int tok = 16 * rt + li;
+            if (tok < rows) {
+                f32x4 v = acc[rt];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += red[w][rt][lane];
+                *(f32x4*)(x + (size_t)(m0 + tok) * D + n) = xv[rt] + (v + bv);
+            }
+        }
+    }
+}
+
+template <typename E, int KD64>
+hipError_t run_layers(const Layout& lay, const Workspace& ws, const char* packed, const FwdArgs& a, char* wsp, int precision,
+                      hipStream_t s) {
+    float* x = (float*)(wsp + ws.x);
+    E* qkv = (E*)(wsp + ws.qkv); E* y = (E*)(wsp + ws.y); E* h = (E*)(wsp + ws.h);
+    const int M = a.vbatch * a.T, D = lay.D;
+    const int rb = (M + kSbRows - 1) / kSbRows;
+    // the head-split LN1 + q|k|v + attention launch: whole samples in a 32-row tile, a head in 64 dims of float4 pieces
+    const int spb = a.T <= kSbRows ? kSbRows / a.T : 0;
+    const bool head_fused = a.T <= 16 && spb >= 1 && lay.hd <= 64 && lay.hd % 4 == 0;
+    auto F = [&](size_t off) { return (const float*)(packed + off); };
+    auto launch_resid = [&](const E* A, int K, const E* Wt, const float* bias) {
+        const int per_wave = (K / SbE<E>::KSTEP + 3) / 4;
+        const dim3 grid((D + 15) / 16, rb);
+        if (per_wave <= 3) hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 3>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D);
+        else if (per_wave <= 6) hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 6>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D);
+        else hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 12>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D);
+    };
+    (void)hipGetLastError();
+    for (int l = 0; l < lay.L; ++l) {
+        const LayerOff& o = lay.layer[l];
+        hipError_t e = hipSuccess;
+        if (head_fused) {
+            // LN1 -> q|k|v -> attention, split by head: one launch
+            hipLaunchKernelGGL((sb_qkv_attn_kernel<E, KD64>), dim3(lay.H, (a.vbatch + spb - 1) / spb), dim3(256), 0, s, (const float*)x,
+                               F(o.ln1_w), F(o.ln1_b), (const E*)(packed + o.w_qkv), F(o.b_qkv), y, a.vbatch, a.T, spb, D, lay.hd,
+                               lay.Kd, 1.0f / sqrtf((float)lay.hd));
+        } else {
+            hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 0>), dim3(lay.Nqkv / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln1_w),
+                               F(o.ln1_b), (const E*)(packed + o.w_qkv), F(o.b_qkv), qkv, M, D, 3 * D, 3 * D);
+            e = launch_attention(qkv, y, a.vbatch, a.T, D, lay.H, lay.Kd, precision, s);
+            if (e != hipSuccess) return e;
+        }
+        launch_resid((const E*)y, lay.Kd, (const E*)(packed + o.w_proj), F(o.b_proj));
+        hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1>), dim3(lay.Nh / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
+                           F(o.ln2_b), (const E*)(packed + o.w_fc1), F(o.b_fc1), h, M, D, lay.Kh, lay.Kh);
+        launch_resid((const E*)h, lay.Kh, (const E*)(packed + o.w_fc2), F(o.b_fc2));
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace
+
+// Shapes and batches this path takes: bf16 / fp32 (the generic section of the packed image), D a multiple of 8 up to 384
+// (LayerNorm tile in static LDS), whatever the per-op embedding / attention / head kernels take.
+bool small_supported(const Layout& lay, int precision) {
+    if (precision != BESO_PREC_BF16 && precision != BESO_PREC_FP32) return false;
+    return lay.D % 8 == 0 && lay.Kd <= 384;
+}
+
+// The library's choice: up to kSmallRows token rows (where the one-launch kernel's latency instance would leave most of the
+// chip idle), unless the call's plan asks for specific kernels (per-op / block forms, a samples-per-workgroup instance) --
+// BESO_PLAN_SMALL asks for this path at any size.
+bool small_wanted(const Layout& lay, const FwdArgs& a, int precision) {
+    if (!small_supported(lay, precision)) return false;
+    if (a.plan & BESO_PLAN_SMALL) return true;
+    if (a.plan & (BESO_PLAN_PER_OP | BESO_PLAN_BLOCKS | BESO_PLAN_FUSED | BESO_PLAN_SPW_MASK)) return false;
+    if (precision == BESO_PREC_FP32) return a.vbatch * a.T <= kSmallRowsF32;
+    // bf16: against the one-launch kernel's latency instance the chain of launches wins where there are weights to spread --
+    // kitchen (6 layers of 360^2: 172 vs 258 us at one sample), not block-push (4 layers of 240^2: 127 vs 114 us)
+    return a.vbatch * a.T <= kSmallRows && (size_t)lay.L * lay.D * lay.D >= kSmallMinLDD;
+}
+
+int forward_small(const Layout& lay, const Workspace& ws, const char* packed, int precision, const FwdArgs& a, char* wsp,
+                  hipStream_t s, hipError_t* err) {
+    float* x = (float*)(wsp + ws.x);
+    profile_begin(BESO_SITE_EMBED, s);
+    hipError_t e = launch_embed(lay, packed, a, x, s, a.vbatch <= 16);
+    profile_end(BESO_SITE_EMBED, s);
+    if (e != hipSuccess) { *err = e; return BESO_ERR_HIP; }
+    profile_begin(BESO_SITE_SMALL, s);
+    const int kd64 = lay.Kd / 64;
+#define SB_RUN(E)                                                                                          \
+    (kd64 <= 1 ? run_layers<E, 1>(lay, ws, packed, a, wsp, precision, s)                                  \
+     : kd64 == 2 ? run_layers<E, 2>(lay, ws, packed, a, wsp, precision, s)                                \
+     : kd64 == 3 ? run_layers<E, 3>(lay, ws, packed, a, wsp, precision, s)                                \
+     : kd64 == 4 ? run_layers<E, 4>(lay, ws, packed, a, wsp, precision, s)                                \
+     : kd64 == 5 ? run_layers<E, 5>(lay, ws, packed, a, wsp, precision, s)                                \
+                 : run_layers<E, 6>(lay, ws, packed, a, wsp, precision, s))
+    e = precision == BESO_PREC_FP32 ? SB_RUN(float) : SB_RUN(uint16_t);
+#undef SB_RUN
+    profile_end(BESO_SITE_SMALL, s);
+    if (e != hipSuccess) { *err = e; return BESO_ERR_HIP; }
+    profile_begin(BESO_SITE_HEAD, s);
+    e = launch_head(lay, packed, a, x, s);
+    profile_end(BESO_SITE_HEAD, s);
+    if (e != hipSuccess) { *err = e; return BESO_ERR_HIP; }
+    return BESO_OK;
+}
+
+}  // namespace beso

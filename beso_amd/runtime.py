@@ -22,7 +22,7 @@ _hints = threading.local()
 @contextlib.contextmanager
 def plan(forward: int = 0, train: int = 0):
     """Execution-plan hints for the library calls the CALLING THREAD makes inside the block: ``forward`` = BESO_PLAN_* bits
-    (``_lib.PLAN_PER_OP``, ``PLAN_BLOCKS``, ``PLAN_SPW2 / 4 / 8``) added to the flags of every forward / sampler call,
+    (``_lib.PLAN_PER_OP``, ``PLAN_BLOCKS``, ``PLAN_SMALL``, ``PLAN_FUSED``, ``PLAN_SPW2 / 4 / 8``) added to the flags of every forward / sampler call,
     ``train`` = ``_lib.TRAIN_PLAN_PER_OP`` / ``TRAIN_PLAN_TILES`` for ``beso_loss_grad``.  They select WHICH kernels run,
     never what is computed (parity tests: per-op kernels against the fused ones; measurements); each library call carries
     its own flags, so nothing process-wide changes."""

@@ -99,11 +99,16 @@ enum {
      * for measurements; a hint the shape or precision cannot honour is ignored. */
     BESO_PLAN_PER_OP = 0x10,  /* per-op kernels only: LayerNorm, GEMMs, attention (bf16 / fp32; any shape) */
     BESO_PLAN_BLOCKS = 0x20,  /* at most the block kernels (LN2 + MLP block, tail block), not the one-launch kernel */
+    BESO_PLAN_SMALL = 0x40,   /* the chip-wide small-batch path (bf16 / fp32, embed_dim <= 384: five short launches per layer
+                                 that spread every weight matrix over the CUs) at ANY batch size; without a hint the library
+                                 takes it up to 256 token rows in bf16 (kitchen: 23 samples) and 1024 in fp32, where one
+                                 workgroup per sample group would stream all the weights alone */
+    BESO_PLAN_FUSED = 0x80,   /* the one-launch / block kernels at every batch size (never the small-batch path) */
     BESO_PLAN_SPW2 = 0x100,   /* samples per workgroup of the one-launch kernel: 2 (default up to 512 samples), */
     BESO_PLAN_SPW4 = 0x200,   /*   4 (up to 1024; the split-bf16 mode: above 512), */
     BESO_PLAN_SPW8 = 0x300,   /*   8 (larger batches) */
     BESO_PLAN_SPW_MASK = 0x300,
-    BESO_PLAN_MASK = 0x330,
+    BESO_PLAN_MASK = 0x3f0,
     BESO_SAMPLE_STEPWISE = 0x1000  /* beso_sample: enqueue evaluation by evaluation (see there) */
 };
 
@@ -313,7 +318,8 @@ enum {
     BESO_SITE_OFF = 0, BESO_SITE_GEMM_QKV = 1, BESO_SITE_GEMM_PROJ = 2, BESO_SITE_GEMM_FC1 = 3,
     BESO_SITE_GEMM_FC2 = 4, BESO_SITE_ATTENTION = 5, BESO_SITE_LAYERNORM = 6, BESO_SITE_EMBED = 7,
     BESO_SITE_HEAD = 8, BESO_SITE_FORWARD = 9 /* one whole score-net forward */,
-    BESO_SITE_FUSED_LAYER = 10 /* the fused kernels (one-launch kernel, block kernels) */
+    BESO_SITE_FUSED_LAYER = 10 /* the fused kernels (one-launch kernel, block kernels) */,
+    BESO_SITE_SMALL = 11 /* the layers of a forward on the chip-wide small-batch path (one pair of events per forward) */
 };
 void beso_profile_enable(int site);
 int  beso_profile_read(double* total_ms, int* launches);
