@@ -116,8 +116,9 @@ def load() -> C.CDLL:
             if hasattr(lib, "beso_loss_grad_overlap") or not os.environ.get("BESO_HIP_LIB"):
                 lib.beso_loss_grad_overlap.restype = i32
                 lib.beso_loss_grad_overlap.argtypes = lib.beso_loss_grad.argtypes + [vp]
-                lib.beso_loss_grad_streams.restype = i32
-                lib.beso_loss_grad_streams.argtypes = lib.beso_loss_grad.argtypes + [vp, vp]
+                if hasattr(lib, "beso_loss_grad_streams") or not os.environ.get("BESO_HIP_LIB"):     # (HipTrainStep.run probes it too)
+                    lib.beso_loss_grad_streams.restype = i32
+                    lib.beso_loss_grad_streams.argtypes = lib.beso_loss_grad.argtypes + [vp, vp]
                 lib.beso_grad_early_range.restype = i32
                 lib.beso_grad_early_range.argtypes = [cfgp, C.POINTER(sz), C.POINTER(sz)]
         if hasattr(lib, "beso_log_logistic") or not os.environ.get("BESO_HIP_LIB"):

@@ -373,7 +373,16 @@ class BesoAgent(BaseAgent):
     def train_step(self, batch: dict):
         """One score-matching step (beso_agent.py:215-248): noise ~ N(0, I), sigma ~ the configured
         density, loss = GCDenoiser.loss, optimizer + LR scheduler + EMA.  Under data parallelism the
-        gradients are averaged over the ranks first."""
+        gradients are averaged over the ranks first.
+
+        Completion semantics (BESO_AMD_ASYNC_LOSS=1, the default): the returned float is this step's loss, but the call
+        returns when the FORWARD half is done -- the backward pass and the optimizer of this step are still queued on the
+        compute stream.  Consequences: (i) a device fault in this step's backward / optimizer surfaces at the next
+        synchronising call (the next step's loss read, `evaluate`, a checkpoint), not here; (ii) timing `train_step()` per
+        call without `torch.cuda.synchronize()` measures the forward half, not the step; (iii) `self._loss_stream` belongs
+        to the step (the library also runs the next step's weight copies on it): nothing else may be queued there.
+        Everything later on the compute stream is ordered behind the update as usual; BESO_AMD_ASYNC_LOSS=0 restores the
+        reference's full synchronisation per step."""
         state, action, goal = self.process_batch(batch, predict=False)
         if not self.model.training:          # (.train() / .eval() set the whole tree: the root's flag tells; walking the 69 modules
             self.model.train()               #  costs 0.1 ms per step)

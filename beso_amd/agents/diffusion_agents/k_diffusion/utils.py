@@ -20,6 +20,11 @@ def rand_log_normal(shape, loc=0., scale=1., device='cpu', dtype=torch.float32):
     return torch.randn(shape, device=device, dtype=dtype).mul_(scale).add_(loc).exp_()
 
 
+def _hip_lib():
+    from .... import _lib
+    return _lib.load()
+
+
 def rand_log_logistic(shape, loc=0., scale=1., min_value=0., max_value=float('inf'), device='cpu',
                       dtype=torch.float32):
     """Truncated log-logistic, drawn in float64 like the reference (utils.py:178-185).  The two CDF bounds
@@ -32,7 +37,7 @@ def rand_log_logistic(shape, loc=0., scale=1., min_value=0., max_value=float('in
         return 1.0 / (1.0 + math.exp(-z)) if z > -700.0 else 0.0
     lo, hi = cdf(float(min_value)), cdf(float(max_value))
     u = torch.rand(shape, device=device, dtype=torch.float64)
-    if u.is_cuda and dtype == torch.float32:
+    if u.is_cuda and dtype == torch.float32 and hasattr(_hip_lib(), "beso_log_logistic"):      # (older A/B libraries: the chain below)
         # the transform behind the draw as ONE HIP launch (beso_log_logistic: the same float64 operations in the same order)
         # instead of seven elementwise ones -- the training step draws its sigmas here every step (beso_agent.py:227)
         import ctypes as C

@@ -1719,6 +1719,39 @@ static hipError_t ensure_lds_t(const void* kernel, size_t bytes, LdsAttrT* done)
     return e;
 }
 
+// compute units of the current device (cached per device; 256 on the MI355X): the row-range heuristics of the grouped
+// weight-gradient launches fill THIS part's workgroup slots
+static int device_cus() {
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> cached[kMaxDev] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+// Events that order the step's side streams, per calling thread AND per device (an event created on device A and
+// recorded on a stream of device B is hipErrorInvalidHandle -- a thread that drives several GPUs one after the other)
+enum { kEvFork = 0, kEvJoin, kEvCopies, kEvLoss, kEvEarly, kEvCount };
+static hipError_t step_event(int which, hipEvent_t* out) {
+    constexpr int kMaxDev = 64;
+    static thread_local hipEvent_t ev[kMaxDev][kEvCount] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDev) return hipErrorInvalidDevice;
+    if (!ev[dev][which]) {
+        e = hipEventCreateWithFlags(&ev[dev][which], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    *out = ev[dev][which];
+    return hipSuccess;
+}
+
 static size_t carve_t(size_t& cur, size_t bytes) {
     const size_t off = cur;
     cur = round_up_sz(cur + bytes, 256);
@@ -1796,7 +1829,8 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
         // long contractions); every output of the launch once per range
         const int tD = (D + kTileMN - 1) / kTileMN, tH = (4 * D + kTileMN - 1) / kTileMN;
         const int tiles = c->n_layers * (2 * tD * tH + 4 * tD * tD) + 4;
-        int sp = (2 * 256 + tiles - 1) / tiles;
+        const int cus = device_cus();
+        int sp = (2 * cus + tiles - 1) / tiles;
         if (sp > 8) sp = 8;
         if ((size_t)sp > M / (4 * (128 / e))) sp = (int)(M / (4 * (128 / e)));      // (ranges of at least four stages)
         w->w_splits = sp < 2 ? 1 : sp;
@@ -1805,7 +1839,7 @@ static bool make_train_ws(const beso_config* c, int batch, int t, int precision,
         if (const int W = wgrad_panel_w(D, e)) {
             (void)W;
             const int ptiles = c->n_layers * (2 * tH + 4 * tD) + 4;
-            int psp = 256 / ptiles;
+            int psp = cus / ptiles;
             if (psp > 8) psp = 8;
             if ((size_t)psp > M / (4 * 64)) psp = (int)(M / (4 * 64));
             w->w_splits_panel = psp < 2 ? 1 : psp;
@@ -1960,15 +1994,13 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // second stream (loss_stream: idle at this point), the copies run THERE beside the gradient buffer's memset, the
     // preconditioning and the embedding on `s` -- two short chains of small kernels side by side instead of one after the
     // other (round 4: -50 us of a 2.5 ms step).  The forward waits for both.
-    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_copies = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_copies = nullptr;
     const bool fork = loss_stream != nullptr;
     hipStream_t ps = fork ? loss_stream : s;
     if (fork) {
-        if (!ev_fork) {
-            TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-            TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-            TRY(hipEventCreateWithFlags(&ev_copies, hipEventDisableTiming));
-        }
+        TRY(step_event(kEvFork, &ev_fork));
+        TRY(step_event(kEvJoin, &ev_join));
+        TRY(step_event(kEvCopies, &ev_copies));
         TRY(hipEventRecord(ev_fork, s));                 // (behind the optimizer step that wrote the parameters)
         TRY(hipStreamWaitEvent(ps, ev_fork, 0));
     }
@@ -2146,8 +2178,8 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         if (loss_stream) {
             // the loss is final here, long before the step is: a stream of the caller's is ordered behind this point, so that
             // reading the loss there (beso_agent.py:248 `loss.item()`) does not wait for the backward pass
-            static thread_local hipEvent_t ev_loss = nullptr;
-            if (!ev_loss) TRY(hipEventCreateWithFlags(&ev_loss, hipEventDisableTiming));
+            hipEvent_t ev_loss = nullptr;
+            TRY(step_event(kEvLoss, &ev_loss));
             TRY(hipEventRecord(ev_loss, s));
             TRY(hipStreamWaitEvent(loss_stream, ev_loss, 0));
         }
@@ -2433,8 +2465,8 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
                                lrt, lnb_grid, D, 0);
             TRY(hipGetLastError());
             ln_reduced = ln_calls;
-            static thread_local hipEvent_t ev = nullptr;
-            if (!ev) TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            hipEvent_t ev = nullptr;
+            TRY(step_event(kEvEarly, &ev));
             TRY(hipEventRecord(ev, s));
             TRY(hipStreamWaitEvent(early_stream, ev, 0));
         }

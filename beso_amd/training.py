@@ -165,15 +165,22 @@ class HipTrainStep:
         loss = torch.empty((), dtype=torch.float32, device=dev)
         if loss_stream is not None:
             loss.record_stream(loss_stream)          # (read there; the caching allocator must not hand it out before that)
+        common = (C.byref(self.cfg), arr, len(params), flat.data_ptr(), precision,
+                  state.data_ptr(), action.data_ptr(), gptr, noise.data_ptr(), sigma.data_ptr(),
+                  loss.data_ptr(), B, t, (_lib.TRAIN_LAST_ACTION_ONLY if last_action_only else 0) | train_hints(), float(embed_p), float(attn_p), float(resid_p),
+                  float(goal_p), C.c_uint(seed & 0xFFFFFFFF), float(grad_scale), ws.data_ptr(), ws.numel(),
+                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+                  C.c_void_p(early_stream.cuda_stream) if early_stream is not None else None)
         with torch.cuda.device(dev):
-            st = self.lib.beso_loss_grad_streams(
-                C.byref(self.cfg), arr, len(params), flat.data_ptr(), precision,
-                state.data_ptr(), action.data_ptr(), gptr, noise.data_ptr(), sigma.data_ptr(),
-                loss.data_ptr(), B, t, (_lib.TRAIN_LAST_ACTION_ONLY if last_action_only else 0) | train_hints(), float(embed_p), float(attn_p), float(resid_p),
-                float(goal_p), C.c_uint(seed & 0xFFFFFFFF), float(grad_scale), ws.data_ptr(), ws.numel(),
-                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
-                C.c_void_p(early_stream.cuda_stream) if early_stream is not None else None,
-                C.c_void_p(loss_stream.cuda_stream) if loss_stream is not None else None)
+            if hasattr(self.lib, "beso_loss_grad_streams"):
+                st = self.lib.beso_loss_grad_streams(*common, C.c_void_p(loss_stream.cuda_stream) if loss_stream is not None else None)
+            else:
+                # (a library loaded through BESO_HIP_LIB that predates the loss stream -- tools/variants.py's '@<revision>' A/B
+                # builds: the loss is then final at the end of the call's work on the compute stream; order the caller's stream
+                # behind that instead of failing)
+                st = self.lib.beso_loss_grad_overlap(*common)
+                if loss_stream is not None:
+                    loss_stream.wait_stream(torch.cuda.current_stream(dev))
         _lib.check(st, "loss_grad")
         return loss, flat, views
 
