@@ -50,6 +50,9 @@ struct TrainWholeBufs {
     int t;                         // steps of the window (action tokens per sample)
     float p_attn; uint32_t seed;   // attention dropout (the per-op kernels' mask)
     float p_resid;                 // dropout on the out-projection and MLP outputs (sites 4 l + 1, 4 l + 2: EpiResid's mask)
+    int x_bf16;                    // 1: the kept residuals x_mid (every layer) and x_out (all but the last layer) go out as bf16
+                                   // [rows][D] at the start of their fp32 buffers (p_resid = 0 only: nothing reads them but
+                                   // the LayerNorm backward, which takes them with TrainLnBwd::x_bf16)
 };
 bool   fused_train_whole_supported(const Layout& lay, int T, int t);
 size_t fused_train_whole_image_bytes(const Layout& lay);
@@ -66,6 +69,7 @@ struct TrainLnBwd {
     const float* dres_in; float* dres_out; void* dxb;           // residual gradient in (or nullptr) / out, its bf16 copy
     float* part;                                                // [fused_train_dgrad_blocks(M)][3][D]: dgamma, dbeta, bias partial sums
     float p; uint32_t seed, site; int skip_mod;                 // dropout of the branch behind the LayerNorm (ln_bwd_kernel's arguments)
+    int x_bf16 = 0;                                             // x holds bf16 rows (TrainWholeBufs::x_bf16)
 };
 // FC2 + GELU' -> FC1 -> LayerNorm-2 backward -> out-projection data gradients of a layer in one launch (dh [M][4D], ln.dxb = dym
 // and dy [M][D] are written; colsum: slab [fused_train_dgrad_blocks(M)][4 D])

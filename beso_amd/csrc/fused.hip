@@ -919,6 +919,26 @@ __device__ __forceinline__ void set_bias_rows(Tile<RPW>& T, const float* __restr
         for (int t = 0; t < NT; ++t) T.acc[i][t] = bv;
     }
 }
+// ... as bf16 rows [rows][D] (the one-launch training forward without residual dropout: the kept x_mid / x_out are read by
+// the LayerNorm backward alone, whose use of them -- x_hat = (x - mean) rstd inside two row sums -- does not need more than
+// the 8 significant bits the other kept activations have; half the bytes of what was 22 % of the forward's stores)
+template <int RPW, int NT>
+__device__ __forceinline__ void store_x_rows_bf16(const Tile<RPW>& T, uint16_t* __restrict__ x, int D, const Rows& rows, int w, int lane) {
+    asm volatile("" : "+v"(lane));
+    const int n = lane & 15, g = lane >> 4;
+    int row[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) row[t] = rows.row(16 * t + n);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int f0 = 16 * (w * RPW + i) + 4 * g;
+        if (f0 >= D) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (row[t] >= 0 && !(BESO_TRAIN_FWD_ABL & 1))
+                *(uint2*)(x + (size_t)row[t] * D + f0) = make_uint2(pack_op2(T.acc[i][t][0], T.acc[i][t][1]), pack_op2(T.acc[i][t][2], T.acc[i][t][3]));
+    }
+}
 template <int RPW, int NT>
 __device__ __forceinline__ void store_x_rows(const Tile<RPW>& T, float* __restrict__ x, int D, const Rows& rows, int w, int lane) {
     asm volatile("" : "+v"(lane));
@@ -3242,7 +3262,8 @@ __global__ __launch_bounds__(512, 2) void train_fwd_kernel(const char* __restric
         if constexpr (RD)
             resid_dropout_add<RPW, NTP>(T, l == 0 ? a.x0 : (const float*)(wl - a.stride + a.x_out), d.D, rows_all, rows_tail,
                                         a.p_resid, inv_keep_r, a.seed, (uint32_t)(4 * l + 1), w, lane);
-        store_x_rows<RPW, NTP>(T, (float*)(wl + a.x_mid), d.D, rows_tail, w, lane);
+        if (!RD && a.x_bf16) store_x_rows_bf16<RPW, NTP>(T, (uint16_t*)(wl + a.x_mid), d.D, rows_tail, w, lane);
+        else store_x_rows<RPW, NTP>(T, (float*)(wl + a.x_mid), d.D, rows_tail, w, lane);
         u32x4 a1r[PF1][kChunkTiles / kWaves];
         mlp_prefetch<KS, kWaves, PF1>(a1r, (const u32x4*)lw, w, lane);
         const LnTrain lx2{(const float*)(lw + ti.o_ln2w), (const float*)(lw + ti.o_ln2b), (float*)(wl + a.st2),
@@ -3255,7 +3276,9 @@ __global__ __launch_bounds__(512, 2) void train_fwd_kernel(const char* __restric
         if constexpr (RD)
             resid_dropout_add<RPW, NTP>(T, (const float*)(wl + a.x_mid), d.D, rows_tail, rows_tail, a.p_resid, inv_keep_r, a.seed,
                                         (uint32_t)(4 * l + 2), w, lane);
-        store_x_rows<RPW, NTP>(T, (float*)(wl + a.x_out), d.D, rows_tail, w, lane);
+        // (the last layer's x_out -- the compact action rows -- stays fp32: the final LayerNorm and the head continue on it)
+        if (!RD && a.x_bf16 && l + 1 < d.L) store_x_rows_bf16<RPW, NTP>(T, (uint16_t*)(wl + a.x_out), d.D, rows_tail, w, lane);
+        else store_x_rows<RPW, NTP>(T, (float*)(wl + a.x_out), d.D, rows_tail, w, lane);
     };
 #pragma unroll 1
     for (int l = 0; l + 1 < d.L; ++l)
@@ -3297,6 +3320,7 @@ struct LnBwdEpi {
     float p, inv_keep; uint32_t seed, site; int skip_mod;       // dropout of the branch behind this LayerNorm (p = 0: none): element
                                                                 // (row, f) keeps drop_scale(seed, site, row D + f); rows with
                                                                 // row % skip_mod == 0 carry none (skip_mod > 0: the sigma token)
+    int x_bf16;                                                 // x is [M][D] bf16 (the one-launch forward's kept residuals, round 5)
 };
 
 // the gradient tile as B fragments: lane (n, g) of fragment (t, kk) holds columns 32 kk + 4 g .. +3 and 32 kk + 16 + 4 g .. +3
@@ -3415,7 +3439,12 @@ __device__ __forceinline__ void ln_bwd_epilogue(const f32x4 (&acc)[RPW][NT], con
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int tok = min(m0 + 16 * t + n, M - 1);
-            const f32x4 xv = *(const f32x4*)(e.x + (size_t)tok * D + (fv ? f0 : 0));
+            f32x4 xv;
+            if (e.x_bf16) {
+                const uint2 u = *(const uint2*)((const uint16_t*)e.x + (size_t)tok * D + (fv ? f0 : 0));
+                xv = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u)};
+            } else xv = *(const f32x4*)(e.x + (size_t)tok * D + (fv ? f0 : 0));
             xh[i][t] = (fv && live[t]) ? (xv - mean[t]) * rstd[t] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -4272,7 +4301,7 @@ int fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, 
     if (ln != nullptr) {
         if (which != 0 && which != 2) return BESO_ERR_BAD_ARG;
         ep = LnBwdEpi{ln->x, ln->stats, ln->gamma, ln->dres_in, ln->dres_out, (uint16_t*)ln->dxb, ln->part,
-                      ln->p, ln->p > 0.f ? 1.0f / (1.0f - ln->p) : 1.f, ln->seed, ln->site, ln->skip_mod};
+                      ln->p, ln->p > 0.f ? 1.0f / (1.0f - ln->p) : 1.f, ln->seed, ln->site, ln->skip_mod, ln->x_bf16};
         a.out32 = nullptr;
     }
     size_t lds_bytes = (size_t)NT * a.parts * a.kt * 1024;
@@ -4310,7 +4339,7 @@ int fused_train_mlp_bwd(const Layout& lay, const char* img, int layer, int M, co
     const MlpBwdArgs a{(const uint16_t*)dyo, (const uint16_t*)h, (uint16_t*)dh, colsum, (uint16_t*)dy, bi.o_w2T, bi.o_w1T, bi.o_pT,
                        lay.D, bi.kt_d, bi.kt_h, bi.n_chunks, M};
     const LnBwdEpi ep{ln.x, ln.stats, ln.gamma, ln.dres_in, ln.dres_out, (uint16_t*)ln.dxb, ln.part,
-                       ln.p, ln.p > 0.f ? 1.0f / (1.0f - ln.p) : 1.f, ln.seed, ln.site, ln.skip_mod};
+                       ln.p, ln.p > 0.f ? 1.0f / (1.0f - ln.p) : 1.f, ln.seed, ln.site, ln.skip_mod, ln.x_bf16};
     const int KC = d.RPW * kWaves / 2;
     const size_t lds_bytes = (size_t)NT * (bi.kt_d + 2 * KC) * 1024;
     const dim3 grid((M + 16 * NT - 1) / (16 * NT)), block(512);

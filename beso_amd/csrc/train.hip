@@ -2014,6 +2014,9 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     }
     if (fork) TRY(hipEventRecord(ev_join, ps));
     const bool use_mlp_bwd = use_dgrad && fused_train_mlp_bwd_supported(flay);
+    // the one-launch forward keeps x_mid / x_out as bf16 when nothing but the fused LayerNorm-backward epilogues read them
+    // (no residual dropout: with it the forward itself adds the residual back from the kept fp32 rows)
+    const int x16 = (use_whole && use_dgrad && use_mlp_bwd && resid_p == 0.f) ? 1 : 0;
     if (use_dgrad) {
         const int pst = fused_train_dgrad_pack(flay, p, ws + w.bimg, ps);
         if (pst != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return pst; }
@@ -2109,7 +2112,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         const TrainLayerWs& y0 = w.layer[0];
         const size_t stride = L > 1 ? w.layer[1].x_mid - y0.x_mid : 0;
         const TrainWholeBufs b{F(w.x0), ws, y0.x_mid, y0.x_out, y0.st1, y0.st2, y0.xn1, y0.qkv, y0.y, y0.xn2, y0.h, y0.g,
-                               stride, w.ya, t, attn_p, seed, resid_p};
+                               stride, w.ya, t, attn_p, seed, resid_p, x16};
         profile_begin(BESO_SITE_FUSED_LAYER, s);
         const int st = fused_train_whole(flay, ws + w.fimg, batch, T, b, s);
         profile_end(BESO_SITE_FUSED_LAYER, s);
@@ -2215,11 +2218,12 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // the same LayerNorm backward as the epilogue of the data gradient in front of it (which = 0: q|k|v, 2: FC1); dxn is never
     // written (dropout at the site: the same (row, feature) hash, evaluated in the epilogue).
     auto dgrad_ln = [&](int l, int which, int rows, const E* in, const float* x, size_t st, const float* gamma, float* dres,
-                        E* dxb, float* dgam, float* dbet, float* dbias, float p_site, uint32_t site, int skip_mod = 0) -> int {
+                        E* dxb, float* dgam, float* dbet, float* dbias, float p_site, uint32_t site, int skip_mod = 0,
+                        int x_is_bf16 = 0) -> int {
         float* part = F(w.ln_part) + (size_t)ln_calls * lnb_grid * 3 * D;
         lrt.nb[ln_calls] = fused_train_dgrad_blocks(rows);
         lrt.c[ln_calls++] = LnRedCall{dgam, dbet, dbias};
-        const TrainLnBwd ln{x, (const float*)F(st), gamma, dres, dres, dxb, part, p_site, seed, site, skip_mod};
+        const TrainLnBwd ln{x, (const float*)F(st), gamma, dres, dres, dxb, part, p_site, seed, site, skip_mod, x_is_bf16};
         return fused_train_dgrad(flay, ws + w.bimg, l, which, rows, in, nullptr, nullptr, nullptr, nullptr, nullptr, s, &ln);
     };
     // The weight gradients are collected and run as one grouped launch after the chain of data gradients: every
@@ -2399,13 +2403,13 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
             lrt.nb[ln_calls] = fused_train_dgrad_blocks(rows);
             lrt.c[ln_calls++] = LnRedCall{lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g};
             const TrainLnBwd ln{F(y.x_mid), (const float*)F(y.st2), lp[l].ln2w.p, dres, dres, P(y.dym), part, resid_p, seed,
-                                (uint32_t)(4 * l + 1), 0};
+                                (uint32_t)(4 * l + 1), 0, x16};
             FUSED(fused_train_mlp_bwd(flay, ws + w.bimg, l, rows, P(y.dyo), P(y.h), P(y.dh), slab, dy_out, ln, s));
         } else if (use_dgrad) {
             // the same chain as three launches (shapes without the one-kernel form)
             FUSED(fused_train_dgrad(flay, ws + w.bimg, l, 3, rows, P(y.dyo), nullptr, nullptr, P(y.h), P(y.dh), slab, s));
             FUSED(dgrad_ln(l, 2, rows, P(y.dh), F(y.x_mid), y.st2, lp[l].ln2w.p, dres, P(y.dym), lp[l].ln2w.g, lp[l].ln2b.g, lp[l].pb.g,
-                           resid_p, (uint32_t)(4 * l + 1)));
+                           resid_p, (uint32_t)(4 * l + 1), 0, x16));
             FUSED(fused_train_dgrad(flay, ws + w.bimg, l, 1, rows, P(y.dym), nullptr, dy_out, nullptr, nullptr, nullptr, s));
         } else {
             // per-op: dh = (dyo W2) * GELU'(h) (+ db1), dxn2 = dh W1, LayerNorm-2 backward, dy = dym Wp
@@ -2448,7 +2452,7 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         if (use_dgrad) {
             FUSED(dgrad_ln(l, 0, M, P(y.dqkv), x_in, y.st1, lp[l].ln1w.p, F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo),
                            lp[l].ln1w.g, lp[l].ln1b.g, first ? nullptr : lp[l - 1].f2b.g, first ? embed_p : resid_p,
-                           first ? kEmbedSite : (uint32_t)(4 * (l - 1) + 2), first ? T : 0));
+                           first ? kEmbedSite : (uint32_t)(4 * (l - 1) + 2), first ? T : 0, first ? 0 : x16));
         } else {
             TRY((tgemm<E, false, true>(P(y.dqkv), D3, P(y.w_qkv), D, M, D, D3, 1, EpiStore<E>{F(w.dxn), nullptr, nullptr, D}, s)));
             TRY(ln_bwd(x_in, y.st1, lp[l].ln1w.p, F(w.dx), F(w.dx), first ? P(w.dx0b) : P(w.layer[l - 1].dyo), M, lp[l].ln1w.g,
