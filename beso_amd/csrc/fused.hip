@@ -797,6 +797,19 @@ struct Rows {
     const unsigned char* tab; int base, n;
     __device__ __forceinline__ int row(int slot) const { return slot < n ? base + (tab ? (int)tab[slot] : slot) : -1; }
 };
+// Two 8-byte row pieces of the accumulator layout -> one 16-byte store per lane.  a = the lane's four bf16 features (f0 .. f0 + 3,
+// f0 = 16 tile + 4 g) of the token `tok_a` of token tile t, b = the same features of `tok_b` of tile t + 1.  After the two swaps
+// (v_permlane16_swap: the odd 16-lane rows of the first operand <-> the even rows of the second) a lane of an even group g holds
+// [its own a | group g + 1's a] = features f0 .. f0 + 7 of tok_a, a lane of an odd group [group g - 1's b | its own b] =
+// features f0 - 4 .. f0 + 3 of tok_b: every lane stores 16 bytes to ONE row.  ld (bf16 elements per row) is a multiple of 8.
+__device__ __forceinline__ void store_pair16(uint16_t* __restrict__ base, int ld, int tok_a, int tok_b, int f0, int g, uint2 a, uint2 b,
+                                             bool on) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+    const u32x2_t sx = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    const u32x2_t sy = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    const int tok = (g & 1) ? tok_b : tok_a, f = f0 - 4 * (g & 1);
+    if (tok >= 0 && f < ld && on) *(u32x4*)(base + (size_t)tok * ld + f) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+}
 struct LnPlain { static constexpr bool on = false; };
 struct LnTrain {
     static constexpr bool on = true;
@@ -1057,8 +1070,11 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
             // operand-typed copy for the weight gradients goes out row-major
             pk.x = pack_op2(fmaf(fmaf(T.acc[i][t][0], a, b), gam[i][0], bet[i][0]), fmaf(fmaf(T.acc[i][t][1], a, b), gam[i][1], bet[i][1]));
             pk.y = pack_op2(fmaf(fmaf(T.acc[i][t][2], a, b), gam[i][2], bet[i][2]), fmaf(fmaf(T.acc[i][t][3], a, b), gam[i][3], bet[i][3]));
-            const int tok = lx.rows.row(16 * t + (lane & 15)), f0 = 16 * (w * RPW + i) + 4 * g;
-            if (tok >= 0 && f0 < lx.D && !(BESO_TRAIN_FWD_ABL & 2)) *(uint2*)(lx.xn + (size_t)tok * lx.D + f0) = pk;
+            // (the kept copy leaves in keep_xn below: 16-byte pieces, two token tiles per store)
+            if constexpr (NT % 2 != 0) {
+                const int tok = lx.rows.row(16 * t + (lane & 15)), f0 = 16 * (w * RPW + i) + 4 * g;
+                if (tok >= 0 && f0 < lx.D && !(BESO_TRAIN_FWD_ABL & 2)) *(uint2*)(lx.xn + (size_t)tok * lx.D + f0) = pk;
+            }
         } else {
             pk.x = pack_op2(fmaf(T.acc[i][t][0], a, b), fmaf(T.acc[i][t][1], a, b));
             pk.y = pack_op2(fmaf(T.acc[i][t][2], a, b), fmaf(T.acc[i][t][3], a, b));
@@ -1072,8 +1088,34 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
         hi = make_uint2(p0.hi, p1.hi);
         lo = make_uint2(p0.lo, p1.lo);
     };
+    // training instances with an even tile count: the operand-typed copy for the weight gradients, row-major, as 16-byte pieces
+    // (store_pair16: the lane groups of two token tiles exchange halves)
+    uint2 kept[LX::on && NT % 2 == 0 ? NT : 1];
+    auto keep_xn = [&](int i) {
+        if constexpr (LX::on && NT % 2 == 0) {
+            const int n = lane & 15, f0 = 16 * (w * RPW + i) + 4 * g;
+#pragma unroll
+            for (int t = 0; t < NT; t += 2)
+                store_pair16(lx.xn, lx.D, lx.rows.row(16 * t + n), lx.rows.row(16 * (t + 1) + n), f0, g, kept[t], kept[t + 1],
+                             !(BESO_TRAIN_FWD_ABL & 2));
+        }
+    };
     auto write_pair = [&](int i) {          // row tiles i, i+1 of this wave: Rf = w*RPW + i is even
         const int ks = (w * RPW + i) >> 1;
+        if constexpr (LX::on && NT % 2 == 0) {
+            if (ks >= KS) return;
+            uint2 hi2[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                kept[t] = half(i, t); hi2[t] = half(i + 1, t);
+                xnT[((size_t)t * KS + ks) * 64 + lane] = u32x4{kept[t].x, kept[t].y, hi2[t].x, hi2[t].y};
+            }
+            keep_xn(i);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) kept[t] = hi2[t];
+            keep_xn(i + 1);
+            return;
+        }
         if (ks < KS) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -1092,6 +1134,16 @@ __device__ __forceinline__ void layernorm_to_lds(Tile<RPW>& T, u32x4* xnT, float
     };
     auto write_single = [&](int i) {
         const int Rf = w * RPW + i;
+        if constexpr (LX::on && NT % 2 == 0) {
+            if ((Rf >> 1) >= KS) return;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                kept[t] = half(i, t);
+                *((uint2*)(xnT + ((size_t)t * KS + (Rf >> 1)) * 64 + lane) + (Rf & 1)) = kept[t];
+            }
+            keep_xn(i);
+            return;
+        }
         if ((Rf >> 1) < KS) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -1662,18 +1714,32 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
     };
     // training instance: the pre-activation and GELU(h) of chunk c, row-major, for the backward pass (the fragment
     // hb[j2][t] is {row tile 2 j2: features 4g..4g+3 | row tile 2 j2 + 1: the same}, i.e. two 8-byte row pieces)
+    // (round 5: the kept rows leave as 16-BYTE pieces.  The accumulator layout gives a lane 4 features = 8 bytes of a token; the
+    //  lane groups g, g + 1 of two token tiles t, t + 1 exchange their halves with two v_permlane16_swap, after which a lane of an
+    //  even group holds 8 consecutive features of tile t's token and a lane of an odd group those of tile t + 1's -- one store
+    //  instruction where there were two.  What the forward's 876 MB of kept activations cost follows the store INSTRUCTIONS: the
+    //  fp32 residuals written as bf16 -- half the bytes, the same instruction count -- changed nothing.)
     auto keep_h = [&](int c, const f32x4 (&hv)[RC][NT]) {
         if constexpr (MX::on) {
             const int n = lane & 15, g = lane >> 4;
 #pragma unroll
             for (int r = 0; r < RC; ++r) {
                 const int f0 = 16 * (c * kChunkTiles + RC * w + r) + 4 * g;
+                if constexpr (NT % 2 == 0) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int tok = mx.rows.row(16 * t + n);
-                    if (tok >= 0 && f0 < mx.ld && !(BESO_TRAIN_FWD_ABL & 8))
-                        *(uint2*)(mx.h + (size_t)tok * mx.ld + f0) = make_uint2(pack_op2(hv[r][t][0], hv[r][t][1]),
-                                                                                 pack_op2(hv[r][t][2], hv[r][t][3]));
+                    for (int t = 0; t < NT; t += 2)
+                        store_pair16(mx.h, mx.ld, mx.rows.row(16 * t + n), mx.rows.row(16 * (t + 1) + n), f0, g,
+                                     make_uint2(pack_op2(hv[r][t][0], hv[r][t][1]), pack_op2(hv[r][t][2], hv[r][t][3])),
+                                     make_uint2(pack_op2(hv[r][t + 1][0], hv[r][t + 1][1]), pack_op2(hv[r][t + 1][2], hv[r][t + 1][3])),
+                                     !(BESO_TRAIN_FWD_ABL & 8));
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int tok = mx.rows.row(16 * t + n);
+                        if (tok >= 0 && f0 < mx.ld && !(BESO_TRAIN_FWD_ABL & 8))
+                            *(uint2*)(mx.h + (size_t)tok * mx.ld + f0) = make_uint2(pack_op2(hv[r][t][0], hv[r][t][1]),
+                                                                                     pack_op2(hv[r][t][2], hv[r][t][3]));
+                    }
                 }
             }
         }
@@ -1686,11 +1752,19 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int f0 = 16 * (c * kChunkTiles + RC * w + 2 * j2 + q) + 4 * g;
+                    if constexpr (NT % 2 == 0) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int tok = mx.rows.row(16 * t + n);
-                        if (tok >= 0 && f0 < mx.ld && !(BESO_TRAIN_FWD_ABL & 16))
-                            *(uint2*)(mx.g + (size_t)tok * mx.ld + f0) = make_uint2(hb[j2][t][2 * q], hb[j2][t][2 * q + 1]);
+                        for (int t = 0; t < NT; t += 2)
+                            store_pair16(mx.g, mx.ld, mx.rows.row(16 * t + n), mx.rows.row(16 * (t + 1) + n), f0, g,
+                                         make_uint2(hb[j2][t][2 * q], hb[j2][t][2 * q + 1]),
+                                         make_uint2(hb[j2][t + 1][2 * q], hb[j2][t + 1][2 * q + 1]), !(BESO_TRAIN_FWD_ABL & 16));
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int tok = mx.rows.row(16 * t + n);
+                            if (tok >= 0 && f0 < mx.ld && !(BESO_TRAIN_FWD_ABL & 16))
+                                *(uint2*)(mx.g + (size_t)tok * mx.ld + f0) = make_uint2(hb[j2][t][2 * q], hb[j2][t][2 * q + 1]);
+                        }
                     }
                 }
         }
