@@ -560,13 +560,58 @@ def other_configs(args, dev):
     sampler_run("configs[4] in fp16", "long_horizon", 256, "euler", 100, 0.005, 1.0, None, 2, "fp16")
     sampler_run("configs[3] in bf16x3 (1e-4 mode)", "block_push", 2048, "heun", 50, 0.05, 1.0, 2.0, 1, "bf16x3")
     sampler_run("configs[4] in bf16x3 (1e-4 mode: split-bf16 block kernels + fp32 attention)", "long_horizon", 256, "euler", 100, 0.005, 1.0, None, 1, "bf16x3")
-    targs = copy.copy(args)
-    targs.workload, targs.batch, targs.steps, targs.warmup, targs.settle_ms, targs.config = "train", 1024, 20, 3, 100.0, "kitchen"
-    tr = run_train(targs, 1, 0, dev)
-    out.append({"config": "configs[2] per-GPU share: kitchen BesoAgent.train_step, 1024 samples", "dtype": "bf16",
-                "steps_timed": targs.steps, "ms_per_step": tr["ms_per_step"], "samples_per_s": tr["samples_per_s"],
-                "tflops": tr["roofline"]["achieved"], "frac_of_bf16_mfma_peak": tr["roofline"]["frac"], "loss": tr["loss"]})
+    for label, shape, B in (("configs[2] per-GPU share: kitchen BesoAgent.train_step, 1024 samples", "kitchen", 1024),
+                            ("configs[2] whole on one GPU: kitchen BesoAgent.train_step, 8192 samples", "kitchen", 8192),
+                            ("block-push BesoAgent.train_step (resid_pdrop 0.05), 1024 samples", "block_push", 1024)):
+        targs = copy.copy(args)
+        targs.workload, targs.batch, targs.steps, targs.warmup, targs.settle_ms, targs.config = "train", B, 20, 3, 100.0, shape
+        tr = run_train(targs, 1, 0, dev)
+        out.append({"config": label, "dtype": "bf16",
+                    "steps_timed": targs.steps, "ms_per_step": tr["ms_per_step"], "samples_per_s": tr["samples_per_s"],
+                    "tflops": tr["roofline"]["achieved"], "frac_of_bf16_mfma_peak": tr["roofline"]["frac"], "loss": tr["loss"]})
+    out.append(small_batches(dev))
     return out
+
+
+def small_batches(dev):
+    """The rollout end of the batch-size range (the reference's workspaces call predict() with B = 1): one GCDenoiser.forward and
+    a 3-step sampler call at 1 / 16 samples through the library's own choice (bf16, kitchen: the chip-wide small-batch path,
+    small.hip) next to the one-launch kernel's latency instance (BESO_PLAN_FUSED), and the same forward in fp32 (small-batch path
+    against the per-op kernels)."""
+    from beso_amd import _lib, synthetic as S
+    from beso_amd.runtime import set_plan
+    from beso_amd.agents.diffusion_agents.k_diffusion import gc_sampling as ks
+    cfg = S.SHAPES["kitchen"]
+    w = S.make_weights(cfg, seed=0, std=0.02)
+    rec = {"config": "small batches (kitchen): one forward / a 3-step DDIM call, microseconds", "rows": []}
+
+    def us(fn, n=200, warm=20):
+        with torch.no_grad():
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    try:
+        for prec, other, hint in (("bf16", "one_launch_kernel", _lib.PLAN_FUSED), ("fp32", "per_op_kernels", _lib.PLAN_PER_OP)):
+            model = build_model(cfg, w, prec, dev)
+            sig3 = ks.get_sigmas_exponential(3, 0.005, 1.0)
+            for B in (1, 16):
+                s, g, a = (torch.from_numpy(v).to(dev) for v in S.make_inputs(cfg, B, seed=1))
+                sg = torch.full((B,), 0.3, device=dev)
+                row = {"dtype": prec, "batch": B}
+                for name, h in (("library", 0), (other, hint)):
+                    set_plan(forward=h)
+                    row[f"forward_us_{name}"] = us(lambda: model(s, a, g, sg))
+                    row[f"ddim3_us_{name}"] = us(lambda: ks.sample_ddim(model, s, a, g, sig3, disable=True), n=50, warm=5)
+                rec["rows"].append(row)
+    finally:
+        set_plan(forward=0)
+    return rec
 
 
 
