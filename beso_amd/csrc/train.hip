@@ -1736,7 +1736,7 @@ static int device_cus() {
 
 // Events that order the step's side streams, per calling thread AND per device (an event created on device A and
 // recorded on a stream of device B is hipErrorInvalidHandle -- a thread that drives several GPUs one after the other)
-enum { kEvFork = 0, kEvJoin, kEvCopies, kEvLoss, kEvEarly, kEvCount };
+enum { kEvFork = 0, kEvJoin, kEvCopies, kEvLoss, kEvEarly, kEvSideFork, kEvSideJoin, kEvCount };
 static hipError_t step_event(int which, hipEvent_t* out) {
     constexpr int kMaxDev = 64;
     static thread_local hipEvent_t ev[kMaxDev][kEvCount] = {};
@@ -1749,6 +1749,24 @@ static hipError_t step_event(int which, hipEvent_t* out) {
         if (e != hipSuccess) return e;
     }
     *out = ev[dev][which];
+    return hipSuccess;
+}
+
+// A stream of the library's own per calling thread and device: work of the step that depends on neither the caller's side
+// streams nor the launch it runs beside (round 5: the small reductions of the bias / LayerNorm partial sums under the grouped
+// weight-gradient launch).  Forked from and joined to the compute stream with events inside the call -- the caller never sees it.
+static hipError_t step_side_stream(hipStream_t* out) {
+    constexpr int kMaxDev = 64;
+    static thread_local hipStream_t st[kMaxDev] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDev) return hipErrorInvalidDevice;
+    if (!st[dev]) {
+        e = hipStreamCreateWithFlags(&st[dev], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *out = st[dev];
     return hipSuccess;
 }
 
@@ -2237,8 +2255,9 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // FC1 bias gradients of the transposed-formulation data-gradient kernel: per-workgroup sums in a slab per layer, added up
     // (assigned, not accumulated) where the LayerNorm partial sums are
     const float* b1_slabs[kMaxLayers]; float* b1_outs[kMaxLayers]; int b1_blocks[kMaxLayers]; int b1_n = 0;
+    hipStream_t rs = s;                                   // stream of the partial-sum reductions (the side stream at the step's end)
     auto flush_b1 = [&]() -> int {
-        const int st = fused_train_bias_reduce(b1_slabs, b1_outs, b1_blocks, b1_n, D4, s);
+        const int st = fused_train_bias_reduce(b1_slabs, b1_outs, b1_blocks, b1_n, D4, rs);
         b1_n = 0;
         return st;
     };
@@ -2478,11 +2497,28 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
 #undef FUSED
     // embeddings: dWcat[Ke][D] = Xemb^T dx0, routed to pos_emb / tok_emb / action_emb / sigma_emb after the launch
     TRY(wgrad(P(w.xemb), Ke, Ke, P(w.dx0b), D, D, M, F(w.dw_cat)));
-    TRY(flush_group());
+    // The reductions of the FC1-bias slabs and of the LayerNorm / bias partial sums read what the data-gradient kernels wrote
+    // and write gradient tensors of their own: nothing ties them to the grouped weight-gradient launch, which leaves 38 of the
+    // 256 CUs idle (218 panel tiles) -- they run BESIDE it on the library's side stream (three launches of 12 + 12 + 24 us off the
+    // step's chain; a dependent launch costs ~5 us whatever it does: tools/microbench/launch_chain).
+    hipEvent_t ev_sf = nullptr, ev_sj = nullptr;
+    if (panel_w) {
+        TRY(step_side_stream(&rs));
+        TRY(step_event(kEvSideFork, &ev_sf));
+        TRY(step_event(kEvSideJoin, &ev_sj));
+        TRY(hipEventRecord(ev_sf, s));
+        TRY(hipStreamWaitEvent(rs, ev_sf, 0));
+    } else TRY(flush_group());
     if (flush_b1() != BESO_OK) { *err = hipGetLastError(); *err_line = __LINE__; return BESO_ERR_HIP; }
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls - ln_reduced), dim3(256), 0, s,
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, 3, ln_calls - ln_reduced), dim3(256), 0, rs,
                        (const float*)F(w.ln_part), lrt, lnb_grid, D, ln_reduced);
     TRY(hipGetLastError());
+    if (panel_w) {
+        TRY(hipEventRecord(ev_sj, rs));
+        TRY(flush_group());
+        TRY(hipStreamWaitEvent(s, ev_sj, 0));
+        rs = s;
+    }
     if (mlp_head) {
         TRY(hipMemcpy2DAsync(hw.g, sizeof(float) * Hh, ws + w.dw_head, sizeof(float) * Hp, sizeof(float) * Hh, act,
                              hipMemcpyDeviceToDevice, s));                                    // [act][Hp] -> [act][100]

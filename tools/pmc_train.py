@@ -16,7 +16,7 @@ for d in sys.argv[1:]:
             n = re.sub(r"beso::\(anonymous namespace\)::", "", r["Kernel_Name"])
             n = re.sub(r"\(.*", "", n).replace("void ", "")
             if not n.startswith(("tgemm", "ln_", "attn_", "colsum", "beso::adam", "train_embed", "train_fwd", "train_pack", "pack_table", "train_dgrad", "train_mlp_bwd",
-                                 "slab_reduce", "wgrad_reduce")):
+                                 "slab_reduce", "wgrad_reduce", "wgrad_panel")):
                 continue
             sums[(n, r["Counter_Name"])] += float(r["Counter_Value"])
             cnts[(n, r["Counter_Name"])] += 1
