@@ -1790,8 +1790,9 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 #pragma unroll
     for (int pi = 0; pi < PAIRS; ++pi) gelu_pair<RC, NT>(h, gq, hb, pi);
     write_hT(hb);
-    keep_g(0, hb);
+    if (NT > 4) keep_g(0, hb);
     if (n_chunks > 1) { fc1(1, h, a1r); keep_h(1, h); }
+    if (NT <= 4) keep_g(0, hb);
     stamp(st, 20);
     __syncthreads();                     // hT(0) complete
 #pragma unroll 1
@@ -1850,8 +1851,15 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
         stamp(st, 21);
         if (!(BESO_ABL_MASK & 2)) __syncthreads();                 // every wave is done reading hT(c-1)
         stamp(st, 22);
-        if (fc1_active) { write_hT(hb); keep_g(pc(c), hb); }
+        // (training instances: GELU(h) of chunk c leaves TOGETHER with h of chunk c + 1, behind FC1(c + 1) -- one burst of stores per
+        //  chunk instead of two.  What the kept activations cost is neither their bytes nor their instruction count but the number of
+        //  BURSTS: a wave's loads queue behind its stores' acknowledgements (in-order vmcnt), ~1.8 us per burst whatever its size.)
+        //  Instances of up to four token tiles; the eight-sample instance is at its 256 registers already and measured 1.3 %
+        //  slower with hb kept alive across FC1: 12.16 -> 12.32 ms per 8192-sample step.)
+        constexpr bool kLateG = NT <= 4;
+        if (fc1_active) { write_hT(hb); if (!kLateG) keep_g(pc(c), hb); }
         if (c + 1 < n_chunks && next_active) { fc1(c + 1, h, a1r); keep_h(pc(c + 1), h); }
+        if (kLateG && fc1_active) keep_g(pc(c), hb);
         stamp(st, 23);
         if (!(BESO_ABL_MASK & 2)) __syncthreads();                 // hT(c) complete
         stamp(st, 24);
@@ -3336,10 +3344,12 @@ __global__ __launch_bounds__(512, 2) void train_fwd_kernel(const char* __restric
         if constexpr (RD)
             resid_dropout_add<RPW, NTP>(T, l == 0 ? a.x0 : (const float*)(wl - a.stride + a.x_out), d.D, rows_all, rows_tail,
                                         a.p_resid, inv_keep_r, a.seed, (uint32_t)(4 * l + 1), w, lane);
-        if (!RD && a.x_bf16) store_x_rows_bf16<RPW, NTP>(T, (uint16_t*)(wl + a.x_mid), d.D, rows_tail, w, lane);
-        else store_x_rows<RPW, NTP>(T, (float*)(wl + a.x_mid), d.D, rows_tail, w, lane);
+        // (the first FC1 weight fragments are requested BEFORE the kept x_mid leaves: loads issued behind a burst of stores wait
+        //  for the stores' acknowledgements)
         u32x4 a1r[PF1][kChunkTiles / kWaves];
         mlp_prefetch<KS, kWaves, PF1>(a1r, (const u32x4*)lw, w, lane);
+        if (!RD && a.x_bf16) store_x_rows_bf16<RPW, NTP>(T, (uint16_t*)(wl + a.x_mid), d.D, rows_tail, w, lane);
+        else store_x_rows<RPW, NTP>(T, (float*)(wl + a.x_mid), d.D, rows_tail, w, lane);
         const LnTrain lx2{(const float*)(lw + ti.o_ln2w), (const float*)(lw + ti.o_ln2b), (float*)(wl + a.st2),
                           (uint16_t*)(wl + a.xn2), rows_tail, d.D};
         layernorm_to_lds<RPW, KS, kWaves, !RD, NTP, 0, LnTrain>(T, xnT, red, d.D, w, lane, (const float*)(lw + d.o_b2), st, 0, lx2);
