@@ -140,12 +140,14 @@ __global__ __launch_bounds__(256) void sb_ln_gemm_kernel(const float* __restrict
     __syncthreads();
     // 3. the tile's product
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const bool two = rows > 16;                            // (one sample of <= 16 tokens: the second row tile is idle)
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const u32x4 a = *(const u32x4*)(at + (16 * rt + li) * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
-            SbE<E>::mma(acc[rt], wf[ks], a);
+        const u32x4 a0 = *(const u32x4*)(at + li * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
+        SbE<E>::mma(acc[0], wf[ks], a0);
+        if (two) {
+            const u32x4 a1 = *(const u32x4*)(at + (16 + li) * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
+            SbE<E>::mma(acc[1], wf[ks], a1);
         }
     }
     // 4. the lane holds features n0 + 4 lg .. +3 of token 16 rt + li
@@ -203,24 +205,9 @@ __global__ __launch_bounds__(256) void sb_qkv_attn_kernel(const float* __restric
     }
     ln.finish(at, rows, D, tid);
     __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        if (NP == 1 && p > 0) {                            // (fp32: one part's 96 registers of fragments at a time)
-            const E* wp = wrow(p);
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) wf[0][ks] = *(const u32x4*)(wp + ks * KSTEP);
-        }
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const u32x4 a = *(const u32x4*)(at + (16 * rt + li) * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
-                SbE<E>::mma(acc[rt], wf[NP == 1 ? 0 : p][ks], a);
-            }
-        }
-        // the lane holds dims 16 wave + 4 lg .. +3 of token 16 rt + li
-        const int d0 = 16 * wave + 4 * lg;
+    const bool two = rows > 16;                            // (one sample of <= 16 tokens: the second row tile is idle)
+    const int d0 = 16 * wave + 4 * lg;                     // the lane ends with dims d0 .. d0 + 3 of token 16 rt + li
+    auto put = [&](int p, const f32x4 (&acc)[2]) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (d0 < hd) bv = *(const f32x4*)(bias + p * D + h * hd + d0);
 #pragma unroll
@@ -228,6 +215,46 @@ __global__ __launch_bounds__(256) void sb_qkv_attn_kernel(const float* __restric
             f32x4 v = acc[rt] + bv;
             if (d0 >= hd) v = f32x4{0.f, 0.f, 0.f, 0.f};
             *(f32x4*)&qs[p][16 * rt + li][d0] = v;
+        }
+    };
+    if constexpr (NP == 3) {
+        // bf16: the three parts' products as independent accumulator chains, k-step by k-step (one activation fragment read
+        // serves all three)
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { acc[p][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[p][1] = acc[p][0]; }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const u32x4 a0 = *(const u32x4*)(at + li * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) SbE<E>::mma(acc[p][0], wf[p][ks], a0);
+            if (two) {
+                const u32x4 a1 = *(const u32x4*)(at + (16 + li) * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
+#pragma unroll
+                for (int p = 0; p < 3; ++p) SbE<E>::mma(acc[p][1], wf[p][ks], a1);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) put(p, acc[p]);
+    } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            if (p > 0) {                                   // (fp32: one part's 96 registers of fragments at a time)
+                const E* wp = wrow(p);
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) wf[0][ks] = *(const u32x4*)(wp + ks * KSTEP);
+            }
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const u32x4 a0 = *(const u32x4*)(at + li * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
+                SbE<E>::mma(acc[0], wf[0][ks], a0);
+                if (two) {
+                    const u32x4 a1 = *(const u32x4*)(at + (16 + li) * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
+                    SbE<E>::mma(acc[1], wf[0][ks], a1);
+                }
+            }
+            put(p, acc);
         }
     }
     __syncthreads();
@@ -307,6 +334,7 @@ __global__ __launch_bounds__(256) void sb_gemm_resid_kernel(const E* __restrict_
             if (16 * rt + li < rows) xv[rt] = *(const f32x4*)(x + (size_t)(m0 + 16 * rt + li) * D + n);
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const bool two = rows > 16;                              // (one sample of <= 16 tokens: the second row tile is not fetched)
     for (int ks0 = wave; ks0 < nkt; ks0 += 4 * kSbChunk) {
         u32x4 wf[kSbChunk], a0[kSbChunk], a1[kSbChunk];
 #pragma unroll
@@ -314,13 +342,13 @@ __global__ __launch_bounds__(256) void sb_gemm_resid_kernel(const E* __restrict_
             const int ks = min(ks0 + 4 * u, nkt - 1);          // (wave-uniform; a clamped step is loaded and not used)
             wf[u] = *(const u32x4*)(wp + ks * KSTEP);
             a0[u] = *(const u32x4*)(ap0 + ks * KSTEP);
-            a1[u] = *(const u32x4*)(ap1 + ks * KSTEP);
+            if (two) a1[u] = *(const u32x4*)(ap1 + ks * KSTEP);
         }
 #pragma unroll
         for (int u = 0; u < kSbChunk; ++u) {
             if (ks0 + 4 * u < nkt) {
                 SbE<E>::mma(acc[0], wf[u], a0[u]);
-                SbE<E>::mma(acc[1], wf[u], a1[u]);
+                if (two) SbE<E>::mma(acc[1], wf[u], a1[u]);
             }
         }
     }
