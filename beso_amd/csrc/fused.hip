@@ -2940,41 +2940,72 @@ __global__ void train_pack_kernel(TrainPackTable t, char* __restrict__ img) {
         for (size_t i = start; i < (size_t)g.cols; i += stride) dst[i] = i < (size_t)g.rows ? g.src[i] : 0.f;
         return;
     }
+    // Matrices: a thread writes the EIGHT bf16 of one lane of a fragment tile (16 bytes) per iteration -- elements j = 0..3 are
+    // columns c0 .. c0 + 3, j = 4..7 columns c0 + 16 .. c0 + 19 of one source row: two 16-byte reads where the source is laid
+    // out along c (32-bit index arithmetic: one element per thread with 64-bit divisions took 35 us per image of the step)
     uint16_t* dst = (uint16_t*)(img + g.dst);
+    const uint32_t total8 = (uint32_t)g.rt * (uint32_t)g.kt * 64u * (g.tr == 2 ? 4u : 1u);
+    const bool vec_ok = ((uintptr_t)g.src & 15) == 0;
+    auto put8 = [&](uint32_t i8, uint32_t dst8, bool row_ok, const float* row, int c0, int ncols, size_t cstride) {
+        // row: &src[row][0] (cstride 1) or &src[0][row] (cstride = rows: the matrix is stored transposed)
+        float v[8];
+        if (row_ok && cstride == 1 && vec_ok && c0 + 20 <= ncols && (ncols & 3) == 0) {
+            const f32x4 lo = *(const f32x4*)(row + c0), hi = *(const f32x4*)(row + c0 + 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + 16 * (j >> 2) + (j & 3);
+                v[j] = (row_ok && c < ncols) ? row[(size_t)c * cstride] : 0.f;
+            }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (uint32_t)f2bf(v[2 * j]) | ((uint32_t)f2bf(v[2 * j + 1]) << 16);
+        *(u32x4*)(dst + (size_t)dst8 * 8) = o;
+    };
+    const uint32_t start8 = (uint32_t)start, stride8 = (uint32_t)stride;
     if (g.tr == 2) {
         // one part (grp: 0 query, 1 key, 2 value) of the head-pair q/k/v image (pack_qkv_kernel's layout, no gamma):
         // rt = virtual heads, rows = their width hdv, cols = D
-        const size_t total = (size_t)g.rt * g.kt * 4 * 512;
-        for (size_t i = start; i < total; i += stride) {
-            const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-            const size_t tile = i >> 9;
-            const int R4 = (int)(tile & 3), kk = (int)((tile >> 2) % g.kt), h = (int)(tile / ((size_t)4 * g.kt));
-            const int dd = 16 * R4 + (lane & 15), c = 32 * kk + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
-            const size_t dtile = ((size_t)(h >> 1) * g.kt + kk) * 24 + (h & 1) * 12 + g.grp * 4 + R4;
-            dst[dtile * 512 + lane * 8 + j] = f2bf((dd < g.rows && c < g.cols) ? g.src[((size_t)h * g.rows + dd) * g.cols + c] : 0.f);
+        for (uint32_t i8 = start8; i8 < total8; i8 += stride8) {
+            const uint32_t lane = i8 & 63, tile = i8 >> 6;
+            const uint32_t R4 = tile & 3, kk = (tile >> 2) % (uint32_t)g.kt, h = tile / (4u * (uint32_t)g.kt);
+            const int dd = 16 * (int)R4 + (int)(lane & 15), c0 = 32 * (int)kk + 4 * (int)(lane >> 4);
+            const uint32_t dtile = ((h >> 1) * (uint32_t)g.kt + kk) * 24 + (h & 1) * 12 + (uint32_t)g.grp * 4 + R4;
+            put8(i8, dtile * 64 + lane, dd < g.rows, g.src + ((size_t)h * g.rows + (dd < g.rows ? dd : 0)) * g.cols, c0, g.cols, 1);
         }
         return;
     }
     if (g.tr == 3) {
         // out-projection per head k-step (pack_proj_kernel's layout): rows = D, cols = hdv, kt = 2 x virtual heads
-        const size_t total = (size_t)g.rt * g.kt * 512;
-        for (size_t i = start; i < total; i += stride) {
-            const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-            const size_t tile = i >> 9;
-            const int R = (int)(tile % g.rt), kk = (int)(tile / g.rt);
-            const int o = 16 * R + (lane & 15), h = kk >> 1, dd = 32 * (kk & 1) + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
-            dst[i] = f2bf((o < g.rows && dd < g.cols) ? g.src[(size_t)o * g.rows + h * g.cols + dd] : 0.f);
+        for (uint32_t i8 = start8; i8 < total8; i8 += stride8) {
+            const uint32_t lane = i8 & 63, tile = i8 >> 6;
+            const uint32_t R = tile % (uint32_t)g.rt, kk = tile / (uint32_t)g.rt;
+            const int o = 16 * (int)R + (int)(lane & 15), h = (int)(kk >> 1), d0 = 32 * (int)(kk & 1) + 4 * (int)(lane >> 4);
+            // (a head's hdv columns of row o: columns past hdv are zeros, not the next head's)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int dd = d0 + 16 * (j >> 2) + (j & 3);
+                v[j] = (o < g.rows && dd < g.cols) ? g.src[(size_t)o * g.rows + h * g.cols + dd] : 0.f;
+            }
+            u32x4 ov;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[j] = (uint32_t)f2bf(v[2 * j]) | ((uint32_t)f2bf(v[2 * j + 1]) << 16);
+            *(u32x4*)(dst + (size_t)i8 * 8) = ov;
         }
         return;
     }
-    const size_t total = (size_t)g.rt * g.kt * 512;
-    for (size_t i = start; i < total; i += stride) {
-        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        const size_t tile = i >> 9;
-        const int rin = (int)(tile % g.grp), kk = (int)((tile / g.grp) % g.kt);
-        const int R = (int)(tile / ((size_t)g.grp * g.kt)) * g.grp + rin;
-        const int r = 16 * R + (lane & 15), c = 32 * kk + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
-        dst[i] = f2bf((r < g.rows && c < g.cols) ? (g.tr ? g.src[(size_t)c * g.rows + r] : g.src[(size_t)r * g.cols + c]) : 0.f);
+    for (uint32_t i8 = start8; i8 < total8; i8 += stride8) {
+        const uint32_t lane = i8 & 63, tile = i8 >> 6;
+        const uint32_t rin = tile % (uint32_t)g.grp, kk = (tile / (uint32_t)g.grp) % (uint32_t)g.kt;
+        const uint32_t R = tile / ((uint32_t)g.grp * (uint32_t)g.kt) * (uint32_t)g.grp + rin;
+        const int r = 16 * (int)R + (int)(lane & 15), c0 = 32 * (int)kk + 4 * (int)(lane >> 4);
+        const bool rv = r < g.rows;
+        if (g.tr) put8(i8, i8, rv, g.src + (rv ? r : 0), c0, g.cols, (size_t)g.rows);
+        else put8(i8, i8, rv, g.src + (size_t)(rv ? r : 0) * g.cols, c0, g.cols, 1);
     }
 }
 
@@ -3742,18 +3773,28 @@ __global__ __launch_bounds__(512, 2) void train_mlp_bwd_kernel(const char* __res
 // out_j[f] = sum_b slab_j[b][f]: the FC1 bias gradients of several layers from their workgroup slabs, one launch
 struct SlabRed { const float* slab[kMaxLayers]; float* out[kMaxLayers]; int n; };
 __global__ __launch_bounds__(256) void slab_reduce_kernel(SlabRed t, int n_blocks, int N) {
-    __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, f = blockIdx.x * 64 + cx;
+    // 16 columns x 16 row groups per workgroup, eight rows in flight per thread (64 columns x 4 row groups with two in flight:
+    // 115 workgroups, each thread 30 L2 round trips in a row -- 26 us for 1.4 MB per layer)
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4, f = blockIdx.x * 16 + cx;
     const float* src = t.slab[blockIdx.y];
-    float a0 = 0.f, a1 = 0.f;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (f < N) {
         int b = ry;
-        for (; b + 4 < n_blocks; b += 8) { a0 += src[(size_t)b * N + f]; a1 += src[(size_t)(b + 4) * N + f]; }
-        for (; b < n_blocks; b += 4) a0 += src[(size_t)b * N + f];
+        for (; b + 112 < n_blocks; b += 128) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += src[(size_t)(b + 16 * u) * N + f];
+        }
+        for (; b < n_blocks; b += 16) a[0] += src[(size_t)b * N + f];
     }
-    red[ry][cx] = a0 + a1;
+    red[ry][cx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
-    if (ry == 0 && f < N) t.out[blockIdx.y][f] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+    if (ry == 0 && f < N) {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += red[r][cx];
+        t.out[blockIdx.y][f] = v;
+    }
 }
 
 // phase stamps: the development build only (beso_debug_set_stamps); the product library carries no such state
@@ -4360,7 +4401,7 @@ int fused_train_bias_reduce(const float* const* slabs, float* const* outs, const
         t.n = 0;
         const int nb = blocks[i];
         while (i < n && blocks[i] == nb && t.n < kMaxLayers) { t.slab[t.n] = slabs[i]; t.out[t.n] = outs[i]; ++t.n; ++i; }
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((N + 63) / 64, t.n), dim3(256), 0, s, t, nb, N);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((N + 15) / 16, t.n), dim3(256), 0, s, t, nb, N);
     }
     return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
