@@ -57,23 +57,25 @@ template <> __device__ __forceinline__ void store4<uint16_t>(uint16_t* p, const 
 
 constexpr int kSbRows = 32;            // token rows of a tile (two MFMA tiles)
 
-// LayerNorm of rows [m0, m0 + rows) (eps 1e-5, biased variance, two passes over the registers: score_gpts.py:96-97), eight
-// threads per row, the affine output as operand type E into the LDS tile `at` (32 rows of pitch Kd sizeof(E) + 16); columns
-// D .. Kd and rows past the end are zeros.  Two steps: load() requests the rows and the affine parameters -- the caller issues
-// it BEFORE its weight-fragment loads (a wave's loads return in order, and the LayerNorm is what runs first) -- finish()
-// reduces, normalises and writes the tile.
-template <typename E, int KD64>
+// LayerNorm of rows [m0, m0 + rows) (eps 1e-5, biased variance, two passes over the registers: score_gpts.py:96-97), the affine
+// output as operand type E into the LDS tile `at` (32 rows of pitch Kd sizeof(E) + 16); columns D .. Kd and rows past the end
+// are zeros.  Eight threads per row -- or SIXTEEN in the instances for a call of at most 16 token rows (one sample: half the
+// threads would normalise rows of zeros, and these launches are bound by the instructions a wave issues, not by what they
+// compute: ~450 of a launch's ~1,000 were this LayerNorm); rows 16 .. 31 of the tile are then neither written nor read.  Two steps: load()
+// requests the rows and the affine parameters -- the caller issues it BEFORE its weight-fragment loads (a wave's loads return
+// in order, and the LayerNorm is what runs first) -- finish() reduces, normalises and writes the tile.
+template <typename E, int KD64, int TPR>          // TPR = threads per row: 8 (tiles of up to 32 rows) or 16 (up to 16 rows)
 struct LnTile {
-    static constexpr int Kd = 64 * KD64, PITCH = Kd * (int)sizeof(E) + 16, NV = Kd / 32;
-    f32x4 v[NV], g4[NV], b4[NV];
+    static constexpr int Kd = 64 * KD64, PITCH = Kd * (int)sizeof(E) + 16, NC = Kd / (4 * TPR);
+    f32x4 v[NC], g4[NC], b4[NC];
     __device__ __forceinline__ void load(const float* __restrict__ x, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, int m0, int rows, int D, int tid) {
-        const int r = tid >> 3, q = tid & 7;
+        const int r = tid / TPR, q = tid % TPR;
         const bool rv = r < rows;
         const float* xr = x + (size_t)(m0 + (rv ? r : 0)) * D;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int c = 4 * q + 32 * j;
+        for (int j = 0; j < NC; ++j) {
+            const int c = 4 * q + 4 * TPR * j;
             const bool ok = c < D;
             v[j] = (rv && ok) ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
             g4[j] = ok ? *(const f32x4*)(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -81,26 +83,28 @@ struct LnTile {
         }
     }
     __device__ __forceinline__ void finish(unsigned char* at, int rows, int D, int tid) {
-        const int r = tid >> 3, q = tid & 7;
+        const int r = tid / TPR, q = tid % TPR;
         const bool rv = r < rows;
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-        sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+        for (int j = 0; j < NC; ++j) sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+#pragma unroll
+        for (int m = 1; m < TPR; m <<= 1) sum += __shfl_xor(sum, m, 64);
         const float mean = sum / (float)D;
         float sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            if (4 * q + 32 * j < D) {
+        for (int j = 0; j < NC; ++j) {
+            if (4 * q + 4 * TPR * j < D) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float dlt = v[j][e] - mean; sq = fmaf(dlt, dlt, sq); }
             }
         }
-        sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+#pragma unroll
+        for (int m = 1; m < TPR; m <<= 1) sq += __shfl_xor(sq, m, 64);
         const float rstd = 1.0f / sqrtf(sq / (float)D + 1e-5f);
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int c = 4 * q + 32 * j;
+        for (int j = 0; j < NC; ++j) {
+            const int c = 4 * q + 4 * TPR * j;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
             if (rv && c < D) {
 #pragma unroll
@@ -113,7 +117,7 @@ struct LnTile {
 
 // out[m][n] = epi( LayerNorm(x[m][:]) . W[n][:] + bias[n] )     EPI 0: store, 1: exact GELU, store
 // grid (Np / 64, ceil(M / 32)), 256 threads: wave w owns features [64 bx + 16 w, +16) of the tile's 32 rows.
-template <typename E, int KD64, int EPI>
+template <typename E, int KD64, int EPI, int TPR>
 __global__ __launch_bounds__(256) void sb_ln_gemm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const E* __restrict__ W,
                                                          const float* __restrict__ bias, E* __restrict__ out, int M, int D,
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void sb_ln_gemm_kernel(const float* __restrict
     const int n0 = (blockIdx.x * 4 + wave) * 16;
     const int li = lane & 15, lg = lane >> 4;
     // 1. the tile's rows, then every weight fragment of this wave's 16 features: all requested at once
-    LnTile<E, KD64> ln;
+    LnTile<E, KD64, TPR> ln;
     ln.load(x, gamma, beta, m0, rows, D, tid);
     u32x4 wf[NK];
     {
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void sb_ln_gemm_kernel(const float* __restrict
 // then 16 lanes per (sample, query) item: each lane 4 dims, the score's partial dot products summed over the item's DPP row,
 // softmax and the weighted sum of v in registers (fp32, expf: the reference's operation order).
 constexpr int kSbHP = 68;              // floats per q / k / v row in LDS (64 dims + 4: rows land on different banks)
-template <typename E, int KD64>
+template <typename E, int KD64, int TPR>
 __global__ __launch_bounds__(256) void sb_qkv_attn_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const E* __restrict__ W,
                                                           const float* __restrict__ bias, E* __restrict__ y, int vbatch, int T,
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void sb_qkv_attn_kernel(const float* __restric
     // feature (dim of the head) of this lane's weight row; dims past hd read a valid row and are zeroed when stored
     const int dw = 16 * wave + li, dwc = dw < hd ? dw : 0;
     auto wrow = [&](int p) { return W + (size_t)(p * D + h * hd + dwc) * Kd + KPL * lg; };
-    LnTile<E, KD64> ln;
+    LnTile<E, KD64, TPR> ln;
     ln.load(x, gamma, beta, m0, rows, D, tid);
     u32x4 wf[NP][NK];
 #pragma unroll
@@ -258,41 +262,61 @@ __global__ __launch_bounds__(256) void sb_qkv_attn_kernel(const float* __restric
         }
     }
     __syncthreads();
-    // attention: item = (sample, query row); 16 lanes of a DPP row per item, lane dq holds dims 4 dq .. +3
+    // attention: item = (sample, query row); 16 lanes of a DPP row per item, lane dq holds dims 4 dq .. +3 of q, k, v and the
+    // output -- and the softmax of key dq: every lane reduces all the scores (the partial dot products summed over the row),
+    // keeps the one of ITS key, and max / exp / sum / divide happen once per (query, key) with butterfly reductions over the
+    // row (each step adds the same two values in both partners: all 16 lanes end with the same bits); the probabilities come
+    // back through 64 bytes of LDS per item (the LayerNorm tile: every wave is past its MFMAs; a wave's LDS operations run in
+    // order).  With every lane evaluating all T exponentials and quotients this section was ~700 of the kernel's ~1,500
+    // instructions per wave -- and these launches are bound by what a wave issues.
     const int dq = tid & 15;
+    float* pl = (float*)at + (tid >> 4) * 16;
+    auto row_max = [](float v) {
+        v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false)));
+        v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false)));
+        v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xf, 0xf, false)));
+        v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xf, 0xf, false)));
+        return v;
+    };
+    auto row_sum = [](float v) {
+        v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false));
+        v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false));
+        v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xf, 0xf, false));
+        v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xf, 0xf, false));
+        return v;
+    };
 #pragma unroll 1
     for (int pass = 0; pass < (rows > 16 ? 2 : 1); ++pass) {
         const int item = pass * 16 + (tid >> 4);
         const bool iv = item < rows;
         const int sm = iv ? item / T : 0, qi = iv ? item - sm * T : 0, r0 = sm * T;
         const f32x4 q4 = *(const f32x4*)&qs[0][r0 + qi][4 * dq];
-        float sc[16];
-        float mx = -INFINITY;
+        float mine = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            sc[j] = -INFINITY;
-            if (j < T) {                                   // (wave-uniform; the causal bound is applied to the value)
+            if (j < T) {                                   // (wave-uniform)
                 const f32x4 k4 = *(const f32x4*)&qs[1][r0 + j][4 * dq];
                 float part = q4[0] * k4[0];
                 part = fmaf(q4[1], k4[1], part); part = fmaf(q4[2], k4[2], part); part = fmaf(q4[3], k4[3], part);
-                part += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0xB1, 0xf, 0xf, false));
-                part += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0x4E, 0xf, 0xf, false));
-                part += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0x124, 0xf, 0xf, false));
-                part += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0x128, 0xf, 0xf, false));
-                if (j <= qi) { sc[j] = part * scale; mx = fmaxf(mx, sc[j]); }
+                part = row_sum(part);
+                mine = dq == j ? part * scale : mine;
             }
         }
-        float den = 0.f;
+        const bool live = dq <= qi;                        // (the causal bound; qi < T)
+        mine = live ? mine : -INFINITY;
+        const float mx = row_max(mine);
+        const float ex = live ? expf(mine - mx) : 0.f;
+        const float den = row_sum(ex);
+        pl[dq] = ex / den;
+        f32x4 p4[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j < T) { sc[j] = j <= qi ? expf(sc[j] - mx) : 0.f; den += sc[j]; }
-        }
+        for (int u = 0; u < 4; ++u) p4[u] = *(const f32x4*)(pl + 4 * u);
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (j < T) {
                 const f32x4 v4 = *(const f32x4*)&qs[2][r0 + j][4 * dq];
-                const float pj = sc[j] / den;
+                const float pj = p4[j >> 2][j & 3];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = fmaf(pj, v4[e], o[e]);
             }
@@ -378,6 +402,8 @@ hipError_t run_layers(const Layout& lay, const Workspace& ws, const char* packed
     // the head-split LN1 + q|k|v + attention launch: whole samples in a 32-row tile, a head in 64 dims of float4 pieces
     const int spb = a.T <= kSbRows ? kSbRows / a.T : 0;
     const bool head_fused = a.T <= 16 && spb >= 1 && lay.hd <= 64 && lay.hd % 4 == 0;
+    // a call of at most 16 token rows (the rollout's one sample): the instances whose LayerNorm uses 16 threads per row
+    const bool one16 = M <= 16;
     auto F = [&](size_t off) { return (const float*)(packed + off); };
     auto launch_resid = [&](const E* A, int K, const E* Wt, const float* bias) {
         const int per_wave = (K / SbE<E>::KSTEP + 3) / 4;
@@ -392,18 +418,26 @@ hipError_t run_layers(const Layout& lay, const Workspace& ws, const char* packed
         hipError_t e = hipSuccess;
         if (head_fused) {
             // LN1 -> q|k|v -> attention, split by head: one launch
-            hipLaunchKernelGGL((sb_qkv_attn_kernel<E, KD64>), dim3(lay.H, (a.vbatch + spb - 1) / spb), dim3(256), 0, s, (const float*)x,
-                               F(o.ln1_w), F(o.ln1_b), (const E*)(packed + o.w_qkv), F(o.b_qkv), y, a.vbatch, a.T, spb, D, lay.hd,
-                               lay.Kd, 1.0f / sqrtf((float)lay.hd));
+            if (one16)
+                hipLaunchKernelGGL((sb_qkv_attn_kernel<E, KD64, 16>), dim3(lay.H, 1), dim3(256), 0, s, (const float*)x, F(o.ln1_w), F(o.ln1_b),
+                                   (const E*)(packed + o.w_qkv), F(o.b_qkv), y, a.vbatch, a.T, spb, D, lay.hd, lay.Kd, 1.0f / sqrtf((float)lay.hd));
+            else
+                hipLaunchKernelGGL((sb_qkv_attn_kernel<E, KD64, 8>), dim3(lay.H, (a.vbatch + spb - 1) / spb), dim3(256), 0, s, (const float*)x,
+                                   F(o.ln1_w), F(o.ln1_b), (const E*)(packed + o.w_qkv), F(o.b_qkv), y, a.vbatch, a.T, spb, D, lay.hd,
+                                   lay.Kd, 1.0f / sqrtf((float)lay.hd));
         } else {
-            hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 0>), dim3(lay.Nqkv / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln1_w),
+            hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 0, 8>), dim3(lay.Nqkv / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln1_w),
                                F(o.ln1_b), (const E*)(packed + o.w_qkv), F(o.b_qkv), qkv, M, D, 3 * D, 3 * D);
             e = launch_attention(qkv, y, a.vbatch, a.T, D, lay.H, lay.Kd, precision, s);
             if (e != hipSuccess) return e;
         }
         launch_resid((const E*)y, lay.Kd, (const E*)(packed + o.w_proj), F(o.b_proj));
-        hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1>), dim3(lay.Nh / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
-                           F(o.ln2_b), (const E*)(packed + o.w_fc1), F(o.b_fc1), h, M, D, lay.Kh, lay.Kh);
+        if (one16)
+            hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1, 16>), dim3(lay.Nh / 64, 1), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
+                               F(o.ln2_b), (const E*)(packed + o.w_fc1), F(o.b_fc1), h, M, D, lay.Kh, lay.Kh);
+        else
+            hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1, 8>), dim3(lay.Nh / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
+                               F(o.ln2_b), (const E*)(packed + o.w_fc1), F(o.b_fc1), h, M, D, lay.Kh, lay.Kh);
         launch_resid((const E*)h, lay.Kh, (const E*)(packed + o.w_fc2), F(o.b_fc2));
         e = hipGetLastError();
         if (e != hipSuccess) return e;
