@@ -1,6 +1,7 @@
 // Memory-bound kernels of the score network: weight packing, token embedding (K1), LayerNorm,
 // final-LN + action head + un-precondition (K7) and the sampler update (K8).
 // Reference semantics: score_gpts.py:272-358, score_wrappers.py:31-96, gc_sampling.py.
+#include <algorithm>
 #include "common.h"
 
 namespace beso {
@@ -43,6 +44,7 @@ hipError_t launch_pack_matrix(const float* src, int rows, int cols, void* dst, i
 //   token G+2+2i       : action_emb(action_i * c_in) + pos[G+i]           :307,325; score_wrappers.py:96
 // One block per token row, one thread per output feature.
 // -----------------------------------------------------------------------------------------------
+constexpr int kEmbFastLen = 32;      // inputs of a token the one-pass form of embed_kernel keeps a weight row in registers for
 __global__ void embed_kernel(const float* __restrict__ state, const float* __restrict__ action,
                              const float* __restrict__ goal, const float* __restrict__ sigma,
                              const float* __restrict__ pos, const float* __restrict__ tok_w,
@@ -72,8 +74,31 @@ __global__ void embed_kernel(const float* __restrict__ state, const float* __res
             if (precondition) scale = 1.0f / sqrtf(sg * sg + sigma_data * sigma_data);   // c_in
         }
     }
-    for (int c = threadIdx.x; c < len; c += blockDim.x) in_vec[c] = src ? src[c] * scale : 0.f;
+    // One feature per thread and a short input (the rollout's few token rows, launched with >= D threads): the thread's weight
+    // row, bias and position entry are requested BEFORE the input is staged -- they do not depend on it -- and all at once (the
+    // loop below waits for every 8 weights before it asks for the next: nine L2 round trips in a row at 30 inputs, most of this
+    // launch's 6-9 us); the same left-to-right fma chain (bit-identical results).
+    const bool fast = kind != 0 && len <= kEmbFastLen && D <= (int)blockDim.x;
+    float wv[kEmbFastLen], bb = 0.f, pp = 0.f;
+    if (fast && (int)threadIdx.x < D) {
+        const int d = threadIdx.x;
+        const float* w = (kind == 1 ? tok_w : act_w) + (size_t)d * len;
+#pragma unroll
+        for (int c = 0; c < kEmbFastLen; ++c) wv[c] = c < len ? w[c] : 0.f;
+        bb = kind == 1 ? tok_b[d] : act_b[d];
+        pp = pos[(size_t)posrow * D + d];
+    }
+    for (int c = threadIdx.x; c < (fast ? kEmbFastLen : len); c += blockDim.x) in_vec[c] = (src && c < len) ? src[c] * scale : 0.f;
     __syncthreads();
+    if (fast) {
+        if ((int)threadIdx.x < D) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < kEmbFastLen; ++c) acc = fmaf(in_vec[c], wv[c], acc);     // (past len: + 0 * 0)
+            x[(size_t)row * D + threadIdx.x] = acc + bb + pp;
+        }
+        return;
+    }
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
         float v;
         if (kind == 0) {
@@ -157,8 +182,9 @@ hipError_t launch_embed(const Layout& lay, const char* packed, const FwdArgs& a,
         return hipGetLastError();
     }
     int rows = a.vbatch * a.T;
-    int threads = lay.D >= 256 ? 256 : round_up(lay.D, 64);
-    size_t shmem = sizeof(float) * (size_t)(lay.obs > lay.act ? lay.obs : lay.act);
+    // (per_row: a thread per feature where a block can hold them -- the kernel's one-pass form)
+    int threads = per_row && lay.D <= 512 ? round_up(lay.D, 64) : lay.D >= 256 ? 256 : round_up(lay.D, 64);
+    size_t shmem = sizeof(float) * (size_t)std::max(kEmbFastLen, lay.obs > lay.act ? lay.obs : lay.act);
     auto P = [&](size_t off) { return (const float*)(packed + off); };
     hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(threads), shmem, s, a.state, a.action, a.goal, a.sigma,
                        P(lay.pos_emb), P(lay.tok_w), P(lay.tok_b), P(lay.sig_w), P(lay.sig_b), P(lay.act_w),

@@ -324,9 +324,14 @@ __global__ __launch_bounds__(256) void sb_qkv_attn_kernel(const float* __restric
         if (iv && 4 * dq < hd) store4<E>(y + (size_t)(m0 + item) * ld_y + h * hd + 4 * dq, o);
     }
     // the K padding of the attention output (columns D .. ld_y of the out-projection's operand): zeros, once per row
+    // (thread = (row, piece of 8 elements): D and ld_y are multiples of 8 and 64, the padding is at most 7 pieces of the 32 rows)
     if (h == 0) {
-        const int padw = ld_y - D;
-        for (int u = tid; u < rows * padw; u += 256) y[(size_t)(m0 + u / padw) * ld_y + D + u % padw] = (E)0;
+        const int r = tid >> 3, c = D + 8 * (tid & 7);
+        if (r < rows && c < ld_y) {
+            E* yp = y + (size_t)(m0 + r) * ld_y + c;
+            *(u32x4*)yp = u32x4{0u, 0u, 0u, 0u};
+            if (sizeof(E) == 4) *(u32x4*)(yp + 4) = u32x4{0u, 0u, 0u, 0u};
+        }
     }
 }
 
