@@ -2175,7 +2175,7 @@ def test_feed_takes_rank_and_seed_from_the_process_group():
 
 
 # -------------------------------------------------------------------------------------------------
-# round 5: the chip-wide small-batch path (small.hip) -- what the library runs BY ITSELF up to 256 token rows in bf16 and 1024 in fp32
+# round 5: the chip-wide small-batch path (small.hip) -- what the library runs BY ITSELF up to 448 token rows in bf16 and 1024 in fp32
 # -------------------------------------------------------------------------------------------------
 _SMALL_FORWARD = [("tiny_forward.npz", "tiny"), ("tiny_mlp_head_forward.npz", "tiny_mlp_head"), ("tiny_nogoal_forward.npz", "tiny_nogoal"),
                   ("kitchen_forward_std002.npz", "kitchen"), ("kitchen_forward_std008.npz", "kitchen"), ("block_push_forward.npz", "block_push")]
