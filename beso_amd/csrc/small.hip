@@ -21,6 +21,8 @@
 // 32-row block of tokens -- for B <= 2 samples exactly once.  The embedding and the head are the per-op kernels.
 // Arithmetic: bf16 mode = the per-op bf16 kernels' (bf16 operands, fp32 accumulate, fp32 LayerNorm / softmax, the fitted
 // GELU); fp32 mode = exact-fp32 MFMA, two-pass LayerNorm, erff -- the per-op fp32 path's results to rounding order.
+#include <algorithm>
+#include <atomic>
 #include "common.h"
 #include "fused.h"
 
@@ -59,7 +61,7 @@ constexpr int kSbRows = 32;            // token rows of a tile (two MFMA tiles)
 
 // LayerNorm of rows [m0, m0 + rows) (eps 1e-5, biased variance, two passes over the registers: score_gpts.py:96-97), the affine
 // output as operand type E into the LDS tile `at` (32 rows of pitch Kd sizeof(E) + 16); columns D .. Kd and rows past the end
-// are zeros.  Eight threads per row -- or SIXTEEN in the instances for a call of at most 16 token rows (one sample: half the
+// are zeros.  Eight threads per row -- or SIXTEEN in the instances with tiles of 16 token rows (few samples: with 32-row tiles half the
 // threads would normalise rows of zeros, and these launches are bound by the instructions a wave issues, not by what they
 // compute: ~450 of a launch's ~1,000 were this LayerNorm); rows 16 .. 31 of the tile are then neither written nor read.  Two steps: load()
 // requests the rows and the affine parameters -- the caller issues it BEFORE its weight-fragment loads (a wave's loads return
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(256) void sb_ln_gemm_kernel(const float* __restrict
     constexpr int PITCH = Kd * (int)sizeof(E) + 16;        // +16 B: the 16 rows of a fragment read land on different banks
     __shared__ __attribute__((aligned(16))) unsigned char at[kSbRows * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * kSbRows, rows = min(kSbRows, M - m0);
+    constexpr int ROWS = TPR == 16 ? 16 : kSbRows;         // token rows of this instance's tile
+    const int m0 = blockIdx.y * ROWS, rows = min(ROWS, M - m0);
     const int n0 = (blockIdx.x * 4 + wave) * 16;
     const int li = lane & 15, lg = lane >> 4;
     // 1. the tile's rows, then every weight fragment of this wave's 16 features: all requested at once
@@ -336,17 +339,18 @@ __global__ __launch_bounds__(256) void sb_qkv_attn_kernel(const float* __restric
 }
 
 // x[m][n] += A[m][:] . W[n][:] + bias[n]      (out-projection: A = attention output, K = Kd; FC2: A = GELU(h), K = Kh)
-// grid (ceil(D / 16), ceil(M / 32)), 256 threads: ONE 16-feature column tile per workgroup, its four waves split the
+// grid (ceil(D / 16), ceil(M / rpb)), 256 threads: ONE 16-feature column tile per workgroup, its four waves split the
 // contraction (k-step ks goes to wave ks % 4) and add up through LDS in a fixed order; both operands as fragments straight
 // from memory, all of a wave's fragments requested at once (chunks of kSbChunk k-steps: the instance that covers K / 4 in one chunk where one exists).  A's rows are padded to a multiple
 // of 128 in the workspace (rows past M are never stored), its K padding holds zeros, W's is zeros.
 template <typename E, int kSbChunk>      // k-steps a wave has in flight at once: 3 (K = 384 in bf16), 6 or 12
 __global__ __launch_bounds__(256) void sb_gemm_resid_kernel(const E* __restrict__ A, int lda, const E* __restrict__ W, int K,
-                                                            const float* __restrict__ bias, float* __restrict__ x, int M, int D) {
+                                                            const float* __restrict__ bias, float* __restrict__ x, int M, int D,
+                                                            int rpb) {
     constexpr int KPL = SbE<E>::KPL, KSTEP = SbE<E>::KSTEP;
     __shared__ __attribute__((aligned(16))) f32x4 red[3][2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * kSbRows, rows = min(kSbRows, M - m0);
+    const int m0 = blockIdx.y * rpb, rows = min(rpb, M - m0);          // rpb: 32 token rows per workgroup, or 16 (one MFMA row tile)
     const int n0 = blockIdx.x * 16;
     const int li = lane & 15, lg = lane >> 4;
     const int nkt = K / KSTEP;
@@ -397,25 +401,43 @@ __global__ __launch_bounds__(256) void sb_gemm_resid_kernel(const E* __restrict_
     }
 }
 
+// compute units of the current device (cached per device; 256 on the MI355X)
+int device_cus_small() {
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> cached[kMaxDev] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 template <typename E, int KD64>
 hipError_t run_layers(const Layout& lay, const Workspace& ws, const char* packed, const FwdArgs& a, char* wsp, int precision,
                       hipStream_t s) {
     float* x = (float*)(wsp + ws.x);
     E* qkv = (E*)(wsp + ws.qkv); E* y = (E*)(wsp + ws.y); E* h = (E*)(wsp + ws.h);
     const int M = a.vbatch * a.T, D = lay.D;
-    const int rb = (M + kSbRows - 1) / kSbRows;
     // the head-split LN1 + q|k|v + attention launch: whole samples in a 32-row tile, a head in 64 dims of float4 pieces
-    const int spb = a.T <= kSbRows ? kSbRows / a.T : 0;
-    const bool head_fused = a.T <= 16 && spb >= 1 && lay.hd <= 64 && lay.hd % 4 == 0;
-    // a call of at most 16 token rows (the rollout's one sample): the instances whose LayerNorm uses 16 threads per row
-    const bool one16 = M <= 16;
+    const bool head_fused = a.T <= 16 && lay.hd <= 64 && lay.hd % 4 == 0;
+    // 16-ROW tiles (one MFMA row tile, LayerNorm with 16 threads per row, whole samples of <= 16 tokens per attention tile)
+    // while every workgroup of a launch still finds a slot at once (two per CU): a launch of this path is as long as the
+    // instructions its waves issue, so twice the workgroups of half the rows each are faster than fewer, fuller ones
+    // (kitchen, 16 samples: 11 row tiles x 24 column tiles = 264 workgroups)
+    const int wide = std::max((D + 15) / 16, lay.Nh / 64);
+    const bool one16 = head_fused && ((M + 15) / 16) * wide <= 2 * device_cus_small();
+    const int rpb = one16 ? 16 : kSbRows, rb = (M + rpb - 1) / rpb;
+    const int spb = a.T <= rpb ? rpb / a.T : 0;
     auto F = [&](size_t off) { return (const float*)(packed + off); };
     auto launch_resid = [&](const E* A, int K, const E* Wt, const float* bias) {
         const int per_wave = (K / SbE<E>::KSTEP + 3) / 4;
         const dim3 grid((D + 15) / 16, rb);
-        if (per_wave <= 3) hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 3>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D);
-        else if (per_wave <= 6) hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 6>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D);
-        else hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 12>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D);
+        if (per_wave <= 3) hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 3>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D, rpb);
+        else if (per_wave <= 6) hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 6>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D, rpb);
+        else hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 12>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D, rpb);
     };
     (void)hipGetLastError();
     for (int l = 0; l < lay.L; ++l) {
@@ -424,8 +446,9 @@ hipError_t run_layers(const Layout& lay, const Workspace& ws, const char* packed
         if (head_fused) {
             // LN1 -> q|k|v -> attention, split by head: one launch
             if (one16)
-                hipLaunchKernelGGL((sb_qkv_attn_kernel<E, KD64, 16>), dim3(lay.H, 1), dim3(256), 0, s, (const float*)x, F(o.ln1_w), F(o.ln1_b),
-                                   (const E*)(packed + o.w_qkv), F(o.b_qkv), y, a.vbatch, a.T, spb, D, lay.hd, lay.Kd, 1.0f / sqrtf((float)lay.hd));
+                hipLaunchKernelGGL((sb_qkv_attn_kernel<E, KD64, 16>), dim3(lay.H, (a.vbatch + spb - 1) / spb), dim3(256), 0, s, (const float*)x,
+                                   F(o.ln1_w), F(o.ln1_b), (const E*)(packed + o.w_qkv), F(o.b_qkv), y, a.vbatch, a.T, spb, D, lay.hd,
+                                   lay.Kd, 1.0f / sqrtf((float)lay.hd));
             else
                 hipLaunchKernelGGL((sb_qkv_attn_kernel<E, KD64, 8>), dim3(lay.H, (a.vbatch + spb - 1) / spb), dim3(256), 0, s, (const float*)x,
                                    F(o.ln1_w), F(o.ln1_b), (const E*)(packed + o.w_qkv), F(o.b_qkv), y, a.vbatch, a.T, spb, D, lay.hd,
@@ -438,7 +461,7 @@ hipError_t run_layers(const Layout& lay, const Workspace& ws, const char* packed
         }
         launch_resid((const E*)y, lay.Kd, (const E*)(packed + o.w_proj), F(o.b_proj));
         if (one16)
-            hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1, 16>), dim3(lay.Nh / 64, 1), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
+            hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1, 16>), dim3(lay.Nh / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
                                F(o.ln2_b), (const E*)(packed + o.w_fc1), F(o.b_fc1), h, M, D, lay.Kh, lay.Kh);
         else
             hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1, 8>), dim3(lay.Nh / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
