@@ -424,11 +424,12 @@ hipError_t run_layers(const Layout& lay, const Workspace& ws, const char* packed
     // the head-split LN1 + q|k|v + attention launch: whole samples in a 32-row tile, a head in 64 dims of float4 pieces
     const bool head_fused = a.T <= 16 && lay.hd <= 64 && lay.hd % 4 == 0;
     // 16-ROW tiles (one MFMA row tile, LayerNorm with 16 threads per row, whole samples of <= 16 tokens per attention tile)
-    // while every workgroup of a launch still finds a slot at once (two per CU): a launch of this path is as long as the
-    // instructions its waves issue, so twice the workgroups of half the rows each are faster than fewer, fuller ones
-    // (kitchen, 16 samples: 11 row tiles x 24 column tiles = 264 workgroups)
+    // while every workgroup of a launch still finds a slot at once (three per CU: 149 VGPRs, 25 KB of LDS): a launch of this
+    // path is as long as the instructions its waves issue, so twice the workgroups of half the rows each are faster than
+    // fewer, fuller ones (kitchen, 16 samples: 11 row tiles x 24 column tiles = 264 workgroups; 3-step DDIM at 32 / 40 samples
+    // 672 / 775 -> 644 / 712 us; beyond three per CU nothing more: fp32 at 64 samples 1478 us with 32-row tiles, 1519 with 16)
     const int wide = std::max((D + 15) / 16, lay.Nh / 64);
-    const bool one16 = head_fused && ((M + 15) / 16) * wide <= 2 * device_cus_small();
+    const bool one16 = head_fused && ((M + 15) / 16) * wide <= 3 * device_cus_small();
     const int rpb = one16 ? 16 : kSbRows, rb = (M + rpb - 1) / rpb;
     const int spb = a.T <= rpb ? rpb / a.T : 0;
     auto F = [&](size_t off) { return (const float*)(packed + off); };
