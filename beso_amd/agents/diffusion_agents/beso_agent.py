@@ -485,7 +485,7 @@ class BesoAgent(BaseAgent):
             if self.window_size > 1 or get_mean is None:
                 x = torch.randn((n, 1, act_dim), device=self.device) * self.sigma_max
                 if self.window_size > 1 and get_mean is None and len(self.action_context) > 0:
-                    x = torch.cat([torch.cat(tuple(self.action_context), dim=1), x], dim=1)
+                    x = torch.cat((*self.action_context, x), dim=1)        # (= cat([cat(context), x]): one launch)
             else:
                 x = torch.randn((n, act_dim), device=self.device) * self.sigma_max
             x_0 = self.sample_loop(sigmas, x, input_state, goal, sampler_type, extra_args)

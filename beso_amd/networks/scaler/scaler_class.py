@@ -69,10 +69,15 @@ class Scaler:
     @torch.no_grad()
     def inverse_scale_output(self, y):
         y = y.to(self.device)
-        return y * (self.y_std + 1e-12) + self.y_mean if self.scale_data else y
+        return y * self._den("y") + self.y_mean if self.scale_data else y
 
     @torch.no_grad()
     def clip_action(self, y):
-        """Clamp to 1.1 x the data bounds (scaler_class.py:162-166)."""
-        lo, hi = self.y_bounds_tensor[0] * 1.1, self.y_bounds_tensor[1] * 1.1
-        return torch.clamp(y, lo, hi).to(self.device).to(torch.float32)
+        """Clamp to 1.1 x the data bounds (scaler_class.py:162-166).  The two scaled bound rows are the same tensors every
+        call: computed once per bounds tensor (two elementwise launches less per environment step)."""
+        b = self.y_bounds_tensor
+        hit = self.__dict__.get("_clip_cache")
+        if hit is None or hit[0] is not b or hit[1] != b._version:
+            hit = (b, b._version, b[0] * 1.1, b[1] * 1.1)
+            self._clip_cache = hit
+        return torch.clamp(y, hit[2], hit[3]).to(self.device).to(torch.float32)
