@@ -303,6 +303,40 @@ def test_agent_predict_trace_matches_reference():
     assert len(agent.obs_context) == 0 and len(agent.action_context) == 0
 
 
+def test_processed_goal_is_reused_only_while_nothing_it_depends_on_changed():
+    """process_batch(predict=True) keeps the processed goal with the tensor it came from (a rollout passes the same goal object
+    step after step): the same object -> the same processed tensor; a write into the goal, another goal object, another
+    scaler or new scaler statistics -> processed afresh, equal to what an agent without a cache computes."""
+    cfg = O.TINY
+    rng = np.random.default_rng(3)
+    mk = lambda: Scaler(rng.standard_normal((64, cfg.obs_dim)).astype(np.float32),            # noqa: E731
+                        rng.standard_normal((64, cfg.act_dim)).astype(np.float32), True, "cpu")
+    agent = build_agent(cfg, lambda: OracleModel(O.make_weights(cfg), cfg))
+    agent.get_scaler(mk())
+    goal = torch.randn(cfg.goal_seq_len, cfg.obs_dim)
+    obs = lambda: torch.randn(1, cfg.obs_dim)                                                  # noqa: E731
+    fresh = lambda g: agent.scaler.scale_input(g.clone())                                      # noqa: E731
+    _, g1, _ = agent.process_batch({"observation": obs(), "goal_observation": goal}, predict=True)
+    _, g2, _ = agent.process_batch({"observation": obs(), "goal_observation": goal}, predict=True)
+    assert g2 is g1 and torch.equal(g1, fresh(goal))
+    goal[0, 0] += 1.0                                               # in-place write: the version counter moves
+    _, g3, _ = agent.process_batch({"observation": obs(), "goal_observation": goal}, predict=True)
+    assert g3 is not g1 and torch.equal(g3, fresh(goal))
+    other = goal.clone()
+    _, g4, _ = agent.process_batch({"observation": obs(), "goal_observation": other}, predict=True)
+    assert g4 is not g3 and torch.equal(g4, g3)
+    agent.get_scaler(mk())                                          # another scaler
+    _, g5, _ = agent.process_batch({"observation": obs(), "goal_observation": other}, predict=True)
+    assert g5 is not g4 and torch.equal(g5, fresh(other)) and not torch.equal(g5, g4)
+    agent.scaler.x_mean.add_(0.5)                                   # new statistics in the same scaler
+    _, g6, _ = agent.process_batch({"observation": obs(), "goal_observation": other}, predict=True)
+    assert g6 is not g5 and torch.equal(g6, fresh(other))
+    # a training batch (it holds the target) never touches the cache
+    state, action, g7 = agent.process_batch({"observation": torch.randn(2, 3, cfg.obs_dim), "action": torch.randn(2, 3, cfg.act_dim),
+                                             "goal_observation": other}, predict=False)
+    assert g7 is not g6 and torch.equal(g7, g6)
+
+
 def test_agent_surface_and_error_conventions():
     cfg = O.TINY
     agent = build_agent(cfg, lambda: OracleModel(O.make_weights(cfg), cfg))
