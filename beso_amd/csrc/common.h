@@ -236,7 +236,7 @@ hipError_t launch_sampler_step(int mode, float* out, float* aux, const float* x,
 // token rows up to which the library takes it by itself (measured, kitchen: bf16 190 ... 228 us for 1 ... 16 samples against
 // 257 ... 264 us of the one-launch kernel's latency instance, equal at 32 samples; fp32 641 ... 1060 us for 1 ... 93 samples
 // against 1620 ... 1960 us of the per-op kernels)
-constexpr int kSmallRows = 448, kSmallRowsF32 = 1024;
+constexpr int kSmallRows = 448, kSmallRowsF32 = 4096;
 constexpr size_t kSmallMinLDD = 500000;      // bf16: layers x embed_dim^2 from which the path beats the one-launch kernel
 bool small_supported(const Layout& lay, int precision);
 bool small_wanted(const Layout& lay, const FwdArgs& a, int precision);

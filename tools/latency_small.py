@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small batches: one GCDenoiser.forward and short sampler calls through the chip-wide small-batch path (the library's choice
-up to 1024 token rows; small.hip) against the one-launch kernel's latency instance (BESO_PLAN_FUSED), bf16 and fp32, with the
+up to 448 (bf16) / 4096 (fp32) token rows; small.hip) against the one-launch kernel's latency instance (BESO_PLAN_FUSED), bf16 and fp32, with the
 deviation of the two from each other:   python tools/latency_small.py [kitchen|block_push]"""
 import os
 import sys
