@@ -16,7 +16,7 @@ bash tools/r05_pmc_kernel.sh train_fwd_kernel ${TAG}_train_fwd 1024 > /dev/null 
 ( python tools/train_host_profile.py 1024; python tools/train_host_profile.py 1024 --pieces ) 2>&1 | grep -v amdgpu.ids > $O/${TAG}_train_host.txt
 bash tools/r05_train_ab.sh 2>&1 | grep -v amdgpu.ids > $O/${TAG}_train_ab.txt
 # small batches
-( python tools/latency_small.py kitchen; python tools/latency_small.py block_push; python tools/latency_predict.py; python tools/r05_graph_small.py 1; python tools/r05_graph_small.py 16; ./tools/microbench/launch_chain; ./tools/microbench/grid_barrier ) 2>&1 | grep -v amdgpu.ids > $O/${TAG}_latency.txt
+( python tools/latency_small.py kitchen; python tools/latency_small.py block_push; python tools/latency_predict.py; python tools/r05_graph_small.py 1; python tools/r05_graph_small.py 16; python tools/r05_fp32_cross.py | grep "^fp32"; ./tools/microbench/launch_chain; ./tools/microbench/grid_barrier ) 2>&1 | grep -v amdgpu.ids > $O/${TAG}_latency.txt
 ( bash tools/r05_small_stats.sh 1 bf16; bash tools/r05_small_stats.sh 16 bf16; bash tools/r05_small_stats.sh 1 fp32; echo '== a 3-step DDIM call at one sample'; bash tools/r05_sampler_stats.sh ) 2>&1 | grep -v amdgpu.ids > $O/${TAG}_small_batch_kernels.txt
 python tools/bench_configs.py --out $O/${TAG}_configs.json > $O/${TAG}_configs.log 2>&1
 python tests/determinism.py --reps 8 2>&1 | grep -v amdgpu.ids | tail -12 > $O/${TAG}_determinism.txt
