@@ -5,20 +5,24 @@
 // Why: the rollout workload of the reference is B = 1 (kitchen_workspace_manager.py:286-294).  The one-launch kernel's
 // latency instance puts a sample group on ONE CU, which then reads the whole packed weight image by itself: 0.25 ms per
 // forward flat from B = 1 to 512 -- ~80 GB/s, 1 % of what the chip can stream, 224+ of 256 CUs idle.  Samples are few here,
-// weights are many: so the WEIGHTS are what gets partitioned.  A dependent launch boundary costs ~1.2-1.5 us on this part
-// (MI355X_MICROARCH.md, "boundary"), less than an in-kernel cross-workgroup exchange, and needs no spin-wait protocol.
+// weights are many: so the WEIGHTS are what gets partitioned.  A dependent launch boundary costs ~1.6 us on this part
+// (tools/microbench/launch_chain), less than an in-kernel cross-workgroup exchange (3.75 us measured), and needs no spin-wait protocol.
 //
-// Per layer five launches (bf16 or exact-fp32 MFMA, operands straight from the GENERIC section of the packed image, torch
+// Per layer FOUR launches (bf16 or exact-fp32 MFMA, operands straight from the GENERIC section of the packed image, torch
 // layout [out][in] = k contiguous: an MFMA operand fragment is one 16-byte load per lane, no transposition anywhere):
-//   sb_ln_gemm      LN1 (recomputed per workgroup: 32 rows) -> q|k|v            tile 32 rows x 64 features, 4 waves x 16 features
-//   attention       the per-op kernel (attention.hip): one (sample, head) pair per thread group
-//   sb_gemm_resid   x += y Wp^T + b                                             tile 32 rows x 16 features, the 4 waves split K
-//   sb_ln_gemm      LN2 -> FC1 -> exact GELU -> h
+//   sb_qkv_attn     LN1 -> q | k | v of ONE head -> that head's causal attention -> y     tile = (head, whole samples of <= 16 tokens)
+//   sb_gemm_resid   x += y Wp^T + b                                             tile rows x 16 features, the 4 waves split K
+//   sb_ln_gemm      LN2 -> FC1 -> exact GELU -> h                               tile rows x 64 features, 4 waves x 16 features
 //   sb_gemm_resid   x += h W2^T + b
-// Every wave requests ALL the weight fragments of its tile at once (one L2 round trip), the activations of a tile come
-// from the fp32 residual through LayerNorm into LDS (or as fragments straight from memory: sb_gemm_resid), so a launch is
-// ~2 dependent memory round trips long.  Weight bytes per workgroup: 46 KB (bf16, kitchen); every matrix is read once per
-// 32-row block of tokens -- for B <= 2 samples exactly once.  The embedding and the head are the per-op kernels.
+// (windows of more than 16 tokens or heads wider than 64: sb_ln_gemm for q|k|v and the per-op attention kernel instead of the
+// first).  A tile is 16 token rows -- one MFMA row tile, LayerNorm with 16 threads per row -- while all of a launch's
+// workgroups find a slot at once (three per CU), 32 rows beyond.  Every wave requests ALL the weight fragments of its tile at
+// once, the activations of a tile come from the fp32 residual through LayerNorm into LDS (or as fragments straight from
+// memory: sb_gemm_resid).  What a launch costs is memory round trips in a row and the instructions its waves issue at one
+// wave per SIMD (4.6 ... 10 us each, whatever the arithmetic): DESIGN.md section 4.4 has the measurements, including the
+// layers as ONE kernel with hand-overs through memory (slower: 3.75 us per hand-over) and the instruction diet that
+// followed.  Weight bytes per workgroup: 46 KB (138 KB: the head-split tile; bf16, kitchen).  The embedding and the head
+// are the per-op kernels.
 // Arithmetic: bf16 mode = the per-op bf16 kernels' (bf16 operands, fp32 accumulate, fp32 LayerNorm / softmax, the fitted
 // GELU); fp32 mode = exact-fp32 MFMA, two-pass LayerNorm, erff -- the per-op fp32 path's results to rounding order.
 #include <algorithm>
