@@ -74,19 +74,30 @@ __device__ __forceinline__ float gelu_poly(float v) {
     p = fmaf(p, s, 0.3978832308f);
     return v * fmaf(vc, p, 0.5f);
 }
-// Derivative of the same GELU, d/dv [v Phi(v)] = Phi(v) + v phi(v), with the fitted Phi and phi through v_exp_f32
-// (training step, bf16 mode; the fp32 mode uses erff / expf).
+// Derivative of the same GELU, d/dv [v Phi(v)] = Phi(v) + v phi(v), as ONE odd polynomial: GELU'(v) - 1/2 = vc R(vc^2),
+// vc = clamp(v, +-4), R of degree 7 fitted to the exact derivative (tools/fit_gelu.py --grad): max |error| 2.7e-4 over all v
+// (beyond the clamp the true derivative is within 5e-4 of its value at +-4), below the bf16 rounding of the product it enters.
+// 10 VALU operations and no transcendental (round 5: the fitted Phi + v phi(v) through v_exp_f32, ~17: the GELU' epilogue
+// was 16 % of train_mlp_bwd_kernel's cycles, VALU bound).  Training step, bf16 mode; the fp32 mode uses erff / expf.
+#define BESO_GELU_GRAD_C0 0.7967216041f
+#define BESO_GELU_GRAD_C1 -0.2620297414f
+#define BESO_GELU_GRAD_C2 0.05591474429f
+#define BESO_GELU_GRAD_C3 -0.007687413836f
+#define BESO_GELU_GRAD_C4 0.0006876406287f
+#define BESO_GELU_GRAD_C5 -3.845913275e-05f
+#define BESO_GELU_GRAD_C6 1.213786018e-06f
+#define BESO_GELU_GRAD_C7 -1.641942029e-08f
 __device__ __forceinline__ float gelu_grad_poly(float v) {
     const float vc = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);
     const float s = vc * vc;
-    float p = fmaf(s, 2.277972093e-08f, -1.598515742e-06f);
-    p = fmaf(p, s, 4.795382804e-05f);
-    p = fmaf(p, s, -0.0008139993719f);
-    p = fmaf(p, s, 0.00877231165f);
-    p = fmaf(p, s, -0.06457294506f);
-    p = fmaf(p, s, 0.3978832308f);
-    const float phi = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * v * v);
-    return fmaf(vc, p, 0.5f) + v * phi;
+    float p = fmaf(s, BESO_GELU_GRAD_C7, BESO_GELU_GRAD_C6);
+    p = fmaf(p, s, BESO_GELU_GRAD_C5);
+    p = fmaf(p, s, BESO_GELU_GRAD_C4);
+    p = fmaf(p, s, BESO_GELU_GRAD_C3);
+    p = fmaf(p, s, BESO_GELU_GRAD_C2);
+    p = fmaf(p, s, BESO_GELU_GRAD_C1);
+    p = fmaf(p, s, BESO_GELU_GRAD_C0);
+    return fmaf(vc, p, 0.5f);
 }
 
 // One sampler update on one element, in the reference's operation order (gc_sampling.py:921-923 DDIM, :205-210 Euler,

@@ -614,6 +614,48 @@ __device__ __forceinline__ void gemm_phase_ring(f32x4 (&acc)[R][NT], u32x4 (&ar)
     }
 }
 
+// gemm_phase_ring whose weight ring never drains (round 6, the training step's data-gradient kernels): the refills of the
+// LAST PFA k-steps fetch the first PFA k-steps of the NEXT phase's image (`nxt`, fragment stride nxt_ks; both images behind the
+// same buffer resource), so the next phase starts with its ring in flight instead of one L2 round trip (~0.8 us: a lone
+// workgroup per CU has nothing to hide it behind) -- and those requests are OLDER than whatever the epilogue in between stores
+// (a wave's memory operations retire in order: a ring requested behind a store burst waits for the burst).  The ring must be
+// full on entry (prefetch_ring, or the phase before).  No next phase: nxt.lo carries bit 31 -- beyond the resource's range, the
+// loads are issued (static vmcnt bookkeeping) and return zeros without touching memory.  ksteps a multiple of PFA, PFA even.
+template <int R, int NT, int PFA>
+__device__ __forceinline__ void gemm_phase_ring_cont(f32x4 (&acc)[R][NT], u32x4 (&ar)[PFA][R], WPtr a, int a_ks, const u32x4* b,
+                                                     int b_ts, int b_ks, int ksteps, WPtr nxt, int nxt_ks) {
+    static_assert(PFA % 2 == 0, "B fragments alternate between two sets");
+    u32x4 bb[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bb[0][t] = b[t * b_ts];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bb[1][t] = b[t * b_ts + b_ks];
+    for (int k0 = 0; k0 < ksteps; k0 += PFA) {
+        const bool tail = k0 + PFA >= ksteps;                 // (uniform) this block's refills belong to the next phase
+        const uint32_t so0 = tail ? nxt.so : a.so + (uint32_t)((k0 + PFA) * a_ks) * 1024u;
+        const uint32_t ksb = (uint32_t)(tail ? nxt_ks : a_ks) * 1024u;
+        const uint32_t lo = tail ? nxt.lo : a.lo;
+#pragma unroll
+        for (int p = 0; p < PFA; ++p) {
+            const int kk = k0 + p;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][t] = mfma_op(ar[p][r], bb[p & 1][t], acc[r][t]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < ksteps) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bb[p & 1][t] = b[t * b_ts + (kk + 2) * b_ks];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                ar[p][r] = __builtin_amdgcn_raw_buffer_load_b128(a.rs, lo, so0 + (uint32_t)p * ksb + (uint32_t)r * 1024u, 0);
+        }
+    }
+}
+__device__ __forceinline__ WPtr wptr_none(WPtr a) { return WPtr{a.rs, 0u, a.lo | 0x80000000u}; }
+
 // ---------------------------------------------------------------------------------------------
 // BF16X3: split-bf16 arithmetic on the same MFMA (`PX` = 1 instances of the phases).  Every GEMM operand is a pair
 // (hi, lo) of bf16 values with hi = bf16(v), lo = bf16(v - hi): hi + lo = v to 2^-16 relative, and
@@ -774,9 +816,12 @@ struct Stamps {
     int cap;
     int n;
 };
+// KIND: which kernels of a -DBESO_FUSED_STAMPS=<kind> build record (every launch starts at the head of the buffer, so a build
+// stamps one family): 1 the forward kernels, 2 train_mlp_bwd_kernel, 3 train_dgrad_kernel (tools/train_stamps.py)
+template <int KIND = 1>
 __device__ __forceinline__ void stamp(Stamps& st, int id) {
     // lane 0 of every wave of workgroup 0 records into its own eighth of the buffer
-    if (BESO_FUSED_STAMPS && st.buf && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && st.n + 2 <= st.cap / 8) {
+    if (BESO_FUSED_STAMPS == KIND && st.buf && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && st.n + 2 <= st.cap / 8) {
         unsigned long long* b = st.buf + (size_t)(threadIdx.x >> 6) * (st.cap / 8);
         b[st.n] = (unsigned long long)id;
         // ids >= 100 record the constant-rate (100 MHz) counter instead of the shader clock: the pair gives the
@@ -3441,24 +3486,29 @@ struct LnBwdEpi {
 // the gradient tile as B fragments: lane (n, g) of fragment (t, kk) holds columns 32 kk + 4 g .. +3 and 32 kk + 16 + 4 g .. +3
 // of token m0 + 16 t + n (zeros beyond K / M: the padded k-steps of the weights are zeros too, but operands must be finite).
 // bT: [t][part][kk][lane] -- a token tile's k-steps of all parts in a row: the parts are ONE contraction of parts kt k-steps
-template <int NT>
+template <int NT, int kStage = 6>
 __device__ __forceinline__ void stage_grad_tile(u32x4* bT, const uint16_t* __restrict__ in, int ld_in, int K, int parts, int kt,
                                                 int M, int m0, int w, int lane) {
     const int n = lane & 15, g = lane >> 4;
     const int per = NT * kt, total = parts * per;
-    // kStage fragments per wave in flight: clamped (always valid) addresses, values selected afterwards -- one fragment at a
-    // time is one L2 round trip per fragment (18 per wave for K = 4 D: two thirds of the kernel's time)
-    constexpr int kStage = 6;
+    // kStage fragments per wave in flight, values selected afterwards -- one fragment at a time is one L2 round trip per fragment
+    // (18 per wave for K = 4 D: two thirds of the kernel's time).  Round 6: (i) the q|k|v data gradient stages 3 x 12 x 3 = 108
+    // fragments = 13.5 per wave; six at a time were three round trips in a row (14.5 k of the kernel's 63 k cycles,
+    // profiles/r06_dgrad_stamps.txt) -- its instance takes all of them at once; (ii) the tile is read through a buffer resource
+    // whose range ends with row M - 1: rows past the end are zeros by the range check, a fragment is ONE 32-bit offset (its
+    // second half 32 bytes on) instead of two clamped 64-bit pointers -- 14 fragments in flight cost 70 registers, not 112
+    // (M ld_in < 2^30 elements: checked on the host).  Columns past K inside a row are read (the next part / row) and dropped.
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)((uint32_t)M * (uint32_t)ld_in * 2u), 0x00020000);
     for (int f0 = w; f0 < total; f0 += kWaves * kStage) {
-        uint2 lo[kStage], hi[kStage];
+        u32x2 lo[kStage], hi[kStage];
 #pragma unroll
         for (int u = 0; u < kStage; ++u) {
             const int f = min(f0 + u * kWaves, total - 1);
             const int p = f / per, r = f - p * per, t = r / kt, kk = r - t * kt;
-            const int tok = min(m0 + 16 * t + n, M - 1), c0 = 32 * kk + 4 * g;
-            const uint16_t* row = in + (size_t)tok * ld_in + (size_t)p * K;
-            lo[u] = *(const uint2*)(row + min(c0, K - 4));
-            hi[u] = *(const uint2*)(row + min(c0 + 16, K - 4));
+            const uint32_t off = ((uint32_t)(m0 + 16 * t + n) * (uint32_t)ld_in + (uint32_t)(p * K + 32 * kk + 4 * g)) * 2u;
+            lo[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+            hi[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, off + 32u, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < kStage; ++u) {
@@ -3466,8 +3516,8 @@ __device__ __forceinline__ void stage_grad_tile(u32x4* bT, const uint16_t* __res
             if (f < total) {
                 const int p = f / per, r = f - p * per, t = r / kt, kk = r - t * kt;
                 const int tok = m0 + 16 * t + n, c0 = 32 * kk + 4 * g;
-                const uint2 z = make_uint2(0u, 0u);
-                const uint2 l2 = (tok < M && c0 < K) ? lo[u] : z, h2 = (tok < M && c0 + 16 < K) ? hi[u] : z;
+                const u32x2 z = {0u, 0u};
+                const u32x2 l2 = (tok < M && c0 < K) ? lo[u] : z, h2 = (tok < M && c0 + 16 < K) ? hi[u] : z;
                 bT[((size_t)(t * parts + p) * kt + kk) * 64 + lane] = u32x4{l2.x, l2.y, h2.x, h2.y};
             }
         }
@@ -3480,6 +3530,22 @@ __device__ __forceinline__ float row16_sum(float v) {       // sum over the 16 l
     v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x124, 0xf, 0xf, false));
     v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, false));
     return v;
+}
+
+// gelu_grad_poly (common.h) on the packed-fp32 pipe, two values per call: the same fma chain, the same bits
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 v) {
+    f32x2 vc;
+    vc.x = __builtin_amdgcn_fmed3f(v.x, -4.0f, 4.0f);
+    vc.y = __builtin_amdgcn_fmed3f(v.y, -4.0f, 4.0f);
+    const f32x2 s = vc * vc;
+    f32x2 p = __builtin_elementwise_fma(s, (f32x2)(BESO_GELU_GRAD_C7), (f32x2)(BESO_GELU_GRAD_C6));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(BESO_GELU_GRAD_C5));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(BESO_GELU_GRAD_C4));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(BESO_GELU_GRAD_C3));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(BESO_GELU_GRAD_C2));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(BESO_GELU_GRAD_C1));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(BESO_GELU_GRAD_C0));
+    return __builtin_elementwise_fma(vc, p, (f32x2)(0.5f));
 }
 
 // the chunk's h values (GELU' epilogue), requested before the GEMM: they arrive under it
@@ -3502,6 +3568,23 @@ template <int RPW, int NT, class Emit>
 __device__ __forceinline__ void gelu_bwd_epilogue(const f32x4 (&acc)[RPW][NT], const uint2 (&hu)[RPW][NT], uint16_t* __restrict__ dh,
                                                   float* __restrict__ colsum_row, int N, int M, int m0, int row0, int lane, Emit emit) {
     const int n = lane & 15, g = lane >> 4;
+    // Round 6: the derivative of ALL RPW x NT pieces first, branch-free (h was loaded through clamped addresses: every value is
+    // finite) -- 2 RPW NT independent packed chains the scheduler can interleave.  Under the per-piece `if (f0 < N && tok < M)`
+    // of round 5 each piece was a basic block of its own: two dependent chains of eight v_pk_fma_f32 (8.4 cycles each when
+    // dependent) with a wait state between every pair, nine times over -- 6.5 ... 9.5 k cycles per chunk of train_mlp_bwd_kernel
+    // for ~300 instructions of arithmetic (profiles/r06_mlp_bwd_stamps.txt).  Only the store stays under the condition.
+    uint2 pkv[RPW][NT];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint2 hv = hu[i][t];
+            const f32x2 d01 = gelu_grad2(f32x2{__uint_as_float(hv.x << 16), __uint_as_float(hv.x & 0xffff0000u)});
+            const f32x2 d23 = gelu_grad2(f32x2{__uint_as_float(hv.y << 16), __uint_as_float(hv.y & 0xffff0000u)});
+            pkv[i][t].x = pack_op2(acc[i][t][0] * d01.x, acc[i][t][1] * d01.y);
+            pkv[i][t].y = pack_op2(acc[i][t][2] * d23.x, acc[i][t][3] * d23.y);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int f0 = 16 * (row0 + i) + 4 * g;
@@ -3509,17 +3592,11 @@ __device__ __forceinline__ void gelu_bwd_epilogue(const f32x4 (&acc)[RPW][NT], c
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int tok = m0 + 16 * t + n;
-            uint2 pk = make_uint2(0u, 0u);
-            if (f0 < N && tok < M) {
-                const uint2 hv = hu[i][t];
-                const float h0 = __uint_as_float(hv.x << 16), h1 = __uint_as_float(hv.x & 0xffff0000u);
-                const float h2 = __uint_as_float(hv.y << 16), h3 = __uint_as_float(hv.y & 0xffff0000u);
-                pk.x = pack_op2(acc[i][t][0] * gelu_grad_poly(h0), acc[i][t][1] * gelu_grad_poly(h1));
-                pk.y = pack_op2(acc[i][t][2] * gelu_grad_poly(h2), acc[i][t][3] * gelu_grad_poly(h3));
-                if (!(BESO_TRAIN_FWD_ABL & 64)) *(uint2*)(dh + (size_t)tok * N + f0) = pk;
-                cs[0] += __uint_as_float(pk.x << 16); cs[1] += __uint_as_float(pk.x & 0xffff0000u);
-                cs[2] += __uint_as_float(pk.y << 16); cs[3] += __uint_as_float(pk.y & 0xffff0000u);
-            }
+            const bool ok = f0 < N && tok < M;
+            const uint2 pk = ok ? pkv[i][t] : make_uint2(0u, 0u);
+            if (ok && !(BESO_TRAIN_FWD_ABL & 64)) *(uint2*)(dh + (size_t)tok * N + f0) = pk;
+            cs[0] += __uint_as_float(pk.x << 16); cs[1] += __uint_as_float(pk.x & 0xffff0000u);
+            cs[2] += __uint_as_float(pk.y << 16); cs[3] += __uint_as_float(pk.y & 0xffff0000u);
             emit(i, t, pk);
         }
 #pragma unroll
@@ -3528,42 +3605,137 @@ __device__ __forceinline__ void gelu_bwd_epilogue(const f32x4 (&acc)[RPW][NT], c
     }
 }
 
-// LnBwdEpi on the accumulators acc = dxn^T (row tiles row0 .. of the D features x NT token tiles); red: 16 NT kRedTok floats of
-// LDS that no wave reads any more once every wave has arrived here.  emit(i, t, pk): the bf16 pair of words stored in dxb (zeros
-// outside D / M).
-template <int RPW, int NT, class Emit>
-__device__ __forceinline__ void ln_bwd_epilogue(const f32x4 (&acc)[RPW][NT], const LnBwdEpi& e, int D, int M, int m0, float* red,
-                                                int w, int lane, Emit emit) {
-    const int n = lane & 15, g = lane >> 4;
-    const float invD = 1.0f / (float)D;
-    f32x4 gam[RPW], xh[RPW][NT];
+struct NoMark { __device__ __forceinline__ void operator()(int) const {} };
+// What the LayerNorm-backward epilogue reads, as registers: requested by ln_bwd_load -- which a kernel may call long before the
+// accumulators exist (train_dgrad_kernel: together with its gradient tile, so that ONE memory round trip serves both; round 6:
+// profiles/r06_dgrad_stamps.txt showed the epilogue's loads + the barrier behind them at 19 k of the kernel's 71 k cycles,
+// a round trip of 5 us to tensors of 16 ... 130 MB) -- and consumed by ln_bwd_finish.
+template <int RPW, int NT, bool X16 = false>       // X16: the LayerNorm input is known to be bf16 (two dwords per piece instead of four held)
+struct LnBwdIn {
+    typedef typename std::conditional<X16, u32x2, f32x4>::type XR;
+    f32x4 gam[RPW], dr[RPW][NT];
+    XR xr[RPW][NT];                                // the LayerNorm input as loaded (bf16 in an f32x4: two dwords used)
     float mean[NT], rstd[NT];
     bool live[NT];
+    uint32_t eoff[NT];                             // element offset of (token of tile t, this lane's first feature), clamped rows
+};
+// Every [M][D] tensor is addressed through a buffer resource on its (uniform) base with ONE 32-bit element offset per token
+// tile: 64-bit pointers per (row tile, token tile) and tensor were ~50 VGPRs of the epilogue (M D < 2^29 elements: checked on the
+// host).  The incoming residual gradient is requested here too (round 5 read it inside the last loop under its per-lane
+// condition: nine loads waited for one after the other).  No incoming gradient: a valid address, values dropped.
+template <int RPW, int NT, bool X16>
+__device__ __forceinline__ void ln_bwd_load(LnBwdIn<RPW, NT, X16>& in, const LnBwdEpi& e, int D, int M, int m0, int w, int lane) {
+    const int n = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)e.x, 0, 0x7fffffff, 0x00020000);
+    const uint32_t fbase = (uint32_t)(16 * w * RPW + 4 * g);      // this lane's first feature; row tile i adds 16 i
+    uint32_t eoff[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int tok = min(m0 + 16 * t + n, M - 1);
-        live[t] = m0 + 16 * t + n < M;
+        in.live[t] = m0 + 16 * t + n < M;
         const float2 st2 = *(const float2*)(e.stats + 2 * (size_t)tok);
-        mean[t] = st2.x; rstd[t] = st2.y;
+        in.mean[t] = st2.x; in.rstd[t] = st2.y;
+        eoff[t] = (uint32_t)tok * (uint32_t)D + fbase;
+        in.eoff[t] = eoff[t];
     }
+    auto eo_of = [&](int i, int t) {                       // (a padding feature tile reads column 0 of its row)
+        return (int)fbase + 16 * i < D ? eoff[t] + 16u * i : eoff[t] - fbase;
+    };
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int f0 = 16 * (w * RPW + i) + 4 * g;
-        const bool fv = f0 < D;
-        gam[i] = fv ? *(const f32x4*)(e.gamma + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < RPW; ++i)
+        in.gam[i] = (int)fbase + 16 * i < D ? *(const f32x4*)(e.gamma + fbase + 16 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // (the uniform choice -- bf16 or fp32 LayerNorm input -- is taken OUTSIDE the unrolled loops: a branch per (row tile, token
+    //  tile) cut the epilogue into ~40 basic blocks and its registers into scratch)
+    if constexpr (X16) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int tok = min(m0 + 16 * t + n, M - 1);
-            f32x4 xv;
-            if (e.x_bf16) {
-                const uint2 u = *(const uint2*)((const uint16_t*)e.x + (size_t)tok * D + (fv ? f0 : 0));
-                xv = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                           __uint_as_float(u.y & 0xffff0000u)};
-            } else xv = *(const f32x4*)(e.x + (size_t)tok * D + (fv ? f0 : 0));
-            xh[i][t] = (fv && live[t]) ? (xv - mean[t]) * rstd[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) in.xr[i][t] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, eo_of(i, t) * 2u, 0, 0);
+    } else {
+        if (e.x_bf16) {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rs_x, eo_of(i, t) * 2u, 0, 0);
+                    in.xr[i][t] = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    in.xr[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, eo_of(i, t) * 4u, 0, 0));
         }
     }
+}
+// ... and the incoming residual gradient (a call of its own: train_dgrad_kernel holds the other inputs across its GEMM, and these
+// 4 RPW NT registers on top of them spilled)
+template <int RPW, int NT, bool X16>
+__device__ __forceinline__ void ln_bwd_load_dr(LnBwdIn<RPW, NT, X16>& in, const LnBwdEpi& e, int D, int w, int lane) {
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(e.dres_in ? e.dres_in : e.dres_out), 0, 0x7fffffff, 0x00020000);
+    const uint32_t fbase = (uint32_t)(16 * w * RPW + 4 * (lane >> 4));
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint32_t eo = (int)fbase + 16 * i < D ? in.eoff[t] + 16u * i : in.eoff[t] - fbase;
+            in.dr[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, eo * 4u, 0, 0));
+        }
+}
+
+// LnBwdEpi on the accumulators acc = dxn^T (row tiles w RPW .. of the D features x NT token tiles); red: 16 NT kRedTok floats of
+// LDS that no wave reads any more once every wave has arrived here.  emit(i, t, pk): the bf16 pair of words stored in dxb (zeros
+// outside D / M).
+template <int RPW, int NT, bool X16, class Emit, class Mark = NoMark>
+__device__ __forceinline__ void ln_bwd_finish(const f32x4 (&acc)[RPW][NT], LnBwdIn<RPW, NT, X16>& in, const LnBwdEpi& e, int D, int M,
+                                              int m0, float* red, int w, int lane, Emit emit, Mark mark = Mark{}) {
+    const int n = lane & 15, g = lane >> 4;
+    const float invD = 1.0f / (float)D;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)e.dres_out, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_xb = __builtin_amdgcn_make_buffer_rsrc((void*)e.dxb, 0, 0x7fffffff, 0x00020000);
+    const bool has_in = e.dres_in != nullptr;
+    const uint32_t fbase = (uint32_t)(16 * w * RPW + 4 * g);
+    // (plain local arrays from here on: through the struct, the closure below kept the small members in scratch)
+    f32x4 xh[RPW][NT], dr[RPW][NT], gam[RPW];
+    float mean[NT], rstd[NT];
+    bool live[NT];
+    uint32_t eoff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { mean[t] = in.mean[t]; rstd[t] = in.rstd[t]; live[t] = in.live[t]; eoff[t] = in.eoff[t]; }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        gam[i] = in.gam[i];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dr[i][t] = in.dr[i][t];
+    }
+    if (X16 || e.x_bf16) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uint32_t ux, uy;
+                if constexpr (X16) { ux = in.xr[i][t].x; uy = in.xr[i][t].y; }
+                else { ux = __float_as_uint(in.xr[i][t][0]); uy = __float_as_uint(in.xr[i][t][1]); }
+                const f32x4 xv = {__uint_as_float(ux << 16), __uint_as_float(ux & 0xffff0000u), __uint_as_float(uy << 16),
+                                  __uint_as_float(uy & 0xffff0000u)};
+                xh[i][t] = ((int)fbase + 16 * i < D && live[t]) ? (xv - mean[t]) * rstd[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    } else if constexpr (!X16) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xh[i][t] = in.xr[i][t];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                xh[i][t] = ((int)fbase + 16 * i < D && live[t]) ? (xh[i][t] - mean[t]) * rstd[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    mark(61);
     __syncthreads();                               // every wave is through its last B fragments: the region becomes `red`
+    mark(62);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         float s1 = 0.f, s2 = 0.f;
@@ -3577,43 +3749,53 @@ __device__ __forceinline__ void ln_bwd_epilogue(const f32x4 (&acc)[RPW][NT], con
         s2 = rows_allreduce<false>(s2);
         if (g == 0) *(float2*)(red + (size_t)(16 * t + n) * kRedTok + 2 * w) = make_float2(s1, s2);
     }
+    mark(63);
     __syncthreads();
+    mark(64);
     f32x4 ag[RPW], ab[RPW], ac[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; ac[i] = ag[i]; }
+    // (dropout or none: chosen once, outside the unrolled loops)
+    auto finish = [&](auto drop_tag) {
+        constexpr bool DROP = decltype(drop_tag)::value;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const f32x4* pr = (const f32x4*)(red + (size_t)(16 * t + n) * kRedTok);
-        float c1 = 0.f, c2 = 0.f;
+        for (int t = 0; t < NT; ++t) {
+            const f32x4* pr = (const f32x4*)(red + (size_t)(16 * t + n) * kRedTok);
+            float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < kWaves / 2; ++k) { const f32x4 v = pr[k]; c1 += v[0] + v[2]; c2 += v[1] + v[3]; }
-        c1 *= invD; c2 *= invD;
-        const int tok = m0 + 16 * t + n;
+            for (int k = 0; k < kWaves / 2; ++k) { const f32x4 v = pr[k]; c1 += v[0] + v[2]; c2 += v[1] + v[3]; }
+            c1 *= invD; c2 *= invD;
+            const int tok = m0 + 16 * t + n;
+            const bool masked = DROP && !(e.skip_mod > 0 && tok % e.skip_mod == 0);
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int f0 = 16 * (w * RPW + i) + 4 * g;
-            uint2 pk = make_uint2(0u, 0u);
-            if (f0 < D && live[t]) {
-                const f32x4 go = acc[i][t], dy = go * gam[i];
-                f32x4 tot = (dy - c1 - xh[i][t] * c2) * rstd[t];
-                const size_t idx = (size_t)tok * D + f0;
-                if (e.dres_in) tot += *(const f32x4*)(e.dres_in + idx);
-                *(f32x4*)(e.dres_out + idx) = tot;
-                if (e.p > 0.f && !(e.skip_mod > 0 && tok % e.skip_mod == 0)) {
+            for (int i = 0; i < RPW; ++i) {
+                const int f0 = (int)fbase + 16 * i;
+                uint2 pk = make_uint2(0u, 0u);
+                if (f0 < D && live[t]) {
+                    const f32x4 go = acc[i][t], dy = go * gam[i];
+                    f32x4 tot = (dy - c1 - xh[i][t] * c2) * rstd[t];
+                    const uint32_t eo = eoff[t] + 16u * i;
+                    if (has_in) tot += dr[i][t];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tot), rs_out, eo * 4u, 0, 0);
+                    if (DROP) {
+                        const size_t idx = (size_t)tok * D + f0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) tot[j] *= drop_scale(e.seed, e.site, idx + j, e.p, e.inv_keep);
+                        for (int j = 0; j < 4; ++j) tot[j] *= masked ? drop_scale(e.seed, e.site, idx + j, e.p, e.inv_keep) : 1.0f;
+                    }
+                    pk = make_uint2(pack_op2(tot[0], tot[1]), pack_op2(tot[2], tot[3]));
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rs_xb, eo * 2u, 0, 0);
+                    ag[i] += go * xh[i][t]; ab[i] += go; ac[i] += tot;
                 }
-                pk = make_uint2(pack_op2(tot[0], tot[1]), pack_op2(tot[2], tot[3]));
-                *(uint2*)(e.dxb + idx) = pk;
-                ag[i] += go * xh[i][t]; ab[i] += go; ac[i] += tot;
+                emit(i, t, pk);
             }
-            emit(i, t, pk);
         }
-    }
+    };
+    if (e.p > 0.f) finish(std::true_type{}); else finish(std::false_type{});
+    mark(65);
     // the workgroup's partial sums over its tokens: 16 lanes of a row by DPP, lane n == 0 writes
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-        const int f0 = 16 * (w * RPW + i) + 4 * g;
+        const int f0 = (int)fbase + 16 * i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ag[i][r] = row16_sum(ag[i][r]); ab[i][r] = row16_sum(ab[i][r]); ac[i][r] = row16_sum(ac[i][r]); }
         if (n == 0 && f0 < D) {
@@ -3623,18 +3805,41 @@ __device__ __forceinline__ void ln_bwd_epilogue(const f32x4 (&acc)[RPW][NT], con
     }
 }
 
-template <int RPW, int NT, int PFA>
-__global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restrict__ wimg, DgradArgs a, LnBwdEpi e) {
+template <int RPW, int NT, int PFA, int MODE>       // MODE 0: plain store or the GELU' epilogue; 1 / 2: the LayerNorm-backward epilogue on an
+                                                     // fp32-or-bf16 / a known-bf16 input (separate instances: a kernel that could take either
+                                                     // path at run time kept both register sets alive across the GEMM and spilled)
+__global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restrict__ wimg, DgradArgs a, LnBwdEpi e,
+                                                            unsigned long long* stamps, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int RT = RPW * kWaves;
+    constexpr bool LN = MODE != 0, X16 = MODE == 2;
+    Stamps st{stamps, cap, 0};
     int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * 16 * NT;
     u32x4* bT = (u32x4*)lds;                               // [part][t][kk][lane]
-    stage_grad_tile<NT>(bT, a.in, a.ld_in, a.K, a.parts, a.kt, a.M, m0, w, lane);
+    stamp<3>(st, 100);
+    stamp<3>(st, 70);
+    // a workgroup alone on its CU streams the weights: the ring keeps PFA k-steps of fragments in flight per wave (with the
+    // two of gemm_phase the kernel ran at 37 GB/s per CU: the L2 round trip is ~0.8 us, a k-step of MFMAs 0.07 us).
+    // parts > 1 (q | k | v): the part images lie back to back (part_bytes = RT kt KiB) and so do a token tile's B fragments:
+    // ONE ring over parts kt k-steps instead of a restart per part.  Round 6: the first chunk's ring is requested in FRONT of
+    // the gradient tile's loads (its round trip runs under the staging).
+    u32x4 ar[PFA][RPW];
+    const WPtr wbase = wptr((const u32x4*)wimg + (size_t)w * RPW * 64, lane);
+    const uint32_t chunk_bytes = (uint32_t)(a.kt * RT) * 1024u;
+    prefetch_ring<RPW, PFA>(ar, wbase, RT);
+    // the LayerNorm-backward epilogue's inputs travel WITH the gradient tile (one memory round trip for both; n_chunks == 1 there)
+    LnBwdIn<RPW, NT, X16> lin;
+    if constexpr (LN) ln_bwd_load<RPW, NT, X16>(lin, e, a.N, a.M, m0, w, lane);
+    // (every fragment of the tile in flight at once where the registers allow it: kt <= 12 per part)
+    if (a.parts == 3) stage_grad_tile<NT, 14>(bT, a.in, a.ld_in, a.K, a.parts, a.kt, a.M, m0, w, lane);
+    else stage_grad_tile<NT, 6>(bT, a.in, a.ld_in, a.K, a.parts, a.kt, a.M, m0, w, lane);
+    stamp<3>(st, 71);
     __syncthreads();
+    stamp<3>(st, 72);
 #pragma unroll 1
-    for (int c = 0; c < a.n_chunks; ++c) {
+    for (int c = 0;; ++c) {
         asm volatile("" : "+v"(lane));
         f32x4 acc[RPW][NT];
 #pragma unroll
@@ -3643,22 +3848,18 @@ __global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restr
             for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int n = lane & 15, g = lane >> 4;
         uint2 hu[RPW][NT];
-        if (a.dh != nullptr) load_h_tile<RPW, NT>(hu, a.h, a.N, a.M, m0, c * RT + w * RPW, lane);
+        if (!LN && a.dh != nullptr) load_h_tile<RPW, NT>(hu, a.h, a.N, a.M, m0, c * RT + w * RPW, lane);
         {
-            // a workgroup alone on its CU streams the weights: the ring keeps PFA k-steps of fragments in flight per wave (with the
-            // two of gemm_phase the kernel ran at 37 GB/s per CU: the L2 round trip is ~0.8 us, a k-step of MFMAs 0.07 us).
-            // parts > 1 (q | k | v): the part images lie back to back (part_bytes = RT kt KiB) and so do a token tile's B fragments:
-            // ONE ring over parts kt k-steps instead of a restart per part
-            u32x4 ar[PFA][RPW];
-            const WPtr wp = wptr((const u32x4*)wimg + ((size_t)c * a.kt * RT + (size_t)w * RPW) * 64, lane);
-            prefetch_ring<RPW, PFA>(ar, wp, RT);
+            const WPtr wp{wbase.rs, wbase.so + (uint32_t)c * chunk_bytes, wbase.lo};
             gemm_phase_ring<RPW, NT, PFA>(acc, ar, wp, RT, (const u32x4*)bT + lane, a.parts * a.kt * 64, 64, a.parts * a.kt);
         }
-        if (a.dh != nullptr) {
+        stamp<3>(st, 73);
+        if constexpr (LN) {
+            ln_bwd_load_dr<RPW, NT, X16>(lin, e, a.N, w, lane);
+            ln_bwd_finish<RPW, NT, X16>(acc, lin, e, a.N, a.M, m0, (float*)lds, w, lane, [](int, int, uint2) {}, [&](int id) { stamp<3>(st, id); });
+        } else if (a.dh != nullptr) {
             gelu_bwd_epilogue<RPW, NT>(acc, hu, a.dh, a.colsum + (size_t)blockIdx.x * a.N, a.N, a.M, m0, c * RT + w * RPW, lane,
                                        [](int, int, uint2) {});
-        } else if (e.x != nullptr) {
-            ln_bwd_epilogue<RPW, NT>(acc, e, a.N, a.M, m0, (float*)lds, w, lane, [](int, int, uint2) {});
         } else {
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
@@ -3674,7 +3875,12 @@ __global__ __launch_bounds__(512, 2) void train_dgrad_kernel(const char* __restr
                 }
             }
         }
+        stamp<3>(st, 74);
+        // (only the stand-alone FC2 + GELU' form has more than one chunk; the ring is dead across the epilogue above)
+        if (LN || c + 1 >= a.n_chunks) break;
+        prefetch_ring<RPW, PFA>(ar, WPtr{wbase.rs, wbase.so + (uint32_t)(c + 1) * chunk_bytes, wbase.lo}, RT);
     }
+    stamp<3>(st, 101);
 }
 
 // The second half of a layer's backward in ONE kernel (round 4): dyo -> FC2 data gradient x GELU'(h) = dh -> FC1 data gradient
@@ -3691,16 +3897,36 @@ struct MlpBwdArgs {
 };
 
 template <int RPW, int NT, int PFA>
-__global__ __launch_bounds__(512, 2) void train_mlp_bwd_kernel(const char* __restrict__ lw, MlpBwdArgs a, LnBwdEpi e) {
+__global__ __launch_bounds__(512, 2) void train_mlp_bwd_kernel(const char* __restrict__ lw, MlpBwdArgs a, LnBwdEpi e,
+                                                              unsigned long long* stamps, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int RT = RPW * kWaves, KC = RT / 2;         // k-steps of FC1 per chunk of dh
+    Stamps st{stamps, cap, 0};
+    stamp<2>(st, 100);
+    stamp<2>(st, 50);
     int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * 16 * NT, N4 = 4 * a.D;
     u32x4* bT = (u32x4*)lds;                               // dyo: [t][kk][lane], kt_d k-steps; later the LayerNorm exchange
     u32x4* hT = bT + (size_t)NT * a.kt_d * 64;             // dh chunk: [2][t][KC][lane]; later dym [t][kt_d][lane]
+    // Round 6 (profiles/r06_mlp_bwd_stamps.txt: the GEMMs of this kernel ran at 2.2 x the time their weight stream needs, each
+    // of its nine phases starting with an empty ring behind the stores of the epilogue in front of it, each chunk with h's HBM
+    // round trip in front of its ring):
+    //  * ONE weight ring from FC2(0) to FC1(last): the tail of every GEMM refills the ring with the first k-steps of the next
+    //    one (gemm_phase_ring_cont), so those requests are older than the dh stores between them;
+    //  * h of chunk c + 1 is requested at the START of chunk c's GELU' epilogue -- behind the ring of FC1(c), in front of ~3 us
+    //    of VALU work -- and h of chunk 0 with the first ring, in front of the dyo tile's own HBM round trip.
+    const WPtr wb = wptr((const u32x4*)lw + (size_t)w * RPW * 64, lane);
+    auto w2_of = [&](int c) { return WPtr{wb.rs, a.o_w2T + (uint32_t)(c * a.kt_d * RT) * 1024u, wb.lo}; };
+    auto w1_of = [&](int c) { return WPtr{wb.rs, a.o_w1T + (uint32_t)(c * KC * RT) * 1024u, wb.lo}; };
+    u32x4 ar[PFA][RPW];
+    prefetch_ring<RPW, PFA>(ar, w2_of(0), RT);
+    uint2 hu[RPW][NT];
+    load_h_tile<RPW, NT>(hu, a.h, N4, a.M, m0, w * RPW, lane);
     stage_grad_tile<NT>(bT, a.dyo, a.D, a.D, 1, a.kt_d, a.M, m0, w, lane);
+    stamp<2>(st, 51);
     __syncthreads();
+    stamp<2>(st, 52);
     f32x4 acc2[RPW][NT];
 #pragma unroll
     for (int i = 0; i < RPW; ++i)
@@ -3715,34 +3941,47 @@ __global__ __launch_bounds__(512, 2) void train_mlp_bwd_kernel(const char* __res
     for (int c = 0; c < a.n_chunks; ++c) {
         asm volatile("" : "+v"(lane));
         u32x4* hc = hT + (size_t)(c & 1) * NT * KC * 64;
+        const int kc = min(KC, a.kt_h - c * KC);           // FC1 k-steps of this chunk (a multiple of PFA; <= 0: padding only)
+        const bool more = c + 1 < a.n_chunks;
         {
             f32x4 acc[RPW][NT];
 #pragma unroll
             for (int i = 0; i < RPW; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            uint2 hu[RPW][NT];
-            load_h_tile<RPW, NT>(hu, a.h, N4, a.M, m0, c * RT + w * RPW, lane);
-            u32x4 ar[PFA][RPW];
-            const WPtr wp = wptr((const u32x4*)(lw + a.o_w2T) + ((size_t)c * a.kt_d * RT + (size_t)w * RPW) * 64, lane);
-            prefetch_ring<RPW, PFA>(ar, wp, RT);
-            gemm_phase_ring<RPW, NT, PFA>(acc, ar, wp, RT, (const u32x4*)bT + lane, a.kt_d * 64, 64, a.kt_d);
+            const WPtr nx = kc > 0 ? w1_of(c) : (more ? w2_of(c + 1) : wptr_none(wb));
+            gemm_phase_ring_cont<RPW, NT, PFA>(acc, ar, w2_of(c), RT, (const u32x4*)bT + lane, a.kt_d * 64, 64, a.kt_d, nx, RT);
+            stamp<2>(st, 53);
+            uint2 hn[RPW][NT];
+            load_h_tile<RPW, NT>(hn, a.h, N4, a.M, m0, (c + 1) * RT + w * RPW, lane);     // (past the last chunk: clamped addresses, unused)
             gelu_bwd_epilogue<RPW, NT>(acc, hu, a.dh, a.colsum + (size_t)blockIdx.x * N4, N4, a.M, m0, c * RT + w * RPW, lane,
                                        [&](int i, int t, uint2 pk) { put(hc, KC, i, t, pk); });
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) hu[i][t] = hn[i][t];
+            stamp<2>(st, 54);
         }
         __syncthreads();                                   // chunk c of dh is in LDS (and every wave is through FC1 of chunk c - 1)
-        const int kc = min(KC, a.kt_h - c * KC);
+        stamp<2>(st, 55);
         if (kc > 0) {
-            u32x4 ar[PFA][RPW];
-            const WPtr wp = wptr((const u32x4*)(lw + a.o_w1T) + ((size_t)c * KC * RT + (size_t)w * RPW) * 64, lane);
-            prefetch_ring<RPW, PFA>(ar, wp, RT);
-            gemm_phase_ring<RPW, NT, PFA>(acc2, ar, wp, RT, (const u32x4*)hc + lane, KC * 64, 64, kc);
+            const WPtr nx = more ? w2_of(c + 1) : wptr_none(wb);
+            gemm_phase_ring_cont<RPW, NT, PFA>(acc2, ar, w1_of(c), RT, (const u32x4*)hc + lane, KC * 64, 64, kc, nx, RT);
         }
+        stamp<2>(st, 56);
     }
     // LayerNorm-2 backward on dxn2 = acc2; dym also as the B fragments of the out-projection's data gradient (the first dh buffer:
     // the epilogue's two barriers lie between the last FC1 read and these writes)
-    ln_bwd_epilogue<RPW, NT>(acc2, e, a.D, a.M, m0, (float*)bT, w, lane, [&](int i, int t, uint2 pk) { put(hT, a.kt_d, i, t, pk); });
+    {
+        LnBwdIn<RPW, NT> lin;
+        ln_bwd_load<RPW, NT, false>(lin, e, a.D, a.M, m0, w, lane);
+        ln_bwd_load_dr<RPW, NT, false>(lin, e, a.D, w, lane);
+        ln_bwd_finish<RPW, NT, false>(acc2, lin, e, a.D, a.M, m0, (float*)bT, w, lane, [&](int i, int t, uint2 pk) { put(hT, a.kt_d, i, t, pk); },
+                               [&](int id) { stamp<2>(st, id); });
+    }
+    stamp<2>(st, 57);
     __syncthreads();
+    stamp<2>(st, 58);
     {
         asm volatile("" : "+v"(lane));
         f32x4 acc[RPW][NT];
@@ -3750,10 +3989,10 @@ __global__ __launch_bounds__(512, 2) void train_mlp_bwd_kernel(const char* __res
         for (int i = 0; i < RPW; ++i)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 ar[PFA][RPW];
-        const WPtr wp = wptr((const u32x4*)(lw + a.o_pT) + (size_t)w * RPW * 64, lane);
+        const WPtr wp{wb.rs, a.o_pT, wb.lo};
         prefetch_ring<RPW, PFA>(ar, wp, RT);
         gemm_phase_ring<RPW, NT, PFA>(acc, ar, wp, RT, (const u32x4*)hT + lane, a.kt_d * 64, 64, a.kt_d);
+        stamp<2>(st, 59);
         const int n = lane & 15, g = lane >> 4;
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
@@ -3768,6 +4007,8 @@ __global__ __launch_bounds__(512, 2) void train_mlp_bwd_kernel(const char* __res
             }
         }
     }
+    stamp<2>(st, 60);
+    stamp<2>(st, 101);
 }
 
 // out_j[f] = sum_b slab_j[b][f]: the FC1 bias gradients of several layers from their workgroup slabs, one launch
@@ -4434,17 +4675,17 @@ int fused_train_dgrad(const Layout& lay, const char* img, int layer, int which, 
     const dim3 grid((M + 16 * NT - 1) / (16 * NT)), block(512);
     hipError_t e;
     (void)hipGetLastError();
-    if (d.RPW == 3) {
-        static LdsAttr attr;
-        e = ensure_lds(train_dgrad_kernel<3, NT, 6>, 150 * 1024, &attr);
-        if (e != hipSuccess) return BESO_ERR_HIP;
-        hipLaunchKernelGGL((train_dgrad_kernel<3, NT, 6>), grid, block, lds_bytes, s, wimg, a, ep);
-    } else {
-        static LdsAttr attr;
-        e = ensure_lds(train_dgrad_kernel<2, NT, 4>, 150 * 1024, &attr);
-        if (e != hipSuccess) return BESO_ERR_HIP;
-        hipLaunchKernelGGL((train_dgrad_kernel<2, NT, 4>), grid, block, lds_bytes, s, wimg, a, ep);
-    }
+    const int mode = ln == nullptr ? 0 : (ln->x_bf16 ? 2 : 1);
+#define BESO_DGRAD_LAUNCH(R, P, X)                                                                                       \
+    do {                                                                                                                 \
+        static LdsAttr attr;                                                                                             \
+        e = ensure_lds(train_dgrad_kernel<R, NT, P, X>, 150 * 1024, &attr);                                              \
+        if (e != hipSuccess) return BESO_ERR_HIP;                                                                        \
+        hipLaunchKernelGGL((train_dgrad_kernel<R, NT, P, X>), grid, block, lds_bytes, s, wimg, a, ep, g_stamps, g_stamps_cap); \
+    } while (0)
+    if (d.RPW == 3) { if (mode == 2) BESO_DGRAD_LAUNCH(3, 6, 2); else if (mode == 1) BESO_DGRAD_LAUNCH(3, 6, 1); else BESO_DGRAD_LAUNCH(3, 6, 0); }
+    else { if (mode == 2) BESO_DGRAD_LAUNCH(2, 4, 2); else if (mode == 1) BESO_DGRAD_LAUNCH(2, 4, 1); else BESO_DGRAD_LAUNCH(2, 4, 0); }
+#undef BESO_DGRAD_LAUNCH
     return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
 
@@ -4474,12 +4715,12 @@ int fused_train_mlp_bwd(const Layout& lay, const char* img, int layer, int M, co
         static LdsAttr attr;
         e = ensure_lds(train_mlp_bwd_kernel<3, NT, 6>, 150 * 1024, &attr);
         if (e != hipSuccess) return BESO_ERR_HIP;
-        hipLaunchKernelGGL((train_mlp_bwd_kernel<3, NT, 6>), grid, block, lds_bytes, s, lw, a, ep);
+        hipLaunchKernelGGL((train_mlp_bwd_kernel<3, NT, 6>), grid, block, lds_bytes, s, lw, a, ep, g_stamps, g_stamps_cap);
     } else {
         static LdsAttr attr;
         e = ensure_lds(train_mlp_bwd_kernel<2, NT, 4>, 150 * 1024, &attr);
         if (e != hipSuccess) return BESO_ERR_HIP;
-        hipLaunchKernelGGL((train_mlp_bwd_kernel<2, NT, 4>), grid, block, lds_bytes, s, lw, a, ep);
+        hipLaunchKernelGGL((train_mlp_bwd_kernel<2, NT, 4>), grid, block, lds_bytes, s, lw, a, ep, g_stamps, g_stamps_cap);
     }
     return hipGetLastError() == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }

@@ -1123,26 +1123,39 @@ struct LnRedCall { float* dgamma; float* dbeta; float* dbias; };
 struct LnRedTable { LnRedCall c[2 * kMaxLayers + 1]; int nb[2 * kMaxLayers + 1]; };    // nb: block partials call z wrote (<= nblk, the slab stride)
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, LnRedTable t, int nblk, int D,
                                                         int call0) {
-    __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, which = blockIdx.y, call = blockIdx.z + call0;
-    const int c = blockIdx.x * 64 + cx;
-    const float* src = part + ((size_t)call * nblk * 3 + which) * D;
+    // thread (cx, ry): four consecutive columns (one 16-byte load: 16 lanes = 256 contiguous bytes of a slab row), block partials
+    // ry, ry + 16, ... with EIGHT loads in flight.  Round 5's form -- one column per thread, four row groups, four loads in
+    // flight -- was nblk / 16 dependent HBM round trips per thread: 375 us at 8192 samples (1878 partials per LayerNorm, 105 MB
+    // of slabs) where the bytes cost ~25 us.  The sum order is fixed (row groups in order, then the 16 groups in order):
+    // deterministic.  D is a multiple of 4 (the training step requires a multiple of 8).
+    __shared__ f32x4 red[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4, which = blockIdx.y, call = blockIdx.z + call0;
+    const int c = blockIdx.x * 64 + 4 * cx;
+    const float* src = part + ((size_t)call * nblk * 3 + which) * D + c;
     nblk = t.nb[call];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;          // four loads in flight per thread
+    const size_t rs = (size_t)3 * D;
+    f32x4 a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < D) {
         int b = ry;
-        for (; b + 12 < nblk; b += 16) {
-            a0 += src[(size_t)b * 3 * D + c]; a1 += src[(size_t)(b + 4) * 3 * D + c];
-            a2 += src[(size_t)(b + 8) * 3 * D + c]; a3 += src[(size_t)(b + 12) * 3 * D + c];
+        for (; b + 112 < nblk; b += 128) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += *(const f32x4*)(src + (size_t)(b + 16 * u) * rs);
         }
-        for (; b < nblk; b += 4) a0 += src[(size_t)b * 3 * D + c];
+        for (; b < nblk; b += 16) a[0] += *(const f32x4*)(src + (size_t)b * rs);
     }
-    red[ry][cx] = (a0 + a1) + (a2 + a3);
+    red[ry][cx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
     if (ry == 0 && c < D) {
         const LnRedCall k = t.c[call];
         float* dst = which == 0 ? k.dgamma : (which == 1 ? k.dbeta : k.dbias);
-        if (dst) dst[c] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+        if (dst) {
+            f32x4 v = red[0][cx];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) v += red[r][cx];
+            *(f32x4*)(dst + c) = v;
+        }
     }
 }
 
@@ -2005,8 +2018,9 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
 
     // The data-gradient GEMMs of the backward pass in the transposed formulation (fused.hip: train_dgrad_kernel; bf16, the shapes
     // with the fused kernels); BESO_TRAIN_PLAN_PER_OP keeps the 128 x 128 tile kernel for them too
+    // (they address the [M][D] ... [M][4 D] tensors with 32-bit byte offsets through buffer resources: M 4 D < 2^30 elements)
     const bool use_dgrad = sizeof(E) == 2 && !(flags & BESO_TRAIN_PLAN_PER_OP) && make_layout(c, BESO_PREC_BF16, &flay) &&
-                           fused_train_dgrad_supported(flay);
+                           fused_train_dgrad_supported(flay) && (size_t)M * D < ((size_t)1 << 28);
 
     // The per-step weight copies depend on the parameters only, the embedding on the batch only: when the caller handed over a
     // second stream (loss_stream: idle at this point), the copies run THERE beside the gradient buffer's memset, the

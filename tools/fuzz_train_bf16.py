@@ -22,7 +22,9 @@ from beso_amd.agents.diffusion_agents.k_diffusion.score_gpts import DiffusionGPT
 from beso_amd.agents.diffusion_agents.k_diffusion.score_wrappers import GCDenoiser  # noqa: E402
 
 
-def run(budget=60.0, seed=0):
+def run(budget=60.0, seed=0, on_case=None):
+    """on_case(desc, names, ref, lib_plan, per_op_plan, inner): called for every case before its assertion; a true return value
+    ends the run (tools/r06_explain_lnf.py replays a seed up to the case it dissects)."""
     rng = random.Random(seed)
     torch.manual_seed(rng.randrange(1 << 30))
     t0, n, worst, worst_at, worst_ratio = time.time(), 0, 0.0, None, 0.0
@@ -94,6 +96,8 @@ def run(budget=60.0, seed=0):
         e, e_op = dist(a), dist(b)
         le = abs(a[0] - ref[0]) / abs(ref[0])
         desc = dict(D=D, H=H, W=W, G=G, obs=obs, act=act, L=L, B=B, t=t, linear=linear, attn_p=attn_p, resid_p=resid_p, embed_p=embed_p)
+        if on_case is not None and on_case(desc, names, ref, a, b, inner):
+            return n, worst, worst_ratio
         assert all(torch.isfinite(x).all() for x in a[1]), ("non-finite gradient", desc)
         lb = max(3e-3, 6e-2 / (B * t * act) ** 0.5)          # (a loss over a handful of elements does not average the bf16 rounding:
                                                               #  two elements measured 3.0e-2 in round 5's seed 11)
