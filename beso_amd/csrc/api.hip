@@ -91,6 +91,7 @@ bool make_workspace(const beso_config* c, const Layout& lay, int batch, int t, i
     const size_t na = (size_t)batch * t * lay.act;
     w->den = carve(cur, f * na); w->x2 = carve(cur, f * na); w->d1 = carve(cur, f * na);
     w->sig = carve(cur, f * batch);
+    w->small = carve(cur, f * (size_t)(lay.H + 1) * kSmallProjRows * lay.D);
     w->fused = carve(cur, 0);
     w->total = cur;
     return true;
@@ -170,7 +171,8 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
     for (int l = 0; l < (fused == 2 ? 0 : lay.L); ++l) {
         const LayerOff& o = lay.layer[l];
         if (lin_blocks && precision == BESO_PREC_BF16X3) {
-            // the same two-launch form in split-bf16 arithmetic: lin_block_x3_kernel around the exact-fp32 attention kernel
+            // the same two-launch form in split-bf16 arithmetic: lin_block_x3_kernel around the split-bf16 attention kernel on the
+            // matrix pipe (round 6; windows of <= 16 tokens and odd head dims: the exact-fp32 kernel)
             if (l == 0) {
                 profile_begin(BESO_SITE_FUSED_LAYER, s);
                 int st0 = fused_lin_x3(lay, packed, -1, 0, x, nullptr, 0, (float*)qkv, M, s);
@@ -178,7 +180,7 @@ static int forward_generic(const Layout& lay, const Workspace& ws, const char* p
                 if (st0 != BESO_OK) return st0;
             }
             profile_begin(BESO_SITE_ATTENTION, s);
-            HIP_TRY(launch_attention(qkv, y, a.vbatch, a.T, lay.D, lay.H, lay.Kd, BESO_PREC_FP32, s));
+            HIP_TRY(launch_attention(qkv, y, a.vbatch, a.T, lay.D, lay.H, lay.Kd, BESO_PREC_BF16X3, s));
             profile_end(BESO_SITE_ATTENTION, s);
             profile_begin(BESO_SITE_FUSED_LAYER, s);
             int st = fused_lin_x3(lay, packed, l, l + 1 < lay.L ? l + 1 : -1, x, (const float*)y, lay.Kd, (float*)qkv, M, s);

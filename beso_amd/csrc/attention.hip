@@ -259,6 +259,165 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const uint16_t* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// BF16X3 (round 6): the same matrix-pipe attention in SPLIT-bf16 arithmetic on fp32 rows -- the attention of the long-sequence
+// shape's 1e-4 mode, which exchanges q | k | v and y as fp32 (fused_lin_x3) and ran attention_kernel<float> above: one query row
+// per thread, a serial loop over the keys -- 591 us per layer at 256 samples of 67 tokens, 54 % of that mode's forward
+// (profiles/r06_x3_stats.txt).  Every operand is a (hi, lo) pair of bf16 planes in LDS, hi = bf16(v), lo = bf16(v - hi); a product
+// is three MFMAs, small terms first (lo hi + hi lo + hi hi, fp32 accumulate: the GEMMs' scheme, fused.hip gemm_x3); the
+// probabilities are split the same way for P.V; softmax in fp32 (exp2 with the scale folded in).  One (sample, head) pair per
+// WORKGROUP of four waves; q, k and v as row-major planes (V^T fragments through ds_read_b64_tr_b16): 69 KB at T = 67, two
+// workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void att_split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t h = att_pack2(v[2 * e], v[2 * e + 1]);
+        hi[e] = h;
+        lo[e] = att_pack2(v[2 * e] - __uint_as_float(h << 16), v[2 * e + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+}
+
+__global__ __launch_bounds__(256) void attention_mfma_x3_kernel(const float* __restrict__ qkv, float* __restrict__ y, int n_pairs,
+                                                                int T, int D, int H, int hd, int ld_y, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int nt = (T + 15) >> 4, Tp = nt * 16;
+    const size_t plane = (size_t)3 * Tp * kAttRow;                        // bf16 elements of one (q | k | v) plane: row-major, 144-byte rows
+    uint16_t* sq = (uint16_t*)smem;                                       // hi plane, the lo plane `plane` elements behind it
+    uint16_t* sk = sq + Tp * kAttRow;
+    uint16_t* sv = sk + Tp * kAttRow;                                     // (V stays row-major: its fragments come through the transpose read)
+    // ONE pair per workgroup, its FOUR waves share the planes and deal the query tiles among themselves (a query tile qi costs
+    // qi + 1 key tiles: dealt in snake order -- 4, 3, 2, 1 | 0 for the five tiles of 67 tokens).  One pair per WAVE (the bf16
+    // kernel's form) left a CU with two waves at 137 KB of LDS: 70 us per layer at 256 samples for ~6 us of MFMA chain per pair.
+    const int pair = blockIdx.x;
+    const int vb = pair / H, h = pair % H;
+    const size_t ldq = (size_t)3 * D;
+    const float* base = qkv + (size_t)vb * T * ldq + (size_t)h * hd;
+    // ---- HBM -> LDS: units of 8 head dims of one token, split into the two planes; dims >= hd and tokens >= T are zero.  Four
+    // units (24 loads) in flight per lane: one unit at a time the loop was ten dependent memory round trips per pair -- most of
+    // the kernel's time (clamped addresses, values selected afterwards: no load under a branch)
+    constexpr int kU = 3;
+    for (int u0 = threadIdx.x; u0 < Tp * 8; u0 += 256 * kU) {
+        f32x4 r[kU][6];
+#pragma unroll
+        for (int j = 0; j < kU; ++j) {
+            const int u = min(u0 + 256 * j, Tp * 8 - 1), tok = min(u >> 3, T - 1), c = u & 7;
+            const float* row = base + (size_t)tok * ldq + min(8 * c, hd - 8);
+            r[j][0] = *(const f32x4*)row; r[j][1] = *(const f32x4*)(row + 4);
+            r[j][2] = *(const f32x4*)(row + D); r[j][3] = *(const f32x4*)(row + D + 4);
+            r[j][4] = *(const f32x4*)(row + 2 * D); r[j][5] = *(const f32x4*)(row + 2 * D + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < kU; ++j) {
+            const int u = u0 + 256 * j;
+            if (u < Tp * 8) {
+                const int tok = u >> 3, c = u & 7;
+                const bool ok = tok < T && 8 * c < hd;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                u32x4 hi, lo;
+                att_split8(ok ? r[j][0] : z, ok ? r[j][1] : z, hi, lo);
+                *(u32x4*)(sq + tok * kAttRow + 8 * c) = hi; *(u32x4*)(sq + plane + tok * kAttRow + 8 * c) = lo;
+                att_split8(ok ? r[j][2] : z, ok ? r[j][3] : z, hi, lo);
+                *(u32x4*)(sk + tok * kAttRow + 8 * c) = hi; *(u32x4*)(sk + plane + tok * kAttRow + 8 * c) = lo;
+                att_split8(ok ? r[j][4] : z, ok ? r[j][5] : z, hi, lo);
+                *(u32x4*)(sv + tok * kAttRow + 8 * c) = hi; *(u32x4*)(sv + plane + tok * kAttRow + 8 * c) = lo;
+            }
+        }
+    }
+    __syncthreads();
+    auto mma32 = [](f32x4 acc, const u32x4& a, const u32x4& b) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    };
+    auto mma16 = [](f32x4 acc, const uint2& a, const uint2& b) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), acc, 0, 0, 0);
+    };
+    for (int it = 0; 4 * it < nt; ++it) {
+        // snake: pass `it` deals tiles nt-1-4it .. downwards to waves 0..3 on even passes, upwards on odd ones
+        const int qi = nt - 1 - 4 * it - ((it & 1) ? 3 - wv : wv);
+        if (qi < 0) break;                        // (wave-uniform)
+        u32x4 qh[2], ql[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            qh[kk] = *(const u32x4*)(sq + (16 * qi + n) * kAttRow + 32 * kk + 8 * g);
+            ql[kk] = *(const u32x4*)(sq + plane + (16 * qi + n) * kAttRow + 32 * kk + 8 * g);
+        }
+        f32x4 sT[kAttMaxTiles];
+        float m = -INFINITY;
+        const int qtok = 16 * qi + n;
+#pragma unroll
+        for (int kj = 0; kj < kAttMaxTiles; ++kj) {
+            if (kj <= qi) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                u32x4 kh[2], kl[2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    kh[kk] = *(const u32x4*)(sk + (16 * kj + n) * kAttRow + 32 * kk + 8 * g);
+                    kl[kk] = *(const u32x4*)(sk + plane + (16 * kj + n) * kAttRow + 32 * kk + 8 * g);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) acc = mma32(acc, kl[kk], qh[kk]);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) acc = mma32(acc, kh[kk], ql[kk]);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) acc = mma32(acc, kh[kk], qh[kk]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * kj + 4 * g + r;
+                    acc[r] = (key <= qtok && key < T) ? acc[r] * scale_log2e : -INFINITY;   // causal over the whole sequence
+                    m = fmaxf(m, acc[r]);
+                }
+                sT[kj] = acc;
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+        uint2 ph[kAttMaxTiles], pl[kAttMaxTiles];
+#pragma unroll
+        for (int kj = 0; kj < kAttMaxTiles; ++kj) {
+            if (kj <= qi) {
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { e[r] = exp2f(sT[kj][r] - m); sum += e[r]; }
+                ph[kj] = make_uint2(att_pack2(e[0], e[1]), att_pack2(e[2], e[3]));
+                pl[kj] = make_uint2(att_pack2(e[0] - __uint_as_float(ph[kj].x << 16), e[1] - __uint_as_float(ph[kj].x & 0xffff0000u)),
+                                    att_pack2(e[2] - __uint_as_float(ph[kj].y << 16), e[3] - __uint_as_float(ph[kj].y & 0xffff0000u)));
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;             // key 0 is never masked: sum >= 1 after the max shift
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            if (16 * dt >= hd) break;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kj = 0; kj < kAttMaxTiles; ++kj) {
+                if (kj <= qi) {
+                    // A operand of Y^T = V^T P^T: lane (d = 16 dt + n, key group g) holds V[16 kj + 4 g + r][d], r = 0 .. 3 -- gfx950's
+                    // transpose read: the 16 lanes of a group address the [4 keys][16 dims] block row by row and each receives
+                    // column n of it (fused.hip v_frag)
+                    typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4;
+                    const uint16_t* pv = sv + (16 * kj + 4 * g + (n >> 2)) * kAttRow + 16 * dt + 4 * (n & 3);
+                    const uint2 vh = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pv)));
+                    const uint2 vl = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pv + plane)));
+                    acc = mma16(acc, vl, ph[kj]);
+                    acc = mma16(acc, vh, pl[kj]);
+                    acc = mma16(acc, vh, ph[kj]);
+                }
+            }
+            // D layout: lane (query i = n, g) holds head dims 16dt + 4g .. +3: heads re-merged side by side
+            const int d0 = 16 * dt + 4 * g;
+            if (qtok < T && d0 < hd) *(f32x4*)(y + ((size_t)vb * T + qtok) * ld_y + (size_t)h * hd + d0) = acc * inv;
+        }
+        if (h == 0 && ld_y > D && qtok < T)        // zero the K padding of the row (once per sample)
+            for (int c = D + g; c < ld_y; c += 4) y[((size_t)vb * T + qtok) * ld_y + c] = 0.f;
+    }
+}
+
 // Fallback for head dims whose rows are not 8-byte multiples: one thread per query row straight
 // from HBM (slow; no shipped configuration takes it).
 template <typename E, int HDP>
@@ -335,8 +494,23 @@ static hipError_t launch_t(const void* qkv, void* y, int vbatch, int T, int D, i
 
 hipError_t launch_attention(const void* qkv, void* y, int vbatch, int T, int D, int H, int ld_y, int precision,
                             hipStream_t s) {
-    if (precision == BESO_PREC_FP32) return launch_t<float>(qkv, y, vbatch, T, D, H, ld_y, s);
     const int hd = D / H;
+    if (precision == BESO_PREC_BF16X3) {
+        // fp32 rows in and out; split-bf16 products on the matrix pipe where the shape allows, the exact-fp32 kernel otherwise
+        const int Tp = ((T + 15) / 16) * 16;
+        const size_t pair_bytes = (size_t)3 * Tp * kAttRow * 4;
+        if (hd <= 64 && hd % 8 == 0 && D % 8 == 0 && ld_y % 4 == 0 && T > 16 && T <= 16 * kAttMaxTiles && pair_bytes <= 160 * 1024) {
+            if (hipFuncSetAttribute((const void*)attention_mfma_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess) return hipErrorInvalidValue;
+            (void)hipGetLastError();
+            const int n_pairs = vbatch * H;
+            hipLaunchKernelGGL(attention_mfma_x3_kernel, dim3(n_pairs), dim3(256), pair_bytes, s, (const float*)qkv, (float*)y, n_pairs,
+                               T, D, H, hd, ld_y, 1.4426950408889634f / sqrtf((float)hd));
+            return hipGetLastError();
+        }
+        return launch_t<float>(qkv, y, vbatch, T, D, H, ld_y, s);
+    }
+    if (precision == BESO_PREC_FP32) return launch_t<float>(qkv, y, vbatch, T, D, H, ld_y, s);
     if (hd <= 64 && hd % 8 == 0 && D % 8 == 0 && T > 16 && T <= 16 * kAttMaxTiles) {
         const int Tp = ((T + 15) / 16) * 16;
         const size_t pair_bytes = (size_t)(2 * Tp * kAttRow + 64 * (Tp + 8)) * 2;

@@ -201,6 +201,7 @@ struct Workspace {
     size_t x2;     // fp32 [B][t][act]     Heun predictor state
     size_t d1;     // fp32 [B][t][act]     Heun first derivative d
     size_t sig;    // fp32 [B]             per-step sigma vector of beso_sample
+    size_t small;  // fp32 [(H + 1)][kSmallProjRows][D]   small-batch path, few token rows: x_mid + the out-projection's per-head slabs
     size_t fused;  // scratch of the fused path
     size_t total;
 };
@@ -248,6 +249,7 @@ hipError_t launch_sampler_step(int mode, float* out, float* aux, const float* x,
 // 257 ... 264 us of the one-launch kernel's latency instance, equal at 32 samples; fp32 641 ... 1060 us for 1 ... 93 samples
 // against 1620 ... 1960 us of the per-op kernels)
 constexpr int kSmallRows = 448, kSmallRowsF32 = 4096;
+constexpr int kSmallProjRows = 96;          // token rows up to which the out-projection rides in the attention launch (small.hip, round 6)
 constexpr size_t kSmallMinLDD = 500000;      // bf16: layers x embed_dim^2 from which the path beats the one-launch kernel
 bool small_supported(const Layout& lay, int precision);
 bool small_wanted(const Layout& lay, const FwdArgs& a, int precision);

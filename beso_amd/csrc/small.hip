@@ -23,6 +23,10 @@
 // layers as ONE kernel with hand-overs through memory (slower: 3.75 us per hand-over) and the instruction diet that
 // followed.  Weight bytes per workgroup: 46 KB (138 KB: the head-split tile; bf16, kitchen).  The embedding and the head
 // are the per-op kernels.
+// Round 6 (bf16): the head-split launch runs TWELVE waves -- a (part, 16-dim tile) per wave: a third of the instructions per
+// wave -- and, up to 96 token rows, carries the out-projection as its epilogue: per-head partial products into H slabs that
+// the FC1 launch's LayerNorm prologue adds to the residual (fixed order) -- THREE launches per layer.  The wide tiles tried for
+// 41 ... 500 samples (32 x 128 FC1, 32 x 32 residual GEMMs) were measured and removed: DESIGN.md section 4.4.
 // Arithmetic: bf16 mode = the per-op bf16 kernels' (bf16 operands, fp32 accumulate, fp32 LayerNorm / softmax, the fitted
 // GELU); fp32 mode = exact-fp32 MFMA, two-pass LayerNorm, erff -- the per-op fp32 path's results to rounding order.
 #include <algorithm>
@@ -88,6 +92,59 @@ struct LnTile {
             b4[j] = ok ? *(const f32x4*)(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    // Round 6 (few token rows): the residual rows PLUS the out-projection that the head-split attention launch left as one
+    // partial product per head -- x_mid = (x + b_p) + slab_0 + ... + slab_{H-1}, added in this fixed order (deterministic), six
+    // slabs in flight at a time.  xm != nullptr: this workgroup also writes x_mid back (one column tile per row tile does).
+    __device__ __forceinline__ void load_sum(const float* __restrict__ x, const float* __restrict__ slab, size_t slab_stride, int H,
+                                             const float* __restrict__ pbias, float* __restrict__ xm,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta, int m0, int rows,
+                                             int D, int tid) {
+        const int r = tid / TPR, q = tid % TPR;
+        const bool rv = r < rows;
+        const size_t ro = (size_t)(m0 + (rv ? r : 0)) * D;
+        f32x4 pb[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = 4 * q + 4 * TPR * j;
+            const bool ok = c < D;
+            v[j] = (rv && ok) ? *(const f32x4*)(x + ro + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            pb[j] = ok ? *(const f32x4*)(pbias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            g4[j] = ok ? *(const f32x4*)(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            b4[j] = ok ? *(const f32x4*)(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) v[j] += pb[j];
+        // (six slabs in flight at a time: every batch is one more memory round trip in front of the LayerNorm -- with three, the
+        //  kitchen shape's six heads cost this launch what the saved out-projection launch had cost; the instances that take
+        //  this path are a few workgroups on an empty chip, registers are free)
+        constexpr int SB = 6;
+        for (int h0 = 0; h0 < H; h0 += SB) {
+            f32x4 sv[SB][NC];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const float* sp = slab + (size_t)min(h0 + u, H - 1) * slab_stride + ro;     // (a clamped slab is loaded and not added)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    const int c = 4 * q + 4 * TPR * j;
+                    sv[u][j] = (rv && c < D) ? *(const f32x4*)(sp + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                if (h0 + u < H) {
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) v[j] += sv[u][j];
+                }
+            }
+        }
+        if (xm != nullptr && rv) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int c = 4 * q + 4 * TPR * j;
+                if (c < D) *(f32x4*)(xm + ro + c) = v[j];
+            }
+        }
+    }
     __device__ __forceinline__ void finish(unsigned char* at, int rows, int D, int tid) {
         const int r = tid / TPR, q = tid % TPR;
         const bool rv = r < rows;
@@ -121,13 +178,19 @@ struct LnTile {
     }
 };
 
+// The out-projection as per-head partial products (round 6, few token rows): slab[h][m][:] = y_h[m][:] Wp[:, h hd ..]^T written by
+// the head-split attention launch, added up -- with the projection's bias and the residual -- by the LayerNorm prologue of
+// the launch behind it, which also leaves the sum in xm.  slab == nullptr: off.
+struct SbSlabs { const float* slab; size_t stride; int H; const float* pbias; float* xm; };
+
 // out[m][n] = epi( LayerNorm(x[m][:]) . W[n][:] + bias[n] )     EPI 0: store, 1: exact GELU, store
 // grid (Np / 64, ceil(M / 32)), 256 threads: wave w owns features [64 bx + 16 w, +16) of the tile's 32 rows.
-template <typename E, int KD64, int EPI, int TPR>
+template <typename E, int KD64, int EPI, int TPR, bool SUM = false>      // SUM: the slab-sum prologue (an instance of its own: its
+                                                                            // registers cost the 32-row instances a workgroup per CU)
 __global__ __launch_bounds__(256) void sb_ln_gemm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const E* __restrict__ W,
                                                          const float* __restrict__ bias, E* __restrict__ out, int M, int D,
-                                                         int ld_out, int n_store) {
+                                                         int ld_out, int n_store, SbSlabs sl) {
     constexpr int Kd = 64 * KD64, KPL = SbE<E>::KPL, KSTEP = SbE<E>::KSTEP, NK = Kd / KSTEP;
     constexpr int PITCH = Kd * (int)sizeof(E) + 16;        // +16 B: the 16 rows of a fragment read land on different banks
     __shared__ __attribute__((aligned(16))) unsigned char at[kSbRows * PITCH];
@@ -138,7 +201,8 @@ __global__ __launch_bounds__(256) void sb_ln_gemm_kernel(const float* __restrict
     const int li = lane & 15, lg = lane >> 4;
     // 1. the tile's rows, then every weight fragment of this wave's 16 features: all requested at once
     LnTile<E, KD64, TPR> ln;
-    ln.load(x, gamma, beta, m0, rows, D, tid);
+    if constexpr (SUM) ln.load_sum(x, sl.slab, sl.stride, sl.H, sl.pbias, blockIdx.x == 0 ? sl.xm : nullptr, gamma, beta, m0, rows, D, tid);
+    else ln.load(x, gamma, beta, m0, rows, D, tid);
     u32x4 wf[NK];
     {
         const E* wp = W + (size_t)(n0 + li) * Kd + KPL * lg;
@@ -349,8 +413,8 @@ __global__ __launch_bounds__(256) void sb_qkv_attn_kernel(const float* __restric
 // of 128 in the workspace (rows past M are never stored), its K padding holds zeros, W's is zeros.
 template <typename E, int kSbChunk>      // k-steps a wave has in flight at once: 3 (K = 384 in bf16), 6 or 12
 __global__ __launch_bounds__(256) void sb_gemm_resid_kernel(const E* __restrict__ A, int lda, const E* __restrict__ W, int K,
-                                                            const float* __restrict__ bias, float* __restrict__ x, int M, int D,
-                                                            int rpb) {
+                                                            const float* __restrict__ bias, const float* xin, float* x, int M, int D,
+                                                            int rpb) {           // xin: the residual read (x itself: in place)
     constexpr int KPL = SbE<E>::KPL, KSTEP = SbE<E>::KSTEP;
     __shared__ __attribute__((aligned(16))) f32x4 red[3][2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -368,7 +432,7 @@ __global__ __launch_bounds__(256) void sb_gemm_resid_kernel(const E* __restrict_
         bv = *(const f32x4*)(bias + n);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
-            if (16 * rt + li < rows) xv[rt] = *(const f32x4*)(x + (size_t)(m0 + 16 * rt + li) * D + n);
+            if (16 * rt + li < rows) xv[rt] = *(const f32x4*)(xin + (size_t)(m0 + 16 * rt + li) * D + n);
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const bool two = rows > 16;                              // (one sample of <= 16 tokens: the second row tile is not fetched)
@@ -405,6 +469,173 @@ __global__ __launch_bounds__(256) void sb_gemm_resid_kernel(const E* __restrict_
     }
 }
 
+// The TWELVE-WAVE form of sb_qkv_attn_kernel (round 6; bf16): wave w owns part w / 4 (q, k, v) and dims 16 (w % 4) .. +15 of the
+// head -- one set of weight fragments and one accumulator chain per wave instead of three of each; 16 ROWS threads normalise the
+// tile's ROWS (16 or 32) rows with sixteen threads per row; the attention's (sample, query) items are one pass of the 48 item
+// slots.  These launches are bound by what a wave issues: the four-wave form is ~1,500 instructions per
+// wave, this one ~600 on three times the waves -- 12.0 -> 10.1 us per launch at 64 samples, 22.1 -> 18.2 at 128
+// (profiles/r06_small_mid.txt).
+// PROJ (few token rows): the out-projection as the EPILOGUE -- the head's attention output goes through LDS as activation
+// fragments, the workgroup multiplies it by its head's hd columns of Wp (wave w: feature tiles w and w + 12) and writes the
+// partial product to slab[h]; the FC1 launch's LayerNorm prologue adds the H slabs, the bias and the residual (LnTile::load_sum).
+// One dependent launch less per layer (~5 us each on this part whatever they compute); y is not written.
+template <int KD64, int ROWS, bool PROJ>
+__global__ __launch_bounds__(768) void sb_qkv_attn_wide_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const uint16_t* __restrict__ W,
+                                                               const float* __restrict__ bias, uint16_t* __restrict__ y, int vbatch,
+                                                               int T, int spb, int D, int hd, int ld_y, float scale,
+                                                               const uint16_t* __restrict__ Wp, float* __restrict__ slab,
+                                                               size_t slab_stride) {
+    typedef uint16_t E;
+    constexpr int Kd = 64 * KD64, KPL = SbE<E>::KPL, KSTEP = SbE<E>::KSTEP, NK = Kd / KSTEP;
+    constexpr int PITCH = Kd * (int)sizeof(E) + 16;
+    __shared__ __attribute__((aligned(16))) unsigned char at[kSbRows * PITCH];
+    __shared__ __attribute__((aligned(16))) float qs[3][kSbRows][kSbHP];
+    __shared__ __attribute__((aligned(16))) uint16_t yts[PROJ ? ROWS * 72 : 8];      // PROJ: the head's attention output, 144-byte rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, s0 = blockIdx.y * spb;
+    const int ns = min(spb, vbatch - s0), rows = ns * T, m0 = s0 * T;
+    const int li = lane & 15, lg = lane >> 4;
+    const int part = wave >> 2, dt = wave & 3;
+    const int dw = 16 * dt + li, dwc = dw < hd ? dw : 0;   // dims past hd read a valid row and are zeroed when stored
+    static_assert(ROWS == 16 || ROWS == kSbRows, "one or two MFMA row tiles");
+    LnTile<E, KD64, 16> ln;
+    if (tid < 16 * ROWS) ln.load(x, gamma, beta, m0, rows, D, tid);
+    u32x4 wf[NK];
+    {
+        const E* wp = W + (size_t)(part * D + h * hd + dwc) * Kd + KPL * lg;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) wf[ks] = *(const u32x4*)(wp + ks * KSTEP);
+    }
+    const int d0 = 16 * dt + 4 * lg;                       // the lane ends with dims d0 .. d0 + 3 of token 16 rt + li
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (d0 < hd) bv = *(const f32x4*)(bias + part * D + h * hd + d0);
+    if (tid < 16 * ROWS) ln.finish(at, rows, D, tid);
+    __syncthreads();
+    const bool two = ROWS > 16 && rows > 16;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const u32x4 a0 = *(const u32x4*)(at + li * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
+        SbE<E>::mma(acc[0], wf[ks], a0);
+        if (two) {
+            const u32x4 a1 = *(const u32x4*)(at + (16 + li) * PITCH + (ks * KSTEP + KPL * lg) * (int)sizeof(E));
+            SbE<E>::mma(acc[1], wf[ks], a1);
+        }
+    }
+    // PROJ: this wave's fragments of Wp[:, h hd ..] -- feature tiles `wave` and `wave + 12`, two k-steps of 32 dims (the head's
+    // columns start at a multiple of hd = 4 n elements: 8-byte pieces; dims past hd meet zeros of the attention output) --
+    // requested here, where the q | k | v fragments are dead: they arrive under the attention
+    uint2 pw[2][2][2];
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int ft = wave + 12 * f;
+            const uint16_t* wp = Wp + (size_t)(16 * min(ft, (D + 15) / 16 - 1) + li) * Kd + h * hd + KPL * lg;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { pw[f][ks][0] = *(const uint2*)(wp + 32 * ks); pw[f][ks][1] = *(const uint2*)(wp + 32 * ks + 4); }
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        f32x4 v = acc[rt] + bv;
+        if (d0 >= hd) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)&qs[part][16 * rt + li][d0] = v;
+    }
+    __syncthreads();
+    // attention as in sb_qkv_attn_kernel: item = (sample, query row), 16 lanes of a DPP row per item -- 48 item slots, one pass
+    const int dq = tid & 15, item = tid >> 4;
+    float* pl = (float*)at + item * 16;
+    auto row_max = [](float v) {
+        v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false)));
+        v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false)));
+        v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xf, 0xf, false)));
+        v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xf, 0xf, false)));
+        return v;
+    };
+    auto row_sum = [](float v) {
+        v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false));
+        v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false));
+        v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xf, 0xf, false));
+        v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xf, 0xf, false));
+        return v;
+    };
+    {
+        const bool iv = item < rows;
+        const int sm = iv ? item / T : 0, qi = iv ? item - sm * T : 0, r0 = sm * T;
+        const f32x4 q4 = *(const f32x4*)&qs[0][r0 + qi][4 * dq];
+        float mine = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < T) {                                   // (wave-uniform)
+                const f32x4 k4 = *(const f32x4*)&qs[1][r0 + j][4 * dq];
+                float part_ = q4[0] * k4[0];
+                part_ = fmaf(q4[1], k4[1], part_); part_ = fmaf(q4[2], k4[2], part_); part_ = fmaf(q4[3], k4[3], part_);
+                part_ = row_sum(part_);
+                mine = dq == j ? part_ * scale : mine;
+            }
+        }
+        const bool live = dq <= qi;                        // (the causal bound; qi < T)
+        mine = live ? mine : -INFINITY;
+        const float mx = row_max(mine);
+        const float ex = live ? expf(mine - mx) : 0.f;
+        const float den = row_sum(ex);
+        pl[dq] = ex / den;
+        f32x4 p4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p4[u] = *(const f32x4*)(pl + 4 * u);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < T) {
+                const f32x4 v4 = *(const f32x4*)&qs[2][r0 + j][4 * dq];
+                const float pj = p4[j >> 2][j & 3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(pj, v4[e], o[e]);
+            }
+        }
+        if constexpr (PROJ) {
+            // y_h as bf16 rows of 64 dims (+ 8: 144-byte rows: conflict-free fragment reads); zeros past hd / rows
+            constexpr int YP = 72;
+            uint16_t* yt = yts;
+            if (item < ROWS) {
+                f32x4 ov = (iv && 4 * dq < hd) ? o : f32x4{0.f, 0.f, 0.f, 0.f};
+                store4<E>(yt + item * YP + 4 * dq, ov);
+            }
+            __syncthreads();
+            constexpr int NRT = ROWS / 16;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int ft = wave + 12 * f, n = 16 * ft + 4 * lg;
+                if (16 * ft < D) {                         // (wave-uniform)
+                    f32x4 pa[NRT];
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt) pa[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const u32x4 wfrag = {pw[f][ks][0].x, pw[f][ks][0].y, pw[f][ks][1].x, pw[f][ks][1].y};
+#pragma unroll
+                        for (int rt = 0; rt < NRT; ++rt) {
+                            const u32x4 a0 = *(const u32x4*)(yt + (16 * rt + li) * YP + 32 * ks + KPL * lg);
+                            SbE<E>::mma(pa[rt], wfrag, a0);
+                        }
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt) {
+                        const int tok = 16 * rt + li;
+                        if (tok < rows && n < D) *(f32x4*)(slab + (size_t)h * slab_stride + (size_t)(m0 + tok) * D + n) = pa[rt];
+                    }
+                }
+            }
+        } else if (iv && 4 * dq < hd) store4<E>(y + (size_t)(m0 + item) * ld_y + h * hd + 4 * dq, o);
+    }
+    // the K padding of the attention output (columns D .. ld_y of the out-projection's operand): zeros, once per row
+    if (!PROJ && h == 0 && tid < 256) {
+        const int r = tid >> 3, c = D + 8 * (tid & 7);
+        if (r < rows && c < ld_y) *(u32x4*)(y + (size_t)(m0 + r) * ld_y + c) = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
 // compute units of the current device (cached per device; 256 on the MI355X)
 int device_cus_small() {
     constexpr int kMaxDev = 64;
@@ -432,17 +663,24 @@ hipError_t run_layers(const Layout& lay, const Workspace& ws, const char* packed
     // path is as long as the instructions its waves issue, so twice the workgroups of half the rows each are faster than
     // fewer, fuller ones (kitchen, 16 samples: 11 row tiles x 24 column tiles = 264 workgroups; 3-step DDIM at 32 / 40 samples
     // 672 / 775 -> 644 / 712 us; beyond three per CU nothing more: fp32 at 64 samples 1478 us with 32-row tiles, 1519 with 16)
-    const int wide = std::max((D + 15) / 16, lay.Nh / 64);
-    const bool one16 = head_fused && ((M + 15) / 16) * wide <= 3 * device_cus_small();
+    const int widest = std::max((D + 15) / 16, lay.Nh / 64);
+    const bool one16 = head_fused && ((M + 15) / 16) * widest <= 3 * device_cus_small();
     const int rpb = one16 ? 16 : kSbRows, rb = (M + rpb - 1) / rpb;
     const int spb = a.T <= rpb ? rpb / a.T : 0;
+    constexpr bool kTwelve = sizeof(E) == 2;             // the twelve-wave head-split attention launch (bf16)
+    // few token rows (bf16): the out-projection rides in the attention launch as per-head partial products, summed by the FC1
+    // launch's LayerNorm prologue -- three launches per layer instead of four (Workspace::small: x_mid + H slabs of kSmallProjRows rows)
+    const bool fuse_proj = kTwelve && one16 && M <= kSmallProjRows;
+    float* xm = (float*)(wsp + ws.small);
+    float* slab = xm + (size_t)kSmallProjRows * D;
+    const size_t slab_stride = (size_t)kSmallProjRows * D;
     auto F = [&](size_t off) { return (const float*)(packed + off); };
-    auto launch_resid = [&](const E* A, int K, const E* Wt, const float* bias) {
+    auto launch_resid = [&](const E* A, int K, const E* Wt, const float* bias, const float* xin) {
         const int per_wave = (K / SbE<E>::KSTEP + 3) / 4;
         const dim3 grid((D + 15) / 16, rb);
-        if (per_wave <= 3) hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 3>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D, rpb);
-        else if (per_wave <= 6) hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 6>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D, rpb);
-        else hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 12>), grid, dim3(256), 0, s, A, K, Wt, K, bias, x, M, D, rpb);
+        if (per_wave <= 3) hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 3>), grid, dim3(256), 0, s, A, K, Wt, K, bias, xin, x, M, D, rpb);
+        else if (per_wave <= 6) hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 6>), grid, dim3(256), 0, s, A, K, Wt, K, bias, xin, x, M, D, rpb);
+        else hipLaunchKernelGGL((sb_gemm_resid_kernel<E, 12>), grid, dim3(256), 0, s, A, K, Wt, K, bias, xin, x, M, D, rpb);
     };
     (void)hipGetLastError();
     for (int l = 0; l < lay.L; ++l) {
@@ -450,7 +688,21 @@ hipError_t run_layers(const Layout& lay, const Workspace& ws, const char* packed
         hipError_t e = hipSuccess;
         if (head_fused) {
             // LN1 -> q|k|v -> attention, split by head: one launch
-            if (one16)
+            if constexpr (kTwelve) {
+                const dim3 grid(lay.H, (a.vbatch + spb - 1) / spb);
+                if (fuse_proj)
+                    hipLaunchKernelGGL((sb_qkv_attn_wide_kernel<KD64, 16, true>), grid, dim3(768), 0, s, (const float*)x, F(o.ln1_w), F(o.ln1_b),
+                                       (const uint16_t*)(packed + o.w_qkv), F(o.b_qkv), (uint16_t*)y, a.vbatch, a.T, spb, D, lay.hd, lay.Kd,
+                                       1.0f / sqrtf((float)lay.hd), (const uint16_t*)(packed + o.w_proj), slab, slab_stride);
+                else if (one16)
+                    hipLaunchKernelGGL((sb_qkv_attn_wide_kernel<KD64, 16, false>), grid, dim3(768), 0, s, (const float*)x, F(o.ln1_w), F(o.ln1_b),
+                                       (const uint16_t*)(packed + o.w_qkv), F(o.b_qkv), (uint16_t*)y, a.vbatch, a.T, spb, D, lay.hd, lay.Kd,
+                                       1.0f / sqrtf((float)lay.hd), nullptr, nullptr, 0);
+                else
+                    hipLaunchKernelGGL((sb_qkv_attn_wide_kernel<KD64, kSbRows, false>), grid, dim3(768), 0, s, (const float*)x, F(o.ln1_w),
+                                       F(o.ln1_b), (const uint16_t*)(packed + o.w_qkv), F(o.b_qkv), (uint16_t*)y, a.vbatch, a.T, spb, D,
+                                       lay.hd, lay.Kd, 1.0f / sqrtf((float)lay.hd), nullptr, nullptr, 0);
+            } else if (one16)
                 hipLaunchKernelGGL((sb_qkv_attn_kernel<E, KD64, 16>), dim3(lay.H, (a.vbatch + spb - 1) / spb), dim3(256), 0, s, (const float*)x,
                                    F(o.ln1_w), F(o.ln1_b), (const E*)(packed + o.w_qkv), F(o.b_qkv), y, a.vbatch, a.T, spb, D, lay.hd,
                                    lay.Kd, 1.0f / sqrtf((float)lay.hd));
@@ -460,18 +712,27 @@ hipError_t run_layers(const Layout& lay, const Workspace& ws, const char* packed
                                    lay.Kd, 1.0f / sqrtf((float)lay.hd));
         } else {
             hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 0, 8>), dim3(lay.Nqkv / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln1_w),
-                               F(o.ln1_b), (const E*)(packed + o.w_qkv), F(o.b_qkv), qkv, M, D, 3 * D, 3 * D);
+                               F(o.ln1_b), (const E*)(packed + o.w_qkv), F(o.b_qkv), qkv, M, D, 3 * D, 3 * D, SbSlabs{nullptr, 0, 0, nullptr, nullptr});
             e = launch_attention(qkv, y, a.vbatch, a.T, D, lay.H, lay.Kd, precision, s);
             if (e != hipSuccess) return e;
         }
-        launch_resid((const E*)y, lay.Kd, (const E*)(packed + o.w_proj), F(o.b_proj));
-        if (one16)
-            hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1, 16>), dim3(lay.Nh / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
-                               F(o.ln2_b), (const E*)(packed + o.w_fc1), F(o.b_fc1), h, M, D, lay.Kh, lay.Kh);
-        else
-            hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1, 8>), dim3(lay.Nh / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
-                               F(o.ln2_b), (const E*)(packed + o.w_fc1), F(o.b_fc1), h, M, D, lay.Kh, lay.Kh);
-        launch_resid((const E*)h, lay.Kh, (const E*)(packed + o.w_fc2), F(o.b_fc2));
+        const SbSlabs none{nullptr, 0, 0, nullptr, nullptr};
+        if (fuse_proj) {
+            // x_mid = x + b_p + the H slabs (into xm), LayerNorm-2, FC1, GELU; then x = x_mid + FC2
+            const SbSlabs sl{slab, slab_stride, lay.H, F(o.b_proj), xm};
+            hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1, 16, true>), dim3(lay.Nh / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
+                               F(o.ln2_b), (const E*)(packed + o.w_fc1), F(o.b_fc1), h, M, D, lay.Kh, lay.Kh, sl);
+            launch_resid((const E*)h, lay.Kh, (const E*)(packed + o.w_fc2), F(o.b_fc2), xm);
+        } else {
+            launch_resid((const E*)y, lay.Kd, (const E*)(packed + o.w_proj), F(o.b_proj), x);
+            if (one16)
+                hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1, 16>), dim3(lay.Nh / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
+                                   F(o.ln2_b), (const E*)(packed + o.w_fc1), F(o.b_fc1), h, M, D, lay.Kh, lay.Kh, none);
+            else
+                hipLaunchKernelGGL((sb_ln_gemm_kernel<E, KD64, 1, 8>), dim3(lay.Nh / 64, rb), dim3(256), 0, s, (const float*)x, F(o.ln2_w),
+                                   F(o.ln2_b), (const E*)(packed + o.w_fc1), F(o.b_fc1), h, M, D, lay.Kh, lay.Kh, none);
+            launch_resid((const E*)h, lay.Kh, (const E*)(packed + o.w_fc2), F(o.b_fc2), x);
+        }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -504,7 +765,9 @@ int forward_small(const Layout& lay, const Workspace& ws, const char* packed, in
                   hipStream_t s, hipError_t* err) {
     float* x = (float*)(wsp + ws.x);
     profile_begin(BESO_SITE_EMBED, s);
-    hipError_t e = launch_embed(lay, packed, a, x, s, a.vbatch <= 16);
+    // (one block per token row up to 2048 rows: the one-block-per-sample form walks a sample's tokens one after the other -- 19 us at
+    //  64 ... 256 samples where the rows' blocks take ~8; bit-identical results)
+    hipError_t e = launch_embed(lay, packed, a, x, s, a.vbatch * a.T <= 2048);
     profile_end(BESO_SITE_EMBED, s);
     if (e != hipSuccess) { *err = e; return BESO_ERR_HIP; }
     profile_begin(BESO_SITE_SMALL, s);

@@ -99,8 +99,9 @@ enum {
      * for measurements; a hint the shape or precision cannot honour is ignored. */
     BESO_PLAN_PER_OP = 0x10,  /* per-op kernels only: LayerNorm, GEMMs, attention (bf16 / fp32; any shape) */
     BESO_PLAN_BLOCKS = 0x20,  /* at most the block kernels (LN2 + MLP block, tail block), not the one-launch kernel */
-    BESO_PLAN_SMALL = 0x40,   /* the chip-wide small-batch path (bf16 / fp32, embed_dim <= 384: five short launches per layer
-                                 that spread every weight matrix over the CUs) at ANY batch size; without a hint the library
+    BESO_PLAN_SMALL = 0x40,   /* the chip-wide small-batch path (bf16 / fp32, embed_dim <= 384: four short launches per layer --
+                                 three up to 96 token rows in bf16 -- that spread every weight matrix over the CUs) at ANY batch
+                                 size; without a hint the library
                                  takes it up to 448 token rows in bf16 (kitchen: 40 samples) and 4096 in fp32, where one
                                  workgroup per sample group would stream all the weights alone */
     BESO_PLAN_FUSED = 0x80,   /* the one-launch / block kernels at every batch size (never the small-batch path) */

@@ -2185,7 +2185,8 @@ _SMALL_FORWARD = [("tiny_forward.npz", "tiny"), ("tiny_mlp_head_forward.npz", "t
 @pytest.mark.parametrize("fixture,cfg_name", _SMALL_FORWARD)
 def test_small_batch_path_vs_reference_vectors(fixture, cfg_name, precision):
     """The library's OWN choice at the fixtures' batch sizes (no plan hint: the rollout workload of the reference is B = 1) is
-    the chip-wide small-batch path -- five short launches per layer that spread every weight matrix over the CUs (small.hip).
+    the chip-wide small-batch path -- four short launches per layer (three up to 96 token rows in bf16: the out-projection rides
+    in the attention launch) that spread every weight matrix over the CUs (small.hip).
     GCDenoiser.forward / DiffusionGPT.forward, t in {1, W/2, W}, cond and uncond against the reference's vectors: fp32
     (exact-fp32 MFMA, two-pass LayerNorm, erff) 2e-5, bf16 inside the bounds of the one-launch kernel on the same vectors;
     every call is one timed region at the small-batch site and none at the fused kernel's."""
@@ -2278,8 +2279,9 @@ def test_small_batch_path_samplers_cfg_and_hints(precision):
         dev_rel = rel_err(outs["small"].cpu().numpy(), outs["other"].cpu().numpy())
         print(f"[parity] small-batch path vs the library's kernels at B = 400, {precision}: {dev_rel:.2e}")
         assert dev_rel < (2e-5 if precision == "fp32" else 2e-2)
-        # ragged: B = 1, 3, 33 (token rows not a multiple of the 32-row tile), short windows
-        for B, t in ((1, 1), (3, 2), (33, cfg.obs_seq_len)):
+        # ragged: B = 1, 3, 33 (token rows not a multiple of the 32-row tile), short windows; B = 64 (BASELINE configs[0]) and 200:
+        # the wide bf16 instances of round 6 (32 rows x 128 / 32 features, a head in twelve waves)
+        for B, t in ((1, 1), (3, 2), (33, cfg.obs_seq_len), (64, cfg.obs_seq_len), (200, cfg.obs_seq_len), (93, 2)):
             s, g, a = (G(v) for v in O.make_inputs(cfg, B, seed=B, t=t))
             sg = G(np.linspace(0.1, 0.8, B).astype(np.float32))
             set_plan(forward=_lib.PLAN_SMALL)
@@ -2290,6 +2292,18 @@ def test_small_batch_path_samplers_cfg_and_hints(precision):
             assert rel_err(o_small.cpu().numpy(), o_ref.cpu().numpy()) < (2e-5 if precision == "fp32" else 2e-2), (B, t)
             assert torch.equal(o_small, mk(s, a, g, sg)), "the small-batch path is deterministic"
         set_plan(forward=0)
+
+
+def test_small_batch_path_fuzz_for_ten_seconds():
+    """tools/fuzz_small.py for ten seconds: random model shapes, batches (1 ... 300 samples: the 16-row, 32-row and wide instances),
+    windows and guidance through the small-batch path against the per-op kernels of the same precision."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_small", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_small.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, worst = mod.run(10.0, 6)
+    print(f"[parity] fuzz_small: {n} cases, fp32 {worst['fp32']:.2e}, bf16 {worst['bf16']:.2e}")
+    assert n >= 20
 
 
 def test_small_batch_path_serves_the_agent_rollout():

@@ -32,7 +32,7 @@ def run(budget=60.0, seed=0):
             continue
         W, G = rng.randint(1, 9), rng.randint(0, 3)
         obs, act, L = rng.randint(1, 32), rng.randint(1, 16), rng.randint(1, 3)
-        B, t = rng.choice([1, 2, 3, 5, 8, 17, 40]), rng.randint(1, W)
+        B, t = rng.choice([1, 2, 3, 5, 8, 17, 40, 64, 130, 300]), rng.randint(1, W)      # (64 ...: the wide bf16 instances, round 6)
         prec = rng.choice(["fp32", "bf16"])
         linear = rng.random() < 0.7
         inner = DiffusionGPT(state_dim=obs, device="cuda", goal_conditioned=G > 0, action_dim=act, embed_dim=D, embed_pdrob=0, attn_pdrop=0,

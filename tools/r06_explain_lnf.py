@@ -35,6 +35,12 @@ def on_case(desc, names, ref, lib, per_op, inner):
     if max(d(lib), d(per_op)) < 0.05:
         return False
     print("case:", desc)
+    print(f"loss: fp32 step {ref[0]:.6f}   library plan {lib[0]:.6f} ({abs(lib[0] - ref[0]) / abs(ref[0]):.2e})   per-op plan {per_op[0]:.6f} "
+          f"({abs(per_op[0] - ref[0]) / abs(ref[0]):.2e})")
+    print("head-bias gradient (= column sums of dpred over the", desc["B"] * desc["t"], "rows): fp32", [f"{v:+.5f}" for v in ref[1][i_b].tolist()],
+          " library", [f"{v:+.5f}" for v in lib[1][i_b].tolist()], " per-op", [f"{v:+.5f}" for v in per_op[1][i_b].tolist()])
+    print("head-weight gradient (no cancellation) vs fp32: library "
+          f"{((lib[1][i_w] - ref[1][i_w]).norm() / ref[1][i_w].norm()).item():.4f}   per-op {((per_op[1][i_w] - ref[1][i_w]).norm() / ref[1][i_w].norm()).item():.4f}")
     print(f"|grad ln_f.bias| fp32 step {ref[1][i_lnf].norm().item():.4e}; the fuzz's floor for this tensor {floor:.4e}; "
           f"largest gradient entry of the step {gmax:.4e}")
     for name, got, Wm in (("fp32 step", ref, W.double()), ("library plan", lib, bf16_round(W)), ("per-op plan", per_op, bf16_round(W))):
