@@ -559,7 +559,7 @@ def other_configs(args, dev):
     sampler_run("configs[3] in fp16", "block_push", 2048, "heun", 50, 0.05, 1.0, 2.0, 2, "fp16")
     sampler_run("configs[4] in fp16", "long_horizon", 256, "euler", 100, 0.005, 1.0, None, 2, "fp16")
     sampler_run("configs[3] in bf16x3 (1e-4 mode)", "block_push", 2048, "heun", 50, 0.05, 1.0, 2.0, 1, "bf16x3")
-    sampler_run("configs[4] in bf16x3 (1e-4 mode: split-bf16 block kernels + fp32 attention)", "long_horizon", 256, "euler", 100, 0.005, 1.0, None, 1, "bf16x3")
+    sampler_run("configs[4] in bf16x3 (1e-4 mode: split-bf16 block kernels + split-bf16 MFMA attention)", "long_horizon", 256, "euler", 100, 0.005, 1.0, None, 1, "bf16x3")
     for label, shape, B in (("configs[2] per-GPU share: kitchen BesoAgent.train_step, 1024 samples", "kitchen", 1024),
                             ("configs[2] whole on one GPU: kitchen BesoAgent.train_step, 8192 samples", "kitchen", 8192),
                             ("block-push BesoAgent.train_step (resid_pdrop 0.05), 1024 samples", "block_push", 1024)):
