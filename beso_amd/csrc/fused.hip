@@ -3381,11 +3381,12 @@ __global__ __launch_bounds__(512, 2) void train_fwd_kernel(const char* __restric
     SlotTabs* tb = (SlotTabs*)(lds + L.tab);
     build_slot_tabs(tb, n_samples, Tn, a.t, d.G, true);
     // LDS that is read but never written by the phases must be finite (layers_kernel): the attention-output fragments of
-    // padding tokens and the 8 q/k/v rows past the last token slot
+    // padding tokens and the 8 q/k/v rows past the last token slot -- of THIS instance's 16 NTA slots (round 6: the four-sample
+    // instance in three token tiles lets the last sample's 16-row window reach row 48)
     for (int i = threadIdx.x; i < kNTT * 2 * 64; i += kBlock) ((u32x4*)(lds + L.u + kQKVBytes))[i] = u32x4{0, 0, 0, 0};
     for (int i = threadIdx.x; i < 3 * 8 * kQKVRow / 2; i += kBlock) {
         const int part = i / (8 * kQKVRow / 2), rem = i % (8 * kQKVRow / 2);
-        ((uint32_t*)(lds + L.u))[((size_t)part * kQKVRows + kMT) * kQKVRow / 2 + rem] = 0u;
+        ((uint32_t*)(lds + L.u))[((size_t)part * kQKVRows + 16 * NTA) * kQKVRow / 2 + rem] = 0u;
     }
     __syncthreads();
     const Rows rows_all{tb->row_of_slot, s0 * Tn, n_samples * Tn};     // token rows b T + position
@@ -4562,12 +4563,18 @@ int fused_train_whole(const Layout& lay, const char* img, int batch, int T, cons
     const TrainImgW ti = train_img_whole(d);
     constexpr int kMidSPW = 4, kMidNT = 4;
     const bool mid = batch <= 2 * kSmallBatchMax && tiles_hold(kMidSPW, T, kMidNT) && (kMidSPW - 1) * T + 16 <= 16 * kMidNT;
+    // Round 6: four samples of <= 12 tokens in THREE token tiles (kitchen: 44 of 48 slots instead of 44 of 64 -- the VERDICT's
+    // "318.7 GFLOP issued for 211 algorithmic" at 1024 samples; the last sample's 16-row attention window ends in the pad rows
+    // behind slot 48, as in the split-bf16 inference instance)
+    const bool mid3 = mid && tiles_hold(kMidSPW, T, 3) && kMidSPW * a.t <= 16 * 2 ;
     hipError_t e;
     if (d.RPW == 3)
-        e = mid ? launch_train_fwd<3, 12, 1, 2, kMidSPW, kMidNT>(img, d, ti, batch, T, a, s)
+        e = mid3 ? launch_train_fwd<3, 12, 1, 2, kMidSPW, 3>(img, d, ti, batch, T, a, s)
+            : mid ? launch_train_fwd<3, 12, 1, 2, kMidSPW, kMidNT>(img, d, ti, batch, T, a, s)
                 : launch_train_fwd<3, 12, 1, 2, kSPW, kNTT>(img, d, ti, batch, T, a, s);
     else
-        e = mid ? launch_train_fwd<2, 8, 3, 4, kMidSPW, kMidNT>(img, d, ti, batch, T, a, s)
+        e = mid3 ? launch_train_fwd<2, 8, 3, 4, kMidSPW, 3>(img, d, ti, batch, T, a, s)
+            : mid ? launch_train_fwd<2, 8, 3, 4, kMidSPW, kMidNT>(img, d, ti, batch, T, a, s)
                 : launch_train_fwd<2, 8, 3, 4, kSPW, kNTT>(img, d, ti, batch, T, a, s);
     return e == hipSuccess ? BESO_OK : BESO_ERR_HIP;
 }
