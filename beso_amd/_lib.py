@@ -30,7 +30,7 @@ EXPORTS = ["beso_version", "beso_status_string", "beso_last_error", "beso_num_pa
            "beso_profile_enable", "beso_profile_read", "beso_adam_step",
            "beso_train_workspace_bytes", "beso_grad_floats", "beso_loss_grad", "beso_gather_windows",
            "beso_loss_grad_overlap", "beso_grad_early_range", "beso_sample_ancestral", "beso_goal_mask",
-           "beso_loss_grad_streams", "beso_log_logistic"]
+           "beso_loss_grad_streams", "beso_log_logistic", "beso_scale_rows"]
 # include/beso_hip_debug.h: the development build only (libbeso_hip_dev.so); the product library exports none of them
 DEV_EXPORTS = ["beso_debug_set_stamps", "beso_debug_gemm"]
 DEV_LIB_PATH = os.path.join(_HERE, "lib", "libbeso_hip_dev.so")
@@ -121,6 +121,9 @@ def load() -> C.CDLL:
                     lib.beso_loss_grad_streams.argtypes = lib.beso_loss_grad.argtypes + [vp, vp]
                 lib.beso_grad_early_range.restype = i32
                 lib.beso_grad_early_range.argtypes = [cfgp, C.POINTER(sz), C.POINTER(sz)]
+        if hasattr(lib, "beso_scale_rows") or not os.environ.get("BESO_HIP_LIB"):
+            lib.beso_scale_rows.restype = i32
+            lib.beso_scale_rows.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
         if hasattr(lib, "beso_log_logistic") or not os.environ.get("BESO_HIP_LIB"):
             lib.beso_log_logistic.restype = i32
             lib.beso_log_logistic.argtypes = [vp, vp, sz, C.c_double, C.c_double, C.c_double, C.c_double, vp]

@@ -717,6 +717,16 @@ int beso_log_logistic(const double* u, float* out, size_t n, double loc, double 
     return BESO_OK;
 }
 
+int beso_scale_rows(const float* const* src, float* const* dst, const float* const* mean, const float* const* den,
+                    const long long* rows, const int* cols, int n, void* stream) {
+    if (n < 0 || n > kScaleMax || (n > 0 && (!src || !dst || !mean || !den || !rows || !cols))) return BESO_ERR_BAD_ARG;
+    for (int k = 0; k < n; ++k)
+        if (rows[k] < 0 || cols[k] < 1 || (rows[k] > 0 && (!src[k] || !dst[k] || !mean[k] || !den[k]))) return BESO_ERR_BAD_ARG;
+    hipError_t e = launch_scale_rows(src, dst, mean, den, rows, cols, n, (hipStream_t)stream);
+    if (e != hipSuccess) return record_hip_error(e, "scale_rows_kernel", __LINE__);
+    return BESO_OK;
+}
+
 int beso_goal_mask(float* mask, int batch, int goal_seq_len, int obs_dim, float goal_drop, unsigned int seed, void* stream) {
     if (batch < 0 || goal_seq_len < 0 || obs_dim < 0) return BESO_ERR_BAD_ARG;
     hipError_t e = hipSuccess;

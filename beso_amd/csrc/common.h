@@ -230,6 +230,9 @@ struct FwdArgs {
 
 hipError_t launch_pack_matrix(const float* src, int rows, int cols, void* dst, int rows_p,
                               int cols_p, int precision, hipStream_t s);
+constexpr int kScaleMax = 4;              // tensors per beso_scale_rows launch
+hipError_t launch_scale_rows(const float* const* src, float* const* dst, const float* const* mean, const float* const* den,
+                             const long long* rows, const int* cols, int n, hipStream_t s);
 hipError_t launch_embed(const Layout& lay, const char* packed, const FwdArgs& a, float* x, hipStream_t s, bool per_row = false);
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, void* out, int rows,
                             int D, int ld_out, int precision, hipStream_t s);

@@ -490,6 +490,48 @@ __global__ void log_logistic_kernel(const double* __restrict__ u, float* __restr
     }
 }
 
+// Scaler.scale_input / scale_output (networks/scaler/scaler_class.py:95-117): out = (x - mean) / den per feature, for up to
+// kScaleMax tensors in ONE launch -- a training step scales state, goal and action: six elementwise launches of ~6 us each in
+// front of the forward (round 6: the 125 us of small launches between the optimizer and the forward are 6 % of the 1024-sample
+// step).  The reference's two rounded operations (a subtraction, a correctly rounded division): same bits.
+struct ScaleTable { const float* src[kScaleMax]; float* dst[kScaleMax]; const float* mean[kScaleMax]; const float* den[kScaleMax];
+                    unsigned long long first[kScaleMax + 1]; int cols[kScaleMax]; int n; };
+__global__ void scale_rows_kernel(ScaleTable t) {
+    const unsigned long long total = t.first[t.n];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < kScaleMax; ++j) k += (j < t.n && i >= t.first[j]) ? 1 : 0;
+        const unsigned long long e = i - t.first[k];
+        const int c = (int)(e % (unsigned long long)t.cols[k]);
+        const float d = t.src[k][e] - t.mean[k][c];        // (a subtraction and a division: nothing to contract)
+        t.dst[k][e] = d / t.den[k][c];
+    }
+}
+
+hipError_t launch_scale_rows(const float* const* src, float* const* dst, const float* const* mean, const float* const* den,
+                             const long long* rows, const int* cols, int n, hipStream_t s) {
+    ScaleTable t;
+    t.n = n;
+    unsigned long long cur = 0;
+    for (int k = 0; k < kScaleMax; ++k) {
+        const bool on = k < n;
+        t.src[k] = on ? src[k] : nullptr; t.dst[k] = on ? dst[k] : nullptr; t.mean[k] = on ? mean[k] : nullptr;
+        t.den[k] = on ? den[k] : nullptr; t.cols[k] = on ? cols[k] : 1;
+        t.first[k] = cur;
+        if (on) cur += (unsigned long long)rows[k] * (unsigned long long)cols[k];
+    }
+    for (int k = n; k <= kScaleMax; ++k) t.first[k] = cur;
+    t.first[n] = cur;
+    (void)hipGetLastError();
+    if (cur == 0) return hipSuccess;
+    unsigned long long grid = (cur + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)grid), dim3(256), 0, s, t);
+    return hipGetLastError();
+}
+
 hipError_t launch_log_logistic(const double* u, float* out, size_t n, double loc, double scale, double lo, double hi, hipStream_t s) {
     (void)hipGetLastError();
     int grid = (int)((n + 255) / 256);

@@ -2036,8 +2036,10 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(hipEventRecord(ev_fork, s));                 // (behind the optimizer step that wrote the parameters)
         TRY(hipStreamWaitEvent(ps, ev_fork, 0));
     }
-    TRY(hipMemsetAsync(gflat, 0, sizeof(float) * n_grad, s));      // (loss_out and the padded head bias: prep_kernel; on `s`: beside the
-                                                                    //  store-bound forward the 37.5 MB memset measured slower)
+    // (loss_out and the padded head bias: prep_kernel.  Beside the store-bound forward the 37.5 MB memset measured slower; round 6:
+    //  in FRONT of the forward image's pack on the side stream -- the forward waits for that stream anyway (ev_join), and the
+    //  compute stream's chain of small launches in front of the forward is 9 us shorter)
+    TRY(hipMemsetAsync(gflat, 0, sizeof(float) * n_grad, ps));
 
     // (first what the forward launch needs -- its fragment image --, then the plain copies the backward pass reads)
     if (use_whole || use_tail) {

@@ -51,6 +51,45 @@ class Scaler:
             return ((y - self.y_mean) / self._den("y")).to(torch.float32)
         return y
 
+    @torch.no_grad()
+    def scale_many(self, items):
+        """[(tensor, 'x' | 'y'), ...] -> the scaled tensors: scale_input / scale_output of every item (scaler_class.py:95-117) as
+        ONE HIP launch (beso_scale_rows: the same subtraction and correctly rounded division per element) where every tensor
+        is a contiguous fp32 CUDA tensor with fp32 statistics -- a training batch is three tensors, i.e. six elementwise launches
+        of ~6 us each in front of the forward.  Anything else (CPU tensors, other dtypes, one-hot goals, scale_data off, a
+        library without the entry point): the per-tensor methods."""
+        plan, ok = [], self.scale_data and 0 < len(items) <= 4
+        for x, which in items:
+            mean = self.x_mean if which == "x" else self.y_mean
+            den = self._den(which) if self.scale_data else None
+            good = (ok and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() > 0
+                    and isinstance(mean, torch.Tensor) and mean.is_cuda and mean.device == x.device and mean.dtype == torch.float32
+                    and den.dtype == torch.float32 and mean.dim() == 1 and mean.numel() == x.shape[-1] and mean.is_contiguous()
+                    and den.is_contiguous() and not (which == "x" and x.shape[-1] == 7 and len(self.x_mean) == 30))
+            ok = ok and good
+            plan.append((x, mean, den))
+        lib = None
+        if ok:
+            from ... import _lib
+            lib = _lib.load()
+            ok = hasattr(lib, "beso_scale_rows")
+        if not ok:
+            return [self.scale_input(x) if which == "x" else self.scale_output(x) for x, which in items]
+        import ctypes as C
+        from ... import _lib
+        n = len(plan)
+        outs = [torch.empty_like(x) for x, _, _ in plan]
+        vp = C.c_void_p * n
+        src = vp(*[x.data_ptr() for x, _, _ in plan]); dst = vp(*[o.data_ptr() for o in outs])
+        mean = vp(*[m.data_ptr() for _, m, _ in plan]); den = vp(*[d.data_ptr() for _, _, d in plan])
+        rows = (C.c_longlong * n)(*[x.numel() // x.shape[-1] for x, _, _ in plan])
+        cols = (C.c_int * n)(*[x.shape[-1] for x, _, _ in plan])
+        dev = plan[0][0].device
+        with torch.cuda.device(dev):
+            _lib.check(lib.beso_scale_rows(src, dst, mean, den, rows, cols, n, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                       "scale_rows")
+        return outs
+
     def _den(self, which: str):
         """std + 1e-12 (scaler_class.py:129,139): the same tensor every call -- computed once per std tensor instead of one
         more elementwise launch per scaled batch (three per training step)."""

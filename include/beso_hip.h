@@ -18,6 +18,7 @@
  *                          (+ DiffusionGPT.mask_cond, training mode     k_diffusion/score_gpts.py:298-299, 360-371)
  *   beso_goal_mask      <- the Bernoulli mask of DiffusionGPT.mask_cond k_diffusion/score_gpts.py:365-368
  *   beso_log_logistic   <- rand_log_logistic (behind the uniform draw)   k_diffusion/utils.py:178-185 (beso_agent.py:227)
+ *   beso_scale_rows     <- Scaler.scale_input / scale_output              networks/scaler/scaler_class.py:95-117 (base_agent.py:111-142)
  *   beso_loss_grad_overlap  (same, with the early gradient range for the overlapped all-reduce: SURVEY 8(e) C1)
  *   beso_loss_grad_streams  (same, plus a stream that is released as soon as the loss value is final)
  *   beso_adam_step      <- optimizer.step() + ema_helper.update()      beso_agent.py:236-244
@@ -283,6 +284,13 @@ int beso_gather_windows(const float* observations, const float* actions, const i
  * (torch.rand(..., dtype=float64): the library has no random number generator); cdf_lo / cdf_hi: the logistic CDF of
  * log(min_value) / log(max_value).                                                                                      */
 int beso_log_logistic(const double* u, float* out, size_t n, double loc, double scale, double cdf_lo, double cdf_hi, void* stream);
+
+/* Scaler.scale_input / scale_output (networks/scaler/scaler_class.py:95-117, called three times per batch by
+ * BaseAgent.process_batch, base_agent.py:111-142): dst_k[r][c] = (src_k[r][c] - mean_k[c]) / den_k[c] for n <= 4 tensors of
+ * rows_k x cols_k fp32 values in ONE launch (den = std + 1e-12, the reference's denominator; a subtraction and a correctly
+ * rounded division per element: the reference's bits).  dst_k may be src_k.                                              */
+int beso_scale_rows(const float* const* src, float* const* dst, const float* const* mean, const float* const* den,
+                    const long long* rows, const int* cols, int n, void* stream);
 
 /* The same call for data-parallel training, where the exchange of the gradients (one all-reduce per range) should start
  * before the backward pass is over.  The gradients of the upper transformer layers l0 .. n_layers-1 and of ln_f are one

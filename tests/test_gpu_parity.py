@@ -2294,6 +2294,24 @@ def test_small_batch_path_samplers_cfg_and_hints(precision):
         set_plan(forward=0)
 
 
+def test_scaler_scale_many_is_one_launch_with_the_reference_bits():
+    """Scaler.scale_many (beso_scale_rows): state, goal and action of a training batch in one launch -- bit for bit the
+    (x - mean) / (std + 1e-12) of scale_input / scale_output (scaler_class.py:95-117), ragged sizes included; CPU tensors and
+    float64 statistics take the per-tensor methods."""
+    from beso_amd.networks.scaler.scaler_class import Scaler
+    rng = np.random.default_rng(3)
+    sc = Scaler(rng.standard_normal((64, 30)).astype(np.float32) * 3 + 1, rng.standard_normal((64, 9)).astype(np.float32), True, DEV)
+    for B in (1, 7, 1024):
+        st, go, ac = (torch.randn(B, 5, 30, device=DEV) * 2, torch.randn(B, 2, 30, device=DEV), torch.randn(B, 5, 9, device=DEV))
+        got = sc.scale_many([(st, "x"), (go, "x"), (ac, "y")])
+        ref = [sc.scale_input(st), sc.scale_input(go), sc.scale_output(ac)]
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), B
+    cpu = sc.scale_many([(st.cpu(), "x")])[0]
+    assert torch.equal(cpu.to(DEV), sc.scale_input(st))
+    sc64 = Scaler(rng.standard_normal((64, 30)), rng.standard_normal((64, 9)), True, DEV)      # float64 statistics: the fallback
+    assert sc64.scale_many([(st, "x")])[0].dtype == torch.float32
+
+
 def test_small_batch_path_fuzz_for_ten_seconds():
     """tools/fuzz_small.py for ten seconds: random model shapes, batches (1 ... 300 samples: the 16-row, 32-row and wide instances),
     windows and guidance through the small-batch path against the per-op kernels of the same precision."""
