@@ -1684,6 +1684,24 @@ __global__ void scatter_rows_kernel(const V* __restrict__ src, V* __restrict__ d
     }
 }
 
+// both scatters of the last layer's backward in one launch (round 6: two dependent launches of ~7 us on the step's chain)
+template <typename E>
+__global__ void scatter_rows2_kernel(const E* __restrict__ src_e, E* __restrict__ dst_e, const float* __restrict__ src_f,
+                                     float* __restrict__ dst_f, int M, int t, int T, int G, int D) {
+    const int d4 = D / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * d4; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / d4), k = (int)(i % d4), b = m / T, idx = m % T - 1 - G;
+        f32x4 ve = {0.f, 0.f, 0.f, 0.f}, vf = ve;
+        if (idx >= 0 && (idx & 1)) {
+            const size_t so = ((size_t)b * t + (idx >> 1)) * D + 4 * k;
+            ve = Vec4<E>::load(src_e + so);
+            vf = Vec4<float>::load(src_f + so);
+        }
+        Vec4<E>::store(dst_e + (size_t)m * D + 4 * k, ve);
+        Vec4<float>::store(dst_f + (size_t)m * D + 4 * k, vf);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // squared-error loss over the (compact) action-token rows (score_wrappers.py:70-79 with pred_last_action_only
 // False: per-sample mean over (t, act), then the batch mean = the mean over all B*t*act elements), its gradient
@@ -1749,7 +1767,7 @@ static int device_cus() {
 
 // Events that order the step's side streams, per calling thread AND per device (an event created on device A and
 // recorded on a stream of device B is hipErrorInvalidHandle -- a thread that drives several GPUs one after the other)
-enum { kEvFork = 0, kEvJoin, kEvCopies, kEvLoss, kEvEarly, kEvSideFork, kEvSideJoin, kEvCount };
+enum { kEvFork = 0, kEvJoin, kEvCopies, kEvLoss, kEvEarly, kEvSideFork, kEvSideJoin, kEvWcat, kEvCount };
 static hipError_t step_event(int which, hipEvent_t* out) {
     constexpr int kMaxDev = 64;
     static thread_local hipEvent_t ev[kMaxDev][kEvCount] = {};
@@ -2039,6 +2057,17 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
     // (loss_out and the padded head bias: prep_kernel.  Beside the store-bound forward the 37.5 MB memset measured slower; round 6:
     //  in FRONT of the forward image's pack on the side stream -- the forward waits for that stream anyway (ev_join), and the
     //  compute stream's chain of small launches in front of the forward is 9 us shorter)
+    // (the embedding's concatenated weight -- parameters only -- is packed there too, first: the compute stream waits for it
+    //  in front of the embedding GEMM, three small launches later)
+    hipEvent_t ev_wcat = nullptr;
+    const bool wcat_side = fork && embed_p == 0.f;
+    if (wcat_side) {
+        hipLaunchKernelGGL(wcat_pack_kernel, dim3((D * Ke + 255) / 256), dim3(256), 0, ps, pos.p, tokw.p, tokb.p, sigw.p, sigb.p,
+                           actw.p, actb.p, F(w.wcat), D, obs, act, seq, Ke);
+        TRY(hipGetLastError());
+        TRY(step_event(kEvWcat, &ev_wcat));
+        TRY(hipEventRecord(ev_wcat, ps));
+    }
     TRY(hipMemsetAsync(gflat, 0, sizeof(float) * n_grad, ps));
 
     // (first what the forward launch needs -- its fragment image --, then the plain copies the backward pass reads)
@@ -2106,13 +2135,15 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         TRY(hipGetLastError());
         if (embed_p == 0.f) {
             // the embedding as one exact-fp32 GEMM over the feature matrix (train_feat_kernel)
-            hipLaunchKernelGGL(wcat_pack_kernel, dim3((D * Ke + 255) / 256), dim3(256), 0, s, pos.p, tokw.p, tokb.p, sigw.p, sigb.p,
-                               actw.p, actb.p, F(w.wcat), D, obs, act, seq, Ke);
+            if (!wcat_side)
+                hipLaunchKernelGGL(wcat_pack_kernel, dim3((D * Ke + 255) / 256), dim3(256), 0, s, pos.p, tokw.p, tokb.p, sigw.p, sigb.p,
+                                   actw.p, actb.p, F(w.wcat), D, obs, act, seq, Ke);
             const size_t nf = (size_t)M * Ke;
             hipLaunchKernelGGL(train_feat_kernel<E>, dim3((unsigned)((nf + 255) / 256 > 4096 ? 4096 : (nf + 255) / 256)), dim3(256), 0, s,
                                state, (const float*)F(w.noised), goal, sigma, P(w.xemb), F(w.xemb32), M, t, T, G, obs, act, Ke,
                                c->sigma_data, goal_p, seed);
             TRY(hipGetLastError());
+            if (wcat_side) TRY(hipStreamWaitEvent(s, ev_wcat, 0));
             TRY((tgemm<float, false, false>(F(w.xemb32), Ke, F(w.wcat), Ke, M, D, Ke, 1, EpiStore<float>{F(w.x0), nullptr, nullptr, D}, s)));
         } else {
         const int threads = D >= 256 ? 256 : round_up(D, 64);
@@ -2460,9 +2491,8 @@ static int loss_grad_e(const beso_config* c, const float* const* p, float* gflat
         if (last) {
             // back to all token rows: dy and the residual gradient are zero off the action rows
             const size_t n4 = (size_t)M * (D / 4);
-            hipLaunchKernelGGL(scatter_rows_kernel<E>, dim3(gs_grid(n4)), dim3(256), 0, s, (const E*)P(w.dya), P(w.dy), M, t, T, G, D);
-            hipLaunchKernelGGL(scatter_rows_kernel<float>, dim3(gs_grid(n4)), dim3(256), 0, s, (const float*)F(w.dxa), F(w.dx), M, t, T,
-                               G, D);
+            hipLaunchKernelGGL(scatter_rows2_kernel<E>, dim3(gs_grid(n4)), dim3(256), 0, s, (const E*)P(w.dya), P(w.dy),
+                               (const float*)F(w.dxa), F(w.dx), M, t, T, G, D);
             TRY(hipGetLastError());
         }
         if (attn_small && sizeof(E) == 2 && !(flags & BESO_TRAIN_PLAN_PER_OP)) {
