@@ -427,7 +427,7 @@ __device__ __forceinline__ f32x4 mfma_op_half(const u32x4& a, const u32x4& b, co
 #endif
 #ifndef BESO_TRAIN_FWD_ABL
 #define BESO_TRAIN_FWD_ABL 0         // timing experiments on train_fwd_kernel (results wrong): stores left out -- 1 x_mid / x_out,
-#endif                               // 2 LayerNorm outputs + statistics, 4 q|k|v and y, 8 h, 16 GELU(h)
+#endif                               // 2 LayerNorm outputs + statistics, 4 q|k|v and y, 8 h, 16 GELU(h); 128 / 256: rows folded (Rows::row)
 __host__ __device__ constexpr bool zero_pad_instance(int RPW, int NT) { return BESO_ZERO_PAD && RPW != 2 && NT >= 5; }
 __device__ __forceinline__ void mixed_chain_pad() {
     __builtin_amdgcn_sched_barrier(0);
@@ -840,7 +840,14 @@ __device__ __forceinline__ void stamp(Stamps& st, int id) {
 // train_fwd_kernel); tab = SlotTabs::row_of_slot: the action-tokens-first slot order of the one-launch kernels.
 struct Rows {
     const unsigned char* tab; int base, n;
-    __device__ __forceinline__ int row(int slot) const { return slot < n ? base + (tab ? (int)tab[slot] : slot) : -1; }
+    __device__ __forceinline__ int row(int slot) const {
+        int r = slot < n ? base + (tab ? (int)tab[slot] : slot) : -1;
+        // (timing experiments, results wrong: every workgroup's kept rows folded onto the first 64 / 4096 rows of each buffer --
+        //  the same store instructions onto an L2-resident / a page-local footprint; profiles/r06_store_wave_probe.txt)
+        if ((BESO_TRAIN_FWD_ABL & 128) && r >= 0) r &= 63;
+        if ((BESO_TRAIN_FWD_ABL & 256) && r >= 0) r &= 4095;
+        return r;
+    }
 };
 // Two 8-byte row pieces of the accumulator layout -> one 16-byte store per lane.  a = the lane's four bf16 features (f0 .. f0 + 3,
 // f0 = 16 tile + 4 g) of the token `tok_a` of token tile t, b = the same features of `tok_b` of tile t + 1.  After the two swaps
