@@ -1140,8 +1140,14 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
     if (c < D) {
         int b = ry;
         for (; b + 112 < nblk; b += 128) {
+            // (the eight loads first, into registers of their own: written as a[u] += load the compiler issued them one at a
+            //  time -- load, s_waitcnt vmcnt(0), add -- i.e. nblk / 16 dependent round trips again: 326 us at 8192 samples)
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += *(const f32x4*)(src + (size_t)(b + 16 * u) * rs);
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load((const f32x4*)(src + (size_t)(b + 16 * u) * rs));
+            __builtin_amdgcn_sched_barrier(0);          // (nor may the scheduler fold the adds back between the loads)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += v[u];
         }
         for (; b < nblk; b += 16) a[0] += *(const f32x4*)(src + (size_t)b * rs);
     }
