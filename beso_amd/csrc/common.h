@@ -20,7 +20,8 @@
 #if defined(BESO_ABL_MASK) || defined(BESO_ZERO_PAD) || defined(BESO_FUSED_ABLATE) || defined(BESO_FUSED_WLOAD) || \
     defined(BESO_RED_PAD) || defined(BESO_FUSED_STAMPS) || defined(BESO_GELU_SCALAR) || defined(BESO_FC1_PF) || \
     defined(BESO_LAT_PF1) || defined(BESO_V_TR) || defined(BESO_LONG_PAIRED) || defined(BESO_LONG_PF1) || \
-    defined(BESO_TGEMM_WAVES) || defined(BESO_TGEMM_NOSTORE) || defined(BESO_TRAIN_FWD_ABL) || defined(BESO_WG_SETS)
+    defined(BESO_TGEMM_WAVES) || defined(BESO_TGEMM_NOSTORE) || defined(BESO_TRAIN_FWD_ABL) || defined(BESO_WG_SETS) || \
+    defined(BESO_KEEP_HYBRID)
 #error "compile-time variants of the kernels need -DBESO_VARIANTS=1 (tools/variants.py); the product build takes none"
 #endif
 #endif

@@ -425,6 +425,9 @@ __device__ __forceinline__ f32x4 mfma_op_half(const u32x4& a, const u32x4& b, co
 #ifndef BESO_ZERO_PAD
 #define BESO_ZERO_PAD 1              // 0: A/B builds
 #endif
+#ifndef BESO_KEEP_HYBRID
+#define BESO_KEEP_HYBRID 1           // odd token-tile counts: h and GELU(h) leave as 16-byte pieces for the tile pairs, 8-byte ones for the last (0: all 8-byte)
+#endif
 #ifndef BESO_TRAIN_FWD_ABL
 #define BESO_TRAIN_FWD_ABL 0         // timing experiments on train_fwd_kernel (results wrong): stores left out -- 1 x_mid / x_out,
 #endif                               // 2 LayerNorm outputs + statistics, 4 q|k|v and y, 8 h, 16 GELU(h); 128 / 256: rows folded (Rows::row)
@@ -1777,16 +1780,19 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 #pragma unroll
             for (int r = 0; r < RC; ++r) {
                 const int f0 = 16 * (c * kChunkTiles + RC * w + r) + 4 * g;
-                if constexpr (NT % 2 == 0) {
+                // (an odd tile count: the pairs as 16-byte pieces, the last tile as 8-byte ones)
+                constexpr int NTE = BESO_KEEP_HYBRID ? (NT & ~1) : (NT % 2 == 0 ? NT : 0);
+                {
 #pragma unroll
-                    for (int t = 0; t < NT; t += 2)
+                    for (int t = 0; t < NTE; t += 2)
                         store_pair16(mx.h, mx.ld, mx.rows.row(16 * t + n), mx.rows.row(16 * (t + 1) + n), f0, g,
                                      make_uint2(pack_op2(hv[r][t][0], hv[r][t][1]), pack_op2(hv[r][t][2], hv[r][t][3])),
                                      make_uint2(pack_op2(hv[r][t + 1][0], hv[r][t + 1][1]), pack_op2(hv[r][t + 1][2], hv[r][t + 1][3])),
                                      !(BESO_TRAIN_FWD_ABL & 8));
-                } else {
+                }
+                {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
+                    for (int t = NTE; t < NT; ++t) {
                         const int tok = mx.rows.row(16 * t + n);
                         if (tok >= 0 && f0 < mx.ld && !(BESO_TRAIN_FWD_ABL & 8))
                             *(uint2*)(mx.h + (size_t)tok * mx.ld + f0) = make_uint2(pack_op2(hv[r][t][0], hv[r][t][1]),
@@ -1804,15 +1810,17 @@ __device__ __forceinline__ void mlp_phase(Tile<RPW>& T, const u32x4* xnT, u32x4*
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int f0 = 16 * (c * kChunkTiles + RC * w + 2 * j2 + q) + 4 * g;
-                    if constexpr (NT % 2 == 0) {
+                    constexpr int NTE = BESO_KEEP_HYBRID ? (NT & ~1) : (NT % 2 == 0 ? NT : 0);
+                    {
 #pragma unroll
-                        for (int t = 0; t < NT; t += 2)
+                        for (int t = 0; t < NTE; t += 2)
                             store_pair16(mx.g, mx.ld, mx.rows.row(16 * t + n), mx.rows.row(16 * (t + 1) + n), f0, g,
                                          make_uint2(hb[j2][t][2 * q], hb[j2][t][2 * q + 1]),
                                          make_uint2(hb[j2][t + 1][2 * q], hb[j2][t + 1][2 * q + 1]), !(BESO_TRAIN_FWD_ABL & 16));
-                    } else {
+                    }
+                    {
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) {
+                        for (int t = NTE; t < NT; ++t) {
                             const int tok = mx.rows.row(16 * t + n);
                             if (tok >= 0 && f0 < mx.ld && !(BESO_TRAIN_FWD_ABL & 16))
                                 *(uint2*)(mx.g + (size_t)tok * mx.ld + f0) = make_uint2(hb[j2][t][2 * q], hb[j2][t][2 * q + 1]);
