@@ -99,8 +99,13 @@ def run(budget=60.0, seed=0, on_case=None):
         if on_case is not None and on_case(desc, names, ref, a, b, inner):
             return n, worst, worst_ratio
         assert all(torch.isfinite(x).all() for x in a[1]), ("non-finite gradient", desc)
-        lb = max(3e-3, 6e-2 / (B * t * act) ** 0.5)          # (a loss over a handful of elements does not average the bf16 rounding:
-                                                              #  two elements measured 3.0e-2 in round 5's seed 11)
+        # (a loss over a handful of elements does not average the bf16 rounding: two elements measured 3.0e-2 in round 5's seed 11.
+        #  And a SMALL loss amplifies it: the loss is mean(err^2), a forward deviation d of the prediction moves it by 2 d / err
+        #  relative -- round 6's seed 23 draws B t act = 2 with an fp32 loss of 0.031 (err ~ 0.18): the library's plan lands
+        #  6.2e-2 away, the per-op plan 8.9e-3, i.e. forward deviations of 5e-3 and 8e-4 of a prediction of size 1, both inside
+        #  the forward's bf16 bound (profiles/r06_loss_bound.txt).  The bound is the old one for losses >= 0.25 and grows as
+        #  1 / sqrt(loss) below.)
+        lb = max(3e-3, 3e-2 / ((B * t * act) ** 0.5 * min(0.5, abs(ref[0]) ** 0.5)))
         # the library's kernels may not be further from fp32 than the bf16 bound of the parity tests, or -- tiny batches, where
         # every bf16 evaluation is that far off -- than 1.5 x the per-op plan's own distance
         # (batches of fewer than 32 token-window rows: the bias-like gradients -- ln_f.bias, the output bias -- are sums over a
