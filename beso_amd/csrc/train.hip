@@ -1534,12 +1534,19 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const E* __restrict__ qk
 constexpr int kAmLd = 72;                          // halfwords per LDS row: 64 dims + pad (144 B: the transpose reads spread over banks)
 
 __device__ __forceinline__ u32x4 row_chunk16(const uint16_t* __restrict__ base, size_t ld, int x, int c0, int T, int hd) {
+    // ONE 16-byte request per chunk (a head's rows are 8-byte aligned when hd is not a multiple of 8: global memory takes the
+    // unaligned dwordx4).  A chunk that straddles the end of the head (hd = 60: columns 56 .. 63) is fetched as the head's last
+    // eight columns and shifted down, so nothing behind the head -- or the tensor -- is read.  hd >= 8, a multiple of 4.
+    typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
     const uint16_t* p = base + (size_t)min(x, T - 1) * ld;
-    uint2 lo = *(const uint2*)(p + min(c0, hd - 4)), hi = *(const uint2*)(p + min(c0 + 4, hd - 4));
-    const uint2 z = make_uint2(0u, 0u);
-    if (!(x < T && c0 < hd)) lo = z;
-    if (!(x < T && c0 + 4 < hd)) hi = z;
-    return u32x4{lo.x, lo.y, hi.x, hi.y};
+    const int cl = min(c0, hd - 8);
+    const u32x4_a8 v = *(const u32x4_a8*)(p + cl);
+    // (selects, not branches: a branch between the loads makes each of them wait for the one before)
+    const bool shifted = cl != c0, half = c0 - cl == 4;               // (c0 - cl is 0, 4 or >= 8)
+    const bool lo_on = x < T && c0 < hd, hi_on = x < T && c0 + 4 < hd;
+    const uint32_t l0 = shifted ? (half ? v[2] : 0u) : v[0], l1 = shifted ? (half ? v[3] : 0u) : v[1];
+    const uint32_t h0 = shifted ? 0u : v[2], h1 = shifted ? 0u : v[3];
+    return u32x4{lo_on ? l0 : 0u, lo_on ? l1 : 0u, hi_on ? h0 : 0u, hi_on ? h1 : 0u};
 }
 __device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) {
     typedef __attribute__((ext_vector_type(2))) float f2_t;
@@ -1649,18 +1656,39 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const uint16_t* __re
     };
     uint16_t* ob = dqkv + ((size_t)b * T + x) * ldq + (size_t)h * hd;      // row x of this pair's dq | dk | dv
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // The results leave as 16-BYTE pieces (round 6): a lane holds dims 16 dt + 4 g .. + 3 of its row = 8 bytes; the lane groups g, g + 1
+    // of the dim tiles dt, dt + 1 exchange halves (two v_permlane16_swap per tensor), after which an even group holds 8 consecutive
+    // dims of tile dt and an odd group 8 of tile dt + 1 -- six requests per lane where there were twelve (a head's rows are 8-byte
+    // aligned when hd is not a multiple of 8: global memory takes the unaligned dwordx4).  A piece that straddles the end of the head
+    // (hd = 60: dims 56 .. 63) goes out as its first 8 bytes.
+    typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+    auto put16 = [&](uint16_t* dst, int dt, uint2 a, uint2 bq) {            // a: tile dt, bq: tile dt + 1 (this lane's four dims of each)
+        const u32x2_t sx = __builtin_amdgcn_permlane16_swap(a.x, bq.x, false, false);
+        const u32x2_t sy = __builtin_amdgcn_permlane16_swap(a.y, bq.y, false, false);
+        const int f = 16 * (dt + (g & 1)) + 4 * (g & ~1);                  // first of the lane's eight dims
+        if (x < T && f + 8 <= hd) *(u32x4_a8*)(dst + f) = u32x4_a8{sx[0], sy[0], sx[1], sy[1]};
+        else if (x < T && f < hd) *(uint2*)(dst + f) = make_uint2(sx[0], sy[0]);
+    };
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    for (int dt = 0; dt < 4; dt += 2) {
         if (16 * dt >= hd) break;                    // (wave-uniform)
-        const f32x4 dq = mma16b(tr(sk, dt), bdsT, zero);     // [d][i]: lane (i, g) holds d = 16 dt + 4 g + r
-        const f32x4 dk = mma16b(tr(sq, dt), bdsN, zero);     // [d][j]
-        const f32x4 dv = mma16b(tr(sg, dt), bpdN, zero);
-        const int d0 = 16 * dt + 4 * g;
-        if (x < T && d0 < hd) {
-            *(uint2*)(ob + d0) = pack4_bf16(dq[0], dq[1], dq[2], dq[3]);
-            *(uint2*)(ob + D + d0) = pack4_bf16(dk[0], dk[1], dk[2], dk[3]);
-            *(uint2*)(ob + 2 * D + d0) = pack4_bf16(dv[0], dv[1], dv[2], dv[3]);
+        uint2 pq[2], pk[2], pv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pq[u] = pk[u] = pv[u] = make_uint2(0u, 0u);
+            if (16 * (dt + u) < hd) {                // (wave-uniform)
+                const f32x4 dq = mma16b(tr(sk, dt + u), bdsT, zero);     // [d][i]: lane (i, g) holds d = 16 (dt + u) + 4 g + r
+                const f32x4 dk = mma16b(tr(sq, dt + u), bdsN, zero);     // [d][j]
+                const f32x4 dv = mma16b(tr(sg, dt + u), bpdN, zero);
+                pq[u] = pack4_bf16(dq[0], dq[1], dq[2], dq[3]);
+                pk[u] = pack4_bf16(dk[0], dk[1], dk[2], dk[3]);
+                pv[u] = pack4_bf16(dv[0], dv[1], dv[2], dv[3]);
+            }
         }
+        put16(ob, dt, pq[0], pq[1]);
+        put16(ob + D, dt, pk[0], pk[1]);
+        put16(ob + 2 * D, dt, pv[0], pv[1]);
     }
 }
 
